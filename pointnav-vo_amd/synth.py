@@ -1,0 +1,127 @@
+"""Deterministic synthetic weights and inputs (numpy only, no torch RNG, stable across library versions).
+
+Used by bench.py, the parity tests and tests/golden/gen_golden.py so that the build container (where the
+reference can be imported) and the GPU box (where it cannot) regenerate bit-identical tensors from a seed;
+the golden fixtures then only need to store the reference's OUTPUTS.
+
+Shapes/ranges follow SURVEY.md §8(d): rgb uint8 U{0..255}; depth U[0.05,0.95] rounded to fp16 and widened
+(the dataset stores fp16, /root/reference/pointnav_vo/vo/dataset/generate_datasets.py:272,290);
+discretized_depth = one-hot of the depth bin; running mean ~U[0,0.5], var ~U[0,0.2].
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fnv1a(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x):
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def bits(seed: int, name: str, n: int) -> np.ndarray:
+    """n uint64 pseudo-random words, a pure function of (seed, name, index)."""
+    key = np.uint64((_fnv1a(name) ^ (seed * 0xD1342543DE82EF95)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        return _splitmix64(_splitmix64(key) ^ idx)
+
+
+def uniform(seed: int, name: str, shape, lo=0.0, hi=1.0) -> np.ndarray:
+    n = int(np.prod(shape))
+    u = (bits(seed, name, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (lo + (hi - lo) * u).reshape(shape)
+
+
+def make_state_dict(spec, seed=0):
+    """spec: list of (name, shape) in reference state_dict naming (model_spec.state_dict_spec).
+    Returns dict name -> float32 ndarray.  Scales mimic a trained net: conv/linear ~ kaiming-uniform-like
+    (std = sqrt(2/fan_in)), GroupNorm gamma in +-[0.5,1.5] (a few negative), beta in [-0.3,0.3]."""
+    sd = {}
+    for name, shape in spec:
+        if name.endswith("_count"):
+            sd[name] = np.array(1000.0, dtype=np.float32)
+        elif name.endswith("_mean"):
+            sd[name] = uniform(seed, name, shape, 0.0, 0.5).astype(np.float32)
+        elif name.endswith("_var"):
+            sd[name] = uniform(seed, name, shape, 0.0, 0.2).astype(np.float32)
+        elif name == "action_embedding.weight":
+            sd[name] = uniform(seed, name, shape, -1.0, 1.0).astype(np.float32)
+        elif len(shape) == 4 or (len(shape) == 2):
+            fan_in = int(np.prod(shape[1:]))
+            a = np.sqrt(3.0) * np.sqrt(2.0 / fan_in)
+            sd[name] = uniform(seed, name, shape, -a, a).astype(np.float32)
+        elif name.endswith(".weight"):  # GroupNorm gamma
+            gmm = uniform(seed, name, shape, 0.5, 1.5)
+            sign = np.where(uniform(seed, name + "#sign", shape) < 0.1, -1.0, 1.0)
+            sd[name] = (gmm * sign).astype(np.float32)
+        elif name.startswith("visual_encoder"):  # GroupNorm beta
+            sd[name] = uniform(seed, name, shape, -0.3, 0.3).astype(np.float32)
+        else:  # linear bias
+            sd[name] = uniform(seed, name, shape, -0.1, 0.1).astype(np.float32)
+    return sd
+
+
+def onehot_depth(depth, bins):
+    """One-hot of floor(depth*bins) clipped to bins-1, float32 {0,1} (same result as the reference's
+    _discretize_depth_func for depth in [0,1]; the exact-edge semantics are tested separately)."""
+    edges = (np.arange(bins, dtype=np.float64) / bins).astype(np.float32)
+    idx = np.clip(np.searchsorted(edges, depth.astype(np.float32), side="right") - 1, 0, bins - 1)
+    out = np.zeros(depth.shape + (bins,), dtype=np.float32)
+    np.put_along_axis(out, idx[..., None], 1.0, axis=-1)
+    return out
+
+
+def make_obs_pairs(B, H, W, *, observation_space, dd_bins=10, seed=0, tdv_sparsity=0.7, start=0):
+    """Synthetic observation pairs in the reference's model-input format (NHWC float32):
+    rgb [B,H,W,6] in 0..255, depth [B,H,W,2] in [0,1], discretized_depth [B,H,W,2*bins], top_down_view
+    [B,H,W,2] (sparse histogram-like values in [0,1]).  `start` offsets the sample index so shards of one
+    global batch can be generated independently (sample i depends only on (seed, start+i))."""
+    obs = {}
+    rgb = np.empty((B, H, W, 6), dtype=np.float32)
+    depth = np.empty((B, H, W, 2), dtype=np.float32)
+    tdv = np.empty((B, H, W, 2), dtype=np.float32)
+    for i in range(B):
+        tag = f"#{start + i}"
+        rgb[i] = (bits(seed, "rgb" + tag, H * W * 6) >> np.uint64(56)).astype(np.float32).reshape(H, W, 6)
+        d = uniform(seed, "depth" + tag, (H, W, 2), 0.05, 0.95)
+        depth[i] = d.astype(np.float16).astype(np.float32)
+        t = uniform(seed, "tdv" + tag, (H, W, 2))
+        m = uniform(seed, "tdvmask" + tag, (H, W, 2))
+        tdv[i] = np.where(m < tdv_sparsity, 0.0, t).astype(np.float32)
+    if "rgb" in observation_space:
+        obs["rgb"] = rgb
+    if "depth" in observation_space:
+        obs["depth"] = depth
+    if "discretized_depth" in observation_space:
+        obs["discretized_depth"] = np.concatenate(
+            [onehot_depth(depth[..., 0], dd_bins), onehot_depth(depth[..., 1], dd_bins)], axis=-1
+        )
+    if "top_down_view" in observation_space:
+        obs["top_down_view"] = tdv
+    return obs
+
+
+def make_raw_obs(H, W, seed=0, index=0, zero_border=0):
+    """One simulator-style observation dict: rgb uint8 [H,W,3], depth float32 [H,W,1] in [0,1]
+    (what _compute_local_delta_states_from_vo receives,
+    /root/reference/pointnav_vo/rl/common/base_trainer_with_vo.py:172-193)."""
+    tag = f"#{index}"
+    rgb = (bits(seed, "raw_rgb" + tag, H * W * 3) >> np.uint64(56)).astype(np.uint8).reshape(H, W, 3)
+    d = uniform(seed, "raw_depth" + tag, (H, W, 1), 0.0, 1.0).astype(np.float16).astype(np.float32)
+    if zero_border:
+        d[:zero_border] = 0
+        d[-zero_border:] = 0
+        d[:, :zero_border] = 0
+        d[:, -2 * zero_border:] = 0
+    return {"rgb": rgb, "depth": d}
