@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py — RGB-D frame-pair VO inferences/s at 341x192 on N x MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the VO hot path — VisualOdometryCNNBase.forward of `vo_cnn_rgb_d_dd_top_down`
+(act_forward model, fp32) — over one batch of 256 synthetic frame pairs whose observation tensors are already
+resident in HBM (BASELINE.json configs[1]).  Data parallel: every rank owns its own 256 pairs (weak scaling), no
+data-path collective (pairs are independent at inference).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pointnav_vo_amd import model_spec as ms  # noqa: E402
+from pointnav_vo_amd import synth  # noqa: E402
+from pointnav_vo_amd.registry import baseline_registry  # noqa: E402
+from pointnav_vo_amd.trainer import NormalizedDepth2TopDownViewHabitatTorch  # noqa: E402
+from pointnav_vo_amd import _lib  # noqa: E402
+import ctypes as C  # noqa: E402
+
+W, H, BINS = 341, 192, 10
+SPACE = ["rgb", "depth", "discretized_depth", "top_down_view"]
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(dev, seed=0):
+    model = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=SPACE, observation_size=(W, H), hidden_size=512, backbone="resnet18",
+        normalize_visual_inputs=True, output_dim=3, dropout_p=0.2, discretized_depth_channels=BINS)
+    sd = synth.make_state_dict(ms.state_dict_spec(model.cfg), seed=seed)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return model.to(dev).eval(), sd
+
+
+def make_inputs(B, dev, rank):
+    """Synthetic pairs generated ON DEVICE: rgb U{0..255}, depth U[0.05,0.95] rounded through fp16,
+    discretized_depth / top_down_view produced from that depth by this build's own pre-processing kernels."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    rgb = torch.randint(0, 256, (B, H, W, 6), device=dev, generator=g, dtype=torch.int32).to(torch.float32)
+    depth = (torch.rand((B, H, W, 2), device=dev, generator=g) * 0.9 + 0.05).to(torch.float16).to(torch.float32)
+    dd = torch.empty((B, H, W, 2 * BINS), device=dev, dtype=torch.float32)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for k in range(2):
+        _lib.check(_lib.lib.pnvo_discretize_depth(C.c_void_p(depth.data_ptr() + 4 * k), B * H * W, 2, BINS,
+                                                  C.c_void_p(dd.data_ptr() + 4 * k * BINS), 2 * BINS, None, stream))
+    gen = NormalizedDepth2TopDownViewHabitatTorch(min_depth=0.1, max_depth=10.0, vis_size_h=H, vis_size_w=W, hfov_rad=70)
+    tdv = torch.empty((B, H, W, 2), device=dev, dtype=torch.float32)
+    for k in range(2):
+        gen.gen_top_down_view_batch(depth[..., k], out=tdv, out_channel=k)
+    return {"rgb": rgb, "depth": depth, "discretized_depth": dd, "top_down_view": tdv}
+
+
+def cpu_baseline(sd, ngroups, budget_s=15.0):
+    """The oracle (CPU port of the reference forward, fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    oracle.set_threads(cores)
+    obs1 = synth.make_obs_pairs(1, H, W, observation_space=SPACE, dd_bins=BINS, seed=99)
+    t0 = time.perf_counter()
+    oracle.forward(sd, obs1, ngroups=ngroups, dtype=np.float32)
+    t1 = time.perf_counter() - t0
+    n = int(max(2, min(32, budget_s / max(t1, 1e-3))))
+    obs = synth.make_obs_pairs(n, H, W, observation_space=SPACE, dd_bins=BINS, seed=100)
+    t0 = time.perf_counter()
+    oracle.forward(sd, obs, ngroups=ngroups, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frame-pairs/s", "cores": oracle.max_threads(), "kind": "port",
+            "sample": f"{n} pairs, one batched fp32 forward of the oracle (OpenMP, {oracle.max_threads()} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step (BASELINE configs[1]: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    model, sd = build_model(dev)
+    B = args.batch
+    obs = make_inputs(B, dev, rank)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        # parity on the first pairs of this rank's batch (fp64 oracle on the same tensors)
+        out = model(obs)
+        torch.cuda.synchronize(dev)
+        rel = None
+        if rank == 0:
+            from oracle import oracle
+            nchk = 2
+            ref = oracle.forward(sd, {k: v[:nchk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups,
+                                 dtype=np.float64)
+            o = out[:nchk].cpu().numpy().astype(np.float64)
+            rel = float((np.linalg.norm(o - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)).max())
+
+        for _ in range(args.warmup):
+            model(obs)
+        model.timing(True)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(obs)
+        sync_all()
+        dt = time.perf_counter() - t0
+        kt = model.timing_read()
+        model.timing(False)
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt
+        flops_pair = 2.0 * ms.macs_per_pair(model.cfg)
+        bytes_pair = float(ms.streaming_bytes_per_pair(model.cfg))
+        dom = max((k for k in kt if k["name"].startswith("conv:")), key=lambda k: k["total_ms"])
+        per_launch_ms = dom["total_ms"] / dom["launches"]
+        ach = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+        total_kernel_ms = sum(k["total_ms"] for k in kt)
+        res = {
+            "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: act_forward VO inference (vo_cnn_rgb_d_dd_top_down, 30 input "
+                                   "channels), 341x192, fp32, seeded random weights", "pairs_per_gpu": B,
+                       "global_batch": world * B, "parallelism": f"dp{world} (independent pairs, no collective)"},
+            "pose_rel_err_vs_fp64_oracle": rel,
+            "model_tflops": value * flops_pair / 1e12,
+            "frac_fp32_peak_whole_path": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
+            "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
+            "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
+                                "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
+                                "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
+                               for k in kt), key=lambda k: -k["ms_per_step"])[:12],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * include/pnvo.h — C ABI of the MI355X-native PointNav-VO visual-odometry hot path (libpnvo.so).
+ *
+ * The reference (Xiaoming-Zhao/PointNav-VO) is 100 % Python and has no FFI; the "plugin API" this path sits
+ * behind is the model registry + nn.Module protocol.  Each entry point below names the
+ * reference interface it replaces (paths relative to /root/reference); INTEGRATION.md shows the ctypes stub
+ * and the registry hook a maintainer would add on the reference side.
+ *
+ * Conventions: plain C types only (no torch / HIP types in signatures; a stream is passed as void* holding a
+ * hipStream_t).  Every function returns 0 (PNVO_OK) or a negative error code and never throws; the message of
+ * the last error on a handle is available from pnvo_last_error().  All tensor arguments of the compute entry
+ * points are DEVICE pointers owned by the caller, NHWC, float32 unless stated; calls are asynchronous on the
+ * given stream and perform no host synchronisation.  A handle is not thread-safe: one handle per
+ * (process, stream), one process per GPU (the reference's own model: launch.py:11-12).
+ */
+#ifndef PNVO_H_
+#define PNVO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNVO_OK 0
+#define PNVO_ERR_ARG (-1)      /* bad argument / unsupported configuration */
+#define PNVO_ERR_HIP (-2)      /* a HIP runtime call failed (message has hipGetErrorString) */
+#define PNVO_ERR_STATE (-3)    /* call order violated (e.g. forward before load_weights) */
+#define PNVO_ERR_WEIGHTS (-4)  /* state_dict table does not match the configured architecture */
+
+typedef struct pnvo_model_s *pnvo_handle;
+
+/*
+ * Architecture of one VO model = the constructor kwargs of the registered reference classes
+ * (pointnav_vo/vo/models/vo_cnn.py:183-198, called at pointnav_vo/rl/common/base_trainer_with_vo.py:68-80).
+ * n_* are PAIR channel counts: 6 / 2 / 2*discretized_depth_channels / 2, or 0 when the modality is not in
+ * observation_space.  ngroups is baseplanes/2 (vo_cnn.py:206); backbone is resnet18 (resnet.py:226-229).
+ */
+typedef struct {
+  int32_t width, height;      /* observation_size = (W, H) */
+  int32_t n_rgb, n_depth, n_dd, n_tdv;
+  int32_t baseplanes;         /* resnet_baseplanes (32; 64 for the *_wider variants, vo_cnn.py:325) */
+  int32_t hidden;             /* hidden_size */
+  int32_t out_dim;            /* output_dim (3: dx, dz, dyaw) */
+  int32_t normalize;          /* normalize_visual_inputs -> RunningMeanAndVar present */
+  int32_t act_embed;          /* 1 for vo_cnn_act_embed variants (vo_cnn_act_embed.py:17-75) */
+  int32_t n_acts;             /* embedding rows - 1 (N_ACTS = 4) */
+  int32_t flat_size;          /* after_compression_flat_size (2048) */
+  int32_t max_batch;          /* workspace sizing hint; the workspace grows on demand */
+} pnvo_config;
+
+/* One entry of the reference state_dict: name exactly as model.state_dict() spells it,
+ * row-major data at blob[offset .. offset+prod(shape)), reference layout (OIHW convs, [N][K] linears). */
+typedef struct {
+  const char *name;
+  uint64_t offset;            /* in floats */
+  int32_t ndim;
+  int64_t shape[4];
+} pnvo_tensor_desc;
+
+/* Replaces: vo_model_cls(**kwargs).to(device)  (base_trainer_with_vo.py:68-81). */
+int pnvo_create(const pnvo_config *cfg, int device, pnvo_handle *out);
+
+/* Replaces: model.load_state_dict(ckpt["model_state"])  (base_trainer_with_vo.py:92-99).
+ * blob is HOST memory (copied and re-laid out for the kernels; the caller keeps ownership).  Every tensor the
+ * architecture needs must be present with the reference's shape, else PNVO_ERR_WEIGHTS. */
+int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const pnvo_tensor_desc *toc, int ntoc);
+
+/*
+ * Replaces: model.eval(); model(obs_pairs[, actions])  (base_trainer_with_vo.py:286-291;
+ * VisualOdometryCNNBase.forward vo_cnn.py:229-233; ResNetEncoder.forward :110-179).
+ *   rgb   [B,H,W,n_rgb]   values 0..255        (obs_pairs["rgb"])
+ *   depth [B,H,W,n_depth] values 0..1          (obs_pairs["depth"])
+ *   dd    [B,H,W,n_dd]    one-hot {0,1}        (obs_pairs["discretized_depth"])
+ *   tdv   [B,H,W,n_tdv]   values 0..1          (obs_pairs["top_down_view"])
+ *   actions [B] int64 (act_embed variants only, else NULL)
+ *   out   [B,out_dim]
+ * Pointers of absent modalities must be NULL.  Dropout is identity (eval); "rnd" mode is not provided.
+ */
+int pnvo_forward(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                 const int64_t *actions, int B, float *out, void *stream);
+
+/* Replaces: BaseRLTrainerWithVO._discretize_depth_func (base_trainer_with_vo.py:135-167), batched and strided so
+ * that it writes straight into obs_pairs["discretized_depth"]:
+ *   for p in [0,n): d = depth[p*in_stride];  onehot[p*out_stride + i] = (e_i <= d < e_{i+1}) for i in [0,bins)
+ * (last bin closed; e_i = float32(i/bins), :105-115).  err_flag (device int32, may be NULL) is set to 1 if any
+ * value is outside [0,1] (the reference asserts, :136-137). */
+int pnvo_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
+                          int64_t out_stride, int32_t *err_flag, void *stream);
+
+/*
+ * Replaces: NormalizedDepth2TopDownViewHabitatTorch.gen_top_down_view (pointnav_vo/utils/geometry_utils.py:
+ * 516-556), batched over N frames with no host round trip (the reference syncs 4..1066 times per frame and
+ * round-trips through cv2 on the host, :529-536,582-606).
+ *   frame f, pixel p=(h*W+w): depth[f*in_fstride + p*in_pstride]  ->  out[f*out_fstride + p*out_pstride]
+ *   consts[7] (HOST): kinv00, kinv02, min_x, x_den, depth_scale, z_den, min_depth — computed by the caller exactly
+ *   as the reference does (torch.inverse(K), _get_x_range; see pointnav-vo_amd/trainer.py).
+ *   work: device scratch of pnvo_topdown_workspace_bytes(N,H,W) bytes.
+ */
+size_t pnvo_topdown_workspace_bytes(int N, int H, int W);
+int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                      const float *consts, int rows_around_center, float *out, int64_t out_fstride,
+                      int64_t out_pstride, void *work, void *stream);
+
+/* Free everything owned by the handle. */
+int pnvo_destroy(pnvo_handle h);
+
+/* Message of the last failing call on this handle (or of the last failing handle-less call if h is NULL). */
+const char *pnvo_last_error(pnvo_handle h);
+
+/* ---- introspection used by tests and bench.py (not part of the drop-in surface) ---- */
+
+/* Copy an intermediate activation of the NEXT pnvo_forward into dst (device, capacity in floats).  Names:
+ * "input", "stem_conv", "maxpool", "layer{1..4}.{0,1}", "compression", "hidden".  Channel-padded NHWC; the
+ * actual shape is returned by pnvo_tap_shape.  Pass name=NULL to clear. */
+int pnvo_set_tap(pnvo_handle h, const char *name, float *dst, size_t capacity);
+int pnvo_tap_shape(pnvo_handle h, const char *name, int B, int64_t shape[4]);
+
+/* Per-kernel timing with HIP events recorded on the launch stream.  mode 0 = off, 1 = on.
+ * pnvo_timing_read synchronises the events, fills up to cap entries and resets the accumulators. */
+typedef struct {
+  char name[96];
+  int64_t launches;
+  double total_ms;
+  double flops;               /* algorithmic FLOPs of those launches (2*MACs), 0 for non-GEMM kernels */
+  double bytes;               /* algorithmic bytes of those launches (tensor reads + writes, once each) */
+} pnvo_kernel_time;
+int pnvo_timing_mode(pnvo_handle h, int mode);
+int pnvo_timing_read(pnvo_handle h, pnvo_kernel_time *entries, int cap, int *n_out);
+
+/* Host-only helper (no GPU needed): pack an OIHW conv weight into the kernel's MFMA operand order.
+ * out must hold pnvo_packed_conv_floats(cout, cin, kh, kw) floats. */
+size_t pnvo_packed_conv_floats(int cout, int cin, int kh, int kw);
+int pnvo_pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, float *out);
+
+const char *pnvo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNVO_H_ */

@@ -1,0 +1,355 @@
+// conv_mfma.hip — implicit-GEMM convolution / linear layer on the CDNA4 fp32 matrix cores (gfx950 only).
+//
+// Computes every conv of the reference backbone (resnet.py:11-26,156-163; vo_cnn.py:85-92) and both Linear
+// layers (vo_cnn.py:219,225) as   D[M = B*Ho*Wo pixels][N = Cout] = A[M][K = KH*KW*Cin] * W[K][N]
+// with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD = the fp32 peak of the chip).
+//
+// Design (MI355X-first, not a tiling of a warp-shaped kernel):
+//  * one wave owns MT x 32 output pixels x NT x 32 output channels; its A rows are PRIVATE to it, so the A operand
+//    never goes through LDS: lane (i = lane&31, h = lane>>5) loads 16 B = 4 consecutive input channels
+//    [8j+4h, 8j+4h+4) of its own pixel straight from HBM/L2 (NHWC => the 4 j-steps of a tap consume exactly the
+//    128-B line of a 32-channel pixel).  The MFMA k index is the lane half h, so K is walked in the order
+//    (tap, j, t, h) and the weights are pre-packed in that order (pack_conv_weight) => one 1-KiB fully coalesced
+//    float4 load per wave per (tap, j, n-tile);
+//  * GroupNorm(+ReLU) of the PRODUCER layer is applied on the fly to A (x*scale[n,c]+shift[n,c], max 0) with the
+//    per-(sample,channel) tables staged in LDS — GroupNorm statistics are per sample at inference, so they cannot
+//    be folded into weights;
+//  * the epilogue writes the raw conv output and deterministic per-wave partial (sum, sumsq) per (sample, channel)
+//    for THIS layer's GroupNorm — no atomics, fixed summation order => bit-reproducible across runs and GPUs;
+//  * no barriers in the K loop: waves are independent, 2-3 waves/SIMD hide the load latency under the 64-cycle MFMAs.
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define PNVO_OOB 0x80000000u   // byte offset >= num_records of every descriptor => buffer load returns 0, store dropped
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ unsigned clamp_records(long bytes) {
+  return (unsigned)(bytes > 0x7FFFF000L ? 0x7FFFF000L : (bytes < 0 ? 0 : bytes));
+}
+
+template <int MT, int NT, bool XF>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WM = MT * 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long P = (long)p.Ho * p.Wo;
+  const long M = (long)p.B * P;
+  const long wg_m0 = (long)blockIdx.x * (4 * WM);
+  const long m_base = wg_m0 + (long)wave * WM;
+  const int CIN = p.CIN;
+  const int J = CIN >> 3;
+  const long HWC = (long)p.H * p.W * CIN;
+
+  // ---- stage the input-transform tables of the samples this workgroup touches into LDS
+  int n_lo = 0, tab = 0;
+  bool use_lds = false;
+  if (XF) {
+    long last = wg_m0 + 4 * WM - 1;
+    if (last > M - 1) last = M - 1;
+    n_lo = (int)(wg_m0 / P);
+    const int cnt = (int)(last / P) - n_lo + 1;
+    tab = cnt * CIN;
+    use_lds = (2 * tab <= p.lds_floats);
+    if (use_lds) {
+      const float *gs = p.in_scale + (long)n_lo * CIN, *gt = p.in_shift + (long)n_lo * CIN;
+      for (int k = threadIdx.x; k < tab; k += 256) {
+        lds[k] = gs[k];
+        lds[tab + k] = gt[k];
+      }
+    }
+    __syncthreads();
+  }
+  if (m_base >= M) return;
+
+  // ---- descriptors: A rows relative to the first sample of this wave, packed weights of this n-tile group
+  const int n0 = (int)(m_base / P);                      // wave-uniform
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.x + (long)n0 * HWC), 0, clamp_records(((long)p.B - n0) * HWC * 4), 0x00020000);
+  const int T = p.KH * p.KW;
+  const int S = T * J;                                   // pipeline stages: (tap, j)
+  const int ntg0 = blockIdx.y * NT;
+  const long w_nt_bytes = (long)S * 1024;                // one n-tile of packed weights
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.wpk + (long)ntg0 * S * 256), 0, clamp_records((long)NT * w_nt_bytes), 0x00020000);
+
+  // ---- per-lane pixel coordinates of the MT pixel tiles
+  int hi0[MT], wi0[MT], nrel[MT];
+  unsigned pbase[MT];
+  bool vm[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long m = m_base + mt * 32 + i;
+    vm[mt] = m < M;
+    if (!vm[mt]) m = M - 1;
+    const int n = (int)(m / P);
+    const int rem = (int)(m - (long)n * P);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    nrel[mt] = n - n0;
+    hi0[mt] = ho * p.stride - p.pad;
+    wi0[mt] = wo * p.stride - p.pad;
+    pbase[mt] = (unsigned)(((long)(n - n0) * HWC + 4 * h) * 4);
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // ---- loader state: the (kh, kw, j) of the next stage to fetch and the byte offsets of its tap
+  int l_kh = 0, l_kw = 0, l_j = 0, l_s = 0;
+  unsigned toff[MT];
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int hi = hi0[mt] + l_kh, wi = wi0[mt] + l_kw;
+      const bool ok = vm[mt] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      toff[mt] = ok ? pbase[mt] + (unsigned)((hi * p.W + wi) * CIN) * 4u : PNVO_OOB;
+    }
+  };
+  set_tap();
+  const unsigned wlane = (unsigned)lane * 16u;
+
+  // fetch stage l_s into (a, b, okm, jc) and advance the loader state
+  auto fetch = [&](f32x4 (&a)[MT], f32x4 (&b)[NT], unsigned &okm, int &jc) {
+    okm = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      a[mt] = buf_load4(rx, toff[mt], (unsigned)l_j * 32u);
+      okm |= (toff[mt] != PNVO_OOB ? 1u : 0u) << mt;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = buf_load4(rw, wlane + (unsigned)(nt * w_nt_bytes), (unsigned)l_s * 1024u);
+    jc = l_j;
+    ++l_s;
+    if (++l_j == J) {
+      l_j = 0;
+      if (++l_kw == p.KW) {
+        l_kw = 0;
+        ++l_kh;
+      }
+      set_tap();
+    }
+  };
+
+  // consume one fetched stage: optional producer GroupNorm+ReLU on A, then 4 k-steps of MFMA
+  auto compute = [&](f32x4 (&a)[MT], f32x4 (&b)[NT], unsigned okm, int jc) {
+    if (XF) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 sc, sh;
+        const int c = 8 * jc + 4 * h;
+        if (use_lds) {
+          const int k = (n0 + nrel[mt] - n_lo) * CIN + c;
+          sc = *reinterpret_cast<const f32x4 *>(lds + k);
+          sh = *reinterpret_cast<const f32x4 *>(lds + tab + k);
+        } else {
+          sc = *reinterpret_cast<const f32x4 *>(p.in_scale + (long)(n0 + nrel[mt]) * CIN + c);
+          sh = *reinterpret_cast<const f32x4 *>(p.in_shift + (long)(n0 + nrel[mt]) * CIN + c);
+        }
+        const bool ok = (okm >> mt) & 1u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float v = fmaxf(__builtin_fmaf(a[mt][t], sc[t], sh[t]), 0.f);
+          a[mt][t] = ok ? v : 0.f;   // zero padding is applied AFTER the producer's GN+ReLU
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
+  };
+
+  // ---- main loop, register double-buffered: stage s+1 is in flight while stage s feeds the matrix cores
+  {
+    f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+    unsigned ok0 = 0, ok1 = 0;
+    int j0 = 0, j1 = 0;
+    fetch(a0, b0, ok0, j0);
+    int s = 0;
+    for (; s + 2 <= S - 1; s += 2) {     // invariant: stage s is in buffer 0, stages s+1, s+2 exist
+      fetch(a1, b1, ok1, j1);
+      compute(a0, b0, ok0, j0);
+      fetch(a0, b0, ok0, j0);
+      compute(a1, b1, ok1, j1);
+    }
+    if (s + 1 <= S - 1) {                // two stages left: s (buffer 0) and s+1
+      fetch(a1, b1, ok1, j1);
+      compute(a0, b0, ok0, j0);
+      compute(a1, b1, ok1, j1);
+    } else {                             // one stage left
+      compute(a0, b0, ok0, j0);
+    }
+  }
+
+  // ---- epilogue 1: store.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  {
+    long rows = M - m_base;
+    if (rows > WM) rows = WM;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.y + m_base * p.y_cstride), 0, clamp_records(rows * p.y_cstride * 4), 0x00020000);
+    const unsigned rstride = (unsigned)p.y_cstride * 4u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = (ntg0 + nt) * 32 + i;
+      const bool cvalid = co < p.y_cstride;   // y_cstride is COUT (exact) or COUTP (padded: zeros are stored)
+      float bv[MT][4];
+      if (p.bias != nullptr) {                // linear layers: bias may depend on the sample (act-embed variants)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) bv[mt][rr] = 0.f;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned vbase = cvalid ? (unsigned)(mt * 32 + 4 * h) * rstride + (unsigned)co * 4u : PNVO_OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          float v = acc[mt][nt][r];
+          if (p.bias != nullptr) {
+            const long m = m_base + mt * 32 + row + 4 * h;
+            const long brow = (p.bias_row != nullptr && m < M) ? p.bias_row[m / P] : 0;
+            v += (co < p.COUT) ? p.bias[brow * p.COUT + co] : 0.f;
+          }
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry,
+                                                cvalid ? vbase + (unsigned)row * rstride : PNVO_OOB, 0, 0);
+        }
+      }
+      (void)bv;
+    }
+  }
+
+  // ---- epilogue 2: per-(sample, channel) partial sums for this layer's GroupNorm
+  if (p.stats != nullptr) {
+    long last = m_base + WM - 1;
+    if (last > M - 1) last = M - 1;
+    const int n_first = n0, n_last = (int)(last / P);
+    const long wt_idx = m_base / WM;
+    for (int n = n_first; n <= n_last; ++n) {
+      const long lo = (long)n * P, hi = lo + P;
+      const int slot = (int)(wt_idx - lo / WM);
+      const int rlo = (int)(lo - m_base), rhi = (int)((hi < M ? hi : M) - m_base);   // valid local rows [rlo, rhi)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = (row >= rlo && row < rhi) ? acc[mt][nt][r] : 0.f;
+            s += v;
+            q = __builtin_fmaf(v, v, q);
+          }
+        }
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (h == 0) {
+          const int co = (ntg0 + nt) * 32 + i;
+          float *dst = p.stats + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
+      }
+    }
+  }
+}
+
+int conv_slots(int P, int MT) {
+  const int WM = MT * 32;
+  return (P + WM - 1) / WM + 1;
+}
+
+void choose_tile(long M, int COUTP, int *MT, int *NT) {
+  const int ntg = COUTP / 32;
+  int nt = ntg >= 4 ? 4 : ntg;      // ntg is 1, 2, or a multiple of 4 for every layer of the supported nets
+  while (ntg % nt) --nt;
+  int mt = 4 / nt;
+  if (mt < 1) mt = 1;
+  auto waves = [&](int mt_, int nt_) { return ((M + mt_ * 32 - 1) / (mt_ * 32)) * (ntg / nt_); };
+  const long want = 256 * 8;        // >= 2 waves per SIMD over the whole chip
+  while (mt > 1 && waves(mt, nt) < want) mt >>= 1;
+  while (nt > 1 && waves(mt, nt) < want) nt >>= 1;
+  *MT = mt;
+  *NT = nt;
+}
+
+template <int MT, int NT>
+static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
+  const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
+  const int WM = MT * 32;
+  dim3 grid((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)(a.COUTP / 32 / NT));
+  ConvArgs p = a;
+  size_t lds_bytes = 0;
+  if (a.in_scale != nullptr) {
+    const long cnt_max = (4L * WM + P - 2) / P + 1;
+    const long need = cnt_max * a.CIN * 2;
+    if (need * 4 <= 48 * 1024) {
+      p.lds_floats = (int)need;
+      lds_bytes = (size_t)need * 4;
+    } else {
+      p.lds_floats = 0;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, true>), grid, dim3(256), lds_bytes, s, p);
+  } else {
+    p.lds_floats = 0;
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, false>), grid, dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvArgs &a, hipStream_t s) {
+  if (a.CIN % 8 != 0 || a.COUTP % 32 != 0 || (a.COUTP / 32) % a.NT != 0) return hipErrorInvalidValue;
+  switch (a.MT * 10 + a.NT) {
+    case 41: return launch_t<4, 1>(a, s);
+    case 21: return launch_t<2, 1>(a, s);
+    case 11: return launch_t<1, 1>(a, s);
+    case 22: return launch_t<2, 2>(a, s);
+    case 12: return launch_t<1, 2>(a, s);
+    case 14: return launch_t<1, 4>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Packed layout consumed by the kernel: float4 index ((ntg*T + tap)*J + j)*64 + lane, lane = h*32 + n,
+// component t  <->  W[cout = ntg*32 + n][cin = 8j + 4h + t][kh][kw]   (zero outside the real Cout/Cin).
+size_t packed_conv_floats(int cout, int cin, int kh, int kw) {
+  const size_t coutp = (size_t)(cout + 31) / 32 * 32, cinp = (size_t)(cin + 7) / 8 * 8;
+  return coutp * cinp * kh * kw;
+}
+
+void pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, float *out) {
+  const int ntg_n = (cout + 31) / 32, J = (cin + 7) / 8, T = kh * kw;
+  for (int ntg = 0; ntg < ntg_n; ++ntg)
+    for (int tap = 0; tap < T; ++tap)
+      for (int j = 0; j < J; ++j)
+        for (int h = 0; h < 2; ++h)
+          for (int n = 0; n < 32; ++n)
+            for (int t = 0; t < 4; ++t) {
+              const int co = ntg * 32 + n, ci = 8 * j + 4 * h + t;
+              float v = 0.f;
+              if (co < cout && ci < cin) v = oihw[((size_t)co * cin + ci) * T + tap];
+              out[((((size_t)ntg * T + tap) * J + j) * 64 + h * 32 + n) * 4 + t] = v;
+            }
+}
+
+}  // namespace pnvo

@@ -1,0 +1,396 @@
+// elementwise.hip — HBM-bound kernels of the VO hot path (gfx950): input assembly + whitening, GroupNorm statistics
+// finalisation, fused GN+ReLU+maxpool, residual tail, one-hot depth and the ego top-down view.
+// All are pure streaming kernels: 16-byte accesses per lane, consecutive lanes on consecutive addresses.
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input assembly + RunningMeanAndVar (vo_cnn.py:110-176, running_mean_and_var.py:62-63):
+//   out[pix][c] = (src_c(pix) [/255 for rgb] - mean[c]) / stdev[c],   channel order
+//   [prev_rgb, prev_d, prev_dd, prev_tdv, cur_rgb, cur_d, cur_dd, cur_tdv], zero-filled up to CP (multiple of 8).
+struct AssembleDev {
+  const float *src[4];
+  int nsrc[4];
+  long npix;
+  float *out;
+  int C, CP, normalize;
+  signed char sid[64];   // source tensor of output channel c (-1: pad)
+  unsigned char sch[64]; // channel inside that tensor
+  float mean[64], stdev[64];
+};
+
+__global__ __launch_bounds__(256) void assemble_kernel(const AssembleDev a) {
+  const int Q = a.CP >> 2;
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.npix * Q) return;
+  const int q = (int)(g % Q);
+  const long pix = g / Q;
+  f32x4 o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = 4 * q + t;
+    const int s = a.sid[c];
+    float v = 0.f;
+    if (s >= 0) {
+      v = a.src[s][pix * a.nsrc[s] + a.sch[c]];
+      if (s == 0) v = __fdiv_rn(v, 255.0f);
+      if (a.normalize) v = __fdiv_rn(__fsub_rn(v, a.mean[c]), a.stdev[c]);
+    }
+    o[t] = v;
+  }
+  reinterpret_cast<f32x4 *>(a.out)[g] = o;
+}
+
+hipError_t launch_assemble(const AssembleArgs &h, hipStream_t s) {
+  if (h.CP > 64 || h.CP % 4) return hipErrorInvalidValue;
+  AssembleDev d;
+  for (int k = 0; k < 4; ++k) {
+    d.src[k] = h.src[k];
+    d.nsrc[k] = h.nsrc[k];
+  }
+  d.npix = h.npix;
+  d.out = h.out;
+  d.C = h.C;
+  d.CP = h.CP;
+  d.normalize = h.mean != nullptr;
+  int c = 0;
+  for (int half = 0; half < 2; ++half)
+    for (int k = 0; k < 4; ++k) {
+      const int n = h.nsrc[k] / 2;
+      for (int j = 0; j < n; ++j, ++c) {
+        d.sid[c] = (signed char)k;
+        d.sch[c] = (unsigned char)(half * n + j);
+      }
+    }
+  for (; c < 64; ++c) {
+    d.sid[c] = -1;
+    d.sch[c] = 0;
+  }
+  for (int k = 0; k < 64; ++k) {
+    d.mean[k] = (h.mean && k < h.C) ? h.mean[k] : 0.f;
+    d.stdev[k] = (h.mean && k < h.C) ? h.stdev[k] : 1.f;
+  }
+  const long total = h.npix * (h.CP / 4);
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm finalisation: per-(sample, group) mean / biased variance from the conv epilogue's per-wave partial
+// (sum, sumsq), reduced in a FIXED order in fp64, folded with the affine parameters into
+//   scale[n][c] = rstd * gamma[c],  shift[n][c] = beta[c] - mean * scale[n][c]
+// (torch.nn.GroupNorm, eps inside the sqrt; used at resnet.py:39,42,165,194 and vo_cnn.py:93).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int slots, int CP, int C, int G, long P,
+                                                        int WM, const float *gamma, const float *beta, float eps,
+                                                        float *scale, float *shift) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const long t0 = ((long)n * P) / WM, t1 = ((long)(n + 1) * P - 1) / WM;
+  const int ns = (int)(t1 - t0 + 1);
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < ns * cpg; k += 64) {
+    const int slot = k / cpg, c = g * cpg + k % cpg;
+    const float *src = stats + (((long)n * slots + slot) * CP + c) * 2;
+    s1 += (double)src[0];
+    s2 += (double)src[1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  const double cnt = (double)P * cpg;
+  const double mu = s1 / cnt;
+  double var = s2 / cnt - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int k = threadIdx.x; k < cpg; k += 64) {
+    const int c = g * cpg + k;
+    const double sc = rstd * (double)gamma[c];
+    scale[(long)n * CP + c] = (float)sc;
+    shift[(long)n * CP + c] = (float)((double)beta[c] - mu * sc);
+  }
+}
+
+hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
+                              const float *gamma, const float *beta, float eps, float *scale, float *shift,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, stats, slots, CP, C, G, P, WM, gamma,
+                     beta, eps, scale, shift);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stem tail: GroupNorm+ReLU (as scale/shift) fused into MaxPool2d(3, stride 2, padding 1) (resnet.py:165-168).
+// The affine transform is applied BEFORE the max (gamma may be negative).
+__global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float *x, const float *scale, const float *shift,
+                                                            int B, int H, int W, int C, int Ho, int Wo, float *out) {
+  const int Q = C >> 2;
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * Ho * Wo * Q;
+  if (g >= total) return;
+  const int q = (int)(g % Q);
+  long r = g / Q;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + 4 * q);
+  const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + 4 * q);
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};   // every window holds >= 1 real pixel and relu(.) >= 0, so 0 == -inf padding
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = 2 * ho - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = 2 * wo - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + hi) * W + wi) * C + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m[t] = fmaxf(m[t], __builtin_fmaf(v[t], sc[t], sh[t]));
+    }
+  }
+  reinterpret_cast<f32x4 *>(out)[g] = m;
+}
+
+hipError_t launch_gn_relu_maxpool(const float *x, const float *scale, const float *shift, int B, int H, int W, int C,
+                                  float *out, hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(gn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, B,
+                     H, W, C, Ho, Wo, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BasicBlock tail (resnet.py:47-55): y = relu(GN2(conv2) + residual), residual = x or GN_d(conv1x1(x)).
+__global__ __launch_bounds__(256) void residual_kernel(const float *a, const float *sa, const float *ta, const float *b,
+                                                     const float *sb, const float *tb, long PC, int C, long total4,
+                                                     float *y) {
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total4) return;
+  const long e = g * 4;
+  const int n = (int)(e / PC);
+  const int c = (int)(e % C);
+  const f32x4 va = reinterpret_cast<const f32x4 *>(a)[g];
+  const f32x4 vb = reinterpret_cast<const f32x4 *>(b)[g];
+  const f32x4 s1 = *reinterpret_cast<const f32x4 *>(sa + (long)n * C + c);
+  const f32x4 t1 = *reinterpret_cast<const f32x4 *>(ta + (long)n * C + c);
+  f32x4 r = vb;
+  if (sb != nullptr) {
+    const f32x4 s2 = *reinterpret_cast<const f32x4 *>(sb + (long)n * C + c);
+    const f32x4 t2 = *reinterpret_cast<const f32x4 *>(tb + (long)n * C + c);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r[t] = __builtin_fmaf(vb[t], s2[t], t2[t]);
+  }
+  f32x4 o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = fmaxf(__builtin_fmaf(va[t], s1[t], t1[t]) + r[t], 0.f);
+  reinterpret_cast<f32x4 *>(y)[g] = o;
+}
+
+hipError_t launch_residual(const float *a, const float *sa, const float *ta, const float *b, const float *sb,
+                           const float *tb, int B, long P, int C, float *y, hipStream_t s) {
+  const long total4 = (long)B * P * C / 4;
+  hipLaunchKernelGGL(residual_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a, sa, ta, b, sb, tb,
+                     P * C, C, total4, y);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void apply_ss_relu_kernel(const float *x, const float *sc, const float *sh, long PC,
+                                                          int C, long total4, float *y) {
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total4) return;
+  const long e = g * 4;
+  const int n = (int)(e / PC);
+  const int c = (int)(e % C);
+  const f32x4 v = reinterpret_cast<const f32x4 *>(x)[g];
+  const f32x4 s1 = *reinterpret_cast<const f32x4 *>(sc + (long)n * C + c);
+  const f32x4 t1 = *reinterpret_cast<const f32x4 *>(sh + (long)n * C + c);
+  f32x4 o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = fmaxf(__builtin_fmaf(v[t], s1[t], t1[t]), 0.f);
+  reinterpret_cast<f32x4 *>(y)[g] = o;
+}
+
+hipError_t launch_apply_ss_relu(const float *x, const float *sc, const float *sh, int B, long P, int C, float *y,
+                                hipStream_t st) {
+  const long total4 = (long)B * P * C / 4;
+  hipLaunchKernelGGL(apply_ss_relu_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, x, sc, sh, P * C, C,
+                     total4, y);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One-hot depth (base_trainer_with_vo.py:105-115,135-167): bin i fires iff e_i <= d < e_{i+1} (last bin closed),
+// edges e_i = float32(i / bins) (python-float edge rounded to the tensor dtype by torch's scalar promotion).
+struct DepthEdges {
+  float e[65];
+};
+
+__global__ __launch_bounds__(256) void discretize_depth_kernel(const float *depth, long n, long in_stride, int bins,
+                                                             float *onehot, long out_stride, int *err_flag,
+                                                             const DepthEdges ed) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float v = depth[p * in_stride];
+  if (!(v >= 0.f && v <= 1.f) && err_flag != nullptr) *err_flag = 1;
+  float *o = onehot + p * out_stride;
+  for (int i = 0; i < bins; ++i) {
+    const float lo = ed.e[i], hi = ed.e[i + 1];
+    const bool hit = (i == bins - 1) ? (v >= lo && v <= hi) : (v >= lo && v < hi);
+    o[i] = hit ? 1.0f : 0.0f;
+  }
+}
+
+hipError_t launch_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
+                                   int64_t out_stride, int32_t *err_flag, hipStream_t s) {
+  if (bins < 1 || bins > 64) return hipErrorInvalidValue;
+  DepthEdges ed;
+  for (int i = 0; i < bins; ++i) ed.e[i] = (float)((double)i * 1.0 / (double)bins);   // :105-115, rounded to fp32
+  ed.e[bins] = 1.0f;
+  hipLaunchKernelGGL(discretize_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, depth, (long)n,
+                     (long)in_stride, bins, onehot, (long)out_stride, err_flag, ed);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ego top-down view (geometry_utils.py:516-721), batched over frames, no host round trip.
+// Every float32 operation of the reference is reproduced with one rounding each (__f*_rn: no FMA contraction),
+// because floor()/ceil() of the results select integer histogram bins.
+struct TopdownWork {       // per frame, in the caller-provided scratch
+  int bbox[4];             // min_row, max_row, min_col, max_col of the non-zero crop (:582-606)
+  int maxcnt;
+  int pad[3];
+};
+
+size_t topdown_workspace_bytes(int N, int H, int W) {
+  return (size_t)N * (sizeof(TopdownWork) + sizeof(int) * (size_t)H * W);
+}
+
+__global__ __launch_bounds__(256) void topdown_bbox_kernel(const float *depth, long fstride, long pstride, int H, int W,
+                                                         TopdownWork *work) {
+  __shared__ int sb[4];
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) {
+    sb[0] = H;
+    sb[1] = -1;
+    sb[2] = W;
+    sb[3] = -1;
+  }
+  __syncthreads();
+  int r0 = H, r1 = -1, c0 = W, c1 = -1;
+  const float *d = depth + (long)n * fstride;
+  for (int p = threadIdx.x; p < H * W; p += 256) {
+    if (d[(long)p * pstride] > 0.f) {   // depth >= 0, so "row/col sum > 0" == "any element > 0"
+      const int r = p / W, c = p - r * W;
+      r0 = min(r0, r);
+      r1 = max(r1, r);
+      c0 = min(c0, c);
+      c1 = max(c1, c);
+    }
+  }
+  atomicMin(&sb[0], r0);
+  atomicMax(&sb[1], r1);
+  atomicMin(&sb[2], c0);
+  atomicMax(&sb[3], c1);
+  __syncthreads();
+  if (threadIdx.x < 4) work[n].bbox[threadIdx.x] = sb[threadIdx.x];
+  if (threadIdx.x == 4) work[n].maxcnt = 0;
+}
+
+__device__ __forceinline__ float blur_row(const float *d, long pstride, int W, int r, int c, int c0, int c1) {
+  // row pass of the separable {1/4,1/2,1/4} blur on the crop [.., c0..c1], zero outside the crop
+  const float m = d[((long)r * W + c) * pstride];
+  const float l = c > c0 ? d[((long)r * W + c - 1) * pstride] : 0.f;
+  const float rr = c < c1 ? d[((long)r * W + c + 1) * pstride] : 0.f;
+  return __fadd_rn(__fmul_rn(m, 0.5f), __fmul_rn(__fadd_rn(l, rr), 0.25f));
+}
+
+struct TopdownConsts {
+  float c[8];
+};
+
+__global__ __launch_bounds__(256) void topdown_project_kernel(const float *depth, long fstride, long pstride, int H,
+                                                            int W, const TopdownConsts tc, int rows_around_center,
+                                                            TopdownWork *work, int *cnt) {
+  const int n = blockIdx.y;
+  const int r0 = work[n].bbox[0], r1 = work[n].bbox[1], c0 = work[n].bbox[2], c1 = work[n].bbox[3];
+  if (r1 < r0 || c1 < c0) return;              // all-zero frame (:522-525)
+  const int hc = r1 - r0 + 1, wc = c1 - c0 + 1;
+  const int half = (hc + 1) / 2;               // int(np.ceil(hc / 2)) (:609-617)
+  int b0 = half - rows_around_center;
+  if (b0 < 0) b0 = 0;
+  int b1 = half + rows_around_center;
+  if (b1 > hc) b1 = hc;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (b1 - b0) * wc) return;
+  const int j = b0 + t / wc, i = t % wc;       // crop coordinates
+  const int r = r0 + j, c = c0 + i;            // image coordinates
+  const float *d = depth + (long)n * fstride;
+  // column pass over the three row-pass values (zero border outside the crop rows)
+  const float m = blur_row(d, pstride, W, r, c, c0, c1);
+  const float u = r > r0 ? blur_row(d, pstride, W, r - 1, c, c0, c1) : 0.f;
+  const float dn = r < r1 ? blur_row(d, pstride, W, r + 1, c, c0, c1) : 0.f;
+  const float db = __fadd_rn(__fmul_rn(m, 0.5f), __fmul_rn(__fadd_rn(u, dn), 0.25f));
+  const float kinv00 = tc.c[0], kinv02 = tc.c[1], min_x = tc.c[2], x_den = tc.c[3], dscale = tc.c[4],
+              z_den = tc.c[5], min_depth = tc.c[6];
+  const float uu = __fadd_rn(__fadd_rn((float)i, (float)c0), 0.5f);        // :626-638
+  const float xc = __fadd_rn(__fmul_rn(kinv00, uu), kinv02);               // :648-650 (row 0 of Kinv @ [u,v,1])
+  const float z = __fadd_rn(__fmul_rn(db, dscale), min_depth);            // :558-560
+  const float X = __fmul_rn(xc, z);                                        // :655
+  const float xn = __fdiv_rn(__fsub_rn(X, min_x), x_den);                  // :676-678
+  const float zn = __fdiv_rn(__fsub_rn(z, min_depth), z_den);              // :679-681
+  const float rf = __fsub_rn((float)H, ceilf(__fmul_rn((float)H, zn)));    // :686-688
+  const float cf = floorf(__fmul_rn((float)W, xn));                        // :689
+  const long row = (long)rf, col = (long)cf;                               // .long() (:692)
+  if (row >= 0 && row < H && col >= 0 && col < W) atomicAdd(&cnt[((long)n * H + row) * W + col], 1);
+}
+
+__global__ __launch_bounds__(256) void topdown_normalize_kernel(int H, int W, TopdownWork *work, const int *cnt,
+                                                              float *out, long ofstride, long opstride) {
+  __shared__ int smax;
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
+  const int *c = cnt + (long)n * H * W;
+  int m = 0;
+  for (int p = threadIdx.x; p < H * W; p += 256) m = max(m, c[p]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(&smax, m);
+  __syncthreads();
+  const int mx = smax;
+  float *o = out + (long)n * ofstride;
+  for (int p = threadIdx.x; p < H * W; p += 256) {
+    float v = 0.f;
+    if (mx > 0) v = fminf(__fdiv_rn((float)c[p], (float)mx), 1.0f);   // :543-554
+    o[(long)p * opstride] = v;
+  }
+}
+
+hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                          const float *consts, int rows_around_center, float *out, int64_t out_fstride,
+                          int64_t out_pstride, void *work, hipStream_t s) {
+  TopdownWork *tw = reinterpret_cast<TopdownWork *>(work);
+  int *cnt = reinterpret_cast<int *>(tw + N);
+  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N * H * W, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(topdown_bbox_kernel, dim3((unsigned)N), dim3(256), 0, s, depth, (long)in_fstride,
+                     (long)in_pstride, H, W, tw);
+  const int band = 2 * rows_around_center < H ? 2 * rows_around_center : H;
+  TopdownConsts tc;
+  for (int k = 0; k < 7; ++k) tc.c[k] = consts[k];   // HOST array
+  tc.c[7] = 0.f;
+  hipLaunchKernelGGL(topdown_project_kernel, dim3((unsigned)((band * W + 255) / 256), (unsigned)N), dim3(256), 0, s,
+                     depth, (long)in_fstride, (long)in_pstride, H, W, tc, rows_around_center, tw, cnt);
+  hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)N), dim3(256), 0, s, H, W, tw, cnt, out,
+                     (long)out_fstride, (long)out_pstride);
+  return hipGetLastError();
+}
+
+}  // namespace pnvo

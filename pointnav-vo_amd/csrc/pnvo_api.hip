@@ -1,0 +1,707 @@
+// pnvo_api.hip — the C ABI of include/pnvo.h: model construction, state_dict import, forward orchestration.
+// Host-side only; every kernel lives in conv_mfma.hip / elementwise.hip.  gfx950 only, no fallbacks.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pnvo.h"
+#include "pnvo_internal.h"
+
+using namespace pnvo;
+
+namespace {
+
+thread_local std::string g_err;
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+inline int halve(int x) { return (x - 1) / 2 + 1; }
+
+struct Layer {
+  std::string name, gn;     // state_dict prefixes (conv weight, following GroupNorm)
+  int cin = 0, cinp = 0, cout = 0, coutp = 0, k = 1, kw = 1, stride = 1, pad = 0;
+  int hin = 0, win = 0, hout = 0, wout = 0, groups = 1;
+  float *wpk = nullptr, *gamma = nullptr, *beta = nullptr;   // device
+};
+
+struct TimingRec {
+  hipEvent_t a, b;
+  int entry;
+};
+
+}  // namespace
+
+struct pnvo_model_s {
+  pnvo_config cfg;
+  int device = 0;
+  std::string err;
+  bool loaded = false;
+
+  int C = 0, CP = 0;                 // input channels, padded to 8
+  int Hs = 0, Ws = 0, Hp = 0, Wp = 0, fh = 0, fw = 0, comp_c = 0, comp_cp = 0;
+  std::vector<Layer> convs;          // stem, residual stages in execution order, compression
+  Layer fc, head;
+  float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
+  std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments
+
+  int cap = 0;                       // batch the workspace is sized for
+  float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
+  float *rawA = nullptr, *rawB = nullptr, *rawD = nullptr, *comp_raw = nullptr, *hid = nullptr, *stats = nullptr;
+  float *ssA[2] = {nullptr, nullptr}, *ssB[2] = {nullptr, nullptr}, *ssD[2] = {nullptr, nullptr},
+        *ssC[2] = {nullptr, nullptr};
+  float *tapbuf = nullptr;
+  size_t tapbuf_floats = 0;
+
+  std::string tap_name;
+  float *tap_dst = nullptr;
+  size_t tap_cap = 0;
+
+  int timing = 0;
+  std::vector<pnvo_kernel_time> tentries;
+  std::map<std::string, int> tindex;
+  std::vector<TimingRec> trecs;
+  std::vector<hipEvent_t> evpool;
+};
+
+namespace {
+
+int fail(pnvo_handle h, int code, const std::string &msg) {
+  if (h) h->err = msg;
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e__ = (expr);                                                                              \
+    if (e__ != hipSuccess)                                                                                \
+      return fail(h, PNVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                  \
+  } while (0)
+
+void free_dev(float *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+Layer make_layer(const std::string &name, const std::string &gn, int cin, int cout, int k, int stride, int pad,
+                 int hin, int win, int groups) {
+  Layer l;
+  l.name = name;
+  l.gn = gn;
+  l.cin = cin;
+  l.cinp = rup(cin, 8);
+  l.cout = cout;
+  l.coutp = rup(cout, 32);
+  l.k = l.kw = k;
+  l.stride = stride;
+  l.pad = pad;
+  l.hin = hin;
+  l.win = win;
+  l.hout = (hin + 2 * pad - k) / stride + 1;
+  l.wout = (win + 2 * pad - k) / stride + 1;
+  l.groups = groups;
+  return l;
+}
+
+// Mirrors ResNet.__init__/_make_layer (resnet.py:153-212) and ResNetEncoder.__init__ (vo_cnn.py:70-101).
+void build_plan(pnvo_model_s *m) {
+  const pnvo_config &c = m->cfg;
+  m->C = c.n_rgb + c.n_depth + c.n_dd + c.n_tdv;
+  m->CP = rup(m->C, 8);
+  m->Hs = halve(c.height);
+  m->Ws = halve(c.width);
+  m->Hp = halve(m->Hs);
+  m->Wp = halve(m->Ws);
+  const int g = c.baseplanes / 2;
+  const std::string bb = "visual_encoder.backbone.";
+  m->convs.clear();
+  m->convs.push_back(make_layer(bb + "conv1.0", bb + "conv1.1", m->C, c.baseplanes, 7, 2, 3, c.height, c.width, g));
+  int h = m->Hp, w = m->Wp, cin = c.baseplanes;
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = c.baseplanes << (li - 1);
+    for (int bi = 0; bi < 2; ++bi) {
+      const std::string p = bb + "layer" + std::to_string(li) + "." + std::to_string(bi) + ".";
+      const int stride = (li > 1 && bi == 0) ? 2 : 1;
+      Layer c1 = make_layer(p + "convs.0", p + "convs.1", cin, planes, 3, stride, 1, h, w, g);
+      m->convs.push_back(c1);
+      m->convs.push_back(make_layer(p + "convs.3", p + "convs.4", planes, planes, 3, 1, 1, c1.hout, c1.wout, g));
+      if (stride != 1 || cin != planes)
+        m->convs.push_back(make_layer(p + "downsample.0", p + "downsample.1", cin, planes, 1, stride, 0, h, w, g));
+      h = c1.hout;
+      w = c1.wout;
+      cin = planes;
+    }
+  }
+  m->fh = h;
+  m->fw = w;
+  m->comp_c = (int)std::lround((double)c.flat_size / (double)(h * w));   // vo_cnn.py:82-84 (python round)
+  {
+    // python round() is banker's rounding; replicate for exact .5 cases
+    const double q = (double)c.flat_size / (double)(h * w);
+    const double fl = std::floor(q);
+    if (q - fl == 0.5) m->comp_c = ((long)fl % 2 == 0) ? (int)fl : (int)fl + 1;
+  }
+  m->comp_cp = rup(m->comp_c, 32);
+  m->convs.push_back(make_layer("visual_encoder.compression.0", "visual_encoder.compression.1", cin, m->comp_c, 3, 1, 1,
+                                h, w, 1));
+  // Linear(flat -> hidden) as a valid (pad 0) fh x fw "conv" over the channel-padded compression map
+  m->fc = make_layer(c.act_embed ? "hidden_generator.1" : "visual_fc.2", "", m->comp_c, c.hidden, 1, 1, 0, h, w, 1);
+  m->fc.cinp = m->comp_cp;
+  m->fc.k = h;
+  m->fc.kw = w;
+  m->fc.hout = m->fc.wout = 1;
+  m->head = make_layer("output_head.1", "", c.hidden, c.out_dim, 1, 1, 0, 1, 1, 1);
+}
+
+struct Toc {
+  std::map<std::string, const pnvo_tensor_desc *> by_name;
+  const float *blob;
+  size_t n;
+};
+
+const float *find_tensor(pnvo_handle h, const Toc &t, const std::string &name, std::vector<int64_t> shape, int *rc) {
+  auto it = t.by_name.find(name);
+  if (it == t.by_name.end()) {
+    *rc = fail(h, PNVO_ERR_WEIGHTS, "state_dict is missing tensor '" + name + "'");
+    return nullptr;
+  }
+  const pnvo_tensor_desc *d = it->second;
+  size_t cnt = 1;
+  bool ok = d->ndim == (int)shape.size();
+  for (int k = 0; ok && k < d->ndim; ++k) {
+    ok = d->shape[k] == shape[k];
+    cnt *= (size_t)d->shape[k];
+  }
+  if (!ok || d->offset + cnt > t.n) {
+    std::string s = "tensor '" + name + "' has the wrong shape (want [";
+    for (auto v : shape) s += std::to_string(v) + ",";
+    s += "])";
+    *rc = fail(h, PNVO_ERR_WEIGHTS, s);
+    return nullptr;
+  }
+  return t.blob + d->offset;
+}
+
+int upload(pnvo_handle h, float *&dst, const float *src, size_t n) {
+  free_dev(dst);
+  HIPCHK(h, hipMalloc((void **)&dst, n * sizeof(float)));
+  HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return PNVO_OK;
+}
+
+// pack with an explicit padded input-channel count (the FC reads a channel-padded activation)
+void pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out) {
+  const int coutp = rup(cout, 32), J = cinp / 8, T = kh * kw, ntg_n = coutp / 32;
+  out.assign((size_t)coutp * cinp * T, 0.f);
+  for (int ntg = 0; ntg < ntg_n; ++ntg)
+    for (int tap = 0; tap < T; ++tap)
+      for (int j = 0; j < J; ++j)
+        for (int hh = 0; hh < 2; ++hh)
+          for (int n = 0; n < 32; ++n)
+            for (int t = 0; t < 4; ++t) {
+              const int co = ntg * 32 + n, ci = 8 * j + 4 * hh + t;
+              if (co < cout && ci < cin)
+                out[((((size_t)ntg * T + tap) * J + j) * 64 + hh * 32 + n) * 4 + t] =
+                    oihw[((size_t)co * cin + ci) * T + tap];
+            }
+}
+
+int load_conv(pnvo_handle h, const Toc &t, Layer &l, bool has_gn) {
+  int rc = PNVO_OK;
+  const float *w = find_tensor(h, t, l.name + ".weight", {l.cout, l.cin, l.k, l.kw}, &rc);
+  if (!w) return rc;
+  std::vector<float> pk;
+  pack_conv_weight_cinp(w, l.cout, l.cin, l.cinp, l.k, l.kw, pk);
+  if ((rc = upload(h, l.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
+  if (has_gn) {
+    const float *g = find_tensor(h, t, l.gn + ".weight", {l.cout}, &rc);
+    if (!g) return rc;
+    const float *b = find_tensor(h, t, l.gn + ".bias", {l.cout}, &rc);
+    if (!b) return rc;
+    if ((rc = upload(h, l.gamma, g, l.cout)) != PNVO_OK) return rc;
+    if ((rc = upload(h, l.beta, b, l.cout)) != PNVO_OK) return rc;
+  }
+  return PNVO_OK;
+}
+
+void free_workspace(pnvo_model_s *m) {
+  free_dev(m->xin);
+  free_dev(m->stem_raw);
+  free_dev(m->bufY[0]);
+  free_dev(m->bufY[1]);
+  free_dev(m->rawA);
+  free_dev(m->rawB);
+  free_dev(m->rawD);
+  free_dev(m->comp_raw);
+  free_dev(m->hid);
+  free_dev(m->stats);
+  for (int k = 0; k < 2; ++k) {
+    free_dev(m->ssA[k]);
+    free_dev(m->ssB[k]);
+    free_dev(m->ssD[k]);
+    free_dev(m->ssC[k]);
+  }
+  free_dev(m->tapbuf);
+  m->cap = 0;
+}
+
+size_t stats_floats(const Layer &l, int B) {
+  const long P = (long)l.hout * l.wout, M = (long)B * P;
+  int MT, NT;
+  choose_tile(M, l.coutp, &MT, &NT);
+  return (size_t)B * conv_slots((int)P, MT) * l.coutp * 2;
+}
+
+int ensure_workspace(pnvo_handle m, int B) {
+  if (B <= m->cap) return PNVO_OK;
+  free_workspace(m);
+  const pnvo_config &c = m->cfg;
+  const size_t npix = (size_t)B * c.height * c.width;
+  const size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes;   // largest residual-stage tensor
+  int maxc = m->comp_cp;
+  size_t st = 0;
+  for (const Layer &l : m->convs) {
+    if (l.coutp > maxc) maxc = l.coutp;
+    const size_t s = stats_floats(l, B);
+    if (s > st) st = s;
+  }
+  auto alloc = [&](float *&p, size_t n) -> hipError_t { return hipMalloc((void **)&p, n * sizeof(float)); };
+  HIPCHK(m, alloc(m->xin, npix * m->CP));
+  HIPCHK(m, alloc(m->stem_raw, (size_t)B * m->Hs * m->Ws * c.baseplanes));
+  HIPCHK(m, alloc(m->bufY[0], act));
+  HIPCHK(m, alloc(m->bufY[1], act));
+  HIPCHK(m, alloc(m->rawA, act));
+  HIPCHK(m, alloc(m->rawB, act));
+  HIPCHK(m, alloc(m->rawD, act));
+  HIPCHK(m, alloc(m->comp_raw, (size_t)B * m->fh * m->fw * m->comp_cp));
+  HIPCHK(m, alloc(m->hid, (size_t)B * c.hidden));
+  HIPCHK(m, alloc(m->stats, st));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(m, alloc(m->ssA[k], (size_t)B * maxc));
+    HIPCHK(m, alloc(m->ssB[k], (size_t)B * maxc));
+    HIPCHK(m, alloc(m->ssD[k], (size_t)B * maxc));
+    HIPCHK(m, alloc(m->ssC[k], (size_t)B * m->comp_cp));
+    HIPCHK(m, hipMemset(m->ssC[k], 0, (size_t)B * m->comp_cp * sizeof(float)));   // pad channels stay (0, 0)
+  }
+  m->tapbuf_floats = (size_t)B * m->fh * m->fw * m->comp_cp;
+  HIPCHK(m, alloc(m->tapbuf, m->tapbuf_floats));
+  m->cap = B;
+  return PNVO_OK;
+}
+
+// ---- timing -----------------------------------------------------------------------------------------------------
+struct Timed {
+  pnvo_model_s *m;
+  hipStream_t s;
+  int rec = -1;
+  Timed(pnvo_model_s *m_, hipStream_t s_, const std::string &name, double flops, double bytes) : m(m_), s(s_) {
+    if (!m->timing) return;
+    auto it = m->tindex.find(name);
+    int idx;
+    if (it == m->tindex.end()) {
+      pnvo_kernel_time e;
+      std::memset(&e, 0, sizeof(e));
+      std::snprintf(e.name, sizeof(e.name), "%s", name.c_str());
+      idx = (int)m->tentries.size();
+      m->tentries.push_back(e);
+      m->tindex[name] = idx;
+    } else {
+      idx = it->second;
+    }
+    m->tentries[idx].launches += 1;
+    m->tentries[idx].flops += flops;
+    m->tentries[idx].bytes += bytes;
+    TimingRec r;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!m->evpool.empty()) {
+        e = m->evpool.back();
+        m->evpool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    r.a = get();
+    r.b = get();
+    r.entry = idx;
+    (void)hipEventRecord(r.a, s);
+    m->trecs.push_back(r);
+    rec = (int)m->trecs.size() - 1;
+  }
+  ~Timed() {
+    if (rec >= 0) (void)hipEventRecord(m->trecs[rec].b, s);
+  }
+};
+
+int maybe_tap(pnvo_handle m, const char *name, const float *src, size_t n, hipStream_t s) {
+  if (m->tap_dst == nullptr || m->tap_name != name) return PNVO_OK;
+  if (n > m->tap_cap) return fail(m, PNVO_ERR_ARG, std::string("tap buffer too small for '") + name + "'");
+  HIPCHK(m, hipMemcpyAsync(m->tap_dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return PNVO_OK;
+}
+
+// One conv + (optionally) the GroupNorm statistics finalisation that follows it.
+int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
+             float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
+             hipStream_t s) {
+  ConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x;
+  a.wpk = l.wpk;
+  a.y = y;
+  a.in_scale = in_scale;
+  a.in_shift = in_shift;
+  a.stats = ss ? m->stats : nullptr;
+  a.bias = bias;
+  a.bias_row = bias_row;
+  a.B = B;
+  a.H = l.hin;
+  a.W = l.win;
+  a.CIN = l.cinp;
+  a.Ho = l.hout;
+  a.Wo = l.wout;
+  a.COUT = l.cout;
+  a.COUTP = l.coutp;
+  a.KH = l.k;
+  a.KW = l.kw;
+  a.stride = l.stride;
+  a.pad = l.pad;
+  a.y_cstride = y_cstride;
+  a.relu_out = relu_out;
+  const long P = (long)l.hout * l.wout, M = (long)B * P;
+  choose_tile(M, l.coutp, &a.MT, &a.NT);
+  a.slots = conv_slots((int)P, a.MT);
+  const double macs = (double)M * l.cout * l.cin * l.k * l.kw;
+  const double bytes = 4.0 * ((double)B * l.hin * l.win * l.cin + (double)M * l.cout + (double)l.cout * l.cin * l.k * l.kw);
+  {
+    Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
+    HIPCHK(m, launch_conv(a, s));
+  }
+  if (ss) {
+    Timed t(m, s, "gn_finalize", 0.0, 0.0);
+    HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, l.coutp, l.cout, l.groups, P, a.MT * 32, l.gamma, l.beta, 1e-5f,
+                                 ss[0], ss[1], s));
+  }
+  return PNVO_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================================
+extern "C" {
+
+const char *pnvo_version(void) { return "pnvo 0.1 (gfx950, fp32 MFMA)"; }
+
+const char *pnvo_last_error(pnvo_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int pnvo_create(const pnvo_config *cfg, int device, pnvo_handle *out) {
+  if (!cfg || !out) return fail(nullptr, PNVO_ERR_ARG, "null argument");
+  const int C = cfg->n_rgb + cfg->n_depth + cfg->n_dd + cfg->n_tdv;
+  if (C <= 0) return fail(nullptr, PNVO_ERR_ARG, "visual odometry must not be blind (no input modality)");   // vo_cnn.py:68
+  if (C > 64 || (cfg->n_rgb % 2) || (cfg->n_depth % 2) || (cfg->n_dd % 2) || (cfg->n_tdv % 2))
+    return fail(nullptr, PNVO_ERR_ARG, "unsupported input channel configuration");
+  if (cfg->width < 32 || cfg->height < 32) return fail(nullptr, PNVO_ERR_ARG, "observation_size must be >= 32x32");
+  if (cfg->baseplanes < 32 || cfg->baseplanes % 32 || cfg->hidden % 8 || cfg->hidden <= 0 || cfg->out_dim <= 0)
+    return fail(nullptr, PNVO_ERR_ARG, "unsupported baseplanes / hidden_size / output_dim");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, PNVO_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, PNVO_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, PNVO_ERR_ARG, std::string("libpnvo is built for gfx950 only, device is ") + prop.gcnArchName);
+  pnvo_model_s *m = new pnvo_model_s();
+  m->cfg = *cfg;
+  m->device = device;
+  if (m->cfg.flat_size <= 0) m->cfg.flat_size = 2048;
+  if (m->cfg.n_acts <= 0) m->cfg.n_acts = 4;
+  build_plan(m);
+  *out = m;
+  return PNVO_OK;
+}
+
+int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const pnvo_tensor_desc *toc, int ntoc) {
+  if (!h || !blob || !toc) return fail(h, PNVO_ERR_ARG, "null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  Toc t;
+  t.blob = blob;
+  t.n = n_floats;
+  for (int k = 0; k < ntoc; ++k) t.by_name[toc[k].name] = &toc[k];
+  int rc = PNVO_OK;
+  const pnvo_config &c = h->cfg;
+  h->mean.assign(h->C, 0.f);
+  h->stdev.assign(h->C, 1.f);
+  if (c.normalize) {
+    const std::string pre = "visual_encoder.running_mean_and_var.";
+    const float *mu = find_tensor(h, t, pre + "_mean", {1, h->C, 1, 1}, &rc);
+    if (!mu) return rc;
+    const float *var = find_tensor(h, t, pre + "_var", {1, h->C, 1, 1}, &rc);
+    if (!var) return rc;
+    for (int k = 0; k < h->C; ++k) {
+      h->mean[k] = mu[k];
+      h->stdev[k] = std::sqrt(std::fmax(var[k], 1e-2f));   // running_mean_and_var.py:62, float32
+    }
+  }
+  for (Layer &l : h->convs)
+    if ((rc = load_conv(h, t, l, true)) != PNVO_OK) return rc;
+  // Linear(flat[+embed] -> hidden): visual columns become the fh x fw "conv"; the embedding columns fold into a
+  // per-action bias row:  bias[a][o] = b[o] + sum_e W[o][flat+e] * emb[a][e]   (vo_cnn_act_embed.py:63-72)
+  const int flat = h->comp_c * h->fh * h->fw;
+  const int fc_in = flat + (c.act_embed ? 32 : 0);
+  const float *w1 = find_tensor(h, t, h->fc.name + ".weight", {c.hidden, fc_in}, &rc);
+  if (!w1) return rc;
+  const float *b1 = find_tensor(h, t, h->fc.name + ".bias", {c.hidden}, &rc);
+  if (!b1) return rc;
+  {
+    std::vector<float> vis((size_t)c.hidden * flat);
+    for (int o = 0; o < c.hidden; ++o) std::memcpy(&vis[(size_t)o * flat], w1 + (size_t)o * fc_in, sizeof(float) * flat);
+    std::vector<float> pk;
+    pack_conv_weight_cinp(vis.data(), c.hidden, h->comp_c, h->comp_cp, h->fh, h->fw, pk);
+    if ((rc = upload(h, h->fc.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
+    const int rows = c.act_embed ? c.n_acts + 1 : 1;
+    std::vector<float> bias((size_t)rows * c.hidden);
+    const float *emb = nullptr;
+    if (c.act_embed) {
+      emb = find_tensor(h, t, "action_embedding.weight", {c.n_acts + 1, 32}, &rc);
+      if (!emb) return rc;
+    }
+    for (int a = 0; a < rows; ++a)
+      for (int o = 0; o < c.hidden; ++o) {
+        double acc = 0.0;
+        if (emb)
+          for (int e = 0; e < 32; ++e) acc += (double)w1[(size_t)o * fc_in + flat + e] * (double)emb[a * 32 + e];
+        bias[(size_t)a * c.hidden + o] = (float)(acc + (double)b1[o]);
+      }
+    if ((rc = upload(h, h->fc_bias, bias.data(), bias.size())) != PNVO_OK) return rc;
+  }
+  const float *w2 = find_tensor(h, t, "output_head.1.weight", {c.out_dim, c.hidden}, &rc);
+  if (!w2) return rc;
+  const float *b2 = find_tensor(h, t, "output_head.1.bias", {c.out_dim}, &rc);
+  if (!b2) return rc;
+  {
+    std::vector<float> pk;
+    pack_conv_weight_cinp(w2, c.out_dim, c.hidden, c.hidden, 1, 1, pk);
+    if ((rc = upload(h, h->head.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
+    if ((rc = upload(h, h->head_bias, b2, c.out_dim)) != PNVO_OK) return rc;
+  }
+  h->loaded = true;
+  return PNVO_OK;
+}
+
+int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                 const int64_t *actions, int B, float *out, void *stream) {
+  if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
+  if (!m->loaded) return fail(m, PNVO_ERR_STATE, "pnvo_forward before pnvo_load_weights");
+  if (B <= 0 || !out) return fail(m, PNVO_ERR_ARG, "bad batch / null output");
+  const pnvo_config &c = m->cfg;
+  if ((c.n_rgb > 0) != (rgb != nullptr) || (c.n_depth > 0) != (depth != nullptr) || (c.n_dd > 0) != (dd != nullptr) ||
+      (c.n_tdv > 0) != (tdv != nullptr))
+    return fail(m, PNVO_ERR_ARG, "observation tensors do not match the model's observation_space");
+  if (c.act_embed && !actions) return fail(m, PNVO_ERR_ARG, "act_embed model needs actions");
+  HIPCHK(m, hipSetDevice(m->device));
+  int rc = ensure_workspace(m, B);
+  if (rc != PNVO_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+
+  // (a4+a5) input assembly + whitening
+  {
+    AssembleArgs a;
+    a.src[0] = rgb;
+    a.src[1] = depth;
+    a.src[2] = dd;
+    a.src[3] = tdv;
+    a.nsrc[0] = c.n_rgb;
+    a.nsrc[1] = c.n_depth;
+    a.nsrc[2] = c.n_dd;
+    a.nsrc[3] = c.n_tdv;
+    a.mean = c.normalize ? m->mean.data() : nullptr;
+    a.stdev = m->stdev.data();
+    a.C = m->C;
+    a.CP = m->CP;
+    a.npix = (long)B * c.height * c.width;
+    a.out = m->xin;
+    Timed t(m, s, "assemble_whiten", 0.0, 4.0 * a.npix * (m->C + m->CP));
+    HIPCHK(m, launch_assemble(a, s));
+  }
+  if ((rc = maybe_tap(m, "input", m->xin, (size_t)B * c.height * c.width * m->CP, s)) != PNVO_OK) return rc;
+
+  // (a6) stem conv + GN statistics
+  size_t li = 0;
+  const Layer &stem = m->convs[li++];
+  if ((rc = run_conv(m, stem, B, m->xin, nullptr, nullptr, m->stem_raw, stem.coutp, m->ssA, nullptr, nullptr, 0, s)) !=
+      PNVO_OK)
+    return rc;
+  if ((rc = maybe_tap(m, "stem_conv", m->stem_raw, (size_t)B * m->Hs * m->Ws * stem.coutp, s)) != PNVO_OK) return rc;
+  // (a7) GN + ReLU + maxpool
+  float *cur = m->bufY[0], *nxt = m->bufY[1];
+  {
+    Timed t(m, s, "gn_relu_maxpool", 0.0, 4.0 * B * ((double)m->Hs * m->Ws + (double)m->Hp * m->Wp) * stem.coutp);
+    HIPCHK(m, launch_gn_relu_maxpool(m->stem_raw, m->ssA[0], m->ssA[1], B, m->Hs, m->Ws, stem.coutp, cur, s));
+  }
+  if ((rc = maybe_tap(m, "maxpool", cur, (size_t)B * m->Hp * m->Wp * stem.coutp, s)) != PNVO_OK) return rc;
+
+  // (a8) residual stages
+  for (int stage = 1; stage <= 4; ++stage) {
+    for (int bi = 0; bi < 2; ++bi) {
+      const Layer &c1 = m->convs[li++];
+      const Layer &c2 = m->convs[li++];
+      const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
+      if ((rc = run_conv(m, c1, B, cur, nullptr, nullptr, m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s)) != PNVO_OK)
+        return rc;
+      if ((rc = run_conv(m, c2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s)) !=
+          PNVO_OK)
+        return rc;
+      const long P = (long)c2.hout * c2.wout;
+      if (ds) {
+        const Layer &cd = m->convs[li++];
+        if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK)
+          return rc;
+        Timed t(m, s, "residual", 0.0, 12.0 * B * P * c2.coutp);
+        HIPCHK(m, launch_residual(m->rawB, m->ssB[0], m->ssB[1], m->rawD, m->ssD[0], m->ssD[1], B, P, c2.coutp, nxt, s));
+      } else {
+        Timed t(m, s, "residual", 0.0, 12.0 * B * P * c2.coutp);
+        HIPCHK(m, launch_residual(m->rawB, m->ssB[0], m->ssB[1], cur, nullptr, nullptr, B, P, c2.coutp, nxt, s));
+      }
+      std::swap(cur, nxt);
+      const std::string tn = "layer" + std::to_string(stage) + "." + std::to_string(bi);
+      if ((rc = maybe_tap(m, tn.c_str(), cur, (size_t)B * P * c2.coutp, s)) != PNVO_OK) return rc;
+    }
+  }
+
+  // (a10) compression conv + GroupNorm(1, C)
+  const Layer &comp = m->convs[li++];
+  if ((rc = run_conv(m, comp, B, cur, nullptr, nullptr, m->comp_raw, comp.coutp, m->ssC, nullptr, nullptr, 0, s)) != PNVO_OK)
+    return rc;
+  if (m->tap_dst != nullptr && m->tap_name == "compression") {
+    HIPCHK(m, launch_apply_ss_relu(m->comp_raw, m->ssC[0], m->ssC[1], B, (long)m->fh * m->fw, m->comp_cp, m->tapbuf, s));
+    if ((rc = maybe_tap(m, "compression", m->tapbuf, (size_t)B * m->fh * m->fw * m->comp_cp, s)) != PNVO_OK) return rc;
+  }
+  // (a11) Flatten + Linear + ReLU, then the output head
+  if ((rc = run_conv(m, m->fc, B, m->comp_raw, m->ssC[0], m->ssC[1], m->hid, c.hidden, nullptr, m->fc_bias,
+                     c.act_embed ? actions : nullptr, 1, s)) != PNVO_OK)
+    return rc;
+  if ((rc = maybe_tap(m, "hidden", m->hid, (size_t)B * c.hidden, s)) != PNVO_OK) return rc;
+  if ((rc = run_conv(m, m->head, B, m->hid, nullptr, nullptr, out, c.out_dim, nullptr, m->head_bias, nullptr, 0, s)) !=
+      PNVO_OK)
+    return rc;
+  return PNVO_OK;
+}
+
+int pnvo_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
+                          int64_t out_stride, int32_t *err_flag, void *stream) {
+  if (!depth || !onehot || n < 0 || bins < 1 || bins > 64) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (n == 0) return PNVO_OK;
+  HIPCHK(nullptr, launch_discretize_depth(depth, n, in_stride, bins, onehot, out_stride, err_flag, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+size_t pnvo_topdown_workspace_bytes(int N, int H, int W) { return topdown_workspace_bytes(N, H, W); }
+
+int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                      const float *consts, int rows_around_center, float *out, int64_t out_fstride,
+                      int64_t out_pstride, void *work, void *stream) {
+  if (!depth || !out || !consts || !work || N < 0 || H <= 0 || W <= 0)
+    return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (N == 0) return PNVO_OK;
+  HIPCHK(nullptr, launch_topdown(depth, N, H, W, in_fstride, in_pstride, consts, rows_around_center, out, out_fstride,
+                                 out_pstride, work, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_destroy(pnvo_handle m) {
+  if (!m) return PNVO_OK;
+  (void)hipSetDevice(m->device);
+  free_workspace(m);
+  for (Layer &l : m->convs) {
+    free_dev(l.wpk);
+    free_dev(l.gamma);
+    free_dev(l.beta);
+  }
+  free_dev(m->fc.wpk);
+  free_dev(m->head.wpk);
+  free_dev(m->fc_bias);
+  free_dev(m->head_bias);
+  for (auto &r : m->trecs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : m->evpool) (void)hipEventDestroy(e);
+  delete m;
+  return PNVO_OK;
+}
+
+int pnvo_set_tap(pnvo_handle h, const char *name, float *dst, size_t capacity) {
+  if (!h) return fail(h, PNVO_ERR_ARG, "null handle");
+  h->tap_name = name ? name : "";
+  h->tap_dst = name ? dst : nullptr;
+  h->tap_cap = capacity;
+  return PNVO_OK;
+}
+
+int pnvo_tap_shape(pnvo_handle h, const char *name, int B, int64_t shape[4]) {
+  if (!h || !name || !shape) return fail(h, PNVO_ERR_ARG, "null argument");
+  const pnvo_config &c = h->cfg;
+  const std::string n = name;
+  auto set = [&](int64_t a, int64_t b, int64_t cc, int64_t d) {
+    shape[0] = a;
+    shape[1] = b;
+    shape[2] = cc;
+    shape[3] = d;
+    return PNVO_OK;
+  };
+  if (n == "input") return set(B, c.height, c.width, h->CP);
+  if (n == "stem_conv") return set(B, h->Hs, h->Ws, c.baseplanes);
+  if (n == "maxpool") return set(B, h->Hp, h->Wp, c.baseplanes);
+  if (n == "compression") return set(B, h->fh, h->fw, h->comp_cp);
+  if (n == "hidden") return set(B, 1, 1, c.hidden);
+  if (n.rfind("layer", 0) == 0 && n.size() == 8) {
+    const int li = n[5] - '0';
+    int hh = h->Hp, ww = h->Wp;
+    for (int k = 1; k < li; ++k) {
+      hh = halve(hh);
+      ww = halve(ww);
+    }
+    return set(B, hh, ww, c.baseplanes << (li - 1));
+  }
+  return fail(h, PNVO_ERR_ARG, "unknown tap '" + n + "'");
+}
+
+int pnvo_timing_mode(pnvo_handle h, int mode) {
+  if (!h) return fail(h, PNVO_ERR_ARG, "null handle");
+  h->timing = mode ? 1 : 0;
+  return PNVO_OK;
+}
+
+int pnvo_timing_read(pnvo_handle h, pnvo_kernel_time *entries, int cap, int *n_out) {
+  if (!h || !n_out) return fail(h, PNVO_ERR_ARG, "null argument");
+  for (auto &r : h->trecs) {
+    HIPCHK(h, hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
+    h->tentries[r.entry].total_ms += ms;
+    h->evpool.push_back(r.a);
+    h->evpool.push_back(r.b);
+  }
+  h->trecs.clear();
+  const int n = (int)h->tentries.size();
+  *n_out = n;
+  for (int k = 0; k < n && k < cap && entries; ++k) entries[k] = h->tentries[k];
+  h->tentries.clear();
+  h->tindex.clear();
+  return PNVO_OK;
+}
+
+size_t pnvo_packed_conv_floats(int cout, int cin, int kh, int kw) { return packed_conv_floats(cout, cin, kh, kw); }
+
+int pnvo_pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, float *out) {
+  if (!oihw || !out || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  pack_conv_weight(oihw, cout, cin, kh, kw, out);
+  return PNVO_OK;
+}
+
+}  // extern "C"

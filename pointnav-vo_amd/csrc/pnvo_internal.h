@@ -1,0 +1,71 @@
+// pnvo_internal.h — declarations shared by the HIP translation units of libpnvo.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnvo {
+
+// One convolution / linear layer as an implicit GEMM:  M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin.
+struct ConvArgs {
+  const float *x;        // [B,H,W,CIN] NHWC, CIN % 8 == 0 (channel-padded)
+  const float *wpk;      // packed weights, see pack_conv_weight()
+  float *y;              // [M, y_cstride] raw output
+  const float *in_scale; // [B,CIN] per-(sample,channel) scale of the fused input transform, or nullptr
+  const float *in_shift; // [B,CIN] shift; transform = relu(x*scale+shift) (GroupNorm+ReLU of the producer)
+  float *stats;          // [B,slots,COUTP,2] per-(sample,slot,channel) partial (sum, sumsq) or nullptr
+  const float *bias;     // [bias_rows,COUT] epilogue bias or nullptr (linear layers)
+  const int64_t *bias_row; // [B] row of `bias` per sample (act-embed variants) or nullptr (row 0)
+  int B, H, W, CIN;
+  int Ho, Wo, COUT, COUTP; // COUTP = COUT rounded up to 32
+  int KH, KW, stride, pad;
+  int y_cstride;         // channel stride of y (COUT or COUTP)
+  int relu_out;          // epilogue ReLU (after bias)
+  int slots;             // stats slots per sample
+  int lds_floats;        // dynamic LDS available for staging the input transform tables
+  int MT, NT;            // wave tile: MT*32 pixels x NT*32 output channels
+};
+
+int conv_slots(int P, int MT);                       // stats slots per sample for a given wave tile
+void choose_tile(long M, int COUTP, int *MT, int *NT);
+hipError_t launch_conv(const ConvArgs &a, hipStream_t s);
+
+size_t packed_conv_floats(int cout, int cin, int kh, int kw);
+void pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, float *out);
+
+// GroupNorm statistics -> per-(sample,channel) scale/shift.
+hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
+                              const float *gamma, const float *beta, float eps, float *scale, float *shift,
+                              hipStream_t s);
+
+// Input assembly + whitening (vo_cnn.py:110-176) into channel-padded NHWC.
+struct AssembleArgs {
+  const float *src[4];   // rgb, depth, dd, tdv (nullptr if absent)
+  int nsrc[4];           // pair channel counts
+  const float *mean;     // [C] or nullptr
+  const float *stdev;    // [C]
+  int C, CP;
+  long npix;             // B*H*W
+  float *out;            // [npix, CP]
+};
+hipError_t launch_assemble(const AssembleArgs &a, hipStream_t s);
+
+// relu(gn(x)) then MaxPool 3x3 s2 p1.
+hipError_t launch_gn_relu_maxpool(const float *x, const float *scale, const float *shift, int B, int H, int W,
+                                  int C, float *out, hipStream_t s);
+
+// y = relu(a*sa+ta + r)  with r = b (plain) or b*sb+tb.  a,b,y: [B,P,C].
+hipError_t launch_residual(const float *a, const float *sa, const float *ta, const float *b, const float *sb,
+                           const float *tb, int B, long P, int C, float *y, hipStream_t s);
+
+// y = relu(x*s+t)  (materialise a normalised activation; used for taps only)
+hipError_t launch_apply_ss_relu(const float *x, const float *s, const float *t, int B, long P, int C, float *y,
+                                hipStream_t st);
+
+hipError_t launch_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
+                                   int64_t out_stride, int32_t *err_flag, hipStream_t s);
+size_t topdown_workspace_bytes(int N, int H, int W);
+hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                          const float *consts_host, int rows_around_center, float *out, int64_t out_fstride,
+                          int64_t out_pstride, void *work, hipStream_t s);
+
+}  // namespace pnvo

@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's VO drop-in boundary.
+
+  BaseRLTrainerWithVO                       /root/reference/pointnav_vo/rl/common/base_trainer_with_vo.py:23-314
+  NormalizedDepth2TopDownViewHabitatTorch   /root/reference/pointnav_vo/utils/geometry_utils.py:491-721
+
+Same method names, argument meaning, return values and error behaviour; the compute (one-hot depth, ego top-down
+view, network forward) runs in libpnvo.so's HIP kernels, batched, with no host synchronisation except the final
+device->host copy of the 3 output floats that the reference also performs (:292).
+``compute_local_delta_states_batch`` is the additive batched sibling: one call per simulator
+step for all environments instead of the reference's per-env Python loop (rl/ppo/ppo_trainer.py:724-841).
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .common_vars import ACT_IDX2NAME, ACT_NAME2IDX
+from .registry import baseline_registry
+from . import vo_cnn  # noqa: F401  (registers the models)
+
+
+class AttrDict(dict):
+    """Minimal stand-in for habitat.Config / yacs CfgNode attribute access (used when habitat is absent)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+    __setattr__ = dict.__setitem__
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class NormalizedDepth2TopDownViewHabitatTorch:
+    """Ego top-down occupancy view from a normalized depth frame; constructor as geometry_utils.py:492-516."""
+
+    def __init__(self, min_depth, max_depth, vis_size_h, vis_size_w, hfov_rad, ksize=3, rows_around_center=50,
+                 flag_center_crop=True):
+        if ksize != 3 or not flag_center_crop:
+            raise NotImplementedError("only ksize=3 / flag_center_crop=True (the reference's call site, "
+                                      "base_trainer_with_vo.py:119-129) is built")
+        self._epsilon = 0.01
+        self._min_depth, self._max_depth = min_depth, max_depth
+        self._vis_size_h, self._vis_size_w = vis_size_h, vis_size_w
+        self._hfov_rad = hfov_rad
+        self._rows_around_center = rows_around_center
+        # geometry_utils.py:562-580 and :676-681, evaluated with the same torch float32 ops as the reference
+        f = (vis_size_w / 2) / (np.tan(hfov_rad / 2))
+        self._K = torch.FloatTensor([[f, 0, vis_size_w / 2], [0, f, vis_size_h / 2], [0, 0, 1.0]])
+        kinv = torch.inverse(self._K)
+        coords = torch.matmul(kinv, torch.FloatTensor((vis_size_w - 0.5, 0, 1)).unsqueeze(-1)) * max_depth
+        min_x, max_x = -coords[0], coords[0]
+        x_den = (max_x - min_x) * (1 + self._epsilon)
+        one = torch.ones(1)
+        self._consts = (C.c_float * 8)(
+            kinv[0, 0].item(), kinv[0, 2].item(), min_x.item(), x_den.item(),
+            (one * (max_depth - min_depth)).item(), (one * ((max_depth - min_depth) * (1 + self._epsilon))).item(),
+            (one * min_depth).item(), 0.0)
+        assert kinv[0, 1].item() == 0.0
+        self._work = None
+
+    def _workspace(self, n, dev):
+        need = _lib.lib.pnvo_topdown_workspace_bytes(int(n), self._vis_size_h, self._vis_size_w)
+        if self._work is None or self._work.numel() < need or self._work.device != dev:
+            self._work = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._work
+
+    def gen_top_down_view_batch(self, depth, out=None, out_channel=None):
+        """depth: CUDA float32 [N,H,W] (any strides with a regular frame/pixel stride).  Returns [N,H,W] or writes
+        channel `out_channel` of `out` [N,H,W,Cc]."""
+        H, W = self._vis_size_h, self._vis_size_w
+        assert depth.is_cuda and depth.dtype == torch.float32 and depth.dim() == 3 and depth.shape[1:] == (H, W)
+        assert depth.stride(1) == W * depth.stride(2)
+        n, dev = depth.shape[0], depth.device
+        if out is None:
+            res = torch.empty((n, H, W), device=dev, dtype=torch.float32)
+            o_ptr, ofs, ops = res.data_ptr(), H * W, 1
+        else:
+            res = out
+            o_ptr = out.data_ptr() + 4 * out_channel
+            ofs, ops = out.stride(0), out.stride(2)
+        work = self._workspace(n, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.pnvo_topdown_view(
+                C.c_void_p(depth.data_ptr()), int(n), H, W, depth.stride(0) if n > 1 else H * W * depth.stride(2),
+                depth.stride(2), self._consts, int(self._rows_around_center), C.c_void_p(o_ptr), int(ofs), int(ops),
+                C.c_void_p(work.data_ptr()), _stream(dev)))
+        return res
+
+    def gen_top_down_view(self, normalized_depth):
+        """normalized_depth: [H, W, 1] -> [H, W, 1]   (geometry_utils.py:516-556)."""
+        d = normalized_depth.to(torch.float32)
+        out = self.gen_top_down_view_batch(d[..., 0].contiguous().unsqueeze(0))
+        return out[0].unsqueeze(-1)
+
+
+class BaseRLTrainerWithVO:
+    """Mirror of BaseRLTrainerWithVO.  Subclass it (or mix it in) exactly as the reference trainers do; it needs
+    ``self.config`` (attribute-style VO / TASK_CONFIG tree) and ``self.device``."""
+
+    def __init__(self, config=None, device=None):
+        self.config = config
+        self.device = device
+
+    def _set_up_vo_obs_transformer(self) -> None:
+        if self.config.VO.OBS_TRANSFORM in ("resize_crop", "resize"):
+            raise NotImplementedError("VO.OBS_TRANSFORM other than 'none' is nav-loop plumbing outside the hot path "
+                                      "(default is 'none', configs/rl/ddppo_pointnav.yaml:99)")
+        self._vo_obs_transformer = None
+
+    def _setup_vo_model(self, all_cfg) -> None:
+        # base_trainer_with_vo.py:37-133
+        if all_cfg.VO.VO_TYPE == "REGRESS":
+            model_cls_name = all_cfg.VO.REGRESS_MODEL.name
+            vo_model_cls = baseline_registry.get_vo_model(model_cls_name)
+        else:
+            raise NotImplementedError
+        assert vo_model_cls is not None, f"{model_cls_name} is not supported"
+        rm = all_cfg.VO.REGRESS_MODEL
+        if rm.regress_type == "unified_act":
+            output_dim, model_names = 3, ["all"]
+        elif rm.regress_type == "sep_act":
+            output_dim, model_names = 3, [_ for _ in list(ACT_IDX2NAME.values()) if _ != "unified"]
+        else:
+            raise ValueError
+        self.vo_model = OrderedDict()
+        for k in model_names:
+            self.vo_model[k] = vo_model_cls(
+                observation_space=rm.visual_type,
+                observation_size=(self.config.VO.VIS_SIZE_W, self.config.VO.VIS_SIZE_H),
+                hidden_size=rm.hidden_size, backbone=rm.visual_backbone, normalize_visual_inputs=True,
+                output_dim=output_dim, dropout_p=rm.dropout_p,
+                discretized_depth_channels=self.config.VO.REGRESS_MODEL.discretized_depth_channels)
+            self.vo_model[k].to(self.device)
+        if rm.pretrained:
+            for k in model_names:
+                ckpt = torch.load(rm.pretrained_ckpt[k], map_location="cpu")
+                if "model_state" in ckpt:
+                    self.vo_model[k].load_state_dict(ckpt["model_state"])
+                elif "model_states" in ckpt:
+                    self.vo_model[k].load_state_dict(ckpt["model_states"][ACT_NAME2IDX[k]])
+                else:
+                    raise ValueError
+        name = self.config.VO.REGRESS_MODEL.name
+        if "discretize_depth" in name or "dd" in name:
+            if self.config.VO.REGRESS_MODEL.discretize_depth not in ["hard"]:
+                raise NotImplementedError
+        if "top_down" in name:
+            ds = self.config.TASK_CONFIG.SIMULATOR.DEPTH_SENSOR
+            self._top_down_view_generator = NormalizedDepth2TopDownViewHabitatTorch(
+                min_depth=ds.MIN_DEPTH, max_depth=ds.MAX_DEPTH, vis_size_h=self.config.VO.VIS_SIZE_H,
+                vis_size_w=self.config.VO.VIS_SIZE_W, hfov_rad=ds.HFOV)
+
+    # ------------------------------------------------------------------ pre-processing
+    def _discretize_depth_func(self, raw_depth):
+        """[..] float32 CUDA depth in [0,1] -> [.., bins] one-hot (base_trainer_with_vo.py:135-167)."""
+        bins = self.config.VO.REGRESS_MODEL.discretized_depth_channels
+        d = raw_depth.to(torch.float32).contiguous()
+        out = torch.empty(d.shape + (bins,), device=d.device, dtype=torch.float32)
+        flag = torch.zeros(1, dtype=torch.int32, device=d.device)
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.lib.pnvo_discretize_depth(C.c_void_p(d.data_ptr()), d.numel(), 1, int(bins),
+                                                      C.c_void_p(out.data_ptr()), int(bins),
+                                                      C.c_void_p(flag.data_ptr()), _stream(d.device)))
+        assert flag.item() == 0, "depth must lie in [0, 1]"      # the reference's asserts (:136-137)
+        return out
+
+    def _build_obs_pairs(self, rgb_pair, depth_pair):
+        """rgb_pair [B,H,W,6], depth_pair [B,H,W,2] on device -> obs_pairs dict (:209-269), batched on device."""
+        obs_pairs = {"rgb": rgb_pair, "depth": depth_pair}
+        name = self.config.VO.REGRESS_MODEL.name
+        B, H, W, _ = depth_pair.shape
+        dev = depth_pair.device
+        if "discretize_depth" in name or "dd" in name:
+            assert depth_pair.size(-1) == 2
+            bins = self.config.VO.REGRESS_MODEL.discretized_depth_channels
+            dd = torch.empty((B, H, W, 2 * bins), device=dev, dtype=torch.float32)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                for k in range(2):   # prev | cur halves (:220-229)
+                    _lib.check(_lib.lib.pnvo_discretize_depth(
+                        C.c_void_p(depth_pair.data_ptr() + 4 * k), B * H * W, 2, int(bins),
+                        C.c_void_p(dd.data_ptr() + 4 * k * bins), 2 * int(bins), C.c_void_p(flag.data_ptr()),
+                        _stream(dev)))
+            self._dd_flag = flag
+            obs_pairs["discretized_depth"] = dd
+        if "top_down" in name:
+            tdv = torch.empty((B, H, W, 2), device=dev, dtype=torch.float32)
+            for k in range(2):       # :239-249
+                self._top_down_view_generator.gen_top_down_view_batch(depth_pair[..., k], out=tdv, out_channel=k)
+            obs_pairs["top_down_view"] = tdv
+        return obs_pairs
+
+    def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts):
+        """Batched sibling of _compute_local_delta_states_from_vo: lists of observation dicts and actions ->
+        float32 array [N,3].  Pairs are grouped per action model (sep_act) and each group is one forward."""
+        assert len(prev_obs_list) == len(cur_obs_list) == len(acts)
+        n = len(acts)
+        rgb = np.stack([np.concatenate([p["rgb"], c["rgb"]], axis=2) for p, c in zip(prev_obs_list, cur_obs_list)])
+        dep = np.stack([np.concatenate([p["depth"], c["depth"]], axis=2) for p, c in zip(prev_obs_list, cur_obs_list)])
+        rgb_pair = torch.from_numpy(rgb).to(self.device).to(torch.float32)       # uint8 over PCIe, widened on device
+        depth_pair = torch.from_numpy(np.ascontiguousarray(dep, dtype=np.float32)).to(self.device)
+        obs_pairs = self._build_obs_pairs(rgb_pair, depth_pair)
+        if getattr(self, "_dd_flag", None) is not None:
+            assert self._dd_flag.item() == 0, "depth must lie in [0, 1]"
+        out = np.zeros((n, 3), dtype=np.float32)
+        rm = self.config.VO.REGRESS_MODEL
+        if rm.mode != "det":
+            raise NotImplementedError("VO.REGRESS_MODEL.mode == 'rnd' (dropout sampling, :295-308) is not provided")
+        keys = ["all"] * n if rm.regress_type == "unified_act" else [ACT_IDX2NAME[a] for a in acts]
+        with torch.no_grad():
+            for key in sorted(set(keys)):
+                idx = [i for i, k in enumerate(keys) if k == key]
+                sel = torch.as_tensor(idx, device=self.device)
+                sub = obs_pairs if len(idx) == n else {k: v.index_select(0, sel) for k, v in obs_pairs.items()}
+                model = self.vo_model[key]
+                model.eval()
+                if "act_embed" in rm.name:
+                    a = torch.as_tensor([acts[i] for i in idx], dtype=torch.long, device=self.device)
+                    res = model(sub, a)
+                else:
+                    res = model(sub)
+                out[idx] = res.cpu().numpy()
+        return out
+
+    def _compute_local_delta_states_from_vo(self, prev_obs, cur_obs, act, vis_video=False):
+        """(prev_obs, cur_obs, act) -> (list of 3 np.float32, [0,0,0], extra_infos)  (:169-314, mode 'det')."""
+        if getattr(self, "_vo_obs_transformer", None) is not None:
+            raise NotImplementedError
+        deltas = self.compute_local_delta_states_batch([prev_obs], [cur_obs], [act])
+        extra_infos = {}
+        if vis_video and "top_down" in self.config.VO.REGRESS_MODEL.name:
+            d = torch.from_numpy(np.ascontiguousarray(cur_obs["depth"], dtype=np.float32)).to(self.device)
+            extra_infos["ego_top_down_map"] = self._top_down_view_generator.gen_top_down_view(d)
+        return list(deltas[0]), [0, 0, 0], extra_infos

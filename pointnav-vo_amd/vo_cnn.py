@@ -1,0 +1,262 @@
+"""HIP-backed VO models registered under the reference's names.
+
+Drop-in for the classes of /root/reference/pointnav_vo/vo/models/vo_cnn.py:182-561 and vo_cnn_act_embed.py:17-112:
+same registry names, same keyword-only constructor contract (base_trainer_with_vo.py:68-80), same ``state_dict``
+keys/shapes, same ``forward(observation_pairs[, actions]) -> Tensor[B, output_dim]``.
+
+The module tree only HOLDS parameters (so ``load_state_dict`` / ``state_dict`` / ``.to`` / ``.parameters`` behave
+like the reference's); the forward is one call into libpnvo.so (hand-written gfx950 kernels) on the caller's
+current HIP stream.  No torch ops run in the forward, and there is no CPU or eager fallback: a model that is not on
+a CUDA(ROCm) device, or whose HIP extension is missing, raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import model_spec as ms
+from .common_vars import DEFAULT_DELTA_STATE_SIZE, N_ACTS, TOP_DOWN_VIEW_PAIR_CHANNEL
+from .registry import baseline_registry
+
+
+class _Holder(nn.Module):
+    """Anonymous container so dotted state_dict names resolve exactly as in the reference module tree."""
+
+
+def _init_tensor(name, shape, fan_in=None):
+    t = torch.empty(shape)
+    if len(shape) == 4 or (len(shape) == 2 and name != "action_embedding.weight"):
+        if name == "output_head.1.weight":
+            nn.init.orthogonal_(t)                      # vo_cnn.py:226
+        else:
+            nn.init.kaiming_uniform_(t, a=math.sqrt(5))  # torch default of nn.Conv2d / nn.Linear
+    elif name == "action_embedding.weight":
+        nn.init.normal_(t)                              # torch default of nn.Embedding
+    elif len(shape) == 1:
+        leaf = name.rsplit(".", 1)[1]
+        is_gn = name.startswith("visual_encoder")
+        if leaf == "weight":
+            t.fill_(1.0)                                # GroupNorm gamma
+        elif is_gn or name == "output_head.1.bias":
+            t.zero_()                                   # GroupNorm beta; head bias (vo_cnn.py:227)
+        else:
+            bound = 1.0 / math.sqrt(fan_in) if fan_in else 0.0   # torch default of nn.Linear bias
+            t.uniform_(-bound, bound)
+    else:
+        t.zero_()
+    return t
+
+
+class VisualOdometryCNNBase(nn.Module):
+    """Mirror of VisualOdometryCNNBase (vo_cnn.py:182-233)."""
+
+    _ACT_EMBED = False
+
+    def __init__(self, *, observation_space, observation_size, hidden_size=512, resnet_baseplanes=32,
+                 backbone="resnet18", normalize_visual_inputs=False, output_dim=DEFAULT_DELTA_STATE_SIZE,
+                 dropout_p=0.2, after_compression_flat_size=2048, rgb_pair_channel=ms.RGB_PAIR_CHANNEL,
+                 depth_pair_channel=ms.DEPTH_PAIR_CHANNEL, discretized_depth_channels=0,
+                 top_down_view_pair_channel=TOP_DOWN_VIEW_PAIR_CHANNEL, n_acts=N_ACTS):
+        super().__init__()
+        self.cfg = ms.config_from_kwargs(
+            observation_space=observation_space, observation_size=observation_size, hidden_size=hidden_size,
+            resnet_baseplanes=resnet_baseplanes, backbone=backbone, normalize_visual_inputs=normalize_visual_inputs,
+            output_dim=output_dim, dropout_p=dropout_p, discretized_depth_channels=discretized_depth_channels,
+            after_compression_flat_size=after_compression_flat_size, rgb_pair_channel=rgb_pair_channel,
+            depth_pair_channel=depth_pair_channel, top_down_view_pair_channel=top_down_view_pair_channel,
+            act_embed=self._ACT_EMBED, n_acts=n_acts)
+        assert self.cfg.in_channels > 0, "visual odometry must not be blind"   # vo_cnn.py:67-68
+        self.dropout_p = dropout_p
+        self._spec = ms.state_dict_spec(self.cfg)
+        for name, shape in self._spec:
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if not hasattr(mod, p):
+                    mod.add_module(p, _Holder())
+                mod = getattr(mod, p)
+            fan_in = dict(self._spec).get(name[: -len("bias")] + "weight", (0, 0))[-1] if name.endswith(".bias") else None
+            t = _init_tensor(name, tuple(shape), fan_in)
+            if parts[-1] in ("_mean", "_var", "_count"):     # RunningMeanAndVar buffers (running_mean_and_var.py:16-18)
+                mod.register_buffer(parts[-1], torch.zeros(tuple(shape)))
+            else:
+                mod.register_parameter(parts[-1], nn.Parameter(t))
+        self._handle = None
+        self._handle_dev = None
+        self._loaded_sig = None
+
+    # ------------------------------------------------------------------ libpnvo plumbing
+    def _tensors(self):
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        return [(name, sd[name]) for name, _ in self._spec]
+
+    def _ensure_handle(self, device):
+        if self._handle is not None and self._handle_dev == device.index:
+            return
+        self._release()
+        c = self.cfg
+        cc = _lib.pnvo_config(width=c.width, height=c.height, n_rgb=c.n_rgb, n_depth=c.n_depth, n_dd=c.n_dd,
+                              n_tdv=c.n_tdv, baseplanes=c.baseplanes, hidden=c.hidden, out_dim=c.out_dim,
+                              normalize=int(c.normalize), act_embed=int(c.act_embed), n_acts=c.n_acts,
+                              flat_size=c.after_compression_flat_size, max_batch=0)
+        h = C.c_void_p()
+        _lib.check(_lib.lib.pnvo_create(C.byref(cc), int(device.index or 0), C.byref(h)))
+        self._handle, self._handle_dev, self._loaded_sig = h, device.index, None
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.lib.pnvo_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _sync_weights(self):
+        tensors = self._tensors()
+        sig = tuple((t.data_ptr(), t._version) for _, t in tensors)
+        if sig == self._loaded_sig:
+            return
+        blob = np.concatenate([t.detach().to("cpu", torch.float32).reshape(-1).numpy() for _, t in tensors])
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        toc = (_lib.pnvo_tensor_desc * len(tensors))()
+        off = 0
+        for i, (name, t) in enumerate(tensors):
+            toc[i].name = name.encode()
+            toc[i].offset = off
+            toc[i].ndim = t.dim()
+            for k, s in enumerate(t.shape):
+                toc[i].shape[k] = int(s)
+            off += t.numel()
+        _lib.check(_lib.lib.pnvo_load_weights(self._handle, blob.ctypes.data_as(C.c_void_p), blob.size, toc,
+                                              len(tensors)), self._handle)
+        self._loaded_sig = sig
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, observation_pairs, actions=None):
+        if self.training:
+            raise RuntimeError(
+                "pointnav_vo_amd VO models implement the deterministic eval() forward only (mode 'det', "
+                "base_trainer_with_vo.py:285-294); call .eval() first.  'rnd' mode / dropout is not provided.")
+        ref = next(self.parameters())
+        if ref.device.type != "cuda":
+            raise RuntimeError("pointnav_vo_amd VO models run on an MI355X only: move the model with .to('cuda') "
+                               "(there is no CPU fallback)")
+        dev = ref.device
+        self._ensure_handle(dev)
+        self._sync_weights()
+        c = self.cfg
+        ptrs, B, keep = [], None, []
+        for key, n in (("rgb", c.n_rgb), ("depth", c.n_depth), ("discretized_depth", c.n_dd), ("top_down_view", c.n_tdv)):
+            if n == 0:
+                ptrs.append(None)
+                continue
+            t = observation_pairs[key]
+            if t.device != dev:
+                raise RuntimeError(f"observation '{key}' is on {t.device}, model on {dev}")
+            t = t.to(torch.float32).contiguous()
+            if t.dim() != 4 or t.shape[1] != c.height or t.shape[2] != c.width or t.shape[3] != n:
+                raise ValueError(f"observation '{key}' has shape {tuple(t.shape)}, expected [B,{c.height},{c.width},{n}]")
+            B = t.shape[0] if B is None else B
+            assert t.shape[0] == B
+            keep.append(t)
+            ptrs.append(C.c_void_p(t.data_ptr()))
+        act_ptr = None
+        if c.act_embed:
+            if actions is None:
+                raise TypeError("forward() missing required argument 'actions' (act_embed model)")
+            a = actions.to(device=dev, dtype=torch.int64).contiguous().reshape(-1)
+            keep.append(a)
+            act_ptr = C.c_void_p(a.data_ptr())
+        out = torch.empty((B, c.out_dim), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(_lib.lib.pnvo_forward(self._handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], act_ptr, int(B),
+                                             C.c_void_p(out.data_ptr()), C.c_void_p(stream)), self._handle)
+        return out
+
+    # ------------------------------------------------------------------ introspection (tests / bench)
+    def tap(self, name, observation_pairs, actions=None):
+        """Run a forward and return (output, intermediate activation `name` as an NHWC tensor)."""
+        dev = next(self.parameters()).device
+        self._ensure_handle(dev)
+        first = next(v for v in observation_pairs.values())
+        B = first.shape[0]
+        shape = (C.c_int64 * 4)()
+        _lib.check(_lib.lib.pnvo_tap_shape(self._handle, name.encode(), int(B), shape), self._handle)
+        buf = torch.empty(tuple(int(s) for s in shape), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.pnvo_set_tap(self._handle, name.encode(), C.c_void_p(buf.data_ptr()), buf.numel()),
+                   self._handle)
+        try:
+            out = self.forward(observation_pairs, actions)
+        finally:
+            _lib.lib.pnvo_set_tap(self._handle, None, None, 0)
+        return out, buf
+
+    def timing(self, enable):
+        dev = next(self.parameters()).device
+        self._ensure_handle(dev)
+        _lib.check(_lib.lib.pnvo_timing_mode(self._handle, int(bool(enable))), self._handle)
+
+    def timing_read(self):
+        ent = (_lib.pnvo_kernel_time * 128)()
+        n = C.c_int(0)
+        _lib.check(_lib.lib.pnvo_timing_read(self._handle, ent, 128, C.byref(n)), self._handle)
+        return [dict(name=ent[i].name.decode(), launches=int(ent[i].launches), total_ms=float(ent[i].total_ms),
+                     flops=float(ent[i].flops), bytes=float(ent[i].bytes)) for i in range(min(n.value, 128))]
+
+
+class VisualOdometryCNNActEmbedBase(VisualOdometryCNNBase):
+    """Mirror of VisualOdometryCNNActEmbed (vo_cnn_act_embed.py:17-75): forward(observation_pairs, actions)."""
+    _ACT_EMBED = True
+
+
+def _variant(name, *, base=VisualOdometryCNNBase, need=(), forbid=(), dd_zero=False, widen=1, default_dd=0,
+             backbone_req="resnet18"):
+    """Build and register one reference variant; the asserts are the reference's own (vo_cnn.py:252-255 etc.)."""
+
+    def __init__(self, *, observation_space, observation_size, hidden_size=512, resnet_baseplanes=32,
+                 backbone="resnet18", normalize_visual_inputs=False, output_dim=DEFAULT_DELTA_STATE_SIZE,
+                 dropout_p=0.2, discretized_depth_channels=default_dd,
+                 top_down_view_pair_channel=TOP_DOWN_VIEW_PAIR_CHANNEL, n_acts=N_ACTS):
+        assert backbone == backbone_req
+        if dd_zero:
+            assert discretized_depth_channels == 0
+        for k in need:
+            assert k in observation_space
+        for k in forbid:
+            assert k not in observation_space
+        base.__init__(self, observation_space=observation_space, observation_size=observation_size,
+                      hidden_size=hidden_size, resnet_baseplanes=widen * resnet_baseplanes, backbone=backbone,
+                      normalize_visual_inputs=normalize_visual_inputs, output_dim=output_dim, dropout_p=dropout_p,
+                      discretized_depth_channels=discretized_depth_channels, after_compression_flat_size=2048,
+                      top_down_view_pair_channel=top_down_view_pair_channel, n_acts=n_acts)
+
+    cls = type("HIP_" + name, (base,), {"__init__": __init__, "__doc__": f"HIP drop-in for registry name '{name}'"})
+    return baseline_registry.register_vo_model(cls, name=name)
+
+
+DD, TDV = "discretized_depth", "top_down_view"
+VisualOdometryCNN = _variant("vo_cnn", forbid=(DD, TDV), dd_zero=True)                                   # :236
+VisualOdometryCNNRGB = _variant("vo_cnn_rgb", forbid=("depth", DD, TDV), dd_zero=True)                   # :269
+VisualOdometryCNNWider = _variant("vo_cnn_wider", forbid=(DD, TDV), dd_zero=True, widen=2)               # :303
+VisualOdometryCNNDeeper = _variant("vo_cnn_deeper", forbid=(DD, TDV), dd_zero=True,
+                                   backbone_req="resnet101")                                             # :339 (raises: resnet101 is SURVEY §8(f) rank 4)
+VisualOdometryCNNDiscretizedDepth = _variant("vo_cnn_rgb_d_dd", need=(DD,), forbid=(TDV,), default_dd=10)  # :373
+VisualOdometryCNN_RGB_D_TopDownView = _variant("vo_cnn_rgb_d_top_down", need=("rgb", "depth", TDV), forbid=(DD,))  # :408
+VisualOdometryCNN_RGB_DD_TopDownView = _variant("vo_cnn_rgb_dd_top_down", need=("rgb", DD, TDV), forbid=("depth",),
+                                                default_dd=10)                                           # :445
+VisualOdometryCNN_D_DD_TopDownView = _variant("vo_cnn_d_dd_top_down", need=("depth", DD, TDV), forbid=("rgb",),
+                                              default_dd=10)                                             # :483
+VisualOdometryCNNDiscretizedDepthTopDownView = _variant("vo_cnn_rgb_d_dd_top_down", need=(DD, TDV), default_dd=10)  # :521
+LegacyVisualOdometryCNNDiscretizedDepthTopDownView = _variant("vo_cnn_discretize_depth_top_down", need=(DD, TDV),
+                                                              default_dd=10)                             # :557
+VisualOdometryCNNActEmbed = _variant("vo_cnn_act_embed", base=VisualOdometryCNNActEmbedBase)             # act_embed.py:17
+VisualOdometryCNNWiderActEmbed = _variant("vo_cnn_wider_act_embed", base=VisualOdometryCNNActEmbedBase,
+                                          forbid=(DD, TDV), dd_zero=True, widen=2)                       # act_embed.py:78

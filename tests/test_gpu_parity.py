@@ -1,0 +1,203 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes -> libpnvo.so), against
+  (1) the committed golden fixtures captured from the imported reference,
+  (2) the oracle on the same seeded inputs,
+  (3) size-independent properties at BASELINE sizes (batch-composition invariance, determinism).
+Tolerance for the network outputs (fp32): per-pair ||out-ref||_2 / max(||ref||_2, 1e-2) < 1e-4 vs the fp64 reference
+(BASELINE.md §5).  Pre-processing (integer/bin work): bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODEL_FIXTURES, golden_case, load_golden, pair_rel_err
+from oracle import oracle
+from pointnav_vo_amd import _lib, synth
+from pointnav_vo_amd.registry import baseline_registry
+from pointnav_vo_amd import vo_cnn  # noqa: F401
+from pointnav_vo_amd.trainer import AttrDict, BaseRLTrainerWithVO, NormalizedDepth2TopDownViewHabitatTorch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def build(rec):
+    cfg, sd, obs, actions = golden_case(rec)
+    space = str(rec["obs_space"]).split(",")
+    kw = dict(observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
+              normalize_visual_inputs=True, output_dim=3, dropout_p=0.2)
+    if int(rec["dd_bins"]):
+        kw["discretized_depth_channels"] = int(rec["dd_bins"])
+    model = baseline_registry.get_vo_model(str(rec["model"]))(**kw)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model = model.to(dev()).eval()
+    tobs = {k: torch.from_numpy(v).to(dev()) for k, v in obs.items()}
+    tact = torch.from_numpy(actions).to(dev()) if actions is not None else None
+    return model, cfg, sd, obs, tobs, actions, tact
+
+
+def test_native_library_is_the_one_running():
+    assert "gfx950" in _lib.version()
+    with open("/proc/self/maps") as f:
+        assert "libpnvo.so" in f.read()
+
+
+@pytest.mark.parametrize("fname", MODEL_FIXTURES)
+def test_forward_matches_reference_golden(fname):
+    rec = load_golden(fname)
+    model, cfg, sd, obs, tobs, actions, tact = build(rec)
+    with torch.no_grad():
+        out = (model(tobs, tact) if tact is not None else model(tobs)).cpu().numpy()
+    assert out.shape == rec["out64"].shape and np.isfinite(out).all()
+    err = pair_rel_err(out, rec["out64"])
+    assert err.max() < TOL, (fname, err)
+    # and against the oracle evaluated here on the regenerated inputs
+    ref = oracle.forward(sd, obs, ngroups=cfg.ngroups, dtype=np.float64, actions=actions)
+    assert pair_rel_err(out, ref).max() < TOL
+
+
+def test_every_intermediate_activation_matches_reference():
+    rec = load_golden("model_default_45x37_b3.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    names = [k[4:] for k in rec if k.startswith("tap/")]
+    assert len(names) >= 12
+    for name in names:
+        want = rec[f"tap/{name}"]
+        with torch.no_grad():
+            _, got = model.tap(name, tobs)
+        got = got.cpu().numpy()
+        if name == "hidden":
+            got = got.reshape(want.shape[0], -1)
+        got = got[..., : want.shape[-1]]
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        scale = np.abs(want).max() + 1e-6
+        assert np.abs(got - want).max() / scale < 2e-5, (name, np.abs(got - want).max(), scale)
+
+
+def test_deterministic_and_batch_composition_invariant():
+    rec = load_golden("model_default_341x192_b2.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    big = synth.make_obs_pairs(5, cfg.height, cfg.width, observation_space=str(rec["obs_space"]).split(","), seed=77)
+    tbig = {k: torch.from_numpy(v).to(dev()) for k, v in big.items()}
+    with torch.no_grad():
+        a = model(tbig).cpu().numpy()
+        b = model(tbig).cpu().numpy()
+        np.testing.assert_array_equal(a, b)                       # fixed-order reductions: bit-reproducible
+        one = model({k: v[3:4] for k, v in tbig.items()}).cpu().numpy()
+        perm = [4, 2, 0, 3, 1]
+        p = model({k: v[perm] for k, v in tbig.items()}).cpu().numpy()
+    assert pair_rel_err(one, a[3:4]).max() < 1e-5                 # pairs are independent (GroupNorm is per sample)
+    assert pair_rel_err(p, a[perm]).max() < 1e-5
+
+
+def test_full_batch_256_properties():
+    """BASELINE configs[1] size: B=256 at 341x192.  Checked through size-independent properties: every pair of the
+    big batch equals the same pair evaluated in a small batch, and a few pairs equal the fp64 oracle."""
+    import bench
+    d = dev()
+    model, sd = bench.build_model(d)
+    obs = bench.make_inputs(256, d, rank=0)
+    with torch.no_grad():
+        out = model(obs)
+        idx = [0, 1, 100, 255]
+        sub = model({k: v[idx] for k, v in obs.items()})
+        torch.cuda.synchronize()
+    out, sub = out.cpu().numpy(), sub.cpu().numpy()
+    assert np.isfinite(out).all()
+    assert pair_rel_err(sub, out[idx]).max() < 1e-5
+    ref = oracle.forward(sd, {k: v[idx[:2]].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups,
+                         dtype=np.float64)
+    assert pair_rel_err(out[idx[:2]], ref).max() < TOL
+    # the synthetic dd/tdv inputs were produced by the HIP pre-processing kernels: check them against the oracle too
+    d0 = obs["depth"][0].cpu().numpy()
+    dd_ref, _ = oracle.discretize_depth(d0[..., 0], 10)
+    np.testing.assert_array_equal(obs["discretized_depth"][0, ..., :10].cpu().numpy(), dd_ref)
+    c = oracle.topdown_consts(192, 341, 70, 0.1, 10.0)
+    np.testing.assert_array_equal(obs["top_down_view"][0, ..., 1].cpu().numpy(), oracle.topdown_view(d0[..., 1], c)[..., 0])
+
+
+# ----------------------------------------------------------------------------- pre-processing (bit-exact)
+def test_discretize_depth_bit_exact():
+    rec = load_golden("preproc.npz")
+    depth = torch.from_numpy(rec["dd_depth"]).to(dev())
+    t = BaseRLTrainerWithVO(AttrDict(VO=dict(REGRESS_MODEL=dict(discretized_depth_channels=int(rec["dd_bins"])))), dev())
+    dd = t._discretize_depth_func(depth).cpu().numpy()
+    assert dd.shape == rec["dd_depth"].shape + (10,)
+    assert dd.sum() == depth.numel()                              # the reference's assert (:163)
+    np.testing.assert_array_equal(dd.argmax(-1).astype(np.uint8), rec["dd_index"])
+    with pytest.raises(AssertionError):
+        t._discretize_depth_func(depth + 1.5)
+
+
+TDV_CASES = ["full_uniform", "full_border", "full_near", "full_fp32", "full_zero", "full_one_pixel",
+             "full_top_band", "small_odd", "small_border"]
+
+
+@pytest.mark.parametrize("case", TDV_CASES)
+def test_topdown_view_bit_exact(case):
+    rec = load_golden("preproc.npz")
+    d = rec[f"tdv_in/{case}"].astype(np.float32)
+    H, W = d.shape[:2]
+    gen = NormalizedDepth2TopDownViewHabitatTorch(min_depth=0.1, max_depth=10.0, vis_size_h=H, vis_size_w=W, hfov_rad=70)
+    np.testing.assert_array_equal(np.array(gen._consts[:7], dtype=np.float32), rec[f"tdv_consts/{H}x{W}"][:7])
+    out = gen.gen_top_down_view(torch.from_numpy(d).to(dev())).cpu().numpy()
+    assert out.shape == (H, W, 1)
+    want = np.zeros(H * W, np.float32)
+    want[rec[f"tdv_nz/{case}"]] = rec[f"tdv_val/{case}"]
+    np.testing.assert_array_equal(out.reshape(-1), want)
+
+
+def test_topdown_view_batched_strided_matches_single():
+    H, W = 192, 341
+    gen = NormalizedDepth2TopDownViewHabitatTorch(min_depth=0.1, max_depth=10.0, vis_size_h=H, vis_size_w=W, hfov_rad=70)
+    pair = torch.from_numpy(np.stack([synth.make_raw_obs(H, W, seed=9, index=i, zero_border=3 * (i % 2))["depth"][..., 0]
+                                      for i in range(6)]).reshape(3, 2, H, W).transpose(0, 2, 3, 1).copy()).to(dev())
+    tdv = torch.zeros((3, H, W, 2), device=dev())
+    for k in range(2):
+        gen.gen_top_down_view_batch(pair[..., k], out=tdv, out_channel=k)
+    c = oracle.topdown_consts(H, W, 70, 0.1, 10.0)
+    for b in range(3):
+        for k in range(2):
+            np.testing.assert_array_equal(tdv[b, ..., k].cpu().numpy(), oracle.topdown_view(pair[b, ..., k].cpu().numpy(), c)[..., 0])
+
+
+# ----------------------------------------------------------------------------- the drop-in boundary (a1 / a13)
+def make_trainer(rec):
+    cfg = AttrDict(
+        VO=dict(VO_TYPE="REGRESS", OBS_TRANSFORM="none", VIS_SIZE_W=int(rec["width"]), VIS_SIZE_H=int(rec["height"]),
+                REGRESS_MODEL=dict(name="vo_cnn_rgb_d_dd_top_down", visual_backbone="resnet18", hidden_size=512,
+                                   visual_type=["rgb", "depth", "discretized_depth", "top_down_view"], dropout_p=0.2,
+                                   discretize_depth="hard", discretized_depth_channels=int(rec["bins"]),
+                                   regress_type="sep_act", mode="det", rnd_mode_n=10, pretrained=False)),
+        TASK_CONFIG=dict(SIMULATOR=dict(DEPTH_SENSOR=dict(MIN_DEPTH=0.1, MAX_DEPTH=10.0, HFOV=70))))
+    t = BaseRLTrainerWithVO(cfg, dev())
+    t._set_up_vo_obs_transformer()
+    t._setup_vo_model(cfg)
+    from pointnav_vo_amd import model_spec as ms
+    for k in ("forward", "left", "right"):
+        sd = synth.make_state_dict(ms.state_dict_spec(t.vo_model[k].cfg), seed=int(rec[f"seed_{k}"]))
+        t.vo_model[k].load_state_dict({n: torch.from_numpy(np.array(v)) for n, v in sd.items()})
+    return t
+
+
+def test_compute_local_delta_states_from_vo_matches_reference():
+    rec = load_golden("boundary.npz")
+    t = make_trainer(rec)
+    assert list(t.vo_model.keys()) == ["forward", "left", "right"]       # base_trainer_with_vo.py:62
+    H, W = int(rec["height"]), int(rec["width"])
+    prevs, curs, acts = [], [], []
+    for (pi, ci, act, zb), want in zip(rec["steps"], rec["deltas"]):
+        prev = synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(pi), zero_border=int(zb))
+        cur = synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(ci), zero_border=int(zb))
+        deltas, std, extra = t._compute_local_delta_states_from_vo(prev, cur, int(act))
+        assert isinstance(deltas, list) and len(deltas) == 3 and std == [0, 0, 0] and extra == {}
+        assert pair_rel_err(np.array(deltas)[None], want[None]).max() < TOL, (deltas, want)
+        prevs.append(prev), curs.append(cur), acts.append(int(act))
+    # batched sibling: same numbers in one call
+    batch = t.compute_local_delta_states_batch(prevs, curs, acts)
+    assert pair_rel_err(batch, rec["deltas"]).max() < TOL
