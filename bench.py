@@ -65,19 +65,27 @@ def make_inputs(B, dev, rank):
 def cpu_baseline(sd, ngroups, budget_s=15.0):
     """The oracle (CPU port of the reference forward, fp32, all host cores) on a bounded sample of the same workload."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
-    oracle.set_threads(cores)
-    obs1 = synth.make_obs_pairs(1, H, W, observation_space=SPACE, dd_bins=BINS, seed=99)
-    t0 = time.perf_counter()
-    oracle.forward(sd, obs1, ngroups=ngroups, dtype=np.float32)
-    t1 = time.perf_counter() - t0
-    n = int(max(2, min(32, budget_s / max(t1, 1e-3))))
+    cores = oracle.usable_cores()
+    obs1 = synth.make_obs_pairs(2, H, W, observation_space=SPACE, dd_bins=BINS, seed=99)
+    oracle.forward(sd, obs1, ngroups=ngroups, dtype=np.float32)            # page-in / warm-up
+    best = None
+    for thr in sorted({min(cores, t) for t in (8, 16, 32, 64, 128, cores)}):   # OpenMP team size that serves best
+        oracle.set_threads(thr)
+        t0 = time.perf_counter()
+        oracle.forward(sd, obs1, ngroups=ngroups, dtype=np.float32)
+        t = (time.perf_counter() - t0) / 2
+        if best is None or t < best[0]:
+            best = (t, thr)
+    t1, thr = best
+    oracle.set_threads(thr)
+    n = int(max(2, min(64, budget_s / max(t1, 1e-3))))
     obs = synth.make_obs_pairs(n, H, W, observation_space=SPACE, dd_bins=BINS, seed=100)
     t0 = time.perf_counter()
     oracle.forward(sd, obs, ngroups=ngroups, dtype=np.float32)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frame-pairs/s", "cores": oracle.max_threads(), "kind": "port",
-            "sample": f"{n} pairs, one batched fp32 forward of the oracle (OpenMP, {oracle.max_threads()} threads)"}
+    return {"value": n / dt, "unit": "frame-pairs/s", "cores": thr, "kind": "port", "host_cores": cores,
+            "sample": f"{n} pairs, one batched fp32 forward of the oracle C port (OpenMP, {thr} threads, "
+                      f"best of several team sizes on a {cores}-core host)"}
 
 
 def main():

@@ -37,12 +37,22 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def _lib(name):
     if name not in _LIBS:
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
         _LIBS[name] = C.CDLL(path)
+        if name != "liboracle_pre.so":
+            # default: a moderate team; a 256-thread OpenMP team on a big host mostly spins (callers may raise it)
+            _LIBS[name].orc_set_threads(min(usable_cores(), 16))
     return _LIBS[name]
 
 

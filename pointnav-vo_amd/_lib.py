@@ -6,6 +6,11 @@ path never routes through oracle/ or any CPU implementation.
 import ctypes as C
 import os
 
+# torch bundles its own ROCm runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  It must be the FIRST HIP
+# runtime mapped into the process, so that libpnvo.so's NEEDED libamdhip64.so.7 resolves to the copy torch uses:
+# two HIP/HSA runtimes in one process do not both get the GPU ("no ROCm-capable device is detected").
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpnvo.so")
 

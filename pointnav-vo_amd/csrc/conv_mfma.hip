@@ -25,6 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define PNVO_OOB 0x80000000u   // byte offset >= num_records of every descriptor => buffer load returns 0, store dropped
 
@@ -36,8 +37,14 @@ __device__ __forceinline__ unsigned clamp_records(long bytes) {
   return (unsigned)(bytes > 0x7FFFF000L ? 0x7FFFF000L : (bytes < 0 ? 0 : bytes));
 }
 
-template <int MT, int NT, bool XF>
+// MODE 0: A = x as stored (already final activations)
+// MODE 1: A = relu(x * scale[n,c] + shift[n,c])   — GroupNorm+ReLU of the producer layer, per-sample tables
+// MODE 2: A gathered from the observation tensors (rgb | depth | discretized_depth | top_down_view) in 2-channel
+//         pieces and whitened on the fly, x * scale[c] + shift[c] — the reference's input assembly + /255 +
+//         RunningMeanAndVar (vo_cnn.py:110-176) fused into the stem's operand fetch; no [B,H,W,30] tensor exists.
+template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
+  constexpr bool XF = (MODE != 0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WM = MT * 32;
   const int lane = threadIdx.x & 63;
@@ -57,8 +64,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   if (XF) {
     long last = wg_m0 + 4 * WM - 1;
     if (last > M - 1) last = M - 1;
-    n_lo = (int)(wg_m0 / P);
-    const int cnt = (int)(last / P) - n_lo + 1;
+    n_lo = (MODE == 2) ? 0 : (int)(wg_m0 / P);
+    const int cnt = (MODE == 2) ? 1 : (int)(last / P) - n_lo + 1;
     tab = cnt * CIN;
     use_lds = (2 * tab <= p.lds_floats);
     if (use_lds) {
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     const int n = (int)(m / P);
     const int rem = (int)(m - (long)n * P);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    nrel[mt] = n - n0;
+    nrel[mt] = (MODE == 2) ? n : n - n0;     // MODE 2 keeps the absolute sample index (pixel index into the sources)
     hi0[mt] = ho * p.stride - p.pad;
     wi0[mt] = wo * p.stride - p.pad;
     pbase[mt] = (unsigned)(((long)(n - n0) * HWC + 4 * h) * 4);
@@ -117,7 +124,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     for (int mt = 0; mt < MT; ++mt) {
       const int hi = hi0[mt] + l_kh, wi = wi0[mt] + l_kw;
       const bool ok = vm[mt] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      toff[mt] = ok ? pbase[mt] + (unsigned)((hi * p.W + wi) * CIN) * 4u : PNVO_OOB;
+      if (MODE == 2)
+        toff[mt] = ok ? (unsigned)((nrel[mt] * p.H + hi) * p.W + wi) : PNVO_OOB;
+      else
+        toff[mt] = ok ? pbase[mt] + (unsigned)((hi * p.W + wi) * CIN) * 4u : PNVO_OOB;
     }
   };
   set_tap();
@@ -128,7 +138,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     okm = 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      a[mt] = buf_load4(rx, toff[mt], (unsigned)l_j * 32u);
+      if (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const SrcPiece e0 = p.pieces[l_j][0][q], e1 = p.pieces[l_j][1][q];   // wave-uniform (scalar loads)
+          const float *base = h ? e1.base : e0.base;
+          const int nch = h ? e1.nch : e0.nch, co = h ? e1.choff : e0.choff;
+          const float *addr = (toff[mt] != PNVO_OOB && base != nullptr) ? base + ((long)toff[mt] * nch + co) : p.zero_page;
+          const f32x2 v = *reinterpret_cast<const f32x2 *>(addr);
+          a[mt][2 * q] = v[0];
+          a[mt][2 * q + 1] = v[1];
+        }
+      } else {
+        a[mt] = buf_load4(rx, toff[mt], (unsigned)l_j * 32u);
+      }
       okm |= (toff[mt] != PNVO_OOB ? 1u : 0u) << mt;
     }
 #pragma unroll
@@ -153,18 +176,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
         f32x4 sc, sh;
         const int c = 8 * jc + 4 * h;
         if (use_lds) {
-          const int k = (n0 + nrel[mt] - n_lo) * CIN + c;
+          const int k = (MODE == 2) ? c : (n0 + nrel[mt] - n_lo) * CIN + c;
           sc = *reinterpret_cast<const f32x4 *>(lds + k);
           sh = *reinterpret_cast<const f32x4 *>(lds + tab + k);
         } else {
-          sc = *reinterpret_cast<const f32x4 *>(p.in_scale + (long)(n0 + nrel[mt]) * CIN + c);
-          sh = *reinterpret_cast<const f32x4 *>(p.in_shift + (long)(n0 + nrel[mt]) * CIN + c);
+          const long row = (MODE == 2) ? 0 : (long)(n0 + nrel[mt]);
+          sc = *reinterpret_cast<const f32x4 *>(p.in_scale + row * CIN + c);
+          sh = *reinterpret_cast<const f32x4 *>(p.in_shift + row * CIN + c);
         }
         const bool ok = (okm >> mt) & 1u;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float v = fmaxf(__builtin_fmaf(a[mt][t], sc[t], sh[t]), 0.f);
-          a[mt][t] = ok ? v : 0.f;   // zero padding is applied AFTER the producer's GN+ReLU
+          float v = __builtin_fmaf(a[mt][t], sc[t], sh[t]);
+          if (MODE == 1) v = fmaxf(v, 0.f);
+          a[mt][t] = ok ? v : 0.f;   // zero padding is applied AFTER the producer's GN+ReLU / the whitening
         }
       }
     }
@@ -300,7 +325,10 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
   dim3 grid((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)(a.COUTP / 32 / NT));
   ConvArgs p = a;
   size_t lds_bytes = 0;
-  if (a.in_scale != nullptr) {
+  if (a.src_mode) {
+    p.lds_floats = 2 * a.CIN;
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 2>), grid, dim3(256), (size_t)p.lds_floats * 4, s, p);
+  } else if (a.in_scale != nullptr) {
     const long cnt_max = (4L * WM + P - 2) / P + 1;
     const long need = cnt_max * a.CIN * 2;
     if (need * 4 <= 48 * 1024) {
@@ -309,10 +337,10 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
     } else {
       p.lds_floats = 0;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, true>), grid, dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 1>), grid, dim3(256), lds_bytes, s, p);
   } else {
     p.lds_floats = 0;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, false>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0>), grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }

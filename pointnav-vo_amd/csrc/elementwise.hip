@@ -3,9 +3,21 @@
 // All are pure streaming kernels: 16-byte accesses per lane, consecutive lanes on consecutive addresses.
 #include "pnvo_internal.h"
 
+// One rounding per source-level operation in this file: the top-down view reproduces the reference's float32 op
+// sequence bit for bit (floor/ceil of the results pick histogram bins), so the compiler must not fuse a*b+c.
+// Kernels that WANT an fma say so with __builtin_fmaf.
+#pragma clang fp contract(off)
+
 namespace pnvo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// single-rounding float32 primitives (HIP's __fmul_rn/__fadd_rn are header inlines that still carry the `contract`
+// fast-math flag and get fused into v_fma by the backend; these, defined under contract(off), do not)
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }   // correctly rounded (hipcc default)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Input assembly + RunningMeanAndVar (vo_cnn.py:110-176, running_mean_and_var.py:62-63):
@@ -36,8 +48,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleDev a) {
     float v = 0.f;
     if (s >= 0) {
       v = a.src[s][pix * a.nsrc[s] + a.sch[c]];
-      if (s == 0) v = __fdiv_rn(v, 255.0f);
-      if (a.normalize) v = __fdiv_rn(__fsub_rn(v, a.mean[c]), a.stdev[c]);
+      if (s == 0) v = div_rn(v, 255.0f);
+      if (a.normalize) v = div_rn(sub_rn(v, a.mean[c]), a.stdev[c]);
     }
     o[t] = v;
   }
@@ -85,11 +97,11 @@ hipError_t launch_assemble(const AssembleArgs &h, hipStream_t s) {
 // (torch.nn.GroupNorm, eps inside the sqrt; used at resnet.py:39,42,165,194 and vo_cnn.py:93).
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int slots, int CP, int C, int G, long P,
                                                         int WM, const float *gamma, const float *beta, float eps,
-                                                        float *scale, float *shift) {
+                                                        float *scale, float *shift, int fixed_ns) {
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const long t0 = ((long)n * P) / WM, t1 = ((long)(n + 1) * P - 1) / WM;
-  const int ns = (int)(t1 - t0 + 1);
+  const int ns = fixed_ns > 0 ? fixed_ns : (int)(t1 - t0 + 1);
   double s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < ns * cpg; k += 64) {
     const int slot = k / cpg, c = g * cpg + k % cpg;
@@ -117,9 +129,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
 
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
-                              hipStream_t s) {
+                              hipStream_t s, int fixed_ns) {
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, stats, slots, CP, C, G, P, WM, gamma,
-                     beta, eps, scale, shift);
+                     beta, eps, scale, shift, fixed_ns);
   return hipGetLastError();
 }
 
@@ -308,7 +320,7 @@ __device__ __forceinline__ float blur_row(const float *d, long pstride, int W, i
   const float m = d[((long)r * W + c) * pstride];
   const float l = c > c0 ? d[((long)r * W + c - 1) * pstride] : 0.f;
   const float rr = c < c1 ? d[((long)r * W + c + 1) * pstride] : 0.f;
-  return __fadd_rn(__fmul_rn(m, 0.5f), __fmul_rn(__fadd_rn(l, rr), 0.25f));
+  return add_rn(mul_rn(m, 0.5f), mul_rn(add_rn(l, rr), 0.25f));
 }
 
 struct TopdownConsts {
@@ -336,17 +348,17 @@ __global__ __launch_bounds__(256) void topdown_project_kernel(const float *depth
   const float m = blur_row(d, pstride, W, r, c, c0, c1);
   const float u = r > r0 ? blur_row(d, pstride, W, r - 1, c, c0, c1) : 0.f;
   const float dn = r < r1 ? blur_row(d, pstride, W, r + 1, c, c0, c1) : 0.f;
-  const float db = __fadd_rn(__fmul_rn(m, 0.5f), __fmul_rn(__fadd_rn(u, dn), 0.25f));
+  const float db = add_rn(mul_rn(m, 0.5f), mul_rn(add_rn(u, dn), 0.25f));
   const float kinv00 = tc.c[0], kinv02 = tc.c[1], min_x = tc.c[2], x_den = tc.c[3], dscale = tc.c[4],
               z_den = tc.c[5], min_depth = tc.c[6];
-  const float uu = __fadd_rn(__fadd_rn((float)i, (float)c0), 0.5f);        // :626-638
-  const float xc = __fadd_rn(__fmul_rn(kinv00, uu), kinv02);               // :648-650 (row 0 of Kinv @ [u,v,1])
-  const float z = __fadd_rn(__fmul_rn(db, dscale), min_depth);            // :558-560
-  const float X = __fmul_rn(xc, z);                                        // :655
-  const float xn = __fdiv_rn(__fsub_rn(X, min_x), x_den);                  // :676-678
-  const float zn = __fdiv_rn(__fsub_rn(z, min_depth), z_den);              // :679-681
-  const float rf = __fsub_rn((float)H, ceilf(__fmul_rn((float)H, zn)));    // :686-688
-  const float cf = floorf(__fmul_rn((float)W, xn));                        // :689
+  const float uu = add_rn(add_rn((float)i, (float)c0), 0.5f);        // :626-638
+  const float xc = add_rn(mul_rn(kinv00, uu), kinv02);               // :648-650 (row 0 of Kinv @ [u,v,1])
+  const float z = add_rn(mul_rn(db, dscale), min_depth);            // :558-560
+  const float X = mul_rn(xc, z);                                        // :655
+  const float xn = div_rn(sub_rn(X, min_x), x_den);                  // :676-678
+  const float zn = div_rn(sub_rn(z, min_depth), z_den);              // :679-681
+  const float rf = sub_rn((float)H, ceilf(mul_rn((float)H, zn)));    // :686-688
+  const float cf = floorf(mul_rn((float)W, xn));                        // :689
   const long row = (long)rf, col = (long)cf;                               // .long() (:692)
   if (row >= 0 && row < H && col >= 0 && col < W) atomicAdd(&cnt[((long)n * H + row) * W + col], 1);
 }
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256) void topdown_normalize_kernel(int H, int W, To
   float *o = out + (long)n * ofstride;
   for (int p = threadIdx.x; p < H * W; p += 256) {
     float v = 0.f;
-    if (mx > 0) v = fminf(__fdiv_rn((float)c[p], (float)mx), 1.0f);   // :543-554
+    if (mx > 0) v = fminf(div_rn((float)c[p], (float)mx), 1.0f);   // :543-554
     o[(long)p * opstride] = v;
   }
 }

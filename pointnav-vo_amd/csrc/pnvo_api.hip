@@ -46,7 +46,13 @@ struct pnvo_model_s {
   std::vector<Layer> convs;          // stem, residual stages in execution order, compression
   Layer fc, head;
   float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
-  std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments
+  std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments (reference channel order)
+  // fused stem: K-order of the stem = observation tensors concatenated (rgb | depth | dd | tdv), 2-channel pieces
+  std::vector<int> stem_ref_of_new;  // new channel -> reference channel (vo_cnn.py:169-174 order), -1 = pad
+  std::vector<int> stem_tensor_of_new, stem_ch_of_new;
+  float *stem_sc = nullptr, *stem_sh = nullptr, *zero_page = nullptr;   // device: whitening table in the new order
+  float *stem_wpk16 = nullptr;       // stem weights packed for the LDS-staged 16x16x4 kernel
+  int CPL = 0;                       // stem channels per pixel in LDS (C rounded up to 16)
 
   int cap = 0;                       // batch the workspace is sized for
   float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
@@ -112,10 +118,36 @@ void build_plan(pnvo_model_s *m) {
   const pnvo_config &c = m->cfg;
   m->C = c.n_rgb + c.n_depth + c.n_dd + c.n_tdv;
   m->CP = rup(m->C, 8);
+  m->CPL = rup(m->C, 16);
   m->Hs = halve(c.height);
   m->Ws = halve(c.width);
   m->Hp = halve(m->Hs);
   m->Wp = halve(m->Ws);
+  {
+    // reference order: [prev_rgb, prev_d, prev_dd, prev_tdv, cur_rgb, cur_d, cur_dd, cur_tdv]; tensor t holds
+    // [prev half | cur half] on its channel axis (vo_cnn.py:114-174)
+    const int n[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+    int prev_off[4], half = 0;
+    for (int t = 0; t < 4; ++t) {
+      prev_off[t] = half;
+      half += n[t] / 2;
+    }
+    m->stem_ref_of_new.clear();
+    m->stem_tensor_of_new.clear();
+    m->stem_ch_of_new.clear();
+    for (int t = 0; t < 4; ++t)
+      for (int ch = 0; ch < n[t]; ++ch) {
+        const int hn = n[t] / 2;
+        m->stem_ref_of_new.push_back(ch < hn ? prev_off[t] + ch : half + prev_off[t] + (ch - hn));
+        m->stem_tensor_of_new.push_back(t);
+        m->stem_ch_of_new.push_back(ch);
+      }
+    while ((int)m->stem_ref_of_new.size() < m->CP) {
+      m->stem_ref_of_new.push_back(-1);
+      m->stem_tensor_of_new.push_back(-1);
+      m->stem_ch_of_new.push_back(0);
+    }
+  }
   const int g = c.baseplanes / 2;
   const std::string bb = "visual_encoder.backbone.";
   m->convs.clear();
@@ -263,14 +295,14 @@ int ensure_workspace(pnvo_handle m, int B) {
   const size_t npix = (size_t)B * c.height * c.width;
   const size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes;   // largest residual-stage tensor
   int maxc = m->comp_cp;
-  size_t st = 0;
+  size_t st = (size_t)B * stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs) * m->convs[0].coutp * 2;   // LDS-staged stem
   for (const Layer &l : m->convs) {
     if (l.coutp > maxc) maxc = l.coutp;
     const size_t s = stats_floats(l, B);
     if (s > st) st = s;
   }
   auto alloc = [&](float *&p, size_t n) -> hipError_t { return hipMalloc((void **)&p, n * sizeof(float)); };
-  HIPCHK(m, alloc(m->xin, npix * m->CP));
+  (void)npix;   // the assembled [B,H,W,CP] input is only materialised for the "input" tap (allocated lazily)
   HIPCHK(m, alloc(m->stem_raw, (size_t)B * m->Hs * m->Ws * c.baseplanes));
   HIPCHK(m, alloc(m->bufY[0], act));
   HIPCHK(m, alloc(m->bufY[1], act));
@@ -348,9 +380,24 @@ int maybe_tap(pnvo_handle m, const char *name, const float *src, size_t n, hipSt
 // One conv + (optionally) the GroupNorm statistics finalisation that follows it.
 int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
              float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
-             hipStream_t s) {
+             hipStream_t s, const float *const *src = nullptr) {
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
+  if (src != nullptr) {          // fused stem: gather A from the observation tensors
+    const int nsrc[4] = {m->cfg.n_rgb, m->cfg.n_depth, m->cfg.n_dd, m->cfg.n_tdv};
+    a.src_mode = 1;
+    a.zero_page = m->zero_page;
+    for (int j = 0; j < m->CP / 8; ++j)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int q = 0; q < 2; ++q) {
+          const int nc = 8 * j + 4 * hh + 2 * q;
+          const int tn = m->stem_tensor_of_new[nc];
+          SrcPiece &pc = a.pieces[j][hh][q];
+          pc.base = tn >= 0 ? src[tn] : nullptr;
+          pc.nch = tn >= 0 ? nsrc[tn] : 0;
+          pc.choff = m->stem_ch_of_new[nc];
+        }
+  }
   a.x = x;
   a.wpk = l.wpk;
   a.y = y;
@@ -449,6 +496,35 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
   }
   for (Layer &l : h->convs)
     if ((rc = load_conv(h, t, l, true)) != PNVO_OK) return rc;
+  {
+    // fused stem: re-pack conv1 with its input channels in observation-tensor order, and fold /255 and the
+    // RunningMeanAndVar whitening into x*sc+sh:  (x/255 - mean)/std = x * 1/(255 std) - mean/std
+    Layer &st = h->convs[0];
+    const float *w = find_tensor(h, t, st.name + ".weight", {st.cout, st.cin, st.k, st.kw}, &rc);
+    if (!w) return rc;
+    const int T = st.k * st.kw;
+    std::vector<float> wp((size_t)st.cout * h->CP * T, 0.f), sc(h->CPL, 0.f), sh(h->CPL, 0.f);
+    for (int nc = 0; nc < h->CP; ++nc) {
+      const int rc_ = h->stem_ref_of_new[nc];
+      if (rc_ < 0) continue;
+      for (int o = 0; o < st.cout; ++o)
+        std::memcpy(&wp[((size_t)o * h->CP + nc) * T], &w[((size_t)o * st.cin + rc_) * T], sizeof(float) * T);
+      const double sd = (double)h->stdev[rc_], mu = (double)h->mean[rc_];
+      const double div = (h->stem_tensor_of_new[nc] == 0) ? 255.0 : 1.0;
+      sc[nc] = (float)(1.0 / (div * sd));
+      sh[nc] = (float)(-mu / sd);
+    }
+    std::vector<float> pk;
+    pack_conv_weight_cinp(wp.data(), st.cout, h->CP, h->CP, st.k, st.kw, pk);
+    if ((rc = upload(h, st.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
+    if ((rc = upload(h, h->stem_sc, sc.data(), sc.size())) != PNVO_OK) return rc;
+    if ((rc = upload(h, h->stem_sh, sh.data(), sh.size())) != PNVO_OK) return rc;
+    std::vector<float> z(64, 0.f);
+    if ((rc = upload(h, h->zero_page, z.data(), z.size())) != PNVO_OK) return rc;
+    std::vector<float> pk16((size_t)49 * h->CPL * st.cout);
+    pack_stem_weight(wp.data(), st.cout, h->CP, h->CPL, pk16.data());
+    if ((rc = upload(h, h->stem_wpk16, pk16.data(), pk16.size())) != PNVO_OK) return rc;
+  }
   // Linear(flat[+embed] -> hidden): visual columns become the fh x fw "conv"; the embedding columns fold into a
   // per-action bias row:  bias[a][o] = b[o] + sum_e W[o][flat+e] * emb[a][e]   (vo_cnn_act_embed.py:63-72)
   const int flat = h->comp_c * h->fh * h->fw;
@@ -508,8 +584,9 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
   if (rc != PNVO_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
 
-  // (a4+a5) input assembly + whitening
-  {
+  // (a4+a5+a6) input assembly + /255 + whitening are fused into the stem conv's operand fetch (MODE 2 of
+  // conv_mfma_kernel): the [B,H,W,30] tensor of the reference (vo_cnn.py:174-176) is never materialised.
+  if (m->tap_dst != nullptr && m->tap_name == "input") {   // introspection only: materialise it for the tap
     AssembleArgs a;
     a.src[0] = rgb;
     a.src[1] = depth;
@@ -524,18 +601,59 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
     a.C = m->C;
     a.CP = m->CP;
     a.npix = (long)B * c.height * c.width;
+    free_dev(m->xin);
+    HIPCHK(m, hipMalloc((void **)&m->xin, (size_t)a.npix * m->CP * sizeof(float)));
     a.out = m->xin;
-    Timed t(m, s, "assemble_whiten", 0.0, 4.0 * a.npix * (m->C + m->CP));
     HIPCHK(m, launch_assemble(a, s));
+    if ((rc = maybe_tap(m, "input", m->xin, (size_t)B * c.height * c.width * m->CP, s)) != PNVO_OK) return rc;
   }
-  if ((rc = maybe_tap(m, "input", m->xin, (size_t)B * c.height * c.width * m->CP, s)) != PNVO_OK) return rc;
-
-  // (a6) stem conv + GN statistics
   size_t li = 0;
   const Layer &stem = m->convs[li++];
-  if ((rc = run_conv(m, stem, B, m->xin, nullptr, nullptr, m->stem_raw, stem.coutp, m->ssA, nullptr, nullptr, 0, s)) !=
-      PNVO_OK)
-    return rc;
+  const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
+  if (lds_stem) {
+    const float *src[4] = {rgb, depth, dd, tdv};
+    const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+    StemArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < m->CPL / 8; ++j)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int q = 0; q < 2; ++q) {
+          const int nc = 8 * j + 4 * hh + 2 * q;
+          const int tn = nc < m->CP ? m->stem_tensor_of_new[nc] : -1;
+          a.pieces[j][hh][q].base = tn >= 0 ? src[tn] : nullptr;
+          a.pieces[j][hh][q].nch = tn >= 0 ? nsrc[tn] : 0;
+          a.pieces[j][hh][q].choff = tn >= 0 ? m->stem_ch_of_new[nc] : 0;
+        }
+    a.sc = m->stem_sc;
+    a.sh = m->stem_sh;
+    a.wpk = m->stem_wpk16;
+    a.zero_page = m->zero_page;
+    a.y = m->stem_raw;
+    a.stats = m->stats;
+    a.B = B;
+    a.H = c.height;
+    a.W = c.width;
+    a.Ho = m->Hs;
+    a.Wo = m->Ws;
+    a.CPL = m->CPL;
+    a.slots = stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs);
+    const double M = (double)B * m->Hs * m->Ws;
+    {
+      Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
+              4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
+      HIPCHK(m, launch_stem_lds(a, stem.coutp, s));
+    }
+    {
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
+                                   stem.gamma, stem.beta, 1e-5f, m->ssA[0], m->ssA[1], s, a.slots));
+    }
+  } else {
+    const float *src[4] = {rgb, depth, dd, tdv};
+    if ((rc = run_conv(m, stem, B, nullptr, m->stem_sc, m->stem_sh, m->stem_raw, stem.coutp, m->ssA, nullptr, nullptr, 0,
+                       s, src)) != PNVO_OK)
+      return rc;
+  }
   if ((rc = maybe_tap(m, "stem_conv", m->stem_raw, (size_t)B * m->Hs * m->Ws * stem.coutp, s)) != PNVO_OK) return rc;
   // (a7) GN + ReLU + maxpool
   float *cur = m->bufY[0], *nxt = m->bufY[1];
@@ -626,6 +744,10 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->head.wpk);
   free_dev(m->fc_bias);
   free_dev(m->head_bias);
+  free_dev(m->stem_sc);
+  free_dev(m->stem_sh);
+  free_dev(m->stem_wpk16);
+  free_dev(m->zero_page);
   for (auto &r : m->trecs) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);

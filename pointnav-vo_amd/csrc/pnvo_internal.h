@@ -5,6 +5,13 @@
 
 namespace pnvo {
 
+// A 2-channel slice of one observation tensor feeding the fused stem (MODE 2 of conv_mfma_kernel).
+struct SrcPiece {
+  const float *base;   // tensor base (nullptr: zero padding piece)
+  int nch;             // channels per pixel of that tensor
+  int choff;           // first channel of the slice
+};
+
 // One convolution / linear layer as an implicit GEMM:  M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin.
 struct ConvArgs {
   const float *x;        // [B,H,W,CIN] NHWC, CIN % 8 == 0 (channel-padded)
@@ -23,7 +30,25 @@ struct ConvArgs {
   int slots;             // stats slots per sample
   int lds_floats;        // dynamic LDS available for staging the input transform tables
   int MT, NT;            // wave tile: MT*32 pixels x NT*32 output channels
+  int src_mode;          // 1: A is gathered from the observation tensors through `pieces` (x unused)
+  const float *zero_page;            // >= 16 B of zeros (target of masked gathers)
+  SrcPiece pieces[8][2][2];          // [j][lane half h][q]: channels 8j+4h+2q, +1 of the stem's K order
 };
+
+// The LDS-staged fused stem (stem_lds.hip).
+struct StemArgs {
+  SrcPiece pieces[8][2][2];   // [j][h][q] -> channels 8j+4h+2q, +1 of the stem's K order (slot g = 2j+h)
+  const float *sc, *sh;       // [CPL] whitening x*sc+sh in the stem's channel order (0 for pad channels)
+  const float *wpk;           // pack_stem_weight()
+  const float *zero_page;     // >= 16 B of zeros (target of masked gathers)
+  float *y;                   // [B,Ho,Wo,COUT] raw conv output
+  float *stats;               // [B,slots,COUT,2]
+  int B, H, W, Ho, Wo, CPL, slots, tiles_x, tiles_y;
+};
+int stem_tiles_x(int Wo);
+int stem_tiles_y(int Ho);
+hipError_t launch_stem_lds(const StemArgs &a, int cout, hipStream_t s);
+void pack_stem_weight(const float *oihw_new, int cout, int cinp, int cpl, float *out);
 
 int conv_slots(int P, int MT);                       // stats slots per sample for a given wave tile
 void choose_tile(long M, int COUTP, int *MT, int *NT);
@@ -33,9 +58,10 @@ size_t packed_conv_floats(int cout, int cin, int kh, int kw);
 void pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, float *out);
 
 // GroupNorm statistics -> per-(sample,channel) scale/shift.
+// fixed_ns > 0: every sample has exactly fixed_ns slots (stem tiles); else slots follow the flattened wave tiles.
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
-                              hipStream_t s);
+                              hipStream_t s, int fixed_ns = 0);
 
 // Input assembly + whitening (vo_cnn.py:110-176) into channel-padded NHWC.
 struct AssembleArgs {
