@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pointnav_vo_amd import model_spec as ms  # noqa: E402
-from pointnav_vo_amd import synth  # noqa: E402
+from pointnav_vo_amd import parallel, synth  # noqa: E402
 from pointnav_vo_amd.registry import baseline_registry  # noqa: E402
 from pointnav_vo_amd.trainer import NormalizedDepth2TopDownViewHabitatTorch  # noqa: E402
 from pointnav_vo_amd import _lib  # noqa: E402
@@ -142,10 +142,7 @@ def main():
         kt = model.timing_read()
         model.timing(False)
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = parallel.max_over_ranks(dt, dev)     # slowest rank
 
     if rank == 0:
         pairs = world * B * args.steps

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -637,6 +638,7 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
     a.Wo = m->Ws;
     a.CPL = m->CPL;
     a.slots = stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs);
+    if (const char *e = std::getenv("PNVO_STEM_DBG")) std::sscanf(e, "%d,%d", &a.dbg, &a.lds_pad);
     const double M = (double)B * m->Hs * m->Ws;
     {
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,

@@ -44,6 +44,7 @@ struct StemArgs {
   float *y;                   // [B,Ho,Wo,COUT] raw conv output
   float *stats;               // [B,slots,COUT,2]
   int B, H, W, Ho, Wo, CPL, slots, tiles_x, tiles_y;
+  int dbg, lds_pad;           // experiment knobs (PNVO_STEM_DBG="<flags>,<lds_pad_bytes>"): 1 skip staging, 2 skip epilogue
 };
 int stem_tiles_x(int Wo);
 int stem_tiles_y(int Ho);
