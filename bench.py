@@ -32,6 +32,10 @@ W, H, BINS = 341, 192, 10
 SPACE = ["rgb", "depth", "discretized_depth", "top_down_view"]
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
 PEAK_HBM_GBS = 8000.0
+# HBM-side bytes of ONE stem launch at B=256 from rocprofv3 PMC passes (profiles/r1_final_pmc_traffic.md):
+# FETCH_SIZE 2.023e6 KiB (x2: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md §HBM) + WRITE_SIZE 5.45e5 KiB.
+# Algorithmic bytes of that launch: 2.01 GB of observation tensors + 0.54 GB of raw stem output.
+STEM_TRAFFIC_B256 = (2 * 2.023e6 + 5.45e5) * 1024
 
 
 def build_model(dev, seed=0):
@@ -165,7 +169,9 @@ def main():
             "frac_fp32_peak_whole_path": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
             "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                         "traffic": STEM_TRAFFIC_B256 if (B == 256 and dom["name"].endswith("conv1.0")) else None,
+                         "traffic_note": "bytes per launch, rocprofv3 PMC of this command (profiles/r1_final_pmc_traffic.md)",
                          "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
                                 "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,

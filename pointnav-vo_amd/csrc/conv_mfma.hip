@@ -42,7 +42,10 @@ __device__ __forceinline__ unsigned clamp_records(long bytes) {
 // MODE 2: A gathered from the observation tensors (rgb | depth | discretized_depth | top_down_view) in 2-channel
 //         pieces and whitened on the fly, x * scale[c] + shift[c] — the reference's input assembly + /255 +
 //         RunningMeanAndVar (vo_cnn.py:110-176) fused into the stem's operand fetch; no [B,H,W,30] tensor exists.
-template <int MT, int NT, int MODE>
+// JC = 8-channel groups fetched per pipeline stage.  JC = 4 makes a stage one (tap, 32-channel chunk): the four 16-B
+// loads of a lane hit ONE 128-B line back to back, so the line comes from L2 once per tap instead of once per 16-B
+// slice (measured 4x L2 over-fetch with JC = 1: profiles/r1_kernel_mfma_busy.md).
+template <int MT, int NT, int MODE, int JC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   constexpr bool XF = (MODE != 0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void *)(p.x + (long)n0 * HWC), 0, clamp_records(((long)p.B - n0) * HWC * 4), 0x00020000);
   const int T = p.KH * p.KW;
-  const int S = T * J;                                   // pipeline stages: (tap, j)
+  const int SJ = T * J;                                  // (tap, 8-channel group) steps; JC of them per pipeline stage
   const int ntg0 = blockIdx.y * NT;
-  const long w_nt_bytes = (long)S * 1024;                // one n-tile of packed weights
+  const long w_nt_bytes = (long)SJ * 1024;               // one n-tile of packed weights
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.wpk + (long)ntg0 * S * 256), 0, clamp_records((long)NT * w_nt_bytes), 0x00020000);
+      (void *)(p.wpk + (long)ntg0 * SJ * 256), 0, clamp_records((long)NT * w_nt_bytes), 0x00020000);
 
   // ---- per-lane pixel coordinates of the MT pixel tiles
   int hi0[MT], wi0[MT], nrel[MT];
@@ -134,31 +137,39 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   const unsigned wlane = (unsigned)lane * 16u;
 
   // fetch stage l_s into (a, b, okm, jc) and advance the loader state
-  auto fetch = [&](f32x4 (&a)[MT], f32x4 (&b)[NT], unsigned &okm, int &jc) {
+  auto fetch = [&](f32x4 (&a)[MT][JC], f32x4 (&b)[NT][JC], unsigned &okm, int &jc) {
     okm = 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      if (MODE == 2) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const SrcPiece e0 = p.pieces[l_j][0][q], e1 = p.pieces[l_j][1][q];   // wave-uniform (scalar loads)
-          const float *base = h ? e1.base : e0.base;
-          const int nch = h ? e1.nch : e0.nch, co = h ? e1.choff : e0.choff;
-          const float *addr = (toff[mt] != PNVO_OOB && base != nullptr) ? base + ((long)toff[mt] * nch + co) : p.zero_page;
-          const f32x2 v = *reinterpret_cast<const f32x2 *>(addr);
-          a[mt][2 * q] = v[0];
-          a[mt][2 * q + 1] = v[1];
+      for (int jj = 0; jj < JC; ++jj) {
+        if (MODE == 2) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const SrcPiece e0 = p.pieces[l_j + jj][0][q], e1 = p.pieces[l_j + jj][1][q];   // wave-uniform (scalar loads)
+            const float *base = h ? e1.base : e0.base;
+            const int nch = h ? e1.nch : e0.nch, co = h ? e1.choff : e0.choff;
+            const float *addr =
+                (toff[mt] != PNVO_OOB && base != nullptr) ? base + ((long)toff[mt] * nch + co) : p.zero_page;
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(addr);
+            a[mt][jj][2 * q] = v[0];
+            a[mt][jj][2 * q + 1] = v[1];
+          }
+        } else {
+          a[mt][jj] = buf_load4(rx, toff[mt], (unsigned)(l_j + jj) * 32u);
         }
-      } else {
-        a[mt] = buf_load4(rx, toff[mt], (unsigned)l_j * 32u);
       }
       okm |= (toff[mt] != PNVO_OOB ? 1u : 0u) << mt;
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = buf_load4(rw, wlane + (unsigned)(nt * w_nt_bytes), (unsigned)l_s * 1024u);
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj)
+        b[nt][jj] = buf_load4(rw, wlane + (unsigned)(nt * w_nt_bytes), (unsigned)(l_s + jj) * 1024u);
     jc = l_j;
-    ++l_s;
-    if (++l_j == J) {
+    l_s += JC;
+    l_j += JC;
+    if (l_j == J) {
       l_j = 0;
       if (++l_kw == p.KW) {
         l_kw = 0;
@@ -169,45 +180,49 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   };
 
   // consume one fetched stage: optional producer GroupNorm+ReLU on A, then 4 k-steps of MFMA
-  auto compute = [&](f32x4 (&a)[MT], f32x4 (&b)[NT], unsigned okm, int jc) {
-    if (XF) {
+  auto compute = [&](f32x4 (&a)[MT][JC], f32x4 (&b)[NT][JC], unsigned okm, int jc0) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 sc, sh;
-        const int c = 8 * jc + 4 * h;
-        if (use_lds) {
-          const int k = (MODE == 2) ? c : (n0 + nrel[mt] - n_lo) * CIN + c;
-          sc = *reinterpret_cast<const f32x4 *>(lds + k);
-          sh = *reinterpret_cast<const f32x4 *>(lds + tab + k);
-        } else {
-          const long row = (MODE == 2) ? 0 : (long)(n0 + nrel[mt]);
-          sc = *reinterpret_cast<const f32x4 *>(p.in_scale + row * CIN + c);
-          sh = *reinterpret_cast<const f32x4 *>(p.in_shift + row * CIN + c);
-        }
-        const bool ok = (okm >> mt) & 1u;
+    for (int jj = 0; jj < JC; ++jj) {
+      if (XF) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float v = __builtin_fmaf(a[mt][t], sc[t], sh[t]);
-          if (MODE == 1) v = fmaxf(v, 0.f);
-          a[mt][t] = ok ? v : 0.f;   // zero padding is applied AFTER the producer's GN+ReLU / the whitening
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 sc, sh;
+          const int c = 8 * (jc0 + jj) + 4 * h;
+          if (use_lds) {
+            const int k = (MODE == 2) ? c : (n0 + nrel[mt] - n_lo) * CIN + c;
+            sc = *reinterpret_cast<const f32x4 *>(lds + k);
+            sh = *reinterpret_cast<const f32x4 *>(lds + tab + k);
+          } else {
+            const long row = (MODE == 2) ? 0 : (long)(n0 + nrel[mt]);
+            sc = *reinterpret_cast<const f32x4 *>(p.in_scale + row * CIN + c);
+            sh = *reinterpret_cast<const f32x4 *>(p.in_shift + row * CIN + c);
+          }
+          const bool ok = (okm >> mt) & 1u;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float v = __builtin_fmaf(a[mt][jj][t], sc[t], sh[t]);
+            if (MODE == 1) v = fmaxf(v, 0.f);
+            a[mt][jj][t] = ok ? v : 0.f;   // zero padding is applied AFTER the producer's GN+ReLU / the whitening
+          }
         }
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj][t], b[nt][jj][t], acc[mt][nt], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
   };
 
   // ---- main loop, register double-buffered: stage s+1 is in flight while stage s feeds the matrix cores
   {
-    f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+    f32x4 a0[MT][JC], b0[NT][JC], a1[MT][JC], b1[NT][JC];
     unsigned ok0 = 0, ok1 = 0;
     int j0 = 0, j1 = 0;
     fetch(a0, b0, ok0, j0);
+    const int S = SJ / JC;               // pipeline stages
     int s = 0;
     for (; s + 2 <= S - 1; s += 2) {     // invariant: stage s is in buffer 0, stages s+1, s+2 exist
       fetch(a1, b1, ok1, j1);
@@ -310,6 +325,7 @@ void choose_tile(long M, int COUTP, int *MT, int *NT) {
   while (ntg % nt) --nt;
   int mt = 4 / nt;
   if (mt < 1) mt = 1;
+  if (mt > 2) mt = 2;               // 32-channel pipeline stages need 16 VGPRs per pixel tile per buffer
   auto waves = [&](int mt_, int nt_) { return ((M + mt_ * 32 - 1) / (mt_ * 32)) * (ntg / nt_); };
   const long want = 256 * 8;        // >= 2 waves per SIMD over the whole chip
   while (mt > 1 && waves(mt, nt) < want) mt >>= 1;
@@ -325,9 +341,14 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
   dim3 grid((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)(a.COUTP / 32 / NT));
   ConvArgs p = a;
   size_t lds_bytes = 0;
+  // 32-channel stages where the register file allows 2 waves/SIMD; the GN-prologue variant of the 4-accumulator
+  // tiles (2x2, 1x4) only fits 16-channel stages
+  constexpr int JCF = (MT == 4) ? 1 : 4;
+  constexpr int JCX = (MT == 4) ? 1 : ((MT * NT >= 4) ? 2 : 4);
+  const bool wide = (JCF > 1) && (a.CIN % 32 == 0);
   if (a.src_mode) {
     p.lds_floats = 2 * a.CIN;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 2>), grid, dim3(256), (size_t)p.lds_floats * 4, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 2, 1>), grid, dim3(256), (size_t)p.lds_floats * 4, s, p);
   } else if (a.in_scale != nullptr) {
     const long cnt_max = (4L * WM + P - 2) / P + 1;
     const long need = cnt_max * a.CIN * 2;
@@ -337,10 +358,16 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
     } else {
       p.lds_floats = 0;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 1>), grid, dim3(256), lds_bytes, s, p);
+    if (wide)
+      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 1, JCX>), grid, dim3(256), lds_bytes, s, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 1, 1>), grid, dim3(256), lds_bytes, s, p);
   } else {
     p.lds_floats = 0;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0>), grid, dim3(256), 0, s, p);
+    if (wide)
+      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0, JCF>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0, 1>), grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }
