@@ -302,6 +302,71 @@ def boundary_fixture(registry, geo):
     print("boundary deltas:\n", rec["deltas"])
 
 
+# ----------------------------------------------------------------------------- training-step fixtures (a14)
+def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtype):
+    """model.train() forward (RunningMeanAndVar update), the reference's own _compute_loss for dx/dz/dyaw
+    (vo/engine/vo_cnn_engine.py:135-198), backward, torch.optim.Adam(lr=2.5e-4, eps=1e-8) as the engine sets it up
+    (vo_cnn_regression_geo_invariance_engine.py:122-133; configs/vo/vo_pointnav.yaml:35-45).  dropout_p = 0 so the step
+    is deterministic (torch's dropout RNG cannot be reproduced elsewhere)."""
+    W, H = size
+    model, cfg, sd = build_ref_model(registry, name, obs_space, size, dd_bins, seed, extra=dict(dropout_p=0.0))
+    model = model.double() if dtype == torch.float64 else model.float()
+    model.train()
+    obs = synth.make_obs_pairs(B, H, W, observation_space=obs_space, dd_bins=max(dd_bins, 1), seed=seed)
+    target = synth.uniform(seed, "train_target", (B, 3), -0.3, 0.3).astype(np.float32)
+    meths = extract_methods(REF + "/pointnav_vo/vo/engine/vo_cnn_engine.py", "VOCNNBaseEngine", ["_compute_loss"])
+    cv = importlib.import_module("pointnav_vo.vo.common.common_vars")
+    nsd = {"torch": torch, "np": np, "DEFAULT_LOSS_WEIGHTS": cv.DEFAULT_LOSS_WEIGHTS, "EPSILON": cv.EPSILON}
+    exec(meths["_compute_loss"], nsd)
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-8, weight_decay=0)
+    rec = dict(model=name, obs_space=",".join(obs_space), width=W, height=H, batch=B, dd_bins=dd_bins, seed=seed,
+               baseplanes=cfg.baseplanes, act_embed=0, target=target, lr=2.5e-4, eps=1e-8)
+    tgt = torch.from_numpy(target).to(dtype)
+    tgts = (tgt[:, 0:1], tgt[:, 1:2], tgt[:, 2:3])
+    for step in (1, 2):
+        opt.zero_grad()
+        out = model({k: torch.from_numpy(v).to(dtype) for k, v in obs.items()})
+        loss = 0
+        for d, dt in enumerate(["dx", "dz", "dyaw"]):
+            loss = loss + nsd["_compute_loss"](None, out[:, d:d + 1], tgts, d_type=dt)[0]
+        loss.backward()
+        rec[f"loss{step}"] = loss.item()
+        rec[f"out{step}"] = out.detach().numpy().astype(np.float64)
+        for k, prm in model.named_parameters():
+            gflat = prm.grad.detach().reshape(-1).double().numpy()
+            idx = sample_idx("grad:" + k, gflat.size, 16)
+            rec[f"gidx/{k}"] = idx
+            rec[f"g{step}val/{k}"] = gflat[idx]
+            rec[f"g{step}norm/{k}"] = np.linalg.norm(gflat)
+        opt.step()
+        for k, prm in model.named_parameters():
+            pflat = prm.detach().reshape(-1).double().numpy()
+            rec[f"p{step}val/{k}"] = pflat[rec[f"gidx/{k}"]]
+        for k, b in model.named_buffers():
+            rec[f"buf{step}/{k}"] = np.array(b.detach().double().numpy(), copy=True)   # copy: _count is updated in place
+    np.savez_compressed(os.path.join(HERE, fname), **rec)
+    print(f"{fname}: loss1={rec['loss1']:.6f} loss2={rec['loss2']:.6f}")
+
+
+def geo_loss_fixture():
+    meths = extract_methods(REF + "/pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py",
+                            "VOCNNRegressionGeometricInvarianceEngine", ["_compute_geo_invariance_inverse_loss"])
+    cv = importlib.import_module("pointnav_vo.vo.common.common_vars")
+    nsd = {"torch": torch, "np": np, "CUR_REL_TO_PREV": cv.CUR_REL_TO_PREV, "PREV_REL_TO_CUR": cv.PREV_REL_TO_CUR,
+           "MOVE_FORWARD": cv.MOVE_FORWARD}
+    exec(meths["_compute_geo_invariance_inverse_loss"], nsd)
+    N = 12
+    deltas = torch.from_numpy(synth.uniform(3, "geo_deltas", (2 * N, 3), -0.5, 0.5)).double().requires_grad_(True)
+    acts = (synth.bits(3, "geo_acts", N) % np.uint64(3)).astype(np.int64) + 1
+    actions = torch.from_numpy(np.repeat(acts, 2))
+    dtypes = torch.from_numpy(np.tile(np.array([cv.CUR_REL_TO_PREV, cv.PREV_REL_TO_CUR]), N))
+    loss = nsd["_compute_geo_invariance_inverse_loss"](None, deltas, actions, dtypes)[0]
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "train_geo_loss.npz"), deltas=deltas.detach().numpy(),
+                        actions=actions.numpy(), loss=loss.item(), grad=deltas.grad.numpy())
+    print("geo loss", loss.item())
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -318,6 +383,9 @@ def main():
                   ["depth", "discretized_depth", "top_down_view"], (66, 34), 2, 10, 6, False)
     preproc_fixture(geo)
     boundary_fixture(registry, geo)
+    train_fixture(registry, "train_default_45x37_b4_f64.npz", "vo_cnn_rgb_d_dd_top_down", full, (45, 37), 4, 10, 31, torch.float64)
+    train_fixture(registry, "train_default_96x64_b3_f32.npz", "vo_cnn_rgb_d_dd_top_down", full, (96, 64), 3, 10, 32, torch.float32)
+    geo_loss_fixture()
 
 
 if __name__ == "__main__":
