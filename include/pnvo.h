@@ -103,6 +103,43 @@ int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstrid
                       const float *consts, int rows_around_center, float *out, int64_t out_fstride,
                       int64_t out_pstride, void *work, void *stream);
 
+/* ---- training step (BASELINE config 4).  One optimisation step of one action model, replacing the body of the
+ * reference's training iteration: zero_grad / forward in train mode / loss / backward / optimizer.step()
+ * (pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py:855-901; loss vo_cnn_engine.py:135-198; Adam
+ * :122-133).  Parameters and gradients are caller-owned DEVICE buffers, flat, in the order of `toc` (the reference's
+ * state_dict parameter order), so a data-parallel job all-reduces ONE buffer (RCCL).  Dropout must be 0. ---- */
+
+/* Bind the flat parameter / gradient buffers (n_floats each) and build the device-side re-packing maps.
+ * toc: parameters only (no RunningMeanAndVar buffers).  Also refreshes the kernel operands from `params`. */
+int pnvo_train_attach(pnvo_handle h, float *params, float *grads, size_t n_floats, const pnvo_tensor_desc *toc, int ntoc);
+
+/* Re-pack the kernel operands from the flat parameters (call after every optimiser step; replaces nothing in the
+ * reference — torch modules read their parameters in place). */
+int pnvo_train_refresh(pnvo_handle h, void *stream);
+
+/* model.train(); out = model(obs_pairs) with every activation kept for the backward pass.  run_mean / run_var: device
+ * [C] RunningMeanAndVar buffers AFTER this step's update (running_mean_and_var.py:23-63; the caller performs the
+ * update — and its all-reduces — with pnvo_input_moments). */
+int pnvo_train_forward(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
+                       const float *run_mean, const float *run_var, float *out, void *stream);
+
+/* loss.backward() given dLoss/dOut [B,out_dim]: fills the whole gradient buffer (overwrites; no accumulation). */
+int pnvo_train_backward(pnvo_handle h, const float *grad_out, void *stream);
+
+/* Per-channel moments of the assembled network input (reference channel order, rgb/255), the statistics behind
+ * RunningMeanAndVar's train-mode update: out[c] = mean_{n,pixel} (x_c - center_c)^power, power in {1,2}; center may be
+ * NULL (0).  out: device [C]. */
+int pnvo_input_moments(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
+                       const float *center, int power, float *out, void *stream);
+
+/* loss = sum_d mean_i (target - pred)^2 (vo_cnn_engine.py:146-194, unit weights) into *loss (device scalar, may be
+ * NULL) and dLoss/dPred into grad [B,D] (may be NULL). */
+int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, void *stream);
+
+/* torch.optim.Adam(weight_decay=0, amsgrad=False) on flat device buffers; step counts from 1. */
+int pnvo_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                   float beta2, float eps, int step, void *stream);
+
 /* Free everything owned by the handle. */
 int pnvo_destroy(pnvo_handle h);
 

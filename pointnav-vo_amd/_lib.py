@@ -48,6 +48,16 @@ _SIGNATURES = {
     "pnvo_topdown_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                     C.c_void_p]),
+    "pnvo_train_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(pnvo_tensor_desc), C.c_int]),
+    "pnvo_train_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pnvo_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_input_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_void_p]),
+    "pnvo_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "pnvo_destroy": (C.c_int, [C.c_void_p]),
     "pnvo_last_error": (C.c_char_p, [C.c_void_p]),
     "pnvo_set_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

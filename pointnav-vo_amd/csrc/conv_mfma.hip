@@ -125,8 +125,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   auto set_tap = [&]() {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int hi = hi0[mt] + l_kh, wi = wi0[mt] + l_kw;
-      const bool ok = vm[mt] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      int hi = hi0[mt] + l_kh, wi = wi0[mt] + l_kw;
+      bool ok = vm[mt];
+      if (p.up == 2) {          // backward-data of a stride-2 conv: the input grid is the output gradient upsampled by 2
+        ok = ok && (((hi | wi) & 1) == 0);
+        hi >>= 1;
+        wi >>= 1;
+      }
+      ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       if (MODE == 2)
         toff[mt] = ok ? (unsigned)((nrel[mt] * p.H + hi) * p.W + wi) : PNVO_OOB;
       else
@@ -270,8 +276,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
             v += (co < p.COUT) ? p.bias[brow * p.COUT + co] : 0.f;
           }
           if (p.relu_out) v = fmaxf(v, 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry,
-                                                cvalid ? vbase + (unsigned)row * rstride : PNVO_OOB, 0, 0);
+          const unsigned yo = cvalid ? vbase + (unsigned)row * rstride : PNVO_OOB;
+          if (p.accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yo, 0, 0));   // y += conv
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yo, 0, 0);
         }
       }
       (void)bv;
@@ -321,8 +328,7 @@ int conv_slots(int P, int MT) {
 
 void choose_tile(long M, int COUTP, int *MT, int *NT) {
   const int ntg = COUTP / 32;
-  int nt = ntg >= 4 ? 4 : ntg;      // ntg is 1, 2, or a multiple of 4 for every layer of the supported nets
-  while (ntg % nt) --nt;
+  int nt = (ntg % 4 == 0) ? 4 : ((ntg % 2 == 0) ? 2 : 1);   // instantiated n-tile counts: 1, 2, 4
   int mt = 4 / nt;
   if (mt < 1) mt = 1;
   if (mt > 2) mt = 2;               // 32-channel pipeline stages need 16 VGPRs per pixel tile per buffer

@@ -97,7 +97,8 @@ hipError_t launch_assemble(const AssembleArgs &h, hipStream_t s) {
 // (torch.nn.GroupNorm, eps inside the sqrt; used at resnet.py:39,42,165,194 and vo_cnn.py:93).
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int slots, int CP, int C, int G, long P,
                                                         int WM, const float *gamma, const float *beta, float eps,
-                                                        float *scale, float *shift, int fixed_ns) {
+                                                        float *scale, float *shift, int fixed_ns, float *mu_out,
+                                                        float *rstd_out) {
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const long t0 = ((long)n * P) / WM, t1 = ((long)(n + 1) * P - 1) / WM;
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
   double var = s2 / cnt - mu * mu;
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (threadIdx.x == 0 && mu_out != nullptr) {
+    mu_out[n * G + g] = (float)mu;
+    rstd_out[n * G + g] = (float)rstd;
+  }
   for (int k = threadIdx.x; k < cpg; k += 64) {
     const int c = g * cpg + k;
     const double sc = rstd * (double)gamma[c];
@@ -129,9 +134,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
 
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
-                              hipStream_t s, int fixed_ns) {
+                              hipStream_t s, int fixed_ns, float *mu_out, float *rstd_out) {
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, stats, slots, CP, C, G, P, WM, gamma,
-                     beta, eps, scale, shift, fixed_ns);
+                     beta, eps, scale, shift, fixed_ns, mu_out, rstd_out);
   return hipGetLastError();
 }
 

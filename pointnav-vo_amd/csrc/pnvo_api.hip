@@ -10,89 +10,28 @@
 #include <string>
 #include <vector>
 
-#include "../../include/pnvo.h"
-#include "pnvo_internal.h"
+#include "pnvo_model.h"
 
 using namespace pnvo;
 
-namespace {
-
 thread_local std::string g_err;
 
-inline int rup(int x, int m) { return (x + m - 1) / m * m; }
-inline int halve(int x) { return (x - 1) / 2 + 1; }
-
-struct Layer {
-  std::string name, gn;     // state_dict prefixes (conv weight, following GroupNorm)
-  int cin = 0, cinp = 0, cout = 0, coutp = 0, k = 1, kw = 1, stride = 1, pad = 0;
-  int hin = 0, win = 0, hout = 0, wout = 0, groups = 1;
-  float *wpk = nullptr, *gamma = nullptr, *beta = nullptr;   // device
-};
-
-struct TimingRec {
-  hipEvent_t a, b;
-  int entry;
-};
-
-}  // namespace
-
-struct pnvo_model_s {
-  pnvo_config cfg;
-  int device = 0;
-  std::string err;
-  bool loaded = false;
-
-  int C = 0, CP = 0;                 // input channels, padded to 8
-  int Hs = 0, Ws = 0, Hp = 0, Wp = 0, fh = 0, fw = 0, comp_c = 0, comp_cp = 0;
-  std::vector<Layer> convs;          // stem, residual stages in execution order, compression
-  Layer fc, head;
-  float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
-  std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments (reference channel order)
-  // fused stem: K-order of the stem = observation tensors concatenated (rgb | depth | dd | tdv), 2-channel pieces
-  std::vector<int> stem_ref_of_new;  // new channel -> reference channel (vo_cnn.py:169-174 order), -1 = pad
-  std::vector<int> stem_tensor_of_new, stem_ch_of_new;
-  float *stem_sc = nullptr, *stem_sh = nullptr, *zero_page = nullptr;   // device: whitening table in the new order
-  float *stem_wpk16 = nullptr;       // stem weights packed for the LDS-staged 16x16x4 kernel
-  int CPL = 0;                       // stem channels per pixel in LDS (C rounded up to 16)
-
-  int cap = 0;                       // batch the workspace is sized for
-  float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
-  float *rawA = nullptr, *rawB = nullptr, *rawD = nullptr, *comp_raw = nullptr, *hid = nullptr, *stats = nullptr;
-  float *ssA[2] = {nullptr, nullptr}, *ssB[2] = {nullptr, nullptr}, *ssD[2] = {nullptr, nullptr},
-        *ssC[2] = {nullptr, nullptr};
-  float *tapbuf = nullptr;
-  size_t tapbuf_floats = 0;
-
-  std::string tap_name;
-  float *tap_dst = nullptr;
-  size_t tap_cap = 0;
-
-  int timing = 0;
-  std::vector<pnvo_kernel_time> tentries;
-  std::map<std::string, int> tindex;
-  std::vector<TimingRec> trecs;
-  std::vector<hipEvent_t> evpool;
-};
-
-namespace {
-
-int fail(pnvo_handle h, int code, const std::string &msg) {
+int pnvo_fail(pnvo_handle h, int code, const std::string &msg) {
   if (h) h->err = msg;
   g_err = msg;
   return code;
 }
 
-#define HIPCHK(h, expr)                                                                                   \
-  do {                                                                                                    \
-    hipError_t e__ = (expr);                                                                              \
-    if (e__ != hipSuccess)                                                                                \
-      return fail(h, PNVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                  \
-  } while (0)
-
-void free_dev(float *&p) {
+void pnvo_free_dev(float *&p) {
   if (p) (void)hipFree(p);
   p = nullptr;
 }
+
+namespace {
+
+inline int fail(pnvo_handle h, int code, const std::string &msg) { return pnvo_fail(h, code, msg); }
+inline void free_dev(float *&p) { pnvo_free_dev(p); }
+
 
 Layer make_layer(const std::string &name, const std::string &gn, int cin, int cout, int k, int stride, int pad,
                  int hin, int win, int groups) {
@@ -226,8 +165,10 @@ int upload(pnvo_handle h, float *&dst, const float *src, size_t n) {
   return PNVO_OK;
 }
 
+}  // namespace
+
 // pack with an explicit padded input-channel count (the FC reads a channel-padded activation)
-void pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out) {
+void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out) {
   const int coutp = rup(cout, 32), J = cinp / 8, T = kh * kw, ntg_n = coutp / 32;
   out.assign((size_t)coutp * cinp * T, 0.f);
   for (int ntg = 0; ntg < ntg_n; ++ntg)
@@ -241,6 +182,11 @@ void pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int k
                 out[((((size_t)ntg * T + tap) * J + j) * 64 + hh * 32 + n) * 4 + t] =
                     oihw[((size_t)co * cin + ci) * T + tap];
             }
+}
+
+namespace {
+inline void pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out) {
+  pnvo_pack_conv_weight_cinp(oihw, cout, cin, cinp, kh, kw, out);
 }
 
 int load_conv(pnvo_handle h, const Toc &t, Layer &l, bool has_gn) {
@@ -289,7 +235,7 @@ size_t stats_floats(const Layer &l, int B) {
   return (size_t)B * conv_slots((int)P, MT) * l.coutp * 2;
 }
 
-int ensure_workspace(pnvo_handle m, int B) {
+int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_workspace)
   if (B <= m->cap) return PNVO_OK;
   free_workspace(m);
   const pnvo_config &c = m->cfg;
@@ -326,50 +272,50 @@ int ensure_workspace(pnvo_handle m, int B) {
   return PNVO_OK;
 }
 
-// ---- timing -----------------------------------------------------------------------------------------------------
-struct Timed {
-  pnvo_model_s *m;
-  hipStream_t s;
-  int rec = -1;
-  Timed(pnvo_model_s *m_, hipStream_t s_, const std::string &name, double flops, double bytes) : m(m_), s(s_) {
-    if (!m->timing) return;
-    auto it = m->tindex.find(name);
-    int idx;
-    if (it == m->tindex.end()) {
-      pnvo_kernel_time e;
-      std::memset(&e, 0, sizeof(e));
-      std::snprintf(e.name, sizeof(e.name), "%s", name.c_str());
-      idx = (int)m->tentries.size();
-      m->tentries.push_back(e);
-      m->tindex[name] = idx;
+}  // namespace
+
+PnvoTimed::PnvoTimed(pnvo_model_s *m_, hipStream_t s_, const std::string &name, double flops, double bytes) : m(m_), s(s_) {
+  if (!m->timing) return;
+  auto it = m->tindex.find(name);
+  int idx;
+  if (it == m->tindex.end()) {
+    pnvo_kernel_time e;
+    std::memset(&e, 0, sizeof(e));
+    std::snprintf(e.name, sizeof(e.name), "%s", name.c_str());
+    idx = (int)m->tentries.size();
+    m->tentries.push_back(e);
+    m->tindex[name] = idx;
+  } else {
+    idx = it->second;
+  }
+  m->tentries[idx].launches += 1;
+  m->tentries[idx].flops += flops;
+  m->tentries[idx].bytes += bytes;
+  TimingRec r;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!m->evpool.empty()) {
+      e = m->evpool.back();
+      m->evpool.pop_back();
     } else {
-      idx = it->second;
+      (void)hipEventCreate(&e);
     }
-    m->tentries[idx].launches += 1;
-    m->tentries[idx].flops += flops;
-    m->tentries[idx].bytes += bytes;
-    TimingRec r;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!m->evpool.empty()) {
-        e = m->evpool.back();
-        m->evpool.pop_back();
-      } else {
-        (void)hipEventCreate(&e);
-      }
-      return e;
-    };
-    r.a = get();
-    r.b = get();
-    r.entry = idx;
-    (void)hipEventRecord(r.a, s);
-    m->trecs.push_back(r);
-    rec = (int)m->trecs.size() - 1;
-  }
-  ~Timed() {
-    if (rec >= 0) (void)hipEventRecord(m->trecs[rec].b, s);
-  }
-};
+    return e;
+  };
+  r.a = get();
+  r.b = get();
+  r.entry = idx;
+  (void)hipEventRecord(r.a, s);
+  m->trecs.push_back(r);
+  rec = (int)m->trecs.size() - 1;
+}
+
+PnvoTimed::~PnvoTimed() {
+  if (rec >= 0) (void)hipEventRecord(m->trecs[rec].b, s);
+}
+
+namespace {
+typedef PnvoTimed Timed;
 
 int maybe_tap(pnvo_handle m, const char *name, const float *src, size_t n, hipStream_t s) {
   if (m->tap_dst == nullptr || m->tap_name != name) return PNVO_OK;
@@ -378,10 +324,12 @@ int maybe_tap(pnvo_handle m, const char *name, const float *src, size_t n, hipSt
   return PNVO_OK;
 }
 
+}  // namespace
+
 // One conv + (optionally) the GroupNorm statistics finalisation that follows it.
-int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
-             float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
-             hipStream_t s, const float *const *src = nullptr) {
+int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
+                  float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
+                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out) {
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
   if (src != nullptr) {          // fused stem: gather A from the observation tensors
@@ -421,6 +369,7 @@ int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *
   a.pad = l.pad;
   a.y_cstride = y_cstride;
   a.relu_out = relu_out;
+  a.up = 1;
   const long P = (long)l.hout * l.wout, M = (long)B * P;
   choose_tile(M, l.coutp, &a.MT, &a.NT);
   a.slots = conv_slots((int)P, a.MT);
@@ -433,12 +382,74 @@ int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *
   if (ss) {
     Timed t(m, s, "gn_finalize", 0.0, 0.0);
     HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, l.coutp, l.cout, l.groups, P, a.MT * 32, l.gamma, l.beta, 1e-5f,
-                                 ss[0], ss[1], s));
+                                 ss[0], ss[1], s, 0, mu_out, rstd_out));
   }
   return PNVO_OK;
 }
 
+namespace {
+inline int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
+                    float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
+                    hipStream_t s, const float *const *src = nullptr) {
+  return pnvo_run_conv(m, l, B, x, in_scale, in_shift, y, y_cstride, ss, bias, bias_row, relu_out, s, src, nullptr, nullptr);
+}
 }  // namespace
+
+// The fused stem: input assembly + /255 + whitening gathered in the operand fetch (LDS-staged kernel when the channel
+// count allows, else MODE 2 of the generic kernel), raw output + GroupNorm scale/shift (+ optional mean/rstd).
+int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
+                  hipStream_t s) {
+  const pnvo_config &c = m->cfg;
+  const Layer &stem = m->convs[0];
+  int rc = PNVO_OK;
+  const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
+  if (lds_stem) {
+    const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+    StemArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < m->CPL / 8; ++j)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int q = 0; q < 2; ++q) {
+          const int nc = 8 * j + 4 * hh + 2 * q;
+          const int tn = nc < m->CP ? m->stem_tensor_of_new[nc] : -1;
+          a.pieces[j][hh][q].base = tn >= 0 ? src[tn] : nullptr;
+          a.pieces[j][hh][q].nch = tn >= 0 ? nsrc[tn] : 0;
+          a.pieces[j][hh][q].choff = tn >= 0 ? m->stem_ch_of_new[nc] : 0;
+        }
+    a.sc = m->stem_sc;
+    a.sh = m->stem_sh;
+    a.wpk = m->stem_wpk16;
+    a.zero_page = m->zero_page;
+    a.y = y;
+    a.stats = m->stats;
+    a.B = B;
+    a.H = c.height;
+    a.W = c.width;
+    a.Ho = m->Hs;
+    a.Wo = m->Ws;
+    a.CPL = m->CPL;
+    a.slots = stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs);
+    if (const char *e = std::getenv("PNVO_STEM_DBG")) std::sscanf(e, "%d,%d", &a.dbg, &a.lds_pad);
+    const double M = (double)B * m->Hs * m->Ws;
+    {
+      Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
+              4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
+      HIPCHK(m, launch_stem_lds(a, stem.coutp, s));
+    }
+    {
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
+                                   stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
+    }
+  } else {
+    if ((rc = pnvo_run_conv(m, stem, B, nullptr, m->stem_sc, m->stem_sh, y, stem.coutp, ss, nullptr, nullptr, 0, s, src,
+                            mu_out, rstd_out)) != PNVO_OK)
+      return rc;
+  }
+  return rc;
+}
+
+int pnvo_ensure_workspace(pnvo_handle m, int B) { return ensure_workspace(m, B); }
 
 // ==================================================================================================================
 extern "C" {
@@ -610,51 +621,9 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
   }
   size_t li = 0;
   const Layer &stem = m->convs[li++];
-  const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
-  if (lds_stem) {
+  {
     const float *src[4] = {rgb, depth, dd, tdv};
-    const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
-    StemArgs a;
-    std::memset(&a, 0, sizeof(a));
-    for (int j = 0; j < m->CPL / 8; ++j)
-      for (int hh = 0; hh < 2; ++hh)
-        for (int q = 0; q < 2; ++q) {
-          const int nc = 8 * j + 4 * hh + 2 * q;
-          const int tn = nc < m->CP ? m->stem_tensor_of_new[nc] : -1;
-          a.pieces[j][hh][q].base = tn >= 0 ? src[tn] : nullptr;
-          a.pieces[j][hh][q].nch = tn >= 0 ? nsrc[tn] : 0;
-          a.pieces[j][hh][q].choff = tn >= 0 ? m->stem_ch_of_new[nc] : 0;
-        }
-    a.sc = m->stem_sc;
-    a.sh = m->stem_sh;
-    a.wpk = m->stem_wpk16;
-    a.zero_page = m->zero_page;
-    a.y = m->stem_raw;
-    a.stats = m->stats;
-    a.B = B;
-    a.H = c.height;
-    a.W = c.width;
-    a.Ho = m->Hs;
-    a.Wo = m->Ws;
-    a.CPL = m->CPL;
-    a.slots = stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs);
-    if (const char *e = std::getenv("PNVO_STEM_DBG")) std::sscanf(e, "%d,%d", &a.dbg, &a.lds_pad);
-    const double M = (double)B * m->Hs * m->Ws;
-    {
-      Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
-              4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
-      HIPCHK(m, launch_stem_lds(a, stem.coutp, s));
-    }
-    {
-      Timed t(m, s, "gn_finalize", 0.0, 0.0);
-      HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
-                                   stem.gamma, stem.beta, 1e-5f, m->ssA[0], m->ssA[1], s, a.slots));
-    }
-  } else {
-    const float *src[4] = {rgb, depth, dd, tdv};
-    if ((rc = run_conv(m, stem, B, nullptr, m->stem_sc, m->stem_sh, m->stem_raw, stem.coutp, m->ssA, nullptr, nullptr, 0,
-                       s, src)) != PNVO_OK)
-      return rc;
+    if ((rc = pnvo_run_stem(m, B, src, m->stem_raw, m->ssA, nullptr, nullptr, s)) != PNVO_OK) return rc;
   }
   if ((rc = maybe_tap(m, "stem_conv", m->stem_raw, (size_t)B * m->Hs * m->Ws * stem.coutp, s)) != PNVO_OK) return rc;
   // (a7) GN + ReLU + maxpool
@@ -736,6 +705,7 @@ int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstrid
 int pnvo_destroy(pnvo_handle m) {
   if (!m) return PNVO_OK;
   (void)hipSetDevice(m->device);
+  pnvo_train_free(m);
   free_workspace(m);
   for (Layer &l : m->convs) {
     free_dev(l.wpk);

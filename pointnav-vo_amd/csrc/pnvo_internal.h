@@ -31,6 +31,8 @@ struct ConvArgs {
   int lds_floats;        // dynamic LDS available for staging the input transform tables
   int MT, NT;            // wave tile: MT*32 pixels x NT*32 output channels
   int src_mode;          // 1: A is gathered from the observation tensors through `pieces` (x unused)
+  int up;                // 2: transposed (backward-data of a stride-2 conv): source = (pos - pad + k) / 2 when even; else 1
+  int accum;             // epilogue adds into y instead of overwriting it
   const float *zero_page;            // >= 16 B of zeros (target of masked gathers)
   SrcPiece pieces[8][2][2];          // [j][lane half h][q]: channels 8j+4h+2q, +1 of the stem's K order
 };
@@ -60,9 +62,10 @@ void pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, floa
 
 // GroupNorm statistics -> per-(sample,channel) scale/shift.
 // fixed_ns > 0: every sample has exactly fixed_ns slots (stem tiles); else slots follow the flattened wave tiles.
+// mu_out / rstd_out (optional, [B,G]) keep the statistics for the backward pass.
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
-                              hipStream_t s, int fixed_ns = 0);
+                              hipStream_t s, int fixed_ns = 0, float *mu_out = nullptr, float *rstd_out = nullptr);
 
 // Input assembly + whitening (vo_cnn.py:110-176) into channel-padded NHWC.
 struct AssembleArgs {
@@ -94,5 +97,55 @@ size_t topdown_workspace_bytes(int N, int H, int W);
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const float *consts_host, int rows_around_center, float *out, int64_t out_fstride,
                           int64_t out_pstride, void *work, hipStream_t s);
+
+// ---- training step (train_kernels.hip) ---------------------------------------------------------------------------
+struct SrcLane {            // stem weight gradient: the observation-tensor slot feeding input channel (lane) i
+  const float *base;
+  int nch, choff;
+  float sc, sh;
+};
+
+struct WgradArgs {
+  const float *x;           // input activation [B,H,W,CIN] (mode 0/1)
+  const float *in_scale, *in_shift;   // [B,CIN] (mode 1: relu(x*scale+shift))
+  const float *dy;          // [B,Ho,Wo,DYC] gradient of the conv's raw output
+  float *partial;           // [units][TG][32][32]
+  const float *zero_page;
+  SrcLane src[32];          // mode 2
+  int B, H, W, CIN, Ho, Wo, COUT, DYC, KH, KW, stride, pad;
+  int mode;                 // 0 plain, 1 producer GN+ReLU recomputed, 2 gathered+whitened observation tensors
+  int TG, groups, ci_tiles, pairs, chunks;
+  long pix_per_chunk;
+};
+void wgrad_plan(WgradArgs &a);
+size_t wgrad_partial_floats(const WgradArgs &a);
+hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int cin_out, hipStream_t s);
+
+hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
+                         const float *rstd, const float *gamma, int B, long P, int C, int Creal, int G, int mask,
+                         float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s);
+hipError_t launch_relu_mask(const float *dy, const float *y, const float *add, long n, float *g, hipStream_t s);
+hipError_t launch_add(const float *a, const float *b, long n, float *o, hipStream_t s);
+hipError_t launch_maxpool_train(const float *x, const float *scale, const float *shift, int B, int H, int W, int C,
+                                float *out, unsigned char *idx, hipStream_t s);
+hipError_t launch_maxpool_bwd(const float *dpool, const unsigned char *idx, int B, int H, int W, int C, float *dact,
+                              hipStream_t s);
+hipError_t launch_colsum(const float *x, int rows, int cols, int ld, float *out, hipStream_t s);
+hipError_t launch_padcopy(const float *src, int rows, int cols, int ldd, float *dst, hipStream_t s);
+hipError_t launch_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, hipStream_t s);
+hipError_t launch_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps,
+                       int step, hipStream_t s);
+hipError_t launch_gather(const float *src, const int *map, long n, float *dst, hipStream_t s);
+hipError_t launch_whiten_table(const float *mean, const float *var, const int *ref_of_new, const int *tensor_of_new, int CPL,
+                               float *sc, float *sh, hipStream_t s);
+struct MomentsArgs {
+  const float *src[4];
+  int nch[4];
+  int tensor[64], ch[64];   // reference channel c -> (observation tensor, channel inside it)
+  const float *center;      // [C] or nullptr
+  long npix;
+  int pw;                   // 1: mean of (x - center), 2: mean of (x - center)^2
+};
+hipError_t launch_moments(const MomentsArgs &a, int C, double *part, float *out, hipStream_t s);
 
 }  // namespace pnvo

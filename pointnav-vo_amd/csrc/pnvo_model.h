@@ -1,0 +1,94 @@
+// pnvo_model.h — host-side model state shared by pnvo_api.hip (inference) and pnvo_train_api.hip (training step).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pnvo.h"
+#include "pnvo_internal.h"
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+static inline int halve(int x) { return (x - 1) / 2 + 1; }
+
+struct Layer {
+  std::string name, gn;     // state_dict prefixes (conv weight, following GroupNorm)
+  int cin = 0, cinp = 0, cout = 0, coutp = 0, k = 1, kw = 1, stride = 1, pad = 0;
+  int hin = 0, win = 0, hout = 0, wout = 0, groups = 1;
+  float *wpk = nullptr, *gamma = nullptr, *beta = nullptr;   // device
+};
+
+struct TimingRec {
+  hipEvent_t a, b;
+  int entry;
+};
+
+struct pnvo_model_s {
+  pnvo_config cfg;
+  int device = 0;
+  std::string err;
+  bool loaded = false;
+
+  int C = 0, CP = 0;                 // input channels, padded to 8
+  int Hs = 0, Ws = 0, Hp = 0, Wp = 0, fh = 0, fw = 0, comp_c = 0, comp_cp = 0;
+  std::vector<Layer> convs;          // stem, residual stages in execution order, compression
+  Layer fc, head;
+  float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
+  std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments (reference channel order)
+  // fused stem: K-order of the stem = observation tensors concatenated (rgb | depth | dd | tdv), 2-channel pieces
+  std::vector<int> stem_ref_of_new;  // new channel -> reference channel (vo_cnn.py:169-174 order), -1 = pad
+  std::vector<int> stem_tensor_of_new, stem_ch_of_new;
+  float *stem_sc = nullptr, *stem_sh = nullptr, *zero_page = nullptr;   // device: whitening table in the new order
+  float *stem_wpk16 = nullptr;       // stem weights packed for the LDS-staged 16x16x4 kernel
+  int CPL = 0;                       // stem channels per pixel in LDS (C rounded up to 16)
+
+  int cap = 0;                       // batch the workspace is sized for
+  float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
+  float *rawA = nullptr, *rawB = nullptr, *rawD = nullptr, *comp_raw = nullptr, *hid = nullptr, *stats = nullptr;
+  float *ssA[2] = {nullptr, nullptr}, *ssB[2] = {nullptr, nullptr}, *ssD[2] = {nullptr, nullptr},
+        *ssC[2] = {nullptr, nullptr};
+  float *tapbuf = nullptr;
+  size_t tapbuf_floats = 0;
+
+  std::string tap_name;
+  float *tap_dst = nullptr;
+  size_t tap_cap = 0;
+
+  void *train = nullptr;             // TrainState (pnvo_train_api.hip), present after pnvo_train_attach
+
+  int timing = 0;
+  std::vector<pnvo_kernel_time> tentries;
+  std::map<std::string, int> tindex;
+  std::vector<TimingRec> trecs;
+  std::vector<hipEvent_t> evpool;
+};
+
+
+// helpers implemented in pnvo_api.hip
+int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
+                  float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
+                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out);
+void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out);
+int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
+                  hipStream_t s);
+void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
+int pnvo_fail(pnvo_handle h, int code, const std::string &msg);
+void pnvo_free_dev(float *&p);
+int pnvo_ensure_workspace(pnvo_handle m, int B);
+
+#define HIPCHK(h, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e__ = (expr);                                                                              \
+    if (e__ != hipSuccess)                                                                                \
+      return pnvo_fail(h, PNVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));             \
+  } while (0)
+
+// scoped HIP-event timing of one launch (no-op unless pnvo_timing_mode(h, 1))
+struct PnvoTimed {
+  pnvo_model_s *m;
+  hipStream_t s;
+  int rec = -1;
+  PnvoTimed(pnvo_model_s *m_, hipStream_t s_, const std::string &name, double flops, double bytes);
+  ~PnvoTimed();
+};

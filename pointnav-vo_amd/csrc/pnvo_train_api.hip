@@ -1,0 +1,734 @@
+// pnvo_train_api.hip — C ABI of the VO training step (BASELINE config 4): forward in train mode with
+// saved activations, backward through the whole network, and the optimiser/loss helpers.  Replaces, for one action
+// model, the body of the reference's training iteration
+//   optimizer.zero_grad(); out = vo_model(batch_pairs); loss = sum_d mse_d; loss.backward(); optimizer.step()
+// (/root/reference/pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py:855-901, :586; loss
+//  vo_cnn_engine.py:135-198; Adam :122-133).  The flat parameter / gradient buffers are caller-owned device memory in
+// the reference's state_dict parameter order, so the data-parallel all-reduce is ONE collective on one buffer.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "pnvo_model.h"
+
+using namespace pnvo;
+
+namespace {
+
+struct PackMap {
+  float *dst;
+  int *map;
+  long n;
+};
+
+struct ConvSave {
+  float *raw = nullptr, *ss[2] = {nullptr, nullptr}, *mu = nullptr, *rstd = nullptr;
+};
+
+struct TocEnt {
+  size_t off;
+  std::vector<int64_t> shape;
+  size_t numel;
+};
+
+struct TrainState {
+  float *params = nullptr, *grads = nullptr;
+  size_t n = 0;
+  std::map<std::string, TocEnt> toc;
+  std::vector<PackMap> maps;
+  std::vector<float *> dgrad_w;     // per conv of m->convs (nullptr for the stem: no input gradient)
+  float *fc_t = nullptr, *head_t = nullptr;
+  int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
+  // saved activations (sized for capB)
+  int capB = 0;
+  int lastB = 0;
+  std::vector<ConvSave> cs;
+  std::vector<float *> y;           // y[0] = pooled stem output, y[k] = output of residual block k
+  unsigned char *pool_idx = nullptr;
+  float *hid = nullptr;
+  const float *src[4] = {nullptr, nullptr, nullptr, nullptr};   // observation tensors of the last forward
+  // scratch
+  float *dYa = nullptr, *dYb = nullptr, *G = nullptr, *dRaw = nullptr, *dA = nullptr, *dStem = nullptr;
+  float *dout8 = nullptr, *dh = nullptr, *gh = nullptr, *dz = nullptr;
+  float *gn_part = nullptr, *gn_coef = nullptr, *wg_partial = nullptr;
+  size_t wg_partial_floats = 0;
+  double *mom_part = nullptr;
+};
+
+TrainState *TS(pnvo_handle m) { return reinterpret_cast<TrainState *>(m->train); }
+
+int dmalloc(pnvo_handle m, void **p, size_t bytes) {
+  HIPCHK(m, hipMalloc(p, bytes ? bytes : 16));
+  return PNVO_OK;
+}
+template <class T>
+void dfree(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// float "index tensor" of a parameter: value = flat offset + 1 (exact in fp32 below 2^24 elements)
+std::vector<float> index_tensor(const TocEnt &e) {
+  std::vector<float> v(e.numel);
+  for (size_t i = 0; i < e.numel; ++i) v[i] = (float)(e.off + i + 1);
+  return v;
+}
+
+int add_map(pnvo_handle m, TrainState *t, float *dst, const std::vector<float> &packed_idx) {
+  std::vector<int> mp(packed_idx.size());
+  for (size_t i = 0; i < mp.size(); ++i) mp[i] = (int)packed_idx[i];
+  PackMap pm;
+  pm.dst = dst;
+  pm.n = (long)mp.size();
+  pm.map = nullptr;
+  int rc = dmalloc(m, (void **)&pm.map, mp.size() * sizeof(int));
+  if (rc != PNVO_OK) return rc;
+  HIPCHK(m, hipMemcpy(pm.map, mp.data(), mp.size() * sizeof(int), hipMemcpyHostToDevice));
+  t->maps.push_back(pm);
+  return PNVO_OK;
+}
+
+const TocEnt *need(pnvo_handle m, TrainState *t, const std::string &name, int *rc) {
+  auto it = t->toc.find(name);
+  if (it == t->toc.end()) {
+    *rc = pnvo_fail(m, PNVO_ERR_WEIGHTS, "parameter table is missing '" + name + "'");
+    return nullptr;
+  }
+  return &it->second;
+}
+
+// OIHW [cout][cin][K][K] -> backward-data weights [cin][cout][K][K], taps flipped
+std::vector<float> transpose_flip(const std::vector<float> &w, int cout, int cin, int kh, int kw) {
+  std::vector<float> o((size_t)cin * cout * kh * kw);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int a = 0; a < kh; ++a)
+        for (int b = 0; b < kw; ++b)
+          o[(((size_t)ci * cout + co) * kh + a) * kw + b] = w[(((size_t)co * cin + ci) * kh + (kh - 1 - a)) * kw + (kw - 1 - b)];
+  return o;
+}
+
+int build_maps(pnvo_handle m, TrainState *t) {
+  int rc = PNVO_OK;
+  const pnvo_config &c = m->cfg;
+  t->dgrad_w.assign(m->convs.size(), nullptr);
+  for (size_t li = 0; li < m->convs.size(); ++li) {
+    Layer &l = m->convs[li];
+    const TocEnt *w = need(m, t, l.name + ".weight", &rc);
+    if (!w) return rc;
+    const std::vector<float> idx = index_tensor(*w);
+    const int T = l.k * l.kw;
+    std::vector<float> pk;
+    if (li == 0) {   // stem: channel order of the fused gather (pnvo_load_weights does the same permutation)
+      std::vector<float> wp((size_t)l.cout * m->CP * T, 0.f);
+      for (int nc = 0; nc < m->CP; ++nc) {
+        const int r = m->stem_ref_of_new[nc];
+        if (r < 0) continue;
+        for (int o = 0; o < l.cout; ++o)
+          std::memcpy(&wp[((size_t)o * m->CP + nc) * T], &idx[((size_t)o * l.cin + r) * T], sizeof(float) * T);
+      }
+      pnvo_pack_conv_weight_cinp(wp.data(), l.cout, m->CP, m->CP, l.k, l.kw, pk);
+      if ((rc = add_map(m, t, l.wpk, pk)) != PNVO_OK) return rc;
+      std::vector<float> pk16((size_t)49 * m->CPL * l.cout);
+      pack_stem_weight(wp.data(), l.cout, m->CP, m->CPL, pk16.data());
+      if ((rc = add_map(m, t, m->stem_wpk16, pk16)) != PNVO_OK) return rc;
+    } else {
+      pnvo_pack_conv_weight_cinp(idx.data(), l.cout, l.cin, l.cinp, l.k, l.kw, pk);
+      if ((rc = add_map(m, t, l.wpk, pk)) != PNVO_OK) return rc;
+      // backward-data operand: "conv" with CIN' = coutp (gradient channels), COUT' = cin
+      const std::vector<float> wt = transpose_flip(idx, l.cout, l.cin, l.k, l.kw);
+      std::vector<float> pkt;
+      pnvo_pack_conv_weight_cinp(wt.data(), l.cin, l.cout, l.coutp, l.k, l.kw, pkt);
+      if ((rc = dmalloc(m, (void **)&t->dgrad_w[li], pkt.size() * sizeof(float))) != PNVO_OK) return rc;
+      if ((rc = add_map(m, t, t->dgrad_w[li], pkt)) != PNVO_OK) return rc;
+    }
+    const TocEnt *g = need(m, t, l.gn + ".weight", &rc);
+    if (!g) return rc;
+    const TocEnt *b = need(m, t, l.gn + ".bias", &rc);
+    if (!b) return rc;
+    if ((rc = add_map(m, t, l.gamma, index_tensor(*g))) != PNVO_OK) return rc;
+    if ((rc = add_map(m, t, l.beta, index_tensor(*b))) != PNVO_OK) return rc;
+  }
+  // linear layers
+  const int T = m->fh * m->fw, flat = m->comp_c * T;
+  const TocEnt *w1 = need(m, t, m->fc.name + ".weight", &rc);
+  if (!w1) return rc;
+  const TocEnt *b1 = need(m, t, m->fc.name + ".bias", &rc);
+  if (!b1) return rc;
+  const TocEnt *w2 = need(m, t, "output_head.1.weight", &rc);
+  if (!w2) return rc;
+  const TocEnt *b2 = need(m, t, "output_head.1.bias", &rc);
+  if (!b2) return rc;
+  if ((int)w1->shape[1] != flat) return pnvo_fail(m, PNVO_ERR_ARG, "training of act_embed variants is not built");
+  {
+    const std::vector<float> i1 = index_tensor(*w1), i2 = index_tensor(*w2);
+    std::vector<float> pk;
+    pnvo_pack_conv_weight_cinp(i1.data(), c.hidden, m->comp_c, m->comp_cp, m->fh, m->fw, pk);
+    if ((rc = add_map(m, t, m->fc.wpk, pk)) != PNVO_OK) return rc;
+    if ((rc = add_map(m, t, m->fc_bias, index_tensor(*b1))) != PNVO_OK) return rc;
+    pnvo_pack_conv_weight_cinp(i2.data(), c.out_dim, c.hidden, c.hidden, 1, 1, pk);
+    if ((rc = add_map(m, t, m->head.wpk, pk)) != PNVO_OK) return rc;
+    if ((rc = add_map(m, t, m->head_bias, index_tensor(*b2))) != PNVO_OK) return rc;
+    // dz = g_h . W1 as a 1x1 conv: CIN' = hidden, COUT' = T*comp_cp, W'[tap*comp_cp + ch][o] = W1[o][ch*T + tap]
+    std::vector<float> wt((size_t)T * m->comp_cp * c.hidden, 0.f);
+    for (int o = 0; o < c.hidden; ++o)
+      for (int ch = 0; ch < m->comp_c; ++ch)
+        for (int tap = 0; tap < T; ++tap)
+          wt[((size_t)tap * m->comp_cp + ch) * c.hidden + o] = i1[(size_t)o * flat + (size_t)ch * T + tap];
+    pnvo_pack_conv_weight_cinp(wt.data(), T * m->comp_cp, c.hidden, c.hidden, 1, 1, pk);
+    if ((rc = dmalloc(m, (void **)&t->fc_t, pk.size() * sizeof(float))) != PNVO_OK) return rc;
+    if ((rc = add_map(m, t, t->fc_t, pk)) != PNVO_OK) return rc;
+    // dh = dOut . W2: CIN' = 8 (out_dim padded), COUT' = hidden, W'[o][d] = W2[d][o]
+    std::vector<float> ht((size_t)c.hidden * c.out_dim);
+    for (int o = 0; o < c.hidden; ++o)
+      for (int d = 0; d < c.out_dim; ++d) ht[(size_t)o * c.out_dim + d] = i2[(size_t)d * c.hidden + o];
+    pnvo_pack_conv_weight_cinp(ht.data(), c.hidden, c.out_dim, rup(c.out_dim, 8), 1, 1, pk);
+    if ((rc = dmalloc(m, (void **)&t->head_t, pk.size() * sizeof(float))) != PNVO_OK) return rc;
+    if ((rc = add_map(m, t, t->head_t, pk)) != PNVO_OK) return rc;
+  }
+  // stem channel tables on device
+  std::vector<int> ron(m->CPL, -1), ton(m->CPL, -1);
+  for (int k = 0; k < m->CP; ++k) {
+    ron[k] = m->stem_ref_of_new[k];
+    ton[k] = m->stem_tensor_of_new[k];
+  }
+  if ((rc = dmalloc(m, (void **)&t->d_ref_of_new, m->CPL * sizeof(int))) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->d_tensor_of_new, m->CPL * sizeof(int))) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->d_ciperm, 32 * sizeof(int))) != PNVO_OK) return rc;
+  std::vector<int> perm(32, -1);
+  for (int k = 0; k < m->CP && k < 32; ++k) perm[k] = m->stem_ref_of_new[k];
+  HIPCHK(m, hipMemcpy(t->d_ref_of_new, ron.data(), m->CPL * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(m, hipMemcpy(t->d_tensor_of_new, ton.data(), m->CPL * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(m, hipMemcpy(t->d_ciperm, perm.data(), 32 * sizeof(int), hipMemcpyHostToDevice));
+  return PNVO_OK;
+}
+
+void free_train_ws(TrainState *t) {
+  for (auto &c : t->cs) {
+    dfree(c.raw);
+    dfree(c.ss[0]);
+    dfree(c.ss[1]);
+    dfree(c.mu);
+    dfree(c.rstd);
+  }
+  t->cs.clear();
+  for (auto &p : t->y) dfree(p);
+  t->y.clear();
+  dfree(t->pool_idx);
+  dfree(t->hid);
+  dfree(t->dYa);
+  dfree(t->dYb);
+  dfree(t->G);
+  dfree(t->dRaw);
+  dfree(t->dA);
+  dfree(t->dStem);
+  dfree(t->dout8);
+  dfree(t->dh);
+  dfree(t->gh);
+  dfree(t->dz);
+  dfree(t->gn_part);
+  dfree(t->gn_coef);
+  dfree(t->wg_partial);
+  dfree(t->mom_part);
+  t->capB = 0;
+}
+
+// weight-gradient launch descriptor of conv `l` for batch B (input geometry = the forward conv's)
+WgradArgs wgrad_args(const Layer &l, int B, int cin_kernel, int dyc) {
+  WgradArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.B = B;
+  a.H = l.hin;
+  a.W = l.win;
+  a.CIN = cin_kernel;
+  a.Ho = l.hout;
+  a.Wo = l.wout;
+  a.COUT = l.cout;
+  a.DYC = dyc;
+  a.KH = l.k;
+  a.KW = l.kw;
+  a.stride = l.stride;
+  a.pad = l.pad;
+  wgrad_plan(a);
+  return a;
+}
+
+int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
+  if (B <= t->capB) return PNVO_OK;
+  free_train_ws(t);
+  int rc = pnvo_ensure_workspace(m, B);    // stats buffer etc. of the inference path are reused
+  if (rc != PNVO_OK) return rc;
+  const pnvo_config &c = m->cfg;
+  t->cs.resize(m->convs.size());
+  size_t wgmax = 0;
+  for (size_t li = 0; li < m->convs.size(); ++li) {
+    const Layer &l = m->convs[li];
+    ConvSave &s = t->cs[li];
+    const size_t n = (size_t)B * l.hout * l.wout * l.coutp;
+    if ((rc = dmalloc(m, (void **)&s.raw, n * 4)) != PNVO_OK) return rc;
+    for (int k = 0; k < 2; ++k) {
+      if ((rc = dmalloc(m, (void **)&s.ss[k], (size_t)B * l.coutp * 4)) != PNVO_OK) return rc;
+      HIPCHK(m, hipMemset(s.ss[k], 0, (size_t)B * l.coutp * 4));
+    }
+    if ((rc = dmalloc(m, (void **)&s.mu, (size_t)B * l.groups * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&s.rstd, (size_t)B * l.groups * 4)) != PNVO_OK) return rc;
+    WgradArgs a = wgrad_args(l, B, li == 0 ? 32 : l.cin, l.coutp);
+    wgmax = std::max(wgmax, wgrad_partial_floats(a));
+  }
+  {
+    WgradArgs a = wgrad_args(m->fc, B, m->comp_c, c.hidden);
+    a.CIN = m->comp_c;
+    wgmax = std::max(wgmax, wgrad_partial_floats(a));
+    WgradArgs h = wgrad_args(m->head, B, c.hidden, 8);
+    wgmax = std::max(wgmax, wgrad_partial_floats(h));
+  }
+  t->wg_partial_floats = wgmax;
+  if ((rc = dmalloc(m, (void **)&t->wg_partial, wgmax * 4)) != PNVO_OK) return rc;
+  // block outputs
+  t->y.assign(9, nullptr);
+  {
+    int h = m->Hp, w = m->Wp, ch = c.baseplanes;
+    if ((rc = dmalloc(m, (void **)&t->y[0], (size_t)B * h * w * ch * 4)) != PNVO_OK) return rc;
+    int k = 1;
+    for (int stage = 1; stage <= 4; ++stage) {
+      if (stage > 1) {
+        h = halve(h);
+        w = halve(w);
+        ch *= 2;
+      }
+      for (int bi = 0; bi < 2; ++bi, ++k)
+        if ((rc = dmalloc(m, (void **)&t->y[k], (size_t)B * h * w * ch * 4)) != PNVO_OK) return rc;
+    }
+  }
+  const size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes, stem = (size_t)B * m->Hs * m->Ws * c.baseplanes;
+  if ((rc = dmalloc(m, (void **)&t->pool_idx, act)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->hid, (size_t)B * c.hidden * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dYa, act * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dYb, act * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->G, act * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dRaw, act * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dA, act * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dStem, stem * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dout8, (size_t)B * 8 * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dh, (size_t)B * c.hidden * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->gh, (size_t)B * c.hidden * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->dz, (size_t)B * m->fh * m->fw * m->comp_cp * 4)) != PNVO_OK) return rc;
+  int maxc = m->comp_cp, maxg = 1;
+  for (const Layer &l : m->convs) {
+    maxc = std::max(maxc, l.coutp);
+    maxg = std::max(maxg, l.groups);
+  }
+  if ((rc = dmalloc(m, (void **)&t->gn_part, (size_t)B * 64 * maxc * 2 * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->gn_coef, (size_t)B * maxg * 2 * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 256 * 8)) != PNVO_OK) return rc;
+  t->capB = B;
+  return PNVO_OK;
+}
+
+float *gradp(pnvo_handle m, TrainState *t, const std::string &name, int *rc) {
+  const TocEnt *e = need(m, t, name, rc);
+  return e ? t->grads + e->off : nullptr;
+}
+
+// backward-data of conv `l`: dX[B, hin, win, cin] (+)= conv(dRaw[B, hout, wout, coutp], flipped/transposed weights)
+int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw, float *dx, bool accum, hipStream_t s) {
+  const Layer &l = m->convs[li];
+  ConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = draw;
+  a.wpk = t->dgrad_w[li];
+  a.y = dx;
+  a.B = B;
+  a.H = l.hout;
+  a.W = l.wout;
+  a.CIN = l.coutp;
+  a.Ho = l.hin;
+  a.Wo = l.win;
+  a.COUT = l.cin;
+  a.COUTP = rup(l.cin, 32);
+  a.KH = l.k;
+  a.KW = l.kw;
+  a.stride = 1;
+  a.pad = l.k - 1 - l.pad;
+  a.up = l.stride;
+  a.accum = accum ? 1 : 0;
+  a.y_cstride = l.cin;
+  const long M = (long)B * l.hin * l.win;
+  choose_tile(M, a.COUTP, &a.MT, &a.NT);
+  a.slots = conv_slots(l.hin * l.win, a.MT);
+  PnvoTimed tm(m, s, "dgrad:" + l.name, 2.0 * (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw, 0.0);
+  HIPCHK(m, launch_conv(a, s));
+  return PNVO_OK;
+}
+
+int run_wgrad(pnvo_handle m, TrainState *t, WgradArgs &a, const std::string &pname, const int *perm, int cin_out,
+              hipStream_t s) {
+  int rc = PNVO_OK;
+  float *g = gradp(m, t, pname, &rc);
+  if (!g) return rc;
+  if (wgrad_partial_floats(a) > t->wg_partial_floats) return pnvo_fail(m, PNVO_ERR_STATE, "wgrad scratch too small");
+  a.partial = t->wg_partial;
+  a.zero_page = m->zero_page;
+  PnvoTimed tm(m, s, "wgrad:" + pname, 2.0 * (double)a.B * a.Ho * a.Wo * a.COUT * a.CIN * a.KH * a.KW, 0.0);
+  HIPCHK(m, launch_wgrad(a, g, perm, cin_out, s));
+  return PNVO_OK;
+}
+
+int run_gn_bwd(pnvo_handle m, TrainState *t, size_t li, int B, const float *dout, int mask, float *dx, hipStream_t s) {
+  const Layer &l = m->convs[li];
+  const ConvSave &c = t->cs[li];
+  int rc = PNVO_OK;
+  float *dg = gradp(m, t, l.gn + ".weight", &rc);
+  if (!dg) return rc;
+  float *db = gradp(m, t, l.gn + ".bias", &rc);
+  if (!db) return rc;
+  PnvoTimed tm(m, s, "gn_bwd", 0.0, 0.0);
+  HIPCHK(m, launch_gn_bwd(c.raw, dout, c.ss[0], c.ss[1], c.mu, c.rstd, l.gamma, B, (long)l.hout * l.wout, l.coutp, l.cout,
+                          l.groups, mask, t->gn_part, t->gn_coef, dg, db, dx, s));
+  return PNVO_OK;
+}
+
+}  // namespace
+
+void pnvo_train_free(pnvo_handle m) {
+  if (!m || !m->train) return;
+  TrainState *t = TS(m);
+  free_train_ws(t);
+  for (auto &pm : t->maps) dfree(pm.map);
+  for (auto &p : t->dgrad_w) dfree(p);
+  dfree(t->fc_t);
+  dfree(t->head_t);
+  dfree(t->d_ref_of_new);
+  dfree(t->d_tensor_of_new);
+  dfree(t->d_ciperm);
+  delete t;
+  m->train = nullptr;
+}
+
+extern "C" {
+
+int pnvo_train_attach(pnvo_handle m, float *params, float *grads, size_t n_floats, const pnvo_tensor_desc *toc, int ntoc) {
+  if (!m || !params || !grads || !toc) return pnvo_fail(m, PNVO_ERR_ARG, "null argument");
+  if (!m->loaded) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach before pnvo_load_weights");
+  if (n_floats >= (1u << 24)) return pnvo_fail(m, PNVO_ERR_ARG, "flat parameter buffer too large for the index maps");
+  HIPCHK(m, hipSetDevice(m->device));
+  pnvo_train_free(m);
+  TrainState *t = new TrainState();
+  m->train = t;
+  t->params = params;
+  t->grads = grads;
+  t->n = n_floats;
+  for (int k = 0; k < ntoc; ++k) {
+    TocEnt e;
+    e.off = toc[k].offset;
+    e.numel = 1;
+    for (int d = 0; d < toc[k].ndim; ++d) {
+      e.shape.push_back(toc[k].shape[d]);
+      e.numel *= (size_t)toc[k].shape[d];
+    }
+    if (e.off + e.numel > n_floats) return pnvo_fail(m, PNVO_ERR_ARG, std::string("parameter '") + toc[k].name + "' out of range");
+    t->toc[toc[k].name] = e;
+  }
+  int rc = build_maps(m, t);
+  if (rc != PNVO_OK) {
+    pnvo_train_free(m);
+    return rc;
+  }
+  return pnvo_train_refresh(m, nullptr);
+}
+
+int pnvo_train_refresh(pnvo_handle m, void *stream) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  HIPCHK(m, hipSetDevice(m->device));
+  TrainState *t = TS(m);
+  for (const PackMap &pm : t->maps) HIPCHK(m, launch_gather(t->params, pm.map, pm.n, pm.dst, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
+                       const float *run_mean, const float *run_var, float *out, void *stream) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  if (B <= 0 || !out) return pnvo_fail(m, PNVO_ERR_ARG, "bad batch / null output");
+  const pnvo_config &c = m->cfg;
+  if ((c.n_rgb > 0) != (rgb != nullptr) || (c.n_depth > 0) != (depth != nullptr) || (c.n_dd > 0) != (dd != nullptr) ||
+      (c.n_tdv > 0) != (tdv != nullptr))
+    return pnvo_fail(m, PNVO_ERR_ARG, "observation tensors do not match the model's observation_space");
+  if (c.normalize && (!run_mean || !run_var)) return pnvo_fail(m, PNVO_ERR_ARG, "running statistics required");
+  HIPCHK(m, hipSetDevice(m->device));
+  TrainState *t = TS(m);
+  int rc = ensure_train_ws(m, t, B);
+  if (rc != PNVO_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  t->lastB = B;
+  t->src[0] = rgb;
+  t->src[1] = depth;
+  t->src[2] = dd;
+  t->src[3] = tdv;
+  if (c.normalize)   // RunningMeanAndVar buffers live on the device and change every step (running_mean_and_var.py:54-60)
+    HIPCHK(m, launch_whiten_table(run_mean, run_var, t->d_ref_of_new, t->d_tensor_of_new, m->CPL, m->stem_sc, m->stem_sh, s));
+
+  size_t li = 0;
+  {
+    ConvSave &cs = t->cs[li];
+    if ((rc = pnvo_run_stem(m, B, t->src, cs.raw, cs.ss, cs.mu, cs.rstd, s)) != PNVO_OK) return rc;
+    const Layer &stem = m->convs[li++];
+    HIPCHK(m, launch_maxpool_train(cs.raw, cs.ss[0], cs.ss[1], B, m->Hs, m->Ws, stem.coutp, t->y[0], t->pool_idx, s));
+  }
+  int yk = 0;
+  for (int stage = 1; stage <= 4; ++stage)
+    for (int bi = 0; bi < 2; ++bi) {
+      const float *xin = t->y[yk];
+      float *yout = t->y[yk + 1];
+      const size_t i1 = li++, i2 = li++;
+      const Layer &c1 = m->convs[i1], &c2 = m->convs[i2];
+      const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
+      ConvSave &s1 = t->cs[i1], &s2 = t->cs[i2];
+      if ((rc = pnvo_run_conv(m, c1, B, xin, nullptr, nullptr, s1.raw, c1.coutp, s1.ss, nullptr, nullptr, 0, s, nullptr,
+                              s1.mu, s1.rstd)) != PNVO_OK)
+        return rc;
+      if ((rc = pnvo_run_conv(m, c2, B, s1.raw, s1.ss[0], s1.ss[1], s2.raw, c2.coutp, s2.ss, nullptr, nullptr, 0, s, nullptr,
+                              s2.mu, s2.rstd)) != PNVO_OK)
+        return rc;
+      const long P = (long)c2.hout * c2.wout;
+      if (ds) {
+        const size_t id = li++;
+        const Layer &cd = m->convs[id];
+        ConvSave &sd = t->cs[id];
+        if ((rc = pnvo_run_conv(m, cd, B, xin, nullptr, nullptr, sd.raw, cd.coutp, sd.ss, nullptr, nullptr, 0, s, nullptr,
+                                sd.mu, sd.rstd)) != PNVO_OK)
+          return rc;
+        HIPCHK(m, launch_residual(s2.raw, s2.ss[0], s2.ss[1], sd.raw, sd.ss[0], sd.ss[1], B, P, c2.coutp, yout, s));
+      } else {
+        HIPCHK(m, launch_residual(s2.raw, s2.ss[0], s2.ss[1], xin, nullptr, nullptr, B, P, c2.coutp, yout, s));
+      }
+      ++yk;
+    }
+  {
+    const size_t ic = li++;
+    const Layer &comp = m->convs[ic];
+    ConvSave &sc = t->cs[ic];
+    if ((rc = pnvo_run_conv(m, comp, B, t->y[8], nullptr, nullptr, sc.raw, comp.coutp, sc.ss, nullptr, nullptr, 0, s, nullptr,
+                            sc.mu, sc.rstd)) != PNVO_OK)
+      return rc;
+    if ((rc = pnvo_run_conv(m, m->fc, B, sc.raw, sc.ss[0], sc.ss[1], t->hid, c.hidden, nullptr, m->fc_bias, nullptr, 1, s,
+                            nullptr, nullptr, nullptr)) != PNVO_OK)
+      return rc;
+    if ((rc = pnvo_run_conv(m, m->head, B, t->hid, nullptr, nullptr, out, c.out_dim, nullptr, m->head_bias, nullptr, 0, s,
+                            nullptr, nullptr, nullptr)) != PNVO_OK)
+      return rc;
+  }
+  return PNVO_OK;
+}
+
+int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  TrainState *t = TS(m);
+  if (t->lastB <= 0 || !grad_out) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_forward first");
+  HIPCHK(m, hipSetDevice(m->device));
+  const pnvo_config &c = m->cfg;
+  const int B = t->lastB;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = PNVO_OK;
+
+  // ---- output head: out = hid . W2^T + b2
+  HIPCHK(m, launch_padcopy(grad_out, B, c.out_dim, 8, t->dout8, s));
+  {
+    float *gb = gradp(m, t, "output_head.1.bias", &rc);
+    if (!gb) return rc;
+    HIPCHK(m, launch_colsum(grad_out, B, c.out_dim, c.out_dim, gb, s));
+    WgradArgs a = wgrad_args(m->head, B, c.hidden, 8);
+    a.x = t->hid;
+    a.dy = t->dout8;
+    a.mode = 0;
+    if ((rc = run_wgrad(m, t, a, "output_head.1.weight", nullptr, c.hidden, s)) != PNVO_OK) return rc;
+    ConvArgs d;
+    std::memset(&d, 0, sizeof(d));
+    d.x = t->dout8;
+    d.wpk = t->head_t;
+    d.y = t->dh;
+    d.B = B;
+    d.H = d.W = d.Ho = d.Wo = 1;
+    d.CIN = 8;
+    d.COUT = c.hidden;
+    d.COUTP = rup(c.hidden, 32);
+    d.KH = d.KW = 1;
+    d.stride = 1;
+    d.up = 1;
+    d.y_cstride = c.hidden;
+    choose_tile(B, d.COUTP, &d.MT, &d.NT);
+    d.slots = conv_slots(1, d.MT);
+    HIPCHK(m, launch_conv(d, s));
+  }
+  // ---- hidden layer: hid = relu(z . W1^T + b1)
+  const size_t icomp = m->convs.size() - 1;
+  {
+    HIPCHK(m, launch_relu_mask(t->dh, t->hid, nullptr, (long)B * c.hidden, t->gh, s));
+    float *gb = gradp(m, t, m->fc.name + ".bias", &rc);
+    if (!gb) return rc;
+    HIPCHK(m, launch_colsum(t->gh, B, c.hidden, c.hidden, gb, s));
+    const ConvSave &sc = t->cs[icomp];
+    WgradArgs a = wgrad_args(m->fc, B, m->comp_c, c.hidden);
+    a.CIN = m->comp_c;
+    a.x = sc.raw;
+    a.in_scale = sc.ss[0];
+    a.in_shift = sc.ss[1];
+    a.dy = t->gh;
+    a.mode = 1;
+    // the activation tensor is channel-padded: tell the kernel the real row pitch through H/W/CIN = (fh, fw, comp_cp)
+    a.CIN = m->comp_cp;
+    wgrad_plan(a);
+    if ((rc = run_wgrad(m, t, a, m->fc.name + ".weight", nullptr, m->comp_c, s)) != PNVO_OK) return rc;
+    ConvArgs d;
+    std::memset(&d, 0, sizeof(d));
+    d.x = t->gh;
+    d.wpk = t->fc_t;
+    d.y = t->dz;
+    d.B = B;
+    d.H = d.W = d.Ho = d.Wo = 1;
+    d.CIN = c.hidden;
+    d.COUT = m->fh * m->fw * m->comp_cp;
+    d.COUTP = rup(d.COUT, 32);
+    d.KH = d.KW = 1;
+    d.stride = 1;
+    d.up = 1;
+    d.y_cstride = d.COUT;
+    choose_tile(B, d.COUTP, &d.MT, &d.NT);
+    d.slots = conv_slots(1, d.MT);
+    HIPCHK(m, launch_conv(d, s));
+  }
+  // ---- compression conv + GroupNorm(1) + ReLU
+  float *dY = t->dYa, *dX = t->dYb;
+  {
+    const Layer &l = m->convs[icomp];
+    if ((rc = run_gn_bwd(m, t, icomp, B, t->dz, 1, t->dz, s)) != PNVO_OK) return rc;   // in place: dz -> dCompRaw
+    WgradArgs a = wgrad_args(l, B, l.cin, l.coutp);
+    a.x = t->y[8];
+    a.dy = t->dz;
+    a.mode = 0;
+    if ((rc = run_wgrad(m, t, a, l.name + ".weight", nullptr, l.cin, s)) != PNVO_OK) return rc;
+    if ((rc = run_dgrad(m, t, icomp, B, t->dz, dY, false, s)) != PNVO_OK) return rc;
+  }
+  // ---- residual blocks, last to first.  Conv indices: walk m->convs backwards from the compression layer.
+  size_t li = icomp;
+  for (int blk = 8; blk >= 1; --blk) {
+    const bool ds = m->convs[li - 1].name.find("downsample") != std::string::npos;
+    const size_t id = ds ? li - 1 : 0;
+    const size_t i2 = ds ? li - 2 : li - 1, i1 = i2 - 1;
+    li = i1;
+    const Layer &c1 = m->convs[i1], &c2 = m->convs[i2];
+    const ConvSave &s1 = t->cs[i1];
+    const float *xin = t->y[blk - 1];
+    const long nout = (long)B * c2.hout * c2.wout * c2.coutp;
+    const long nin = (long)B * c1.hin * c1.win * c1.cin;
+    // G = dY * (y > 0)
+    HIPCHK(m, launch_relu_mask(dY, t->y[blk], nullptr, nout, t->G, s));
+    // second conv: GN2 (no ReLU) <- G
+    if ((rc = run_gn_bwd(m, t, i2, B, t->G, 0, t->dRaw, s)) != PNVO_OK) return rc;
+    {
+      WgradArgs a = wgrad_args(c2, B, c2.cin, c2.coutp);
+      a.x = s1.raw;
+      a.in_scale = s1.ss[0];
+      a.in_shift = s1.ss[1];
+      a.dy = t->dRaw;
+      a.mode = 1;
+      if ((rc = run_wgrad(m, t, a, c2.name + ".weight", nullptr, c2.cin, s)) != PNVO_OK) return rc;
+    }
+    if ((rc = run_dgrad(m, t, i2, B, t->dRaw, t->dA, false, s)) != PNVO_OK) return rc;
+    // first conv: GN1 + ReLU <- dA
+    if ((rc = run_gn_bwd(m, t, i1, B, t->dA, 1, t->dRaw, s)) != PNVO_OK) return rc;
+    {
+      WgradArgs a = wgrad_args(c1, B, c1.cin, c1.coutp);
+      a.x = xin;
+      a.dy = t->dRaw;
+      a.mode = 0;
+      if ((rc = run_wgrad(m, t, a, c1.name + ".weight", nullptr, c1.cin, s)) != PNVO_OK) return rc;
+    }
+    if ((rc = run_dgrad(m, t, i1, B, t->dRaw, dX, false, s)) != PNVO_OK) return rc;
+    // skip connection
+    if (ds) {
+      const Layer &cd = m->convs[id];
+      if ((rc = run_gn_bwd(m, t, id, B, t->G, 0, t->dRaw, s)) != PNVO_OK) return rc;
+      WgradArgs a = wgrad_args(cd, B, cd.cin, cd.coutp);
+      a.x = xin;
+      a.dy = t->dRaw;
+      a.mode = 0;
+      if ((rc = run_wgrad(m, t, a, cd.name + ".weight", nullptr, cd.cin, s)) != PNVO_OK) return rc;
+      if ((rc = run_dgrad(m, t, id, B, t->dRaw, dX, true, s)) != PNVO_OK) return rc;
+    } else {
+      HIPCHK(m, launch_add(dX, t->G, nin, dX, s));
+    }
+    std::swap(dY, dX);
+  }
+  // ---- stem: maxpool <- dY, GroupNorm + ReLU, weight gradient (no input gradient)
+  {
+    const Layer &l = m->convs[0];
+    HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
+    if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
+    WgradArgs a = wgrad_args(l, B, 32, l.coutp);
+    a.dy = t->dStem;
+    a.mode = 2;
+    const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+    std::vector<float> sc(m->CPL), sh(m->CPL);
+    // the whitening constants are on the device (stem_sc/sh); the kernel wants them per lane: read them back once per
+    // call is a sync — instead pass pointers: lanes load sc/sh from the device table themselves
+    for (int k = 0; k < 32; ++k) {
+      const int tn = k < m->CP ? m->stem_tensor_of_new[k] : -1;
+      a.src[k].base = tn >= 0 ? t->src[tn] : nullptr;
+      a.src[k].nch = tn >= 0 ? nsrc[tn] : 0;
+      a.src[k].choff = tn >= 0 ? m->stem_ch_of_new[k] : 0;
+      a.src[k].sc = 0.f;
+      a.src[k].sh = 0.f;
+    }
+    a.in_scale = m->stem_sc;     // mode 2 reads its per-channel whitening from these device tables
+    a.in_shift = m->stem_sh;
+    if ((rc = run_wgrad(m, t, a, l.name + ".weight", t->d_ciperm, l.cin, s)) != PNVO_OK) return rc;
+  }
+  return PNVO_OK;
+}
+
+int pnvo_input_moments(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
+                       const float *center, int power, float *out, void *stream) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  if (!out || (power != 1 && power != 2)) return pnvo_fail(m, PNVO_ERR_ARG, "bad argument");
+  HIPCHK(m, hipSetDevice(m->device));
+  TrainState *t = TS(m);
+  int rc = ensure_train_ws(m, t, B);
+  if (rc != PNVO_OK) return rc;
+  const pnvo_config &c = m->cfg;
+  MomentsArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.src[0] = rgb;
+  a.src[1] = depth;
+  a.src[2] = dd;
+  a.src[3] = tdv;
+  a.nch[0] = c.n_rgb;
+  a.nch[1] = c.n_depth;
+  a.nch[2] = c.n_dd;
+  a.nch[3] = c.n_tdv;
+  for (int k = 0; k < m->CP; ++k) {
+    const int r = m->stem_ref_of_new[k];
+    if (r < 0) continue;
+    a.tensor[r] = m->stem_tensor_of_new[k];
+    a.ch[r] = m->stem_ch_of_new[k];
+  }
+  a.center = center;
+  a.npix = (long)B * c.height * c.width;
+  a.pw = power;
+  HIPCHK(m, launch_moments(a, m->C, t->mom_part, out, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, void *stream) {
+  if (!pred || !target || B <= 0 || D <= 0) return pnvo_fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  HIPCHK(nullptr, launch_mse_loss(pred, target, B, D, loss, grad, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_adam_step(float *p, const float *g, float *mom, float *var, size_t n, float lr, float beta1, float beta2, float eps,
+                   int step, void *stream) {
+  if (!p || !g || !mom || !var || step < 1) return pnvo_fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  HIPCHK(nullptr, launch_adam(p, g, mom, var, (long)n, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,637 @@
+// train_kernels.hip — kernels of the VO training step (BASELINE config 4), gfx950 only.
+//   weight gradient of every conv / linear on the fp32 matrix cores (wgrad_kernel + fixed-order reduction),
+//   GroupNorm backward (reduce / finalize / apply), ReLU masks, max-pool with argmax and its backward, bias gradients,
+//   squared-error loss, Adam, device-side re-packing of the kernel operands after an optimiser step, and the per-channel
+//   moments behind RunningMeanAndVar's train-mode update.
+// Backward-DATA of the convs reuses conv_mfma_kernel (flipped/transposed packed weights, `up` = forward stride).
+// Reductions have one writer per partial and a fixed summation order: gradients are bit-reproducible.
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PNVO_OOB 0x80000000u
+
+__device__ __forceinline__ unsigned clampb(long bytes) {
+  return (unsigned)(bytes > 0x7FFFF000L ? 0x7FFFF000L : (bytes < 0 ? 0 : bytes));
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dW[co][ci][kh][kw] = sum over pixels m=(n,ho,wo) of dY[m][co] * Xin[n, ho*s-p+kh, wo*s-p+kw, ci]
+// as D[i = ci][j = co] += sum_k A[i][k = pixel] * B[k][j] with v_mfma_f32_32x32x2_f32 (2 pixels per instruction):
+// lane (i, h) feeds ONE dword per operand: A = Xin[pixel(2s+h) shifted by the tap][ci0+i], B = dY[pixel(2s+h)][co0+i]
+// (32 consecutive channels of one pixel = one coalesced 128-B segment per half wave).  A wave owns one
+// (ci-tile, co-tile, tap-group, pixel-chunk) unit and keeps TG accumulators (one per tap of its group); partial results
+// go to `partial[unit]` and are summed over the pixel chunks in a fixed order by wgrad_reduce_kernel.
+// Xin modes: 0 plain tensor, 1 relu(x*scale[n,c]+shift[n,c]) (the producer's GroupNorm+ReLU, recomputed),
+//            2 gathered from the observation tensors and whitened (the stem's input).
+template <int TG, int MODE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long unit = (long)blockIdx.x * 4 + wave;
+  const long nunits = (long)p.chunks * p.pairs * p.groups;
+  if (unit >= nunits) return;
+  const int chunk = (int)(unit % p.chunks);
+  long rest = unit / p.chunks;
+  const int pair = (int)(rest % p.pairs);
+  const int grp = (int)(rest / p.pairs);
+  const int cit = pair % p.ci_tiles, cot = pair / p.ci_tiles;
+  const int ci = cit * 32 + i, co = cot * 32 + i;
+  const long P = (long)p.Ho * p.Wo, M = (long)p.B * P;
+  const long m0 = (long)chunk * p.pix_per_chunk;
+  long m1 = m0 + p.pix_per_chunk;
+  if (m1 > M) m1 = M;
+  const int T = p.KH * p.KW;
+  const int t0 = grp * TG;
+
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void *)p.dy, 0, clampb(M * p.DYC * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)p.x, 0, clampb((long)p.B * p.H * p.W * p.CIN * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)p.in_scale, 0, clampb((long)p.B * p.CIN * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)p.in_shift, 0, clampb((long)p.B * p.CIN * 4), 0x00020000);
+
+  // MODE 2: this lane's input channel lives in one of the observation tensors
+  const float *sbase = nullptr;
+  int snch = 0, schoff = 0;
+  float ssc = 0.f, ssh = 0.f;
+  if (MODE == 2) {
+    sbase = p.src[i].base;
+    snch = p.src[i].nch;
+    schoff = p.src[i].choff;
+    ssc = p.in_scale ? p.in_scale[i] : p.src[i].sc;     // whitening x*sc+sh of this lane's channel (device table)
+    ssh = p.in_shift ? p.in_shift[i] : p.src[i].sh;
+  }
+
+  f32x16 acc[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // this lane's pixel m = m0 + 2s + h, tracked as (n, ho, wo)
+  long m = m0 + h;
+  int n = (int)(m / P);
+  int rem = (int)(m - (long)n * P);
+  int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+
+  struct Stage {
+    float b;
+    float a[TG];
+    bool ok[TG];
+  };
+  auto fetch = [&](Stage &st) {
+    const bool vm = m < m1;
+    st.b = bload(rdy, (vm && co < p.DYC) ? (unsigned)((m * p.DYC + co) * 4) : PNVO_OOB);
+    float sc = 1.f, sh = 0.f;
+    if (MODE == 1) {
+      sc = bload(rsc, (vm && ci < p.CIN) ? (unsigned)(((long)n * p.CIN + ci) * 4) : PNVO_OOB);
+      sh = bload(rsh, (vm && ci < p.CIN) ? (unsigned)(((long)n * p.CIN + ci) * 4) : PNVO_OOB);
+    }
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      const int tap = t0 + t;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+      const bool ok = vm && tap < T && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      st.ok[t] = ok;
+      float v;
+      if (MODE == 2) {
+        const long pix = ((long)n * p.H + hi) * p.W + wi;
+        const float *addr = (ok && sbase != nullptr) ? sbase + pix * snch + schoff : p.zero_page;
+        v = __builtin_fmaf(*addr, ssc, ssh);
+      } else {
+        v = bload(rx, (ok && ci < p.CIN) ? (unsigned)(((((long)n * p.H + hi) * p.W + wi) * p.CIN + ci) * 4) : PNVO_OOB);
+        if (MODE == 1) v = fmaxf(__builtin_fmaf(v, sc, sh), 0.f);
+      }
+      st.a[t] = v;
+    }
+    // advance this lane by 2 pixels
+    m += 2;
+    wo += 2;
+    while (wo >= p.Wo) {
+      wo -= p.Wo;
+      ++ho;
+    }
+    while (ho >= p.Ho) {
+      ho -= p.Ho;
+      ++n;
+    }
+  };
+  auto compute = [&](Stage &st) {
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      const float a = st.ok[t] ? st.a[t] : 0.f;   // zero padding AFTER the input transform
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st.b, acc[t], 0, 0, 0);
+    }
+  };
+
+  const long steps = (m1 - m0 + 1) / 2;
+  Stage s0, s1;
+  if (steps > 0) fetch(s0);
+  long s = 0;
+  for (; s + 2 <= steps - 1; s += 2) {
+    fetch(s1);
+    compute(s0);
+    fetch(s0);
+    compute(s1);
+  }
+  if (s + 1 <= steps - 1) {
+    fetch(s1);
+    compute(s0);
+    compute(s1);
+  } else if (steps > 0) {
+    compute(s0);
+  }
+
+  // C/D layout: col j (= co) = lane&31, row i (= ci) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float *dst = p.partial + ((unit * TG) * 32) * 32;
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[((long)t * 32 + row) * 32 + i] = acc[t][r];
+    }
+}
+
+// grad[map(co, ci, tap)] = sum over chunks (fixed order) of partial[chunk, pair, grp][t][ci_row][co_col]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p, int TG, float *grad, const int *ci_perm,
+                                                         int cin_out) {
+  const int T = p.KH * p.KW;
+  const long total = (long)p.COUT * p.CIN * T;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int tap = (int)(e % T);
+  const int ci = (int)((e / T) % p.CIN);
+  const int co = (int)(e / ((long)T * p.CIN));
+  const int cit = ci >> 5, cot = co >> 5, grp = tap / TG, t = tap - grp * TG;
+  const int pair = cot * p.ci_tiles + cit;
+  double acc = 0.0;
+  for (int c = 0; c < p.chunks; ++c) {
+    const long unit = ((long)grp * p.pairs + pair) * p.chunks + c;
+    acc += (double)p.partial[(((unit * TG) + t) * 32 + (ci & 31)) * 32 + (co & 31)];
+  }
+  const int cio = ci_perm ? ci_perm[ci] : ci;       // stem: kernel channel order -> reference channel order
+  if (cio >= 0 && cio < cin_out) grad[((long)co * cin_out + cio) * T + tap] = (float)acc;
+}
+
+template <int TG>
+static hipError_t launch_wgrad_t(const WgradArgs &a, hipStream_t s) {
+  const long nunits = (long)a.chunks * a.pairs * a.groups;
+  dim3 grid((unsigned)((nunits + 3) / 4));
+  if (a.mode == 2)
+    hipLaunchKernelGGL((wgrad_kernel<TG, 2>), grid, dim3(256), 0, s, a);
+  else if (a.mode == 1)
+    hipLaunchKernelGGL((wgrad_kernel<TG, 1>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<TG, 0>), grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+void wgrad_plan(WgradArgs &a) {
+  const int T = a.KH * a.KW;
+  a.TG = T >= 9 ? (T % 9 == 0 ? 9 : (T % 7 == 0 ? 7 : (T % 6 == 0 ? 6 : 9))) : (T >= 3 ? 3 : 1);
+  if (T == 1) a.TG = 1;
+  a.groups = (T + a.TG - 1) / a.TG;
+  a.ci_tiles = (a.CIN + 31) / 32;
+  a.pairs = a.ci_tiles * ((a.COUT + 31) / 32);
+  const long M = (long)a.B * a.Ho * a.Wo;
+  long chunks = 4096 / ((long)a.pairs * a.groups);
+  if (chunks < 1) chunks = 1;
+  long ppc = (M + chunks - 1) / chunks;
+  if (ppc < 64) ppc = 64;
+  ppc = (ppc + 1) / 2 * 2;
+  a.pix_per_chunk = ppc;
+  a.chunks = (int)((M + ppc - 1) / ppc);
+}
+
+size_t wgrad_partial_floats(const WgradArgs &a) { return (size_t)a.chunks * a.pairs * a.groups * a.TG * 1024; }
+
+hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int cin_out, hipStream_t s) {
+  hipError_t e;
+  switch (a.TG) {
+    case 9: e = launch_wgrad_t<9>(a, s); break;
+    case 7: e = launch_wgrad_t<7>(a, s); break;
+    case 6: e = launch_wgrad_t<6>(a, s); break;
+    case 3: e = launch_wgrad_t<3>(a, s); break;
+    case 1: e = launch_wgrad_t<1>(a, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  const long total = (long)a.COUT * a.CIN * a.KH * a.KW;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, a.TG, grad, ci_perm,
+                     cin_out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm backward.  y = gamma*xh + beta, xh = (x - mu)*rstd;  g = dOut [* (mask_src > 0)]:
+//   dgamma_c = sum_{n,p} g*xh,  dbeta_c = sum_{n,p} g
+//   dx = rstd * (gamma*g - S1/N - xh*S2/N),  S1 = sum_{group} gamma*g,  S2 = sum_{group} gamma*g*xh,  N = cpg*P
+// mask: 0 none, 1 recompute a = x*scale+shift (this layer's own GN+ReLU output) and use a > 0.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *x, const float *dout, const float *scale,
+                                                          const float *shift, const float *mu, const float *rstd, int C,
+                                                          int Creal, int G, long P, int chunks, int mask, float *part) {
+  // grid = B * chunks; thread t owns channel c = t % C for pixels t / C, + 256 / C, ...   (C divides 256 or C >= 256)
+  __shared__ float red[512];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long ppc = (P + chunks - 1) / chunks;
+  const long p0 = (long)chunk * ppc;
+  long p1 = p0 + ppc;
+  if (p1 > P) p1 = P;
+  const int cpg = Creal / G;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int lanes_c = C - cb < 256 ? C - cb : 256;      // channels handled in this pass
+    const int c = cb + (int)(threadIdx.x % lanes_c);
+    const int pl = threadIdx.x / lanes_c, pstep = 256 / lanes_c;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < Creal) {
+      const float m_ = mu[n * G + c / cpg], r_ = rstd[n * G + c / cpg];
+      const float sc = mask ? scale[(long)n * C + c] : 0.f, sh = mask ? shift[(long)n * C + c] : 0.f;
+      for (long p = p0 + pl; p < p1; p += pstep) {
+        const long idx = ((long)n * P + p) * C + c;
+        const float xv = x[idx];
+        float g = dout[idx];
+        if (mask && !(__builtin_fmaf(xv, sc, sh) > 0.f)) g = 0.f;
+        s1 += g;
+        s2 = __builtin_fmaf(g, (xv - m_) * r_, s2);
+      }
+    }
+    red[threadIdx.x * 2] = s1;
+    red[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < lanes_c) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int k = 0; k < pstep; ++k) {
+        a1 += red[(k * lanes_c + threadIdx.x) * 2];
+        a2 += red[(k * lanes_c + threadIdx.x) * 2 + 1];
+      }
+      float *dst = part + (((long)n * chunks + chunk) * C + cb + threadIdx.x) * 2;
+      dst[0] = a1;
+      dst[1] = a2;
+    }
+    __syncthreads();
+  }
+}
+
+// per (n, group): c1 = S1/N, c2 = S2/N;  per channel: dgamma, dbeta (sum over n in a fixed order, fp64)
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float *part, int B, int C, int Creal, int G, long P,
+                                                           int chunks, const float *gamma, float *coef, float *dgamma,
+                                                           float *dbeta) {
+  // grid = G blocks; block handles group g for all n
+  const int g = blockIdx.x, cpg = Creal / G;
+  const double N = (double)cpg * (double)P;
+  for (int k = threadIdx.x; k < cpg; k += 64) {   // per-channel parameter gradients
+    const int c = g * cpg + k;
+    double dg = 0.0, db = 0.0;
+    for (int n = 0; n < B; ++n)
+      for (int ch = 0; ch < chunks; ++ch) {
+        const float *src = part + (((long)n * chunks + ch) * C + c) * 2;
+        db += (double)src[0];
+        dg += (double)src[1];
+      }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+  }
+  for (int n = threadIdx.x; n < B; n += 64) {     // per-(sample, group) coefficients
+    double S1 = 0.0, S2 = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      const int c = g * cpg + k;
+      double a1 = 0.0, a2 = 0.0;
+      for (int ch = 0; ch < chunks; ++ch) {
+        const float *src = part + (((long)n * chunks + ch) * C + c) * 2;
+        a1 += (double)src[0];
+        a2 += (double)src[1];
+      }
+      S1 += (double)gamma[c] * a1;
+      S2 += (double)gamma[c] * a2;
+    }
+    coef[((long)n * G + g) * 2] = (float)(S1 / N);
+    coef[((long)n * G + g) * 2 + 1] = (float)(S2 / N);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, const float *dout, const float *scale,
+                                                         const float *shift, const float *mu, const float *rstd,
+                                                         const float *gamma, const float *coef, int C, int Creal, int G,
+                                                         long P, long total, int mask, float *dx) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const int n = (int)(e / (P * C));
+  float out = 0.f;
+  if (c < Creal) {
+    const int cpg = Creal / G, g = c / cpg;
+    const float xv = x[e];
+    float gd = dout[e];
+    if (mask && !(__builtin_fmaf(xv, scale[(long)n * C + c], shift[(long)n * C + c]) > 0.f)) gd = 0.f;
+    const float r_ = rstd[n * G + g];
+    const float xh = (xv - mu[n * G + g]) * r_;
+    out = r_ * (gamma[c] * gd - coef[((long)n * G + g) * 2] - xh * coef[((long)n * G + g) * 2 + 1]);
+  }
+  dx[e] = out;     // channel-pad lanes (compression 31 -> 32) get 0
+}
+
+hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
+                         const float *rstd, const float *gamma, int B, long P, int C, int Creal, int G, int mask,
+                         float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s) {
+  int chunks = (int)(P / 256);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  // the reduce kernel walks channels 0..C-1 of the padded tensor; pad channels are never read by finalize
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, dout, scale, shift, mu, rstd,
+                     C, Creal, G, P, chunks, mask, part);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)G), dim3(64), 0, s, part, B, C, Creal, G, P, chunks, gamma,
+                     coef, dgamma, dbeta);
+  const long total = (long)B * P * C;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dout, scale, shift, mu,
+                     rstd, gamma, coef, C, Creal, G, P, total, mask, dx);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// g = dy * (y > 0)   (ReLU backward on a materialised activation);  optionally  g += add
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float *dy, const float *y, const float *add, long n4,
+                                                      float *g) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const f32x4 d = reinterpret_cast<const f32x4 *>(dy)[e], v = reinterpret_cast<const f32x4 *>(y)[e];
+  f32x4 o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = v[t] > 0.f ? d[t] : 0.f;
+  if (add != nullptr) {
+    const f32x4 a = reinterpret_cast<const f32x4 *>(add)[e];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] += a[t];
+  }
+  reinterpret_cast<f32x4 *>(g)[e] = o;
+}
+
+hipError_t launch_relu_mask(const float *dy, const float *y, const float *add, long n, float *g, hipStream_t s) {
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dy, y, add, n4, g);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float *a, const float *b, long n4, float *o) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const f32x4 x = reinterpret_cast<const f32x4 *>(a)[e], y = reinterpret_cast<const f32x4 *>(b)[e];
+  reinterpret_cast<f32x4 *>(o)[e] = x + y;
+}
+
+hipError_t launch_add(const float *a, const float *b, long n, float *o, hipStream_t s) {
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, b, n4, o);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stem tail in training: relu(gn(x)) + MaxPool(3, 2, 1) that also records WHICH window element won (first maximum in
+// (kh, kw) scan order, as torch's max_pool2d backward does), and the backward that routes dPool to those elements.
+__global__ __launch_bounds__(256) void gn_relu_maxpool_idx_kernel(const float *x, const float *scale, const float *shift,
+                                                                int B, int H, int W, int C, int Ho, int Wo, float *out,
+                                                                unsigned char *idx) {
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * Ho * Wo * C;
+  if (g >= total) return;
+  const int c = (int)(g % C);
+  long r = g / C;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  const float sc = scale[(long)n * C + c], sh = shift[(long)n * C + c];
+  float m = -INFINITY;
+  int best = 0;
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = 2 * ho - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = 2 * wo - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const float v = fmaxf(__builtin_fmaf(x[(((long)n * H + hi) * W + wi) * C + c], sc, sh), 0.f);
+      if (v > m) {
+        m = v;
+        best = kh * 3 + kw;
+      }
+    }
+  }
+  out[g] = m;
+  idx[g] = (unsigned char)best;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *dpool, const unsigned char *idx, int B, int H,
+                                                        int W, int C, int Ho, int Wo, float *dact) {
+  // gather form (deterministic): input pixel (hi, wi) collects dPool of every window that elected it
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * H * W * C;
+  if (g >= total) return;
+  const int c = (int)(g % C);
+  long r = g / C;
+  const int wi = (int)(r % W);
+  r /= W;
+  const int hi = (int)(r % H);
+  const int n = (int)(r / H);
+  float acc = 0.f;
+  for (int kh = 0; kh < 3; ++kh) {
+    const int t = hi + 1 - kh;          // 2*ho = hi + 1 - kh
+    if (t < 0 || (t & 1)) continue;
+    const int ho = t >> 1;
+    if (ho >= Ho) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int u = wi + 1 - kw;
+      if (u < 0 || (u & 1)) continue;
+      const int wo = u >> 1;
+      if (wo >= Wo) continue;
+      const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
+      if (idx[o] == kh * 3 + kw) acc += dpool[o];
+    }
+  }
+  dact[g] = acc;
+}
+
+hipError_t launch_maxpool_train(const float *x, const float *scale, const float *shift, int B, int H, int W, int C,
+                                float *out, unsigned char *idx, hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * Ho * Wo * C;
+  hipLaunchKernelGGL(gn_relu_maxpool_idx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, B,
+                     H, W, C, Ho, Wo, out, idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_maxpool_bwd(const float *dpool, const unsigned char *idx, int B, int H, int W, int C, float *dact,
+                              hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpool, idx, B, H, W, C, Ho,
+                     Wo, dact);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// out[c] = sum_r x[r][c]  (bias gradients), fixed order, fp64
+__global__ __launch_bounds__(256) void colsum_kernel(const float *x, int rows, int cols, int ld, float *out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  double a = 0.0;
+  for (int r = 0; r < rows; ++r) a += (double)x[(long)r * ld + c];
+  out[c] = (float)a;
+}
+
+hipError_t launch_colsum(const float *x, int rows, int cols, int ld, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, x, rows, cols, ld, out);
+  return hipGetLastError();
+}
+
+// dst[r][0..ldd) = src[r][0..cols) zero padded (grad_out [B,3] -> [B,8] so it can feed the conv kernel)
+__global__ __launch_bounds__(256) void padcopy_kernel(const float *src, int rows, int cols, int ldd, float *dst) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)rows * ldd) return;
+  const int c = (int)(e % ldd);
+  const long r = e / ldd;
+  dst[e] = c < cols ? src[r * cols + c] : 0.f;
+}
+
+hipError_t launch_padcopy(const float *src, int rows, int cols, int ldd, float *dst, hipStream_t s) {
+  const long total = (long)rows * ldd;
+  hipLaunchKernelGGL(padcopy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, rows, cols, ldd, dst);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// loss = sum_d mean_i (target - pred)^2  (vo_cnn_engine.py:146-194, unit weights);  grad = dloss/dpred
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float *pred, const float *target, int B, int D, float *loss,
+                                                     float *grad) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int e = threadIdx.x; e < B * D; e += 256) {
+    const float d = target[e] - pred[e];
+    a += (double)d * (double)d;
+    if (grad) grad[e] = -2.0f * d / (float)B;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss) *loss = (float)(red[0] / (double)B);
+}
+
+hipError_t launch_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, hipStream_t s) {
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, s, pred, target, B, D, loss, grad);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (weight_decay 0, amsgrad off) on flat buffers; step counts from 1
+__global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, long n, float lr, float b1,
+                                                 float b2, float eps, float bc1, float sqrt_bc2) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float gi = g[e];
+  const float mi = b1 * m[e] + (1.f - b1) * gi;
+  const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+  m[e] = mi;
+  v[e] = vi;
+  p[e] -= (lr / bc1) * mi / (sqrtf(vi) / sqrt_bc2 + eps);
+}
+
+hipError_t launch_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps,
+                       int step, hipStream_t s) {
+  const float bc1 = 1.f - (float)pow((double)b1, (double)step);
+  const float sq2 = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1,
+                     sq2);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dst[i] = map[i] > 0 ? src[map[i] - 1] : 0   (re-pack kernel operands from the flat parameter buffer on device)
+__global__ __launch_bounds__(256) void gather_kernel(const float *src, const int *map, long n, float *dst) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int k = map[e];
+  dst[e] = k > 0 ? src[k - 1] : 0.f;
+}
+
+hipError_t launch_gather(const float *src, const int *map, long n, float *dst, hipStream_t s) {
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, map, n, dst);
+  return hipGetLastError();
+}
+
+// whitening table of the fused stem from device-resident running statistics (reference channel order -> stem order)
+__global__ void whiten_table_kernel(const float *mean, const float *var, const int *ref_of_new, const int *tensor_of_new,
+                                    int CPL, float *sc, float *sh) {
+  const int c = threadIdx.x;
+  if (c >= CPL) return;
+  const int r = ref_of_new[c];
+  float a = 0.f, b = 0.f;
+  if (r >= 0) {
+    const double sd = sqrt(fmax((double)var[r], 1e-2));
+    const double div = tensor_of_new[c] == 0 ? 255.0 : 1.0;
+    a = (float)(1.0 / (div * sd));
+    b = (float)(-(double)mean[r] / sd);
+  }
+  sc[c] = a;
+  sh[c] = b;
+}
+
+hipError_t launch_whiten_table(const float *mean, const float *var, const int *ref_of_new, const int *tensor_of_new, int CPL,
+                               float *sc, float *sh, hipStream_t s) {
+  hipLaunchKernelGGL(whiten_table_kernel, dim3(1), dim3(64), 0, s, mean, var, ref_of_new, tensor_of_new, CPL, sc, sh);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-channel moments of the assembled input for RunningMeanAndVar's train-mode update (running_mean_and_var.py:24-38):
+//   out[c] = mean over (n, pixel) of (x_c - center_c)^pw,  x_c in the reference channel order, rgb / 255.
+// Two stages (per-block partial, then fixed-order fp64 sum).
+__global__ __launch_bounds__(256) void moments_partial_kernel(const MomentsArgs a, double *part) {
+  __shared__ double red[256];
+  const int c = blockIdx.y;
+  const int t = a.tensor[c];
+  const float *base = a.src[t];
+  const int nch = a.nch[t], ch = a.ch[c];
+  const float div = t == 0 ? 255.0f : 1.0f;
+  const float ctr = a.center ? a.center[c] : 0.f;
+  double s = 0.0;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < a.npix; p += (long)gridDim.x * 256) {
+    const float d = base[p * nch + ch] / div - ctr;
+    s += a.pw == 2 ? (double)d * (double)d : (double)d;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(long)c * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ void moments_final_kernel(const double *part, int nblk, long npix, int C, float *out) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += part[(long)c * nblk + k];
+  out[c] = (float)(s / (double)npix);
+}
+
+hipError_t launch_moments(const MomentsArgs &a, int C, double *part, float *out, hipStream_t s) {
+  const int nblk = 256;
+  hipLaunchKernelGGL(moments_partial_kernel, dim3(nblk, (unsigned)C), dim3(256), 0, s, a, part);
+  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(64), 0, s, part, nblk, a.npix, C, out);
+  return hipGetLastError();
+}
+
+}  // namespace pnvo

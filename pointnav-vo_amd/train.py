@@ -1,0 +1,160 @@
+"""One optimisation step of a VO action model on the MI355X (BASELINE config 4).
+
+Mirrors, for one action model, the body of the reference's training iteration
+(/root/reference/pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py:855-901):
+
+    optimizer.zero_grad(); out = vo_model(batch_pairs)      (model.train(): RunningMeanAndVar updates, dropout)
+    loss = sum_d mean((gt_d - pred_d)^2)                     (vo_cnn_engine.py:135-198, loss_weight_fixed)
+    loss.backward(); optimizer.step()                        (Adam lr 2.5e-4, eps 1e-8, wd 0: :122-133)
+
+Forward, backward, loss and Adam are HIP kernels behind the C ABI (pnvo_train_*); this class only owns the flat
+device buffers and performs the collectives the reference semantics call for when torch.distributed is initialised:
+RunningMeanAndVar's three all-reduces (running_mean_and_var.py:27-38) and ONE all-reduce of the flat gradient buffer
+(RCCL over xGMI on the GPU box; 15.85 MB for the default model).  Dropout must be 0 (the reference's 0.2 uses torch's
+RNG stream, which cannot be reproduced; hash-based dropout is future work).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class VOTrainStep:
+    def __init__(self, model, lr=2.5e-4, eps=1e-8, betas=(0.9, 0.999)):
+        if model.cfg.act_embed:
+            raise NotImplementedError("training of act_embed variants is not built")
+        if getattr(model, "dropout_p", 0.0) != 0.0:
+            raise NotImplementedError("training needs dropout_p = 0 (torch's dropout RNG stream cannot be reproduced)")
+        self.model = model
+        self.lr, self.eps, self.betas = float(lr), float(eps), betas
+        ref = next(model.parameters())
+        if ref.device.type != "cuda":
+            raise RuntimeError("VOTrainStep runs on an MI355X only: move the model with .to('cuda') first")
+        self.dev = ref.device
+        model._ensure_handle(self.dev)
+        model._sync_weights()                                   # allocates the kernel operand buffers
+        named = [(n, p) for n, p in model.named_parameters()]
+        total = sum(p.numel() for _, p in named)
+        self.flat = torch.empty(total, device=self.dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        toc = (_lib.pnvo_tensor_desc * len(named))()
+        off = 0
+        self.offsets = {}
+        with torch.no_grad():
+            for i, (n, p) in enumerate(named):
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)    # the module's parameters alias the flat buffer
+                p.grad = self.grad[off:off + k].view(p.shape)
+                toc[i].name = n.encode()
+                toc[i].offset = off
+                toc[i].ndim = p.dim()
+                for d, sz in enumerate(p.shape):
+                    toc[i].shape[d] = int(sz)
+                self.offsets[n] = (off, k)
+                off += k
+        self._toc = toc
+        _lib.check(_lib.lib.pnvo_train_attach(model._handle, _ptr(self.flat), _ptr(self.grad), total, toc, len(named)),
+                   model._handle)
+        self.step_count = 0
+        enc = model.visual_encoder
+        self.rmv = getattr(enc, "running_mean_and_var", None) if model.cfg.normalize else None
+        Cc = model.cfg.in_channels
+        self._m1 = torch.empty(Cc, device=self.dev)
+        self._m2 = torch.empty(Cc, device=self.dev)
+        self._loss = torch.zeros(1, device=self.dev)
+
+    # ------------------------------------------------------------------ pieces
+    def _obs_ptrs(self, obs):
+        c = self.model.cfg
+        ptrs, keep, B = [], [], None
+        for key, n in (("rgb", c.n_rgb), ("depth", c.n_depth), ("discretized_depth", c.n_dd), ("top_down_view", c.n_tdv)):
+            if n == 0:
+                ptrs.append(None)
+                continue
+            t = obs[key].to(device=self.dev, dtype=torch.float32).contiguous()
+            assert t.shape[1:] == (c.height, c.width, n), (key, tuple(t.shape))
+            B = t.shape[0] if B is None else B
+            keep.append(t)
+            ptrs.append(_ptr(t))
+        return ptrs, keep, B
+
+    def _update_running_stats(self, ptrs, B, stream):
+        """RunningMeanAndVar.forward, training branch (running_mean_and_var.py:23-60), statistics by HIP kernels."""
+        h = self.model._handle
+        rmv = self.rmv
+        distributed = dist.is_available() and dist.is_initialized()
+        _lib.check(_lib.lib.pnvo_input_moments(h, *ptrs, int(B), None, 1, _ptr(self._m1), stream), h)
+        new_mean = (self._m1 * B).view(1, -1, 1, 1)                 # = adaptive_avg_pool2d(x, 1).sum(0)
+        new_count = torch.full_like(rmv._count, B)
+        if distributed:
+            dist.all_reduce(new_mean)
+            dist.all_reduce(new_count)
+        new_mean = new_mean / new_count
+        ctr = new_mean.reshape(-1).contiguous()
+        _lib.check(_lib.lib.pnvo_input_moments(h, *ptrs, int(B), _ptr(ctr), 2, _ptr(self._m2), stream), h)
+        new_var = (self._m2 * B).view(1, -1, 1, 1)
+        if distributed:
+            dist.all_reduce(new_var)
+        new_var = new_var / new_count
+        m_a = rmv._var * rmv._count
+        m_b = new_var * new_count
+        M2 = m_a + m_b + (new_mean - rmv._mean).pow(2) * rmv._count * new_count / (rmv._count + new_count)
+        rmv._var = M2 / (rmv._count + new_count)
+        rmv._mean = (rmv._count * rmv._mean + new_count * new_mean) / (rmv._count + new_count)
+        rmv._count += new_count
+
+    def forward_backward(self, obs_pairs, target=None, grad_out=None):
+        """Train-mode forward + backward.  Either `target` [B,3] (the reference's regression loss) or an explicit
+        `grad_out` = dLoss/dOut [B,3] (e.g. from the geometric-invariance loss computed on the [B,3] outputs).
+        Returns (out, loss or None); gradients are left in self.grad (not yet all-reduced)."""
+        h = self.model._handle
+        ptrs, keep, B = self._obs_ptrs(obs_pairs)
+        out = torch.empty((B, self.model.cfg.out_dim), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev), torch.no_grad():
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            mean = var = None
+            if self.rmv is not None:
+                self._update_running_stats(ptrs, B, stream)
+                mean = self.rmv._mean.reshape(-1).contiguous()
+                var = self.rmv._var.reshape(-1).contiguous()
+            _lib.check(_lib.lib.pnvo_train_forward(h, *ptrs, int(B), _ptr(mean), _ptr(var), _ptr(out), stream), h)
+            loss = None
+            if grad_out is None:
+                tgt = target.to(device=self.dev, dtype=torch.float32).contiguous()
+                grad_out = torch.empty_like(out)
+                _lib.check(_lib.lib.pnvo_mse_loss(_ptr(out), _ptr(tgt), int(B), out.shape[1], _ptr(self._loss),
+                                                  _ptr(grad_out), stream))
+                loss = self._loss.clone()
+            else:
+                grad_out = grad_out.to(device=self.dev, dtype=torch.float32).contiguous()
+            _lib.check(_lib.lib.pnvo_train_backward(h, _ptr(grad_out), stream), h)
+        return out, loss
+
+    def optimizer_step(self):
+        """All-reduce (mean) of the flat gradient buffer across ranks, Adam, re-pack of the kernel operands."""
+        h = self.model._handle
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad)                                # ONE RCCL collective, 15.85 MB
+            self.grad /= dist.get_world_size()
+        self.step_count += 1
+        with torch.cuda.device(self.dev):
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            _lib.check(_lib.lib.pnvo_adam_step(_ptr(self.flat), _ptr(self.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                               self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                               self.step_count, stream))
+            _lib.check(_lib.lib.pnvo_train_refresh(h, stream), h)
+
+    def step(self, obs_pairs, target):
+        """zero_grad / forward / loss / backward / all-reduce / Adam — returns (out [B,3], loss tensor)."""
+        out, loss = self.forward_backward(obs_pairs, target=target)
+        self.optimizer_step()
+        return out, loss

@@ -1,0 +1,83 @@
+"""GPU (-m gpu): the HIP training step (forward in train mode, backward, Adam) against the golden vectors captured
+from the imported reference and against the pinned fp64 torch checker on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case, load_golden
+from oracle import torch_train_ref as ref
+from pointnav_vo_amd.registry import baseline_registry
+from pointnav_vo_amd import vo_cnn  # noqa: F401
+from pointnav_vo_amd.train import VOTrainStep
+
+pytestmark = pytest.mark.gpu
+
+
+def build(rec):
+    cfg, sd, obs, _ = golden_case(rec)
+    space = str(rec["obs_space"]).split(",")
+    model = baseline_registry.get_vo_model(str(rec["model"]))(
+        observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
+        normalize_visual_inputs=True, output_dim=3, dropout_p=0.0, discretized_depth_channels=int(rec["dd_bins"]))
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model = model.to("cuda:0")
+    tobs = {k: torch.from_numpy(v).to("cuda:0") for k, v in obs.items()}
+    return model, cfg, sd, obs, tobs
+
+
+@pytest.mark.parametrize("fname", ["train_default_96x64_b3_f32.npz", "train_default_45x37_b4_f64.npz"])
+def test_train_step_matches_reference(fname):
+    rec = load_golden(fname)
+    model, cfg, sd, obs, tobs = build(rec)
+    ts = VOTrainStep(model, lr=float(rec["lr"]), eps=float(rec["eps"]))
+    target = torch.from_numpy(rec["target"]).to("cuda:0")
+    out, loss = ts.forward_backward(tobs, target=target)
+    torch.cuda.synchronize()
+    # fp64 checker on the same inputs (full gradients)
+    chk = ref.train_step(sd, obs, rec["target"], ngroups=cfg.ngroups, lr=float(rec["lr"]), eps=float(rec["eps"]),
+                         dtype=torch.float64)
+    # forward (train mode: updated RunningMeanAndVar statistics) and loss
+    np.testing.assert_allclose(out.cpu().numpy(), rec["out1"], rtol=2e-4, atol=2e-5)
+    assert abs(loss.item() - float(rec["loss1"])) < 1e-4 * max(1.0, abs(float(rec["loss1"])))
+    for k in ("_mean", "_var", "_count"):
+        b = getattr(model.visual_encoder.running_mean_and_var, k).cpu().double().numpy().reshape(-1)
+        np.testing.assert_allclose(b, rec[f"buf1/visual_encoder.running_mean_and_var.{k}"].reshape(-1), rtol=1e-5, atol=1e-6)
+    # every parameter gradient
+    bad = []
+    for name, (off, n) in ts.offsets.items():
+        g = ts.grad[off:off + n].cpu().double().numpy()
+        gr = chk["grads"][name].reshape(-1).numpy()
+        err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
+        gn = float(rec[f"g1norm/{name}"])
+        if err > 2e-3 or abs(np.linalg.norm(g) - gn) > 5e-3 * max(gn, 1e-9):
+            bad.append((name, err, np.linalg.norm(g), gn))
+    assert not bad, bad
+    # Adam: first step moves every parameter by lr * sign(g) (|m|/sqrt(v) = 1); compare with the checker where |g| is
+    # large enough for the sign to be well defined
+    before = ts.flat.clone()
+    ts.optimizer_step()
+    torch.cuda.synchronize()
+    for name, (off, n) in ts.offsets.items():
+        gr = chk["grads"][name].reshape(-1).numpy()
+        pr = chk["params"][name].reshape(-1).numpy()
+        sel = np.abs(gr) > 1e-6 * max(np.abs(gr).max(), 1e-30)
+        got = ts.flat[off:off + n].cpu().double().numpy()
+        np.testing.assert_allclose(got[sel], pr[sel], rtol=0, atol=2e-6, err_msg=name)
+    assert not torch.equal(before, ts.flat)
+    # the re-packed kernel operands are the updated parameters: eval forward == checker forward with the new params
+    newsd = {**{k: v.numpy() for k, v in chk["params"].items()}, **{k: v.numpy() for k, v in chk["buffers"].items()}}
+    from oracle import oracle
+    want = oracle.forward(newsd, obs, ngroups=cfg.ngroups, dtype=np.float64)
+    with torch.no_grad():
+        got = model.eval()(tobs).cpu().numpy()
+    err = np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-2)
+    assert err.max() < 5e-3, err          # parameters differ by <= 2e-6 where the gradient sign was ambiguous
+
+
+def test_two_steps_reduce_loss_on_a_fixed_batch():
+    rec = load_golden("train_default_96x64_b3_f32.npz")
+    model, cfg, sd, obs, tobs = build(rec)
+    ts = VOTrainStep(model, lr=1e-5)
+    target = torch.from_numpy(rec["target"]).to("cuda:0")
+    losses = [ts.step(tobs, target)[1].item() for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
