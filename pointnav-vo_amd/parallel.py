@@ -37,3 +37,12 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place mean of a flat buffer over all ranks — the ONE data-path collective of the training step (the
+    3 962 305-float gradient buffer of an action model: 15.85 MB; ring all-reduce over xGMI)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+        flat /= dist.get_world_size()
+    return flat

@@ -36,8 +36,9 @@ def _worker(rank, world, port, q):
     out = torch.from_numpy(_forward(sd, cfg, obs))
     full = parallel.gather_results(out, TOTAL)
     tmax = parallel.max_over_ranks(1.0 + rank)
+    g = parallel.allreduce_mean_(torch.arange(6, dtype=torch.float32) * (rank + 1))   # gradient averaging
     if rank == 0:
-        q.put((full.numpy(), tmax))
+        q.put((full.numpy(), tmax, g.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +61,7 @@ def test_two_rank_sharded_inference_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full, tmax = q.get()
+    full, tmax, g = q.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -68,3 +69,4 @@ def test_two_rank_sharded_inference_equals_single_process():
     ref = _forward(sd, cfg, synth.make_obs_pairs(TOTAL, H, W, observation_space=SPACE, seed=5))
     np.testing.assert_array_equal(full, ref)        # N-rank result == 1-process result, in pair order
     assert tmax == 2.0                               # MAX over ranks
+    np.testing.assert_array_equal(g, np.arange(6, dtype=np.float32) * 1.5)   # mean of rank 0 (x1) and rank 1 (x2)
