@@ -318,7 +318,7 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
     maxc = std::max(maxc, l.coutp);
     maxg = std::max(maxg, l.groups);
   }
-  if ((rc = dmalloc(m, (void **)&t->gn_part, (size_t)B * 64 * maxc * 2 * 4)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->gn_part, (size_t)B * 65 * maxc * 2 * 4)) != PNVO_OK) return rc;   // 64 chunks + [B][C][2]
   if ((rc = dmalloc(m, (void **)&t->gn_coef, (size_t)B * maxg * 2 * 4)) != PNVO_OK) return rc;
   if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 256 * 8)) != PNVO_OK) return rc;
   t->capB = B;

@@ -96,20 +96,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       sc = bload(rsc, (vm && ci < p.CIN) ? (unsigned)(((long)n * p.CIN + ci) * 4) : PNVO_OOB);
       sh = bload(rsh, (vm && ci < p.CIN) ? (unsigned)(((long)n * p.CIN + ci) * 4) : PNVO_OOB);
     }
+    // this pixel's window origin; the tap only adds wave-uniform constants
+    const int hb = ho * p.stride - p.pad, wb = wo * p.stride - p.pad;
+    const long pix0 = ((long)n * p.H + hb) * p.W + wb;
+    const bool cok = vm && ci < p.CIN;
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-      const int tap = t0 + t;
+      const int tap = t0 + t;                       // wave-uniform
       const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-      const bool ok = vm && tap < T && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const bool ok = vm && tap < T && (unsigned)(hb + kh) < (unsigned)p.H && (unsigned)(wb + kw) < (unsigned)p.W;
       st.ok[t] = ok;
+      const long pix = pix0 + (long)kh * p.W + kw;
       float v;
       if (MODE == 2) {
-        const long pix = ((long)n * p.H + hi) * p.W + wi;
         const float *addr = (ok && sbase != nullptr) ? sbase + pix * snch + schoff : p.zero_page;
         v = __builtin_fmaf(*addr, ssc, ssh);
       } else {
-        v = bload(rx, (ok && ci < p.CIN) ? (unsigned)(((((long)n * p.H + hi) * p.W + wi) * p.CIN + ci) * 4) : PNVO_OOB);
+        v = bload(rx, (ok && cok) ? (unsigned)((pix * p.CIN + ci) * 4) : PNVO_OOB);
         if (MODE == 1) v = fmaxf(__builtin_fmaf(v, sc, sh), 0.f);
       }
       st.a[t] = v;
@@ -205,7 +208,7 @@ void wgrad_plan(WgradArgs &a) {
   a.ci_tiles = (a.CIN + 31) / 32;
   a.pairs = a.ci_tiles * ((a.COUT + 31) / 32);
   const long M = (long)a.B * a.Ho * a.Wo;
-  long chunks = 4096 / ((long)a.pairs * a.groups);
+  long chunks = 2048 / ((long)a.pairs * a.groups);
   if (chunks < 1) chunks = 1;
   long ppc = (M + chunks - 1) / chunks;
   if (ppc < 64) ppc = 64;
@@ -283,37 +286,43 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *x, cons
   }
 }
 
-// per (n, group): c1 = S1/N, c2 = S2/N;  per channel: dgamma, dbeta (sum over n in a fixed order, fp64)
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float *part, int B, int C, int Creal, int G, long P,
-                                                           int chunks, const float *gamma, float *coef, float *dgamma,
-                                                           float *dbeta) {
-  // grid = G blocks; block handles group g for all n
-  const int g = blockIdx.x, cpg = Creal / G;
-  const double N = (double)cpg * (double)P;
-  for (int k = threadIdx.x; k < cpg; k += 64) {   // per-channel parameter gradients
-    const int c = g * cpg + k;
-    double dg = 0.0, db = 0.0;
-    for (int n = 0; n < B; ++n)
-      for (int ch = 0; ch < chunks; ++ch) {
-        const float *src = part + (((long)n * chunks + ch) * C + c) * 2;
-        db += (double)src[0];
-        dg += (double)src[1];
-      }
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
+// stage A: per (n, channel) sum of the chunk partials (fixed order) -> nc[n][c][2]
+__global__ __launch_bounds__(256) void gn_bwd_sum_chunks_kernel(const float *part, int B, int C, int chunks, float *nc) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)B * C) return;
+  const int n = (int)(e / C), c = (int)(e % C);
+  double a1 = 0.0, a2 = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const float *src = part + (((long)n * chunks + ch) * C + c) * 2;
+    a1 += (double)src[0];
+    a2 += (double)src[1];
   }
-  for (int n = threadIdx.x; n < B; n += 64) {     // per-(sample, group) coefficients
+  nc[e * 2] = (float)a1;
+  nc[e * 2 + 1] = (float)a2;
+}
+
+// stage B: per (n, group): c1 = S1/N, c2 = S2/N;  per channel: dgamma, dbeta (sum over n in a fixed order, fp64)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, int B, int C, int Creal, int G, long P,
+                                                            const float *gamma, float *coef, float *dgamma, float *dbeta) {
+  const int cpg = Creal / G;
+  const double N = (double)cpg * (double)P;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < Creal) {                               // per-channel parameter gradients
+    double dg = 0.0, db = 0.0;
+    for (int n = 0; n < B; ++n) {
+      db += (double)nc[((long)n * C + e) * 2];
+      dg += (double)nc[((long)n * C + e) * 2 + 1];
+    }
+    dgamma[e] = (float)dg;
+    dbeta[e] = (float)db;
+  }
+  if (e < B * G) {                               // per-(sample, group) coefficients
+    const int n = e / G, g = e % G;
     double S1 = 0.0, S2 = 0.0;
     for (int k = 0; k < cpg; ++k) {
       const int c = g * cpg + k;
-      double a1 = 0.0, a2 = 0.0;
-      for (int ch = 0; ch < chunks; ++ch) {
-        const float *src = part + (((long)n * chunks + ch) * C + c) * 2;
-        a1 += (double)src[0];
-        a2 += (double)src[1];
-      }
-      S1 += (double)gamma[c] * a1;
-      S2 += (double)gamma[c] * a2;
+      S1 += (double)gamma[c] * (double)nc[((long)n * C + c) * 2];
+      S2 += (double)gamma[c] * (double)nc[((long)n * C + c) * 2 + 1];
     }
     coef[((long)n * G + g) * 2] = (float)(S1 / N);
     coef[((long)n * G + g) * 2 + 1] = (float)(S2 / N);
@@ -350,8 +359,12 @@ hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, 
   // the reduce kernel walks channels 0..C-1 of the padded tensor; pad channels are never read by finalize
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, dout, scale, shift, mu, rstd,
                      C, Creal, G, P, chunks, mask, part);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)G), dim3(64), 0, s, part, B, C, Creal, G, P, chunks, gamma,
-                     coef, dgamma, dbeta);
+  float *nc = part + (size_t)B * chunks * C * 2;     // [B][C][2] right behind the chunk partials
+  hipLaunchKernelGGL(gn_bwd_sum_chunks_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, s, part, B, C, chunks,
+                     nc);
+  const int work = (B * G > Creal) ? B * G : Creal;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, nc, B, C, Creal, G, P,
+                     gamma, coef, dgamma, dbeta);
   const long total = (long)B * P * C;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dout, scale, shift, mu,
                      rstd, gamma, coef, C, Creal, G, P, total, mask, dx);
