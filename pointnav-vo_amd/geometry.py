@@ -1,0 +1,56 @@
+"""Goal / pose bookkeeping that consumes the VO output in the nav loop.
+
+Restates /root/reference/pointnav_vo/utils/geometry_utils.py:69-99 (`compute_global_state`) and :115-144
+(`compute_goal_pos`).  The reference delegates the rotations to third-party packages that are absent from
+/root/reference and from this image — `quaternion` (numpy-quaternion, unpinned, environment.yml) and habitat-lab's
+`quaternion_rotate_vector` / `cartesian_to_polar` — so the arithmetic is restated here from their published
+definitions (q v q^-1 rotation; polar = (hypot(x, y), atan2(y, x))) in closed form for rotations about the y axis.
+PARITY UNPINNED (no golden vectors can be captured without those packages); covered by property tests.
+Quaternions are numpy arrays [x, y, z, w] (habitat's `quaternion_to_list` order).
+"""
+import numpy as np
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw,
+                     aw * bw - ax * bx - ay * by - az * bz], dtype=np.float64)
+
+
+def _quat_rotate(q, v):
+    """q v q^-1 for a unit quaternion q = [x, y, z, w]."""
+    qv = np.asarray(q[:3], dtype=np.float64)
+    w = float(q[3])
+    v = np.asarray(v, dtype=np.float64)
+    t = 2.0 * np.cross(qv, v)
+    return v + w * t + np.cross(qv, t)
+
+
+def quat_from_angle_axis_y(theta):
+    """quaternion.from_rotation_vector(theta * [0, 1, 0])  (geometry_utils.py:57-66)."""
+    return np.array([0.0, np.sin(theta / 2.0), 0.0, np.cos(theta / 2.0)], dtype=np.float64)
+
+
+def compute_global_state(prev_global_state, local_delta_state):
+    """(rotation [x,y,z,w], position [3]) at t  +  (dx, dz, dyaw) in the local frame -> state at t+1
+    (geometry_utils.py:69-99): v2 = v1 + q1 * [dx,0,dz] * q1^-1 ;  q2 = q1 * rot_y(dyaw)."""
+    prev_rot, prev_pos = prev_global_state
+    dx, dz, dyaw = local_delta_state
+    cur_pos = np.asarray(prev_pos, dtype=np.float64) + _quat_rotate(prev_rot, [dx, 0.0, dz])
+    cur_rot = _quat_mul(np.asarray(prev_rot, dtype=np.float64), quat_from_angle_axis_y(dyaw))
+    return cur_rot, cur_pos
+
+
+def compute_goal_pos(prev_goal_pos, local_delta_state):
+    """Goal position in the agent frame at t+1 from the one at t and the VO estimate (geometry_utils.py:115-144):
+    g' = q^-1 (g - [dx,0,dz]) q with q = rot_y(dyaw);  polar = (rho, -phi) of (-g'_z, g'_x)."""
+    dx, dz, dyaw = local_delta_state
+    q = quat_from_angle_axis_y(dyaw)
+    qinv = np.array([-q[0], -q[1], -q[2], q[3]])
+    cur = _quat_rotate(qinv, np.asarray(prev_goal_pos, dtype=np.float64) - np.array([dx, 0.0, dz]))
+    rho = np.hypot(-cur[2], cur[0])
+    phi = np.arctan2(cur[0], -cur[2])
+    return {"cartesian": cur, "polar": np.array([rho, -phi], dtype=np.float32)}
