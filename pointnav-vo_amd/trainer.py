@@ -203,10 +203,25 @@ class BaseRLTrainerWithVO:
         float32 array [N,3].  Pairs are grouped per action model (sep_act) and each group is one forward."""
         assert len(prev_obs_list) == len(cur_obs_list) == len(acts)
         n = len(acts)
-        rgb = np.stack([np.concatenate([p["rgb"], c["rgb"]], axis=2) for p, c in zip(prev_obs_list, cur_obs_list)])
-        dep = np.stack([np.concatenate([p["depth"], c["depth"]], axis=2) for p, c in zip(prev_obs_list, cur_obs_list)])
-        rgb_pair = torch.from_numpy(rgb).to(self.device).to(torch.float32)       # uint8 over PCIe, widened on device
-        depth_pair = torch.from_numpy(np.ascontiguousarray(dep, dtype=np.float32)).to(self.device)
+        H, W = prev_obs_list[0]["depth"].shape[:2]
+        # host -> device: every frame is copied ONCE into a reusable pinned staging buffer (uint8 rgb, fp32 depth) and
+        # shipped in one async transfer; the (prev | cur) channel concatenation and the uint8 -> float widening happen
+        # on the device (the reference builds FloatTensors on the host and copies 4 tensors per pair, :172-193)
+        st = getattr(self, "_staging", None)
+        if st is None or st[0].shape[0] < n or st[0].shape[2:4] != (H, W):
+            st = (torch.empty((n, 2, H, W, 3), dtype=torch.uint8).pin_memory(),
+                  torch.empty((n, 2, H, W, 1), dtype=torch.float32).pin_memory())
+            self._staging = st
+        prgb, pdep = st[0][:n].numpy(), st[1][:n].numpy()
+        for i, (p, c) in enumerate(zip(prev_obs_list, cur_obs_list)):
+            prgb[i, 0] = p["rgb"]
+            prgb[i, 1] = c["rgb"]
+            pdep[i, 0] = p["depth"]
+            pdep[i, 1] = c["depth"]
+        drgb = st[0][:n].to(self.device, non_blocking=True)
+        ddep = st[1][:n].to(self.device, non_blocking=True)
+        rgb_pair = drgb.permute(0, 2, 3, 1, 4).reshape(n, H, W, 6).to(torch.float32)     # [prev_rgb | cur_rgb]
+        depth_pair = ddep.permute(0, 2, 3, 1, 4).reshape(n, H, W, 2).contiguous()        # [prev_d | cur_d]
         obs_pairs = self._build_obs_pairs(rgb_pair, depth_pair)
         if getattr(self, "_dd_flag", None) is not None:
             assert self._dd_flag.item() == 0, "depth must lie in [0, 1]"
