@@ -28,6 +28,7 @@ extern "C" {
 #define PNVO_ERR_HIP (-2)      /* a HIP runtime call failed (message has hipGetErrorString) */
 #define PNVO_ERR_STATE (-3)    /* call order violated (e.g. forward before load_weights) */
 #define PNVO_ERR_WEIGHTS (-4)  /* state_dict table does not match the configured architecture */
+#define PNVO_ERR_INPUT (-5)    /* observation data violates the reference's own contract (see pnvo_check_inputs) */
 
 typedef struct pnvo_model_s *pnvo_handle;
 
@@ -163,6 +164,13 @@ typedef struct {
   double flops;               /* algorithmic FLOPs of those launches (2*MACs), 0 for non-GEMM kernels */
   double bytes;               /* algorithmic bytes of those launches (tensor reads + writes, once each) */
 } pnvo_kernel_time;
+/* The discretised-depth observation must be one-hot per frame — what _discretize_depth_func produces and asserts
+ * (pointnav_vo/rl/common/base_trainer_with_vo.py:163); the fused stem exploits it.  A forward that meets a depth pixel
+ * that is not exactly one 1 and zeros raises a host-visible flag: pnvo_check_inputs returns PNVO_ERR_INPUT once that
+ * has been observed (definitive after the caller synchronised the stream), and so does every later pnvo_forward.
+ * Callers that feed soft depth codes select the dense stem with the environment variable PNVO_STEM=dense. */
+int pnvo_check_inputs(pnvo_handle h);
+
 int pnvo_timing_mode(pnvo_handle h, int mode);
 int pnvo_timing_read(pnvo_handle h, pnvo_kernel_time *entries, int cap, int *n_out);
 

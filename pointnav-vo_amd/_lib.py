@@ -62,6 +62,7 @@ _SIGNATURES = {
     "pnvo_last_error": (C.c_char_p, [C.c_void_p]),
     "pnvo_set_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "pnvo_tap_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
+    "pnvo_check_inputs": (C.c_int, [C.c_void_p]),
     "pnvo_timing_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pnvo_timing_read": (C.c_int, [C.c_void_p, C.POINTER(pnvo_kernel_time), C.c_int, C.POINTER(C.c_int)]),
     "pnvo_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

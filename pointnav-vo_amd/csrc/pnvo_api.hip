@@ -403,7 +403,49 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
   const Layer &stem = m->convs[0];
   int rc = PNVO_OK;
   const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
-  if (lds_stem) {
+  const char *sel = std::getenv("PNVO_STEM");
+  if (m->dd_ok && m->train == nullptr && !(sel && std::strcmp(sel, "dense") == 0)) {
+    // one-hot-aware stem.  (The training path keeps the dense kernel: its operands are re-packed by pure gathers.)
+    const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+    StemDDArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < 3; ++j)
+      for (int q = 0; q < 2; ++q) {
+        const int d = 4 * j + 2 * q;
+        const int tn = m->dd_dense_tensor[d];
+        a.pieces[j][0][q].base = tn >= 0 ? src[tn] : nullptr;
+        a.pieces[j][0][q].nch = tn >= 0 ? nsrc[tn] : 0;
+        a.pieces[j][0][q].choff = tn >= 0 ? m->dd_dense_ch[d] : 0;
+      }
+    a.sc = m->dd_sc;
+    a.sh = m->dd_sh;
+    a.wpk = m->dd_wpk;
+    a.table = m->dd_table;
+    a.dd = src[2];
+    a.zero_page = m->zero_page;
+    a.bad_onehot = m->dd_flag;
+    a.y = y;
+    a.stats = m->stats;
+    a.B = B;
+    a.H = c.height;
+    a.W = c.width;
+    a.Ho = m->Hs;
+    a.Wo = m->Ws;
+    a.bins = m->dd_bins;
+    a.slots = stem_dd_slots(m->Hs, m->Ws);
+    if (const char *e = std::getenv("PNVO_STEM_DBG")) a.dbg = std::atoi(e);
+    const double M = (double)B * m->Hs * m->Ws;
+    {
+      Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
+              4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
+      HIPCHK(m, launch_stem_dd(a, s));
+    }
+    {
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
+                                   stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
+    }
+  } else if (lds_stem) {
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
     StemArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -536,6 +578,70 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     std::vector<float> pk16((size_t)49 * h->CPL * st.cout);
     pack_stem_weight(wp.data(), st.cout, h->CP, h->CPL, pk16.data());
     if ((rc = upload(h, h->stem_wpk16, pk16.data(), pk16.size())) != PNVO_OK) return rc;
+    // ---- one-hot-aware stem: split the input channels into dense (matrix cores) and one-hot depth bins (table gather)
+    h->dd_ok = false;
+    const int bins = c.n_dd / 2;
+    if (c.n_dd > 0 && stem_dd_supported(bins) && st.cout == 32 && c.normalize) {
+      h->dd_dense_tensor.clear();
+      h->dd_dense_ch.clear();
+      std::vector<int> dense_ref;
+      for (int nc = 0; nc < h->CP; ++nc)
+        if (h->stem_ref_of_new[nc] >= 0 && h->stem_tensor_of_new[nc] != 2) {
+          h->dd_dense_tensor.push_back(h->stem_tensor_of_new[nc]);
+          h->dd_dense_ch.push_back(h->stem_ch_of_new[nc]);
+          dense_ref.push_back(h->stem_ref_of_new[nc]);
+        }
+      const int nd = (int)dense_ref.size();
+      if (nd % 2 == 0 && nd + 1 <= 12) {
+        std::vector<float> wd((size_t)st.cout * 12 * T, 0.f), sc16(12, 0.f), sh16(12, 0.f);
+        for (int d = 0; d < nd; ++d) {
+          const int r = dense_ref[d];
+          for (int o = 0; o < st.cout; ++o)
+            std::memcpy(&wd[((size_t)o * 12 + d) * T], &w[((size_t)o * st.cin + r) * T], sizeof(float) * T);
+          const double sd = (double)h->stdev[r], mu = (double)h->mean[r];
+          const double div = (h->dd_dense_tensor[d] == 0) ? 255.0 : 1.0;
+          sc16[d] = (float)(1.0 / (div * sd));
+          sh16[d] = (float)(-mu / sd);
+        }
+        sh16[nd] = 1.0f;                                   // indicator channel: 1 inside the image (x = 0, sc = 0)
+        while ((int)h->dd_dense_tensor.size() < 12) {
+          h->dd_dense_tensor.push_back(-1);
+          h->dd_dense_ch.push_back(0);
+        }
+        // reference channel of one-hot entry (frame f, bin b)
+        std::vector<int> ddref(2 * bins, -1);
+        for (int nc = 0; nc < h->CP; ++nc)
+          if (h->stem_ref_of_new[nc] >= 0 && h->stem_tensor_of_new[nc] == 2) ddref[h->stem_ch_of_new[nc]] = h->stem_ref_of_new[nc];
+        const int slice = stem_dd_slice_floats(bins), brows = bins + 1;
+        std::vector<float> tab((size_t)7 * slice, 0.f);
+        for (int kh = 0; kh < 7; ++kh)
+          for (int kw = 0; kw < 7; ++kw) {
+            const int tap = kh * 7 + kw;
+            for (int o = 0; o < st.cout; ++o) {
+              double ind = 0.0;
+              for (int f = 0; f < 2; ++f)
+                for (int b = 0; b < bins; ++b) {
+                  const int r = ddref[f * bins + b];
+                  const double wv = (double)w[((size_t)o * st.cin + r) * T + tap];
+                  const double sd = (double)h->stdev[r], mu = (double)h->mean[r];
+                  tab[(size_t)kh * slice + (((size_t)kw * brows + b) * 2 + f) * 32 + o] = (float)(wv / sd);
+                  ind -= wv * mu / sd;
+                }
+              wd[((size_t)o * 12 + nd) * T + tap] = (float)ind;   // weight of the "inside the image" indicator
+            }
+          }
+        std::vector<float> pkd((size_t)49 * 12 * st.cout);
+        pack_stem_dd_weight(wd.data(), st.cout, pkd.data());
+        if ((rc = upload(h, h->dd_wpk, pkd.data(), pkd.size())) != PNVO_OK) return rc;
+        if ((rc = upload(h, h->dd_table, tab.data(), tab.size())) != PNVO_OK) return rc;
+        if ((rc = upload(h, h->dd_sc, sc16.data(), 12)) != PNVO_OK) return rc;
+        if ((rc = upload(h, h->dd_sh, sh16.data(), 12)) != PNVO_OK) return rc;
+        if (!h->dd_flag) HIPCHK(h, hipHostMalloc((void **)&h->dd_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+        *(volatile int *)h->dd_flag = 0;
+        h->dd_bins = bins;
+        h->dd_ok = true;
+      }
+    }
   }
   // Linear(flat[+embed] -> hidden): visual columns become the fh x fw "conv"; the embedding columns fold into a
   // per-action bias row:  bias[a][o] = b[o] + sum_e W[o][flat+e] * emb[a][e]   (vo_cnn_act_embed.py:63-72)
@@ -581,6 +687,15 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
   return PNVO_OK;
 }
 
+int pnvo_check_inputs(pnvo_handle m) {
+  if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
+  if (m->dd_flag && *(volatile int *)m->dd_flag != 0)
+    return fail(m, PNVO_ERR_INPUT,
+                "an earlier forward met a discretised-depth pixel that is not one-hot (base_trainer_with_vo.py:163); "
+                "its outputs are invalid.  Feed one-hot depth, or set PNVO_STEM=dense for soft depth codes");
+  return PNVO_OK;
+}
+
 int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
                  const int64_t *actions, int B, float *out, void *stream) {
   if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
@@ -591,6 +706,7 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
       (c.n_tdv > 0) != (tdv != nullptr))
     return fail(m, PNVO_ERR_ARG, "observation tensors do not match the model's observation_space");
   if (c.act_embed && !actions) return fail(m, PNVO_ERR_ARG, "act_embed model needs actions");
+  if (int rc0 = pnvo_check_inputs(m)) return rc0;
   HIPCHK(m, hipSetDevice(m->device));
   int rc = ensure_workspace(m, B);
   if (rc != PNVO_OK) return rc;
@@ -719,6 +835,11 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->stem_sc);
   free_dev(m->stem_sh);
   free_dev(m->stem_wpk16);
+  free_dev(m->dd_wpk);
+  free_dev(m->dd_table);
+  free_dev(m->dd_sc);
+  free_dev(m->dd_sh);
+  if (m->dd_flag) (void)hipHostFree(m->dd_flag);
   free_dev(m->zero_page);
   for (auto &r : m->trecs) {
     (void)hipEventDestroy(r.a);

@@ -53,6 +53,25 @@ int stem_tiles_y(int Ho);
 hipError_t launch_stem_lds(const StemArgs &a, int cout, hipStream_t s);
 void pack_stem_weight(const float *oihw_new, int cout, int cinp, int cpl, float *out);
 
+// The one-hot-aware fused stem (stem_dd.hip): dense channels on the matrix cores, one-hot depth bins as a table gather.
+struct StemDDArgs {
+  SrcPiece pieces[8][2][2];   // [slot][0][q]: dense channels 4*slot + 2q (rgb | depth | tdv | indicator | pad) of 12
+  const float *sc, *sh;       // [12] whitening of the dense channels; indicator: sc = 0, sh = 1
+  const float *wpk;           // pack_stem_dd_weight of the dense + indicator weights
+  const float *table;         // [7 kh][slice]: [7 kw][bins + 1][2 frames][32] one-hot weight rows (row `bins` = 0)
+  const float *dd;            // discretised-depth tensor [B,H,W,2*bins]
+  const float *zero_page;
+  int *bad_onehot;            // device flag: a depth pixel was not one-hot
+  float *y, *stats;
+  int B, H, W, Ho, Wo, bins, slots, tiles_x, tiles_y, slice_floats;
+  int dbg;                    // experiment knobs (PNVO_STEM_DBG): 1 skip the gathers, 2 skip the MFMAs
+};
+int stem_dd_slice_floats(int bins);
+bool stem_dd_supported(int bins);
+int stem_dd_slots(int Ho, int Wo);                  // GroupNorm partial-sum slots per sample (tiles)
+void pack_stem_dd_weight(const float *w_o12t, int cout, float *out);
+hipError_t launch_stem_dd(const StemDDArgs &a, hipStream_t s);
+
 int conv_slots(int P, int MT);                       // stats slots per sample for a given wave tile
 void choose_tile(long M, int COUTP, int *MT, int *NT);
 hipError_t launch_conv(const ConvArgs &a, hipStream_t s);

@@ -42,6 +42,12 @@ struct pnvo_model_s {
   float *stem_sc = nullptr, *stem_sh = nullptr, *zero_page = nullptr;   // device: whitening table in the new order
   float *stem_wpk16 = nullptr;       // stem weights packed for the LDS-staged 16x16x4 kernel
   int CPL = 0;                       // stem channels per pixel in LDS (C rounded up to 16)
+  // one-hot-aware stem (stem_dd.hip): dense channels + indicator on the matrix cores, depth bins as a table gather
+  bool dd_ok = false;
+  int dd_bins = 0;
+  std::vector<int> dd_dense_tensor, dd_dense_ch;   // dense channel d -> (observation tensor, channel), -1 = indicator/pad
+  float *dd_wpk = nullptr, *dd_table = nullptr, *dd_sc = nullptr, *dd_sh = nullptr;
+  int *dd_flag = nullptr;            // device: set when a depth pixel was not one-hot
 
   int cap = 0;                       // batch the workspace is sized for
   float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};

@@ -1,0 +1,352 @@
+// stem_dd.hip — the fused 7x7 stride-2 stem for models whose input carries one-hot discretised-depth channels
+// (gfx950 only).  Same role / epilogue contract as stem_lds.hip, but the K loop is split by the STRUCTURE of the input:
+//
+//   * DENSE channels (rgb, depth, top-down view: 10 of the default model's 30) + one INDICATOR channel (12 with padding)
+//     go through the fp32 matrix cores: 3 x v_mfma_f32_16x16x4_f32 per tap and 16-channel output tile instead of 8;
+//   * the 2 x BINS ONE-HOT channels contribute, per tap and frame, exactly one pre-scaled weight row
+//         sum_c W[co][c][tap] * (onehot_c - mean_c)/std_c  =  W[co][bin][tap]/std_bin  -  sum_c W[co][c][tap]*mean_c/std_c
+//     The first term is a GATHER from a table T[tap][bin][frame][co] (LDS-resident per kernel row kh) added on the VALU,
+//     concurrently with the MFMAs; the second term is constant wherever the tap lies inside the image and 0 in the conv's
+//     zero padding (padding is applied AFTER whitening, vo_cnn.py:176-177), i.e. it is the weight of an "inside the
+//     image" indicator channel — which is how it rides the matrix-core path and stays exact at the borders.
+//   Every product the reference computes is either computed here or is an exact zero; only the fp32 summation order
+//   differs.  SURVEY.md §7 "hard parts" names this design choice; roofline figures still use the algorithmic FLOPs.
+//
+// Workgroup = 8 waves, tile = 8 output rows x 16 columns, wave w = output row w (persistent workgroups, 2 per CU):
+//   MFMA   : the wave's 16 pixels x 32 channels, all 49 taps, K = 12 per tap; weights stream from L2 (b96 buffer loads,
+//            prefetched two taps ahead), the whitened dense patch [21 x 37 pixels][12] sits in LDS;
+//   gather : lane = (frame, channel): one ds_read_b32 fetches both frames' weight rows of one pixel, and the 64 lanes hit
+//            64 distinct LDS banks whatever the bins are (a table row is [2 frames][32 channels] = 256 B).  The row
+//            offsets (bin * 256) of the 37 patch columns of a kernel row are held in registers for its 7 taps;
+//   table  : one kernel-row slice (7 taps, 19.25 KiB) is resident, the next one arrives by LDS-DMA (global_load_lds) while
+//            the current one is used: one workgroup barrier per kernel row.
+//   LDS    : 2 x 20 KiB table + 777 x 48 B dense patch + 777 x 4 B row offsets = 79.5 KiB -> 2 workgroups per CU.
+//
+// Contract: the discretised-depth input must be one-hot per frame (what the reference's _discretize_depth_func
+// produces and asserts, base_trainer_with_vo.py:163).  A pixel whose BINS values are not exactly one 1 and zeros raises
+// the host-visible flag `p.bad_onehot` (pnvo_check_inputs); callers with soft depth codes select PNVO_STEM=dense.
+#include <type_traits>
+
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+
+namespace {
+constexpr int TH = 8, TW = 16;
+constexpr int PH = 2 * TH + 5, PW = 2 * TW + 5;   // 21 x 37
+constexpr int NPIX = PH * PW;                     // 777
+constexpr int NTHREADS = 512;
+constexpr int CD = 12;                            // dense channels per pixel in LDS (3 x 16-byte slots)
+constexpr int NT16 = 2, COUT = 32;
+constexpr int GP = 36;                            // pitch of the gather-result exchange rows (bank spread)
+
+constexpr int slice_floats_c(int bins) { return (7 * (bins + 1) * 64 + 255) / 256 * 256; }   // whole KiB (LDS-DMA)
+
+__device__ __forceinline__ f32x3 wload3(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0));
+}
+}  // namespace
+
+template <int BINS>
+__global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p) {
+  constexpr int BROWS = BINS + 1;                 // + the all-zero row for padding pixels
+  constexpr int KWB = BROWS * 256;                // bytes of one kernel-column block of the table
+  constexpr int SLICE_F = slice_floats_c(BINS), SLICE_B = SLICE_F * 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tab = lds;                                                         // 2 x [7 kw][BROWS][2 f][32 c]  (offset 0:
+  float *dense = lds + 2 * SLICE_F;                                         //   gather immediates stay < 64 KiB)
+  unsigned short *offs = reinterpret_cast<unsigned short *>(dense + NPIX * CD);   // [NPIX][2 f] byte offsets bin*256
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // = output row of the tile
+  const int i = lane & 15, kq = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpk, 0, 49u * NT16 * 768u, 0x00020000);
+  const unsigned wlane = (unsigned)lane * 12u;
+  constexpr unsigned SB = NT16 * 768u;
+
+  // Table slice: global -> LDS by LDS-DMA (16 B per lane, 1 KiB per wave instruction, no VGPRs).  Issued through inline
+  // asm on purpose: the compiler would otherwise order every later LDS read behind the copy (s_waitcnt vmcnt(0) right
+  // after issue).  The waves wait for it explicitly (row_end) one kernel row later.
+  const unsigned tab_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)tab;
+  auto dma_slice = [&](int kh, int buf) {
+    const char *g = reinterpret_cast<const char *>(p.table + (long)kh * SLICE_F) + lane * 16;
+    for (int c = wave; c < SLICE_B / 1024; c += NTHREADS / 64) {
+      const char *gc = g + c * 1024;
+      const unsigned lc = tab_lds + (unsigned)(buf * SLICE_B + c * 1024);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gc), "s"(lc) : "m0", "memory");
+    }
+  };
+
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int n = bid / p.tiles_y;
+    const int ho0 = ty * TH, wo0 = tx * TW;
+    const int hi_base = 2 * ho0 - 3, wi_base = 2 * wo0 - 3;
+
+    dma_slice(0, 0);                              // the previous tile's last barrier freed both table buffers
+    // dense staging role: thread -> (pixel, 16-byte slot); 510 threads cover 170 pixels per pass.  Re-derived per tile
+    // (the empty asm stops the compiler from keeping ~40 loop-invariant staging registers alive across the K loop).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int sg = tid % 3, pp0 = tid / 3;
+    const bool stager = tid < 510;
+    const SrcPiece e0 = p.pieces[sg][0][0], e1 = p.pieces[sg][0][1];
+    const f32x4 wsc = *reinterpret_cast<const f32x4 *>(p.sc + 4 * sg);
+    const f32x4 wsh = *reinterpret_cast<const f32x4 *>(p.sh + 4 * sg);
+    // ---- stage 1/2: dense patch (whitened; indicator channel = 1 inside the image), loads batched for MLP
+    {
+      constexpr int PSTEP = 170;
+      constexpr int NB = (NPIX + PSTEP - 1) / PSTEP;        // 5
+      f32x2 x0[NB], x1[NB];
+      bool ok[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pp = pp0 + b * PSTEP;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int hi = hi_base + pr, wi = wi_base + pc;
+        ok[b] = stager && pp < NPIX && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const long pix = ((long)n * p.H + hi) * p.W + wi;
+        const float *a0 = (ok[b] && e0.base != nullptr) ? e0.base + pix * e0.nch + e0.choff : p.zero_page;
+        const float *a1 = (ok[b] && e1.base != nullptr) ? e1.base + pix * e1.nch + e1.choff : p.zero_page;
+        x0[b] = *reinterpret_cast<const f32x2 *>(a0);
+        x1[b] = *reinterpret_cast<const f32x2 *>(a1);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pp = pp0 + b * PSTEP;
+        if (stager && pp < NPIX) {
+          f32x4 v = {x0[b][0], x0[b][1], x1[b][0], x1[b][1]};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = ok[b] ? __builtin_fmaf(v[t], wsc[t], wsh[t]) : 0.f;
+          *reinterpret_cast<f32x4 *>(dense + pp * CD + 4 * sg) = v;
+        }
+      }
+    }
+    // ---- stage 2/2: depth bins of the patch pixels: thread -> pixel (both frames), bin = position of the single 1
+    {
+      constexpr int NB = (NPIX + NTHREADS - 1) / NTHREADS;  // 2
+      constexpr int NV = 2 * BINS / 4;                      // float4 per pixel
+      f32x4 dv[NB][NV];
+      bool okp[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pp = tid + b * NTHREADS;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int hi = hi_base + pr, wi = wi_base + pc;
+        okp[b] = pp < NPIX && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const long pix = ((long)n * p.H + hi) * p.W + wi;
+        const float *src = okp[b] ? p.dd + pix * (2 * BINS) : p.zero_page;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) dv[b][k] = *reinterpret_cast<const f32x4 *>(src + (okp[b] ? 4 * k : 0));
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int pp = tid + b * NTHREADS;
+        if (pp < NPIX) {
+          int bin[2] = {BINS, BINS}, ones[2] = {0, 0};
+          bool clean = true;
+          if (okp[b]) {
+#pragma unroll
+            for (int e = 0; e < 2 * BINS; ++e) {
+              const float v = dv[b][e >> 2][e & 3];
+              if (v == 1.0f) {
+                bin[e / BINS] = e % BINS;
+                ++ones[e / BINS];
+              } else if (v != 0.0f) {
+                clean = false;
+              }
+            }
+            if (!clean || ones[0] != 1 || ones[1] != 1) *p.bad_onehot = 1;
+          }
+          *reinterpret_cast<unsigned *>(offs + 2 * pp) = (unsigned)(bin[0] * 256) | ((unsigned)(bin[1] * 256) << 16);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of table slice 0 is in LDS
+    __syncthreads();
+
+    // ---- K loop.  One BLOCK = (kernel row kh, pixel half HP, kernel column kw): 8 gathers (pixels 8*HP.. of this wave's
+    //      row, both frames) + the 3 MFMAs of tap (kh,kw) for output channels 16*HP..  Blocks are written as inline asm:
+    //      left to itself the compiler hoists every gather of a kernel row above the adds and spills them to scratch.
+    //      In-order issue does the overlap: 8 ds_reads go out, the 3 MFMAs cover their latency, then the 8 adds.
+    f32x4 acc[NT16];
+    float gacc[16];
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gacc[q] = 0.f;
+    const float *abase = dense + ((2 * wave) * PW + 2 * i) * CD + 3 * kq;       // MFMA A: pixel i, channels 3kq..3kq+2
+    const unsigned short *obase = offs + ((2 * wave) * PW) * 2 + (lane >> 5);   // gather: this lane's frame
+    const unsigned lane4 = tab_lds + (unsigned)lane * 4u;               // LDS address of (frame*32 + channel) in row 0
+
+    auto ld_b = [&](int tap, int nt) -> f32x3 {                         // tap >= 49: out of range -> zeros
+      return wload3(rw, wlane + (unsigned)nt * 768u, (unsigned)tap * SB);
+    };
+    auto ld_a = [&](int kh, int kw) -> f32x3 {                          // (kh = 7 reads past the patch: unused)
+      const float *a = abase + (kh * PW + kw) * CD;
+      return f32x3{a[0], a[1], a[2]};
+    };
+    f32x3 b_cur = ld_b(0, 0), b_nxt = ld_b(1, 0), a_cur = ld_a(0, 0);
+    dma_slice(1, 1);
+
+    auto grow = [&](int kh, auto bufc) {
+      constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+      for (int HP = 0; HP < 2; ++HP) {
+        unsigned o[21];
+        const unsigned short *orow = obase + (kh * PW + 16 * HP) * 2;
+#pragma unroll
+        for (int j = 0; j < 21; ++j) o[j] = (unsigned)orow[2 * j] + lane4;
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+          const int x2 = HP * 7 + kw + 2, x1 = HP * 7 + kw + 1;       // blocks g+2 (weights) and g+1 (pixels)
+          const f32x3 b_pre = ld_b((kh + x2 / 14) * 7 + (x2 % 14) % 7, (x2 % 14) / 7);
+          const f32x3 a_nxt = ld_a(kh + x1 / 14, (x1 % 14) % 7);
+          float *g = gacc + 8 * HP;
+          asm volatile(
+              "ds_read_b32 v120, %[o0] offset:%[imm]\n\t"
+              "ds_read_b32 v121, %[o1] offset:%[imm]\n\t"
+              "ds_read_b32 v122, %[o2] offset:%[imm]\n\t"
+              "ds_read_b32 v123, %[o3] offset:%[imm]\n\t"
+              "ds_read_b32 v124, %[o4] offset:%[imm]\n\t"
+              "ds_read_b32 v125, %[o5] offset:%[imm]\n\t"
+              "ds_read_b32 v126, %[o6] offset:%[imm]\n\t"
+              "ds_read_b32 v127, %[o7] offset:%[imm]\n\t"
+              "v_mfma_f32_16x16x4_f32 %[c], %[a0], %[b0], %[c]\n\t"
+              "v_mfma_f32_16x16x4_f32 %[c], %[a1], %[b1], %[c]\n\t"
+              "v_mfma_f32_16x16x4_f32 %[c], %[a2], %[b2], %[c]\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "v_add_f32 %[g0], %[g0], v120\n\t"
+              "v_add_f32 %[g1], %[g1], v121\n\t"
+              "v_add_f32 %[g2], %[g2], v122\n\t"
+              "v_add_f32 %[g3], %[g3], v123\n\t"
+              "v_add_f32 %[g4], %[g4], v124\n\t"
+              "v_add_f32 %[g5], %[g5], v125\n\t"
+              "v_add_f32 %[g6], %[g6], v126\n\t"
+              "v_add_f32 %[g7], %[g7], v127"
+              : [c] "+v"(acc[HP]), [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),
+                [g5] "+v"(g[5]), [g6] "+v"(g[6]), [g7] "+v"(g[7])
+              : [o0] "v"(o[kw]), [o1] "v"(o[kw + 2]), [o2] "v"(o[kw + 4]), [o3] "v"(o[kw + 6]), [o4] "v"(o[kw + 8]),
+                [o5] "v"(o[kw + 10]), [o6] "v"(o[kw + 12]), [o7] "v"(o[kw + 14]), [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]),
+                [a2] "v"(a_cur[2]), [b0] "v"(b_cur[0]), [b1] "v"(b_cur[1]), [b2] "v"(b_cur[2]),
+                [imm] "i"(BUF * SLICE_B + kw * KWB)
+              : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+          b_cur = b_nxt;
+          b_nxt = b_pre;
+          a_cur = a_nxt;
+        }
+      }
+    };
+    auto row_end = [&](int kh) {                  // slice kh+1 has landed for everyone; slice kh's buffer is free
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kh + 2 < 7) dma_slice(kh + 2, kh & 1);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    for (int kh = 0; kh < 6; kh += 2) {
+      grow(kh, C0{});
+      row_end(kh);
+      grow(kh + 1, C1{});
+      row_end(kh + 1);
+    }
+    grow(6, C0{});
+
+    // ---- epilogue: gathered sums (lane = frame x channel) -> MFMA C layout through LDS, store, per-tile GroupNorm
+    //      partials.  Fixed order: mfma + (prev-frame row + cur-frame row).
+    __syncthreads();
+    float *gx = dense;                                      // [8 rows][16 pixels][GP]
+    float *red = gx + TH * 16 * GP;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float s = gacc[q] + __shfl_xor(gacc[q], 32);
+      if (lane < 32) gx[(wave * 16 + q) * GP + lane] = s;
+    }
+    // (each wave reads back only what it wrote itself: LDS executes one wave's accesses in order, no barrier needed)
+    {
+      const int ho = ho0 + wave;
+      const bool rvalid = ho < p.Ho;
+      float *yrow = p.y + (((long)n * p.Ho + ho) * p.Wo) * COUT;
+#pragma unroll
+      for (int nt = 0; nt < NT16; ++nt) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int wo = wo0 + 4 * kq + r;
+          const bool ok = rvalid && wo < p.Wo;
+          const float g = gx[(wave * 16 + 4 * kq + r) * GP + nt * 16 + i];
+          const float v = ok ? acc[nt][r] + g : 0.f;
+          if (ok) yrow[(long)wo * COUT + nt * 16 + i] = v;
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
+        }
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (kq == 0) {
+          red[(wave * COUT + nt * 16 + i) * 2] = s1;
+          red[(wave * COUT + nt * 16 + i) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < COUT) {
+      const int c = threadIdx.x;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < TH; ++w) {
+        s1 += red[(w * COUT + c) * 2];
+        s2 += red[(w * COUT + c) * 2 + 1];
+      }
+      const int slot = ty * p.tiles_x + tx;
+      float *dst = p.stats + (((long)n * p.slots + slot) * COUT + c) * 2;
+      dst[0] = s1;
+      dst[1] = s2;
+    }
+    __syncthreads();
+  }
+}
+
+int stem_dd_slice_floats(int bins) { return slice_floats_c(bins); }
+
+bool stem_dd_supported(int bins) { return bins == 10; }
+
+int stem_dd_slots(int Ho, int Wo) { return ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW); }
+
+// Dense + indicator weights [cout][12][49] (OIHW over the 12 dense channels) -> MFMA B operand order
+// [tap][n-tile][lane = kq*16 + n][t] = W[n-tile*16 + n][3*kq + t][tap]   (12 B per lane, b96 loads).
+void pack_stem_dd_weight(const float *w, int cout, float *out) {
+  for (int tap = 0; tap < 49; ++tap)
+    for (int nt = 0; nt < cout / 16; ++nt)
+      for (int kq = 0; kq < 4; ++kq)
+        for (int n = 0; n < 16; ++n)
+          for (int t = 0; t < 3; ++t)
+            out[(((size_t)tap * (cout / 16) + nt) * 64 + kq * 16 + n) * 3 + t] = w[((size_t)(nt * 16 + n) * CD + 3 * kq + t) * 49 + tap];
+}
+
+hipError_t launch_stem_dd(const StemDDArgs &a, hipStream_t s) {
+  StemDDArgs p = a;
+  p.tiles_x = (a.Wo + TW - 1) / TW;
+  p.tiles_y = (a.Ho + TH - 1) / TH;
+  p.slice_floats = stem_dd_slice_floats(a.bins);
+  if (!stem_dd_supported(a.bins)) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(2 * p.slice_floats + NPIX * CD + NPIX) * 4;
+  const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
+  const long resident = (long)(160 * 1024 / lds) * 256;
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
+  hipLaunchKernelGGL(stem_dd_kernel<10>, grid, dim3(NTHREADS), lds, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace pnvo

@@ -199,6 +199,13 @@ class VisualOdometryCNNBase(nn.Module):
             _lib.lib.pnvo_set_tap(self._handle, None, None, 0)
         return out, buf
 
+    def check_inputs(self):
+        """Raise PnvoError if an earlier forward met discretised depth that was not one-hot (the reference asserts
+        this where it builds the observation, base_trainer_with_vo.py:163).  Synchronise first for a definitive
+        answer; forward() performs the same check on entry."""
+        if self._handle is not None:
+            _lib.check(_lib.lib.pnvo_check_inputs(self._handle), self._handle)
+
     def timing(self, enable):
         dev = next(self.parameters()).device
         self._ensure_handle(dev)

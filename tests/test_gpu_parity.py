@@ -121,6 +121,61 @@ def test_full_batch_256_properties():
     np.testing.assert_array_equal(obs["top_down_view"][0, ..., 1].cpu().numpy(), oracle.topdown_view(d0[..., 1], c)[..., 0])
 
 
+def test_onehot_stem_agrees_with_dense_stem(monkeypatch):
+    """The default model's stem gathers the one-hot depth channels from a weight table (stem_dd.hip); PNVO_STEM=dense
+    selects the all-MFMA stem (stem_lds.hip).  Both compute the same products; they must agree to summation-order
+    noise at every output pixel, borders (zero padding after whitening) included, and both must match the reference."""
+    rec = load_golden("model_default_341x192_b2.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    with torch.no_grad():
+        out_dd, stem_dd = model.tap("stem_conv", tobs)
+        monkeypatch.setenv("PNVO_STEM", "dense")
+        out_dense, stem_dense = model.tap("stem_conv", tobs)
+        monkeypatch.delenv("PNVO_STEM")
+    a, b = stem_dd.cpu().numpy(), stem_dense.cpu().numpy()
+    assert a.shape == b.shape and np.abs(b).max() > 0.1
+    assert not np.array_equal(a, b), "PNVO_STEM=dense did not select a different kernel"
+    assert np.abs(a - b).max() / np.abs(b).max() < 2e-6
+    want = rec["tap/stem_conv"] if "tap/stem_conv" in rec else None
+    if want is not None:
+        assert np.abs(a[..., : want.shape[-1]] - want).max() / np.abs(want).max() < 2e-5
+    assert pair_rel_err(out_dd.cpu().numpy(), rec["out64"]).max() < TOL
+    assert pair_rel_err(out_dense.cpu().numpy(), rec["out64"]).max() < TOL
+
+
+def test_non_onehot_depth_is_reported_not_silently_wrong():
+    """base_trainer_with_vo.py:163 asserts the discretised depth is one-hot; the fused stem relies on it and must say so
+    loudly when the contract is broken (PNVO_ERR_INPUT), while PNVO_STEM=dense accepts soft codes."""
+    rec = load_golden("model_default_45x37_b3.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    bad = dict(tobs)
+    bad["discretized_depth"] = tobs["discretized_depth"].clone()
+    bad["discretized_depth"][1, 5, 7, :] = 0.1
+    with torch.no_grad():
+        model(tobs)
+        torch.cuda.synchronize()
+        model.check_inputs()                                       # clean input: no complaint
+        model(bad)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.PnvoError, match="one-hot"):
+            model.check_inputs()
+        with pytest.raises(_lib.PnvoError, match="one-hot"):
+            model(tobs)
+
+
+def test_soft_depth_codes_on_the_dense_stem(monkeypatch):
+    rec = load_golden("model_default_45x37_b3.npz")
+    monkeypatch.setenv("PNVO_STEM", "dense")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    soft = {k: v.copy() for k, v in obs.items()}
+    soft["discretized_depth"] = (0.8 * soft["discretized_depth"] + 0.02).astype(np.float32)
+    with torch.no_grad():
+        out = model({k: torch.from_numpy(v).to(dev()) for k, v in soft.items()}).cpu().numpy()
+        model.check_inputs()
+    ref = oracle.forward(sd, soft, ngroups=cfg.ngroups, dtype=np.float64)
+    assert pair_rel_err(out, ref).max() < TOL
+
+
 # ----------------------------------------------------------------------------- pre-processing (bit-exact)
 def test_discretize_depth_bit_exact():
     rec = load_golden("preproc.npz")
