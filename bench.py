@@ -32,10 +32,10 @@ W, H, BINS = 341, 192, 10
 SPACE = ["rgb", "depth", "discretized_depth", "top_down_view"]
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes of ONE stem launch at B=256 from rocprofv3 PMC passes (profiles/r1_final_pmc_traffic.md):
-# FETCH_SIZE 2.023e6 KiB (x2: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md §HBM) + WRITE_SIZE 5.45e5 KiB.
-# Algorithmic bytes of that launch: 2.01 GB of observation tensors + 0.54 GB of raw stem output.
-STEM_TRAFFIC_B256 = (2 * 2.023e6 + 5.45e5) * 1024
+# HBM-side bytes of ONE stem launch at B=256 from rocprofv3 PMC passes (profiles/r1b_stem_dd_pmc.md; the dense stem:
+# profiles/r1_final_pmc_traffic.md): FETCH_SIZE in KiB (x2: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md
+# §HBM) + WRITE_SIZE in KiB.  Algorithmic bytes of that launch: 2.01 GB of observation tensors + 0.54 GB of stem output.
+STEM_TRAFFIC_B256 = {"onehot": (2 * 1.625e6 + 5.339e5) * 1024, "dense": (2 * 2.023e6 + 5.45e5) * 1024}
 
 
 def build_model(dev, seed=0):
@@ -158,6 +158,22 @@ def main():
         per_launch_ms = dom["total_ms"] / dom["launches"]
         ach = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
         total_kernel_ms = sum(k["total_ms"] for k in kt)
+        stem_kind = "dense" if os.environ.get("PNVO_STEM") == "dense" else "onehot"
+        is_stem = dom["name"].endswith("conv1.0")
+        executed = None
+        if is_stem and stem_kind == "onehot":
+            # stem_dd.hip multiplies only the 10 dense channels + 1 indicator (K = 12 per tap) on the matrix cores and
+            # GATHERS the 20 one-hot channels from an LDS table: the algorithmic FLOPs (30 channels) exceed the executed
+            # ones, so `frac` (algorithmic / peak, the contract's definition) can pass 1.  The executed-work figures
+            # below are the ones the kernel is actually bounded by.
+            ho, wo = (H + 1) // 2, (W + 1) // 2
+            px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128          # pixels of the 8x16 tiles, padding included
+            mfma_tf = 2.0 * px * 32 * 12 * 49 / (per_launch_ms * 1e-3) / 1e12
+            lds_gbs = px * 49 * 256.0 / (per_launch_ms * 1e-3) / 1e9
+            executed = {"mfma_tflops": mfma_tf, "mfma_frac": mfma_tf / PEAK_FP32_TFLOPS,
+                        "lds_gather_GBps": lds_gbs, "lds_gather_frac": lds_gbs / (256 * 128 * 2.4),
+                        "note": "one-hot depth channels are gathered from an LDS weight table instead of multiplied; "
+                                "K = 12 of the 30 input channels run on the MFMA pipe (DESIGN.md section 4)"}
         res = {
             "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -171,9 +187,10 @@ def main():
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
             "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": STEM_TRAFFIC_B256 if (B == 256 and dom["name"].endswith("conv1.0")) else None,
-                         "traffic_note": "bytes per launch, rocprofv3 PMC of this command (profiles/r1_final_pmc_traffic.md)",
-                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
+                         "traffic": STEM_TRAFFIC_B256[stem_kind] if (B == 256 and is_stem) else None,
+                         "traffic_note": "bytes per launch, rocprofv3 PMC of this command (profiles/r1b_stem_dd_pmc.md)",
+                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms,
+                         "executed": executed},
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
                                 "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}

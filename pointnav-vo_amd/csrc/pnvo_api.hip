@@ -434,6 +434,13 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.bins = m->dd_bins;
     a.slots = stem_dd_slots(m->Hs, m->Ws);
     if (const char *e = std::getenv("PNVO_STEM_DBG")) a.dbg = std::atoi(e);
+    if (a.dbg == 9) {
+      if (!m->dd_prof) {
+        HIPCHK(m, hipMalloc((void **)&m->dd_prof, 32));
+        HIPCHK(m, hipMemset(m->dd_prof, 0, 32));
+      }
+      a.prof = m->dd_prof;
+    }
     const double M = (double)B * m->Hs * m->Ws;
     {
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
@@ -840,6 +847,14 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->dd_sc);
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
+  if (m->dd_prof) {
+    unsigned long long pr[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(pr, m->dd_prof, 32, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[pnvo] stem_dd phases (cycles per tile, workgroup thread 0): staging %.0f  k-loop %.0f  epilogue %.0f  (%llu tiles)\n",
+                 (double)pr[0] / (double)(pr[3] ? pr[3] : 1), (double)pr[1] / (double)(pr[3] ? pr[3] : 1),
+                 (double)pr[2] / (double)(pr[3] ? pr[3] : 1), pr[3]);
+    (void)hipFree(m->dd_prof);
+  }
   free_dev(m->zero_page);
   for (auto &r : m->trecs) {
     (void)hipEventDestroy(r.a);

@@ -64,7 +64,8 @@ struct StemDDArgs {
   int *bad_onehot;            // device flag: a depth pixel was not one-hot
   float *y, *stats;
   int B, H, W, Ho, Wo, bins, slots, tiles_x, tiles_y, slice_floats;
-  int dbg;                    // experiment knobs (PNVO_STEM_DBG): 1 skip the gathers, 2 skip the MFMAs
+  int dbg;                    // experiment variants (PNVO_STEM_DBG); 9 = per-phase cycle counters into prof[4]
+  unsigned long long *prof;
 };
 int stem_dd_slice_floats(int bins);
 bool stem_dd_supported(int bins);

@@ -47,7 +47,8 @@ struct pnvo_model_s {
   int dd_bins = 0;
   std::vector<int> dd_dense_tensor, dd_dense_ch;   // dense channel d -> (observation tensor, channel), -1 = indicator/pad
   float *dd_wpk = nullptr, *dd_table = nullptr, *dd_sc = nullptr, *dd_sh = nullptr;
-  int *dd_flag = nullptr;            // device: set when a depth pixel was not one-hot
+  int *dd_flag = nullptr;            // host-mapped: set when a depth pixel was not one-hot
+  unsigned long long *dd_prof = nullptr;   // PNVO_STEM_DBG=9: {staging, K loop, epilogue} cycles, tiles
 
   int cap = 0;                       // batch the workspace is sized for
   float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};

@@ -12,15 +12,24 @@
 //   Every product the reference computes is either computed here or is an exact zero; only the fp32 summation order
 //   differs.  SURVEY.md §7 "hard parts" names this design choice; roofline figures still use the algorithmic FLOPs.
 //
-// Workgroup = 8 waves, tile = 8 output rows x 16 columns, wave w = output row w (persistent workgroups, 2 per CU):
-//   MFMA   : the wave's 16 pixels x 32 channels, all 49 taps, K = 12 per tap; weights stream from L2 (b96 buffer loads,
-//            prefetched two taps ahead), the whitened dense patch [21 x 37 pixels][12] sits in LDS;
-//   gather : lane = (frame, channel): one ds_read_b32 fetches both frames' weight rows of one pixel, and the 64 lanes hit
-//            64 distinct LDS banks whatever the bins are (a table row is [2 frames][32 channels] = 256 B).  The row
-//            offsets (bin * 256) of the 37 patch columns of a kernel row are held in registers for its 7 taps;
+// Workgroup = 8 waves, tile = 8 output rows x 16 columns, wave w = output row w (persistent workgroups, 2 per CU).
+// The K loop is a sequence of BLOCKS (kernel row kh, pixel half HP, kernel column kw), 98 per tile and wave:
+//   MFMA   : block (kh,HP,kw) multiplies the wave's 16 pixels with tap (kh,kw) for output channels 16*HP.. (K = 12:
+//            3 MFMAs); weights stream from L2 (b96 buffer loads, prefetched 4 blocks ahead), the whitened dense patch
+//            sits in LDS as 12 channel planes of 21 x 37 pixels (odd plane pitch: the A reads of a half-wave cover the
+//            32 banks exactly once; a pixel-major [777][12] layout was 4-way conflicted and cost half the LDS time);
+//   gather : block (kh,HP,kw) adds the table rows of pixels 8*HP.. of the wave's row.  lane = (frame, channel): one
+//            ds_read_b32 fetches both frames' rows of one pixel and the 64 lanes hit distinct banks whatever the bins are
+//            (a table row is [2 frames][32 channels] = 256 B).  The row offsets (bin * 256) of the 21 patch columns a
+//            half-row needs are held in registers for its 7 taps.  The gathers of block g+1 are issued between the
+//            MFMAs of block g (software pipeline inside a half-row), their adds follow one block later;
 //   table  : one kernel-row slice (7 taps, 19.25 KiB) is resident, the next one arrives by LDS-DMA (global_load_lds) while
-//            the current one is used: one workgroup barrier per kernel row.
-//   LDS    : 2 x 20 KiB table + 777 x 48 B dense patch + 777 x 4 B row offsets = 79.5 KiB -> 2 workgroups per CU.
+//            the current one is used: one workgroup barrier per kernel row.  The last slice's buffer doubles as the
+//            epilogue's exchange area;
+//   LDS    : 2 x 20 KiB table + 12 x 777 x 4 B dense patch + 2 x 21 x 38 x 2 B row offsets = 79.5 KiB -> 2 WGs per CU.
+// The blocks are inline asm: left to itself the compiler hoists every gather of a kernel row above the adds and spills
+// them (840 B scratch/lane, 4x slower).  Measured (B=256, 341x192): 2.29 ms vs 3.73 ms for the dense stem; phases per
+// tile in cycles (PNVO_STEM_DBG=9): staging 10.8k, K loop 51.6k (MFMA-bound would be 37.6k), epilogue 3.7k.
 //
 // Contract: the discretised-depth input must be one-hot per frame (what the reference's _discretize_depth_func
 // produces and asserts, base_trainer_with_vo.py:163).  A pixel whose BINS values are not exactly one 1 and zeros raises
@@ -41,7 +50,9 @@ constexpr int TH = 8, TW = 16;
 constexpr int PH = 2 * TH + 5, PW = 2 * TW + 5;   // 21 x 37
 constexpr int NPIX = PH * PW;                     // 777
 constexpr int NTHREADS = 512;
-constexpr int CD = 12;                            // dense channels per pixel in LDS (3 x 16-byte slots)
+constexpr int CD = 12;                            // dense channels in LDS: 12 planes of NPIX floats (odd plane pitch:
+                                                  //   the MFMA A reads of a half-wave then cover all 32 banks once)
+constexpr int OW = 38;                            // row pitch of the u16 row-offset planes (even: pairs are dwords)
 constexpr int NT16 = 2, COUT = 32;
 constexpr int GP = 36;                            // pitch of the gather-result exchange rows (bank spread)
 
@@ -52,7 +63,7 @@ __device__ __forceinline__ f32x3 wload3(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 }  // namespace
 
-template <int BINS>
+template <int BINS, bool PROF>   // PROF: per-phase s_memtime brackets into p.prof (PNVO_STEM_DBG=9)
 __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p) {
   constexpr int BROWS = BINS + 1;                 // + the all-zero row for padding pixels
   constexpr int KWB = BROWS * 256;                // bytes of one kernel-column block of the table
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tab = lds;                                                         // 2 x [7 kw][BROWS][2 f][32 c]  (offset 0:
   float *dense = lds + 2 * SLICE_F;                                         //   gather immediates stay < 64 KiB)
-  unsigned short *offs = reinterpret_cast<unsigned short *>(dense + NPIX * CD);   // [NPIX][2 f] byte offsets bin*256
+  unsigned short *offs = reinterpret_cast<unsigned short *>(dense + NPIX * CD);   // [2 f][PH][OW] byte offsets bin*256
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // = output row of the tile
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     }
   };
 
+  long long pt[4] = {0, 0, 0, 0};
   const int ntiles = p.B * p.tiles_x * p.tiles_y;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int bid = tile;
@@ -93,6 +105,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     const int ho0 = ty * TH, wo0 = tx * TW;
     const int hi_base = 2 * ho0 - 3, wi_base = 2 * wo0 - 3;
 
+    const long long tp0 = PROF ? clock64() : 0;
     dma_slice(0, 0);                              // the previous tile's last barrier freed both table buffers
     // dense staging role: thread -> (pixel, 16-byte slot); 510 threads cover 170 pixels per pass.  Re-derived per tile
     // (the empty asm stops the compiler from keeping ~40 loop-invariant staging registers alive across the K loop).
@@ -128,7 +141,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
           f32x4 v = {x0[b][0], x0[b][1], x1[b][0], x1[b][1]};
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = ok[b] ? __builtin_fmaf(v[t], wsc[t], wsh[t]) : 0.f;
-          *reinterpret_cast<f32x4 *>(dense + pp * CD + 4 * sg) = v;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dense[(4 * sg + t) * NPIX + pp] = v[t];
         }
       }
     }
@@ -153,28 +167,38 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
       for (int b = 0; b < NB; ++b) {
         const int pp = tid + b * NTHREADS;
         if (pp < NPIX) {
-          int bin[2] = {BINS, BINS}, ones[2] = {0, 0};
-          bool clean = true;
+          // branch-free: sum = 1 and every value in {0, 1} (v*v == v)  <=>  exactly one 1; bin = sum of k * v[k]
+          int bin[2] = {BINS, BINS};
           if (okp[b]) {
+            float dev = 0.f;
 #pragma unroll
-            for (int e = 0; e < 2 * BINS; ++e) {
-              const float v = dv[b][e >> 2][e & 3];
-              if (v == 1.0f) {
-                bin[e / BINS] = e % BINS;
-                ++ones[e / BINS];
-              } else if (v != 0.0f) {
-                clean = false;
+            for (int f = 0; f < 2; ++f) {
+              float sum = 0.f, pos = 0.f;
+#pragma unroll
+              for (int k = 0; k < BINS; ++k) {
+                const float v = dv[b][(f * BINS + k) >> 2][(f * BINS + k) & 3];
+                sum += v;
+                pos = __builtin_fmaf(v, (float)k, pos);
+                dev = __builtin_fmaxf(dev, __builtin_fabsf(__builtin_fmaf(v, v, -v)));
               }
+              dev = __builtin_fmaxf(dev, __builtin_fabsf(sum - 1.0f));
+              bin[f] = (int)pos;
             }
-            if (!clean || ones[0] != 1 || ones[1] != 1) *p.bad_onehot = 1;
+            if (!(dev == 0.f)) {                            // also catches NaN
+              *p.bad_onehot = 1;
+              bin[0] = bin[1] = BINS;
+            }
           }
-          *reinterpret_cast<unsigned *>(offs + 2 * pp) = (unsigned)(bin[0] * 256) | ((unsigned)(bin[1] * 256) << 16);
+          const int pr = pp / PW, pc = pp - pr * PW;
+          offs[pr * OW + pc] = (unsigned short)(bin[0] * 256);
+          offs[(PH + pr) * OW + pc] = (unsigned short)(bin[1] * 256);
         }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of table slice 0 is in LDS
     __syncthreads();
 
+    const long long tp1 = PROF ? clock64() : 0;
     // ---- K loop.  One BLOCK = (kernel row kh, pixel half HP, kernel column kw): 8 gathers (pixels 8*HP.. of this wave's
     //      row, both frames) + the 3 MFMAs of tap (kh,kw) for output channels 16*HP..  Blocks are written as inline asm:
     //      left to itself the compiler hoists every gather of a kernel row above the adds and spills them to scratch.
@@ -185,18 +209,21 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     for (int nt = 0; nt < NT16; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 16; ++q) gacc[q] = 0.f;
-    const float *abase = dense + ((2 * wave) * PW + 2 * i) * CD + 3 * kq;       // MFMA A: pixel i, channels 3kq..3kq+2
-    const unsigned short *obase = offs + ((2 * wave) * PW) * 2 + (lane >> 5);   // gather: this lane's frame
+    const float *abase = dense + (3 * kq) * NPIX + (2 * wave) * PW + 2 * i;      // MFMA A: pixel i, channels 3kq..3kq+2
+    const unsigned *obase = reinterpret_cast<const unsigned *>(offs + ((lane >> 5) * PH + 2 * wave) * OW);   // this lane's frame
     const unsigned lane4 = tab_lds + (unsigned)lane * 4u;               // LDS address of (frame*32 + channel) in row 0
 
     auto ld_b = [&](int tap, int nt) -> f32x3 {                         // tap >= 49: out of range -> zeros
       return wload3(rw, wlane + (unsigned)nt * 768u, (unsigned)tap * SB);
     };
     auto ld_a = [&](int kh, int kw) -> f32x3 {                          // (kh = 7 reads past the patch: unused)
-      const float *a = abase + (kh * PW + kw) * CD;
-      return f32x3{a[0], a[1], a[2]};
+      const float *a = abase + kh * PW + kw;
+      return f32x3{a[0], a[NPIX], a[2 * NPIX]};
     };
-    f32x3 b_cur = ld_b(0, 0), b_nxt = ld_b(1, 0), a_cur = ld_a(0, 0);
+    constexpr int BD = 4;                                               // weight prefetch distance in blocks
+    f32x3 bq[BD], a_cur = ld_a(0, 0);
+#pragma unroll
+    for (int d = 0; d < BD; ++d) bq[d] = ld_b(d, 0);
     dma_slice(1, 1);
 
     auto grow = [&](int kh, auto bufc) {
@@ -204,45 +231,88 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
 #pragma unroll
       for (int HP = 0; HP < 2; ++HP) {
         unsigned o[21];
-        const unsigned short *orow = obase + (kh * PW + 16 * HP) * 2;
+        float tg[2][8];
+        const unsigned *orow = obase + (kh * OW + 16 * HP) / 2;        // 11 dwords = 22 columns (21 used)
 #pragma unroll
-        for (int j = 0; j < 21; ++j) o[j] = (unsigned)orow[2 * j] + lane4;
+        for (int j = 0; j < 11; ++j) {
+          const unsigned pr = orow[j];
+          o[2 * j] = (pr & 0xffffu) + lane4;
+          if (2 * j + 1 < 21) o[2 * j + 1] = (pr >> 16) + lane4;
+        }
 #pragma unroll
         for (int kw = 0; kw < 7; ++kw) {
-          const int x2 = HP * 7 + kw + 2, x1 = HP * 7 + kw + 1;       // blocks g+2 (weights) and g+1 (pixels)
+          const int x2 = HP * 7 + kw + BD, x1 = HP * 7 + kw + 1;      // blocks g+BD (weights) and g+1 (pixels)
           const f32x3 b_pre = ld_b((kh + x2 / 14) * 7 + (x2 % 14) % 7, (x2 % 14) / 7);
           const f32x3 a_nxt = ld_a(kh + x1 / 14, (x1 % 14) % 7);
           float *g = gacc + 8 * HP;
-          asm volatile(
-              "ds_read_b32 v120, %[o0] offset:%[imm]\n\t"
-              "ds_read_b32 v121, %[o1] offset:%[imm]\n\t"
-              "ds_read_b32 v122, %[o2] offset:%[imm]\n\t"
-              "ds_read_b32 v123, %[o3] offset:%[imm]\n\t"
-              "ds_read_b32 v124, %[o4] offset:%[imm]\n\t"
-              "ds_read_b32 v125, %[o5] offset:%[imm]\n\t"
-              "ds_read_b32 v126, %[o6] offset:%[imm]\n\t"
-              "ds_read_b32 v127, %[o7] offset:%[imm]\n\t"
-              "v_mfma_f32_16x16x4_f32 %[c], %[a0], %[b0], %[c]\n\t"
-              "v_mfma_f32_16x16x4_f32 %[c], %[a1], %[b1], %[c]\n\t"
-              "v_mfma_f32_16x16x4_f32 %[c], %[a2], %[b2], %[c]\n\t"
-              "s_waitcnt lgkmcnt(0)\n\t"
-              "v_add_f32 %[g0], %[g0], v120\n\t"
-              "v_add_f32 %[g1], %[g1], v121\n\t"
-              "v_add_f32 %[g2], %[g2], v122\n\t"
-              "v_add_f32 %[g3], %[g3], v123\n\t"
-              "v_add_f32 %[g4], %[g4], v124\n\t"
-              "v_add_f32 %[g5], %[g5], v125\n\t"
-              "v_add_f32 %[g6], %[g6], v126\n\t"
-              "v_add_f32 %[g7], %[g7], v127"
-              : [c] "+v"(acc[HP]), [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]),
-                [g5] "+v"(g[5]), [g6] "+v"(g[6]), [g7] "+v"(g[7])
-              : [o0] "v"(o[kw]), [o1] "v"(o[kw + 2]), [o2] "v"(o[kw + 4]), [o3] "v"(o[kw + 6]), [o4] "v"(o[kw + 8]),
-                [o5] "v"(o[kw + 10]), [o6] "v"(o[kw + 12]), [o7] "v"(o[kw + 14]), [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]),
-                [a2] "v"(a_cur[2]), [b0] "v"(b_cur[0]), [b1] "v"(b_cur[1]), [b2] "v"(b_cur[2]),
-                [imm] "i"(BUF * SLICE_B + kw * KWB)
-              : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
-          b_cur = b_nxt;
-          b_nxt = b_pre;
+          float(&tc)[8] = tg[kw & 1];                                   // this block's gathered rows
+          float(&tn)[8] = tg[(kw & 1) ^ 1];                             // next block's (in flight)
+          if (kw == 0)                                                  // first block of the half-row: own gathers
+            asm volatile(
+                "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
+                "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
+                "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
+                "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
+                "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
+                "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
+                "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
+                "ds_read_b32 %[t7], %[o7] offset:%[imm]"
+                : [t0] "=&v"(tc[0]), [t1] "=&v"(tc[1]), [t2] "=&v"(tc[2]), [t3] "=&v"(tc[3]), [t4] "=&v"(tc[4]),
+                  [t5] "=&v"(tc[5]), [t6] "=&v"(tc[6]), [t7] "=&v"(tc[7])
+                : [o0] "v"(o[0]), [o1] "v"(o[2]), [o2] "v"(o[4]), [o3] "v"(o[6]), [o4] "v"(o[8]), [o5] "v"(o[10]),
+                  [o6] "v"(o[12]), [o7] "v"(o[14]), [imm] "i"(BUF * SLICE_B));
+          if (kw < 6) {                                                 // MFMAs of this block + gathers of the next one
+            asm volatile(
+                "v_mfma_f32_16x16x4_f32 %[c], %[a0], %[b0], %[c]\n\t"
+                "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
+                "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
+                "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
+                "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c], %[a1], %[b1], %[c]\n\t"
+                "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
+                "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
+                "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
+                "ds_read_b32 %[t7], %[o7] offset:%[imm]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c], %[a2], %[b2], %[c]"
+                : [c] "+v"(acc[HP]), [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3]),
+                  [t4] "=&v"(tn[4]), [t5] "=&v"(tn[5]), [t6] "=&v"(tn[6]), [t7] "=&v"(tn[7])
+                : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 3]), [o2] "v"(o[kw + 5]), [o3] "v"(o[kw + 7]),
+                  [o4] "v"(o[kw + 9]), [o5] "v"(o[kw + 11]), [o6] "v"(o[kw + 13]), [o7] "v"(o[kw + 15]),
+                  [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]), [a2] "v"(a_cur[2]), [b0] "v"(bq[0][0]), [b1] "v"(bq[0][1]),
+                  [b2] "v"(bq[0][2]), [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
+          } else {
+            asm volatile(
+                "v_mfma_f32_16x16x4_f32 %[c], %[a0], %[b0], %[c]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c], %[a1], %[b1], %[c]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c], %[a2], %[b2], %[c]"
+                : [c] "+v"(acc[HP])
+                : [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]), [a2] "v"(a_cur[2]), [b0] "v"(bq[0][0]), [b1] "v"(bq[0][1]),
+                  [b2] "v"(bq[0][2]));
+          }
+          // this block's rows were requested one block ago: LDS returns in order, so "at most 8 outstanding" = landed
+#define PNVO_DD_ADDS(WAIT)                                                                                              \
+  asm volatile(WAIT "\n\t"                                                                                              \
+               "v_add_f32 %[g0], %[g0], %[t0]\n\t"                                                                      \
+               "v_add_f32 %[g1], %[g1], %[t1]\n\t"                                                                      \
+               "v_add_f32 %[g2], %[g2], %[t2]\n\t"                                                                      \
+               "v_add_f32 %[g3], %[g3], %[t3]\n\t"                                                                      \
+               "v_add_f32 %[g4], %[g4], %[t4]\n\t"                                                                      \
+               "v_add_f32 %[g5], %[g5], %[t5]\n\t"                                                                      \
+               "v_add_f32 %[g6], %[g6], %[t6]\n\t"                                                                      \
+               "v_add_f32 %[g7], %[g7], %[t7]\n\t"                                                                      \
+               "s_nop 1"                                                                                                \
+               : [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]), [g5] "+v"(g[5]), \
+                 [g6] "+v"(g[6]), [g7] "+v"(g[7])                                                                       \
+               : [t0] "v"(tc[0]), [t1] "v"(tc[1]), [t2] "v"(tc[2]), [t3] "v"(tc[3]), [t4] "v"(tc[4]), [t5] "v"(tc[5]), \
+                 [t6] "v"(tc[6]), [t7] "v"(tc[7]))
+          if (kw < 6)
+            PNVO_DD_ADDS("s_waitcnt lgkmcnt(8)");
+          else
+            PNVO_DD_ADDS("s_waitcnt lgkmcnt(0)");
+#undef PNVO_DD_ADDS
+#pragma unroll
+          for (int d = 0; d + 1 < BD; ++d) bq[d] = bq[d + 1];
+          bq[BD - 1] = b_pre;
           a_cur = a_nxt;
         }
       }
@@ -262,17 +332,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     }
     grow(6, C0{});
 
+    const long long tp2 = PROF ? clock64() : 0;
     // ---- epilogue: gathered sums (lane = frame x channel) -> MFMA C layout through LDS, store, per-tile GroupNorm
-    //      partials.  Fixed order: mfma + (prev-frame row + cur-frame row).
-    __syncthreads();
-    float *gx = dense;                                      // [8 rows][16 pixels][GP]
+    //      partials.  Fixed order: mfma + (prev-frame row + cur-frame row).  The exchange lives in table buffer 1 (free
+    //      since the barrier after kernel row 5), so no barrier is needed here: a wave only reads back its own rows.
+    static_assert(TH * 16 * GP + TH * COUT * 2 <= SLICE_F, "exchange area must fit one table buffer");
+    float *gx = tab + SLICE_F;                              // [8 rows][16 pixels][GP]
     float *red = gx + TH * 16 * GP;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float s = gacc[q] + __shfl_xor(gacc[q], 32);
-      if (lane < 32) gx[(wave * 16 + q) * GP + lane] = s;
+    for (int q = 0; q < 8; ++q) {                           // v_permlane32_swap: lanes 0-31 <- pixel q, 32-63 <- pixel q+8
+      float lo = gacc[q], hi = gacc[q + 8];               // (inline asm: the builtin's second result was miscompiled)
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+      const float sgl = lo + hi;
+      gx[(wave * 16 + q + 8 * (lane >> 5)) * GP + (lane & 31)] = sgl;
     }
-    // (each wave reads back only what it wrote itself: LDS executes one wave's accesses in order, no barrier needed)
     {
       const int ho = ho0 + wave;
       const bool rvalid = ho < p.Ho;
@@ -300,8 +373,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
         }
       }
     }
-    __syncthreads();
-    if ((int)threadIdx.x < COUT) {
+    const long long tp3 = PROF ? clock64() : 0;
+    __syncthreads();                                        // every wave is past the K loop: dense / offs / table buffer 0
+    if ((int)threadIdx.x < COUT) {                          //   may be overwritten by the next tile's staging
       const int c = threadIdx.x;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -314,8 +388,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
       dst[0] = s1;
       dst[1] = s2;
     }
-    __syncthreads();
+    if (PROF) {
+      pt[0] += tp1 - tp0;
+      pt[1] += tp2 - tp1;
+      pt[2] += tp3 - tp2;
+      pt[3] += 1;
+    }
   }
+  if (PROF && threadIdx.x == 0 && p.prof != nullptr)
+    for (int k = 0; k < 4; ++k) atomicAdd(p.prof + k, (unsigned long long)pt[k]);
 }
 
 int stem_dd_slice_floats(int bins) { return slice_floats_c(bins); }
@@ -341,11 +422,14 @@ hipError_t launch_stem_dd(const StemDDArgs &a, hipStream_t s) {
   p.tiles_y = (a.Ho + TH - 1) / TH;
   p.slice_floats = stem_dd_slice_floats(a.bins);
   if (!stem_dd_supported(a.bins)) return hipErrorInvalidValue;
-  const size_t lds = (size_t)(2 * p.slice_floats + NPIX * CD + NPIX) * 4;
+  const size_t lds = (size_t)(2 * p.slice_floats + NPIX * CD) * 4 + (size_t)2 * PH * OW * 2;
   const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
   const long resident = (long)(160 * 1024 / lds) * 256;
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
-  hipLaunchKernelGGL(stem_dd_kernel<10>, grid, dim3(NTHREADS), lds, s, p);
+  if (a.dbg == 9)
+    hipLaunchKernelGGL((stem_dd_kernel<10, true>), grid, dim3(NTHREADS), lds, s, p);
+  else
+    hipLaunchKernelGGL((stem_dd_kernel<10, false>), grid, dim3(NTHREADS), lds, s, p);
   return hipGetLastError();
 }
 
