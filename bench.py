@@ -194,7 +194,7 @@ def main():
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
                                 "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
-                               for k in kt), key=lambda k: -k["ms_per_step"])[:12],
+                               for k in kt), key=lambda k: -k["ms_per_step"])[:40],
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)

@@ -1,0 +1,276 @@
+// conv3_lds.hip — 3x3 stride-1 convolution of the residual stages with the input patch staged in LDS (gfx950 only).
+//
+// Same math, weight packing and epilogue contract as conv_mfma.hip (implicit GEMM on v_mfma_f32_32x32x2_f32, raw output
+// + deterministic GroupNorm partial sums), but the A operand no longer comes from L2 per lane and per tap:
+//   * a workgroup owns a TH x TW rectangle of ONE sample's output and stages the (TH+2) x (TW+2) input patch, 32 input
+//     channels at a time, into LDS with fully coalesced 16-byte loads.  The producer's GroupNorm+ReLU (MODE 1:
+//     relu(x*scale[n,c]+shift[n,c]), resnet.py:50-67 order conv -> GN -> ReLU) and the zero padding (applied AFTER it)
+//     are done ONCE per patch element while staging instead of once per tap in the operand fetch (9x fewer VALU ops);
+//   * a wave owns a 4x8 (or 8x4) block of output pixels = the 32 rows of the MFMA tile and NT x 32 output channels;
+//     lane (i, h) reads 16 B = channels [8j+4h, 8j+4h+4) of its pixel for tap (kh,kw) with ONE ds_read_b128 per
+//     4 MFMA k-steps; the LDS pixel pitch is 36 floats (and the patch row pitch odd for 8x4 blocks) so that the 8 lanes
+//     of a b128 phase cover the 32 banks exactly once;
+//   * weights stream from L2 in pack_conv_weight() order (one coalesced 1-KiB load per (tap, 8 channels, n-tile)),
+//     prefetched two stages ahead; with fp32 MFMA (64 cycles per 32x32x2) both operand streams are tiny: per MFMA a
+//     wave needs 256 B from LDS and 256 B from L1, so the matrix pipe is the only busy resource in the K loop;
+//   * input channels beyond 32 are walked in chunks with the next chunk's global loads in flight during the MFMAs of
+//     the current one (double-buffered LDS, one barrier per chunk).
+// Statistics slot = (tile, wave): one writer per (sample, slot, channel), fixed summation order in gn_finalize.
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr unsigned OOB = 0x80000000u;
+constexpr int PP = 36;   // floats per pixel in LDS
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__host__ __device__ constexpr int patch_pitch(int blk, int pwr) { return (blk && (pwr % 2 == 0)) ? pwr + 1 : pwr; }
+}  // namespace
+
+// BLK 0: wave block = 4 rows x 8 cols (lane i -> x = i&7, y = i>>3); BLK 1: 8 rows x 4 cols (y = i&7, x = i>>3).
+// WY x WX wave blocks per workgroup.  MODE 0: x holds final activations; MODE 1: relu(x*scale+shift) while staging.
+template <int BLK, int WY, int WX, int NT, int MODE>
+__global__ __launch_bounds__(64 * WY * WX) void conv3_lds_kernel(const ConvArgs p, int tiles_x, int tiles_y) {
+  constexpr int BH = BLK ? 8 : 4, BW = BLK ? 4 : 8;
+  constexpr int TH = BH * WY, TW = BW * WX, PH = TH + 2, PWR = TW + 2, PWP = patch_pitch(BLK, PWR);
+  constexpr int BUF = PH * PWP * PP;                 // floats per LDS buffer
+  constexpr int NTHR = 64 * WY * WX;
+  constexpr int ITEMS = PH * PWR * 8;                // (pixel, 16-byte slot) staging items per 32-channel chunk
+  constexpr int NIT = (ITEMS + NTHR - 1) / NTHR;
+  static_assert(NTHR % 8 == 0, "a thread keeps its 16-byte slot across staging passes");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int CIN = p.CIN, J = CIN >> 3, NCH = CIN >> 5;
+  const int H = p.H, W = p.W;
+
+  // ---- staging plan of this thread (the same for every channel chunk)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.x + (long)n * H * W * CIN), 0, (unsigned)((long)H * W * CIN * 4), 0x00020000);
+  unsigned goff[NIT];   // byte offset of the item's 16 B in the sample (chunk 0) or OOB (zero padding / no item)
+  int loff[NIT];        // float offset in an LDS buffer or -1
+  const int g = tid & 7;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int it = tid + k * NTHR;
+    const int pix = it >> 3;
+    const int pr = pix / PWR, pc = pix - pr * PWR;
+    const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+    const bool item = it < ITEMS;
+    const bool inimg = item && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    goff[k] = inimg ? (unsigned)(((yy * W + xx) * CIN + 4 * g) * 4) : OOB;
+    loff[k] = item ? (pr * PWP + pc) * PP + 4 * g : -1;
+  }
+  auto gload = [&](int c, f32x4 (&v)[NIT]) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) v[k] = bload4(rx, goff[k], (unsigned)c * 128u);
+  };
+  auto lstore = [&](int c, float *buf, f32x4 (&v)[NIT]) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+      sc = *reinterpret_cast<const f32x4 *>(p.in_scale + (long)n * CIN + 32 * c + 4 * g);
+      sh = *reinterpret_cast<const f32x4 *>(p.in_shift + (long)n * CIN + 32 * c + 4 * g);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      if (loff[k] >= 0) {
+        f32x4 t = v[k];
+        if (MODE == 1) {
+          const bool in = goff[k] != OOB;            // zero padding is applied AFTER the producer's GroupNorm + ReLU
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = in ? fmaxf(__builtin_fmaf(t[e], sc[e], sh[e]), 0.f) : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(buf + loff[k]) = t;
+      }
+    }
+  };
+
+  // ---- this lane's pixel and operand addresses
+  const int wy = wave / WX, wx = wave - wy * WX;
+  const int ly = BLK ? (i & 7) : (i >> 3), lx = BLK ? (i >> 3) : (i & 7);
+  const int lane_base = ((wy * BH + ly) * PWP + (wx * BW + lx)) * PP + 4 * h;
+  const int T = 9, SJ = T * J;
+  const int ntg0 = blockIdx.y * NT;
+  const unsigned w_nt_bytes = (unsigned)SJ * 1024u;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.wpk + (long)ntg0 * SJ * 256), 0, (unsigned)NT * w_nt_bytes, 0x00020000);
+  const unsigned wlane = (unsigned)lane * 16u;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  // one chunk = 36 stages (tap, 8-channel group): A one stage ahead (LDS), B two stages ahead (L2)
+  auto compute = [&](int c, const float *L) {
+    const float *la = L + lane_base;
+    auto lda = [&](int s) -> f32x4 {
+      const int tap = s >> 2, j = s & 3;
+      return *reinterpret_cast<const f32x4 *>(la + ((tap / 3) * PWP + tap % 3) * PP + 8 * j);
+    };
+    auto ldb = [&](int s, f32x4 (&b)[NT]) {
+      const int tap = s >> 2, j = s & 3;
+      const unsigned soff = (unsigned)((tap * J + 4 * c + j) * 1024);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = bload4(rw, wlane + (unsigned)nt * w_nt_bytes, soff);
+    };
+    f32x4 a[2], b[3][NT];
+    ldb(0, b[0]);
+    ldb(1, b[1]);
+    a[0] = lda(0);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      if (s + 2 < 36) ldb(s + 2, b[(s + 2) % 3]);
+      if (s + 1 < 36) a[(s + 1) & 1] = lda(s + 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][t], b[s % 3][nt][t], acc[nt], 0, 0, 0);
+    }
+  };
+
+  {
+    f32x4 sv[NIT];
+    gload(0, sv);
+    lstore(0, lds, sv);
+    __syncthreads();
+    for (int c = 0; c < NCH; ++c) {
+      const bool more = c + 1 < NCH;
+      if (more) gload(c + 1, sv);                    // in flight while the matrix cores work on chunk c
+      compute(c, lds + (c & 1) * BUF);
+      if (more) lstore(c + 1, lds + ((c + 1) & 1) * BUF, sv);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int Ho = p.Ho, Wo = p.Wo;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(p.y + (long)n * Ho * Wo * p.y_cstride), 0, (unsigned)((long)Ho * Wo * p.y_cstride * 4), 0x00020000);
+  bool rok[16];
+  unsigned roff[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int ry_ = BLK ? (row & 7) : (row >> 3), rx_ = BLK ? (row >> 3) : (row & 7);
+    const int oy = y0 + wy * BH + ry_, ox = x0 + wx * BW + rx_;
+    rok[r] = oy < Ho && ox < Wo;
+    roff[r] = (unsigned)((oy * Wo + ox) * p.y_cstride) * 4u;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = (ntg0 + nt) * 32 + i;
+    const bool cvalid = co < p.y_cstride;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = rok[r] ? acc[nt][r] : 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry,
+                                            (rok[r] && cvalid) ? roff[r] + (unsigned)co * 4u : OOB, 0, 0);
+      s1 += v;
+      s2 = __builtin_fmaf(v, v, s2);
+    }
+    if (p.stats != nullptr) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        const int slot = (ty * tiles_x + tx) * (WY * WX) + wave;
+        float *dst = p.stats + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+}
+
+namespace {
+struct Cfg {
+  int blk, wy, wx;
+};
+constexpr Cfg CFGS[3] = {{0, 4, 1}, {1, 3, 1}, {0, 3, 1}};
+
+inline void cfg_tiles(const Cfg &c, int Ho, int Wo, int *tx, int *ty) {
+  const int th = (c.blk ? 8 : 4) * c.wy, tw = (c.blk ? 4 : 8) * c.wx;
+  *tx = (Wo + tw - 1) / tw;
+  *ty = (Ho + th - 1) / th;
+}
+inline double cfg_waste(const Cfg &c, int Ho, int Wo) {
+  int tx, ty;
+  cfg_tiles(c, Ho, Wo, &tx, &ty);
+  const int th = (c.blk ? 8 : 4) * c.wy, tw = (c.blk ? 4 : 8) * c.wx;
+  return (double)tx * tw * ty * th / ((double)Ho * Wo);
+}
+inline int pick_cfg(int Ho, int Wo) {
+  int best = 0;
+  for (int k = 1; k < 3; ++k)
+    if (cfg_waste(CFGS[k], Ho, Wo) < cfg_waste(CFGS[best], Ho, Wo) - 1e-9) best = k;
+  return best;
+}
+
+template <int BLK, int WY, int WX, int NT>
+hipError_t launch_cfg(const ConvArgs &a, int tiles_x, int tiles_y, hipStream_t s) {
+  constexpr int BH = BLK ? 8 : 4, BW = BLK ? 4 : 8;
+  constexpr int PH = BH * WY + 2, PWR = BW * WX + 2, PWP = patch_pitch(BLK, PWR);
+  const size_t lds = (size_t)PH * PWP * PP * 4 * (a.CIN > 32 ? 2 : 1);
+  dim3 grid((unsigned)((long)a.B * tiles_x * tiles_y), (unsigned)(a.COUTP / 32 / NT));
+  if (a.in_scale != nullptr)
+    hipLaunchKernelGGL((conv3_lds_kernel<BLK, WY, WX, NT, 1>), grid, dim3(64 * WY * WX), lds, s, a, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL((conv3_lds_kernel<BLK, WY, WX, NT, 0>), grid, dim3(64 * WY * WX), lds, s, a, tiles_x, tiles_y);
+  return hipGetLastError();
+}
+}  // namespace
+
+// Can this layer run on the LDS-staged kernel?  (3x3, stride 1, pad 1, 32-channel multiples, per-sample image big
+// enough that the rectangular tiles waste < 15 % of the MFMA rows, offsets within 32 bits.)
+bool conv3_lds_supported(const ConvArgs &a) {
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.up == 2 || a.accum || a.src_mode || a.bias != nullptr ||
+      a.relu_out)
+    return false;
+  if (a.CIN % 32 != 0 || a.COUTP % 32 != 0 || a.H != a.Ho || a.W != a.Wo) return false;
+  if ((long)a.H * a.W * a.CIN * 4 >= 0x7FFFF000L || (long)a.Ho * a.Wo * a.y_cstride * 4 >= 0x7FFFF000L) return false;
+  return cfg_waste(CFGS[pick_cfg(a.Ho, a.Wo)], a.Ho, a.Wo) < 1.15;
+}
+
+int conv3_lds_slots(const ConvArgs &a) {
+  const Cfg &c = CFGS[pick_cfg(a.Ho, a.Wo)];
+  int tx, ty;
+  cfg_tiles(c, a.Ho, a.Wo, &tx, &ty);
+  return tx * ty * c.wy * c.wx;
+}
+
+// nt: output n-tiles (32 channels) per wave, 1 or 2 (a.COUTP / 32 must be divisible by it).
+hipError_t launch_conv3_lds(const ConvArgs &a, int nt, hipStream_t s) {
+  if (!conv3_lds_supported(a) || (nt != 1 && nt != 2) || (a.COUTP / 32) % nt != 0) return hipErrorInvalidValue;
+  const int k = pick_cfg(a.Ho, a.Wo);
+  int tx, ty;
+  cfg_tiles(CFGS[k], a.Ho, a.Wo, &tx, &ty);
+  switch (k * 10 + nt) {
+    case 1: return launch_cfg<0, 4, 1, 1>(a, tx, ty, s);
+    case 2: return launch_cfg<0, 4, 1, 2>(a, tx, ty, s);
+    case 11: return launch_cfg<1, 3, 1, 1>(a, tx, ty, s);
+    case 12: return launch_cfg<1, 3, 1, 2>(a, tx, ty, s);
+    case 21: return launch_cfg<0, 3, 1, 1>(a, tx, ty, s);
+    case 22: return launch_cfg<0, 3, 1, 2>(a, tx, ty, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace pnvo

@@ -228,11 +228,35 @@ void free_workspace(pnvo_model_s *m) {
   m->cap = 0;
 }
 
+// Would this (GroupNorm-ed, bias-free) conv layer run on the LDS-staged 3x3 kernel?  *slots: its statistics slots.
+bool layer_on_lds(const Layer &l, int *slots) {
+  ConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.KH = l.k;
+  a.KW = l.kw;
+  a.stride = l.stride;
+  a.pad = l.pad;
+  a.up = 1;
+  a.CIN = l.cinp;
+  a.COUTP = l.coutp;
+  a.H = l.hin;
+  a.W = l.win;
+  a.Ho = l.hout;
+  a.Wo = l.wout;
+  a.y_cstride = l.coutp;
+  const char *sel = std::getenv("PNVO_CONV");
+  if (!conv3_lds_supported(a) || (sel && std::strcmp(sel, "generic") == 0)) return false;
+  if (slots) *slots = conv3_lds_slots(a);
+  return true;
+}
+
 size_t stats_floats(const Layer &l, int B) {
   const long P = (long)l.hout * l.wout, M = (long)B * P;
   int MT, NT;
   choose_tile(M, l.coutp, &MT, &NT);
-  return (size_t)B * conv_slots((int)P, MT) * l.coutp * 2;
+  int slots = conv_slots((int)P, MT), s2 = 0;
+  if (layer_on_lds(l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
+  return (size_t)B * (size_t)slots * l.coutp * 2;
 }
 
 int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_workspace)
@@ -375,6 +399,23 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   a.slots = conv_slots((int)P, a.MT);
   const double macs = (double)M * l.cout * l.cin * l.k * l.kw;
   const double bytes = 4.0 * ((double)B * l.hin * l.win * l.cin + (double)M * l.cout + (double)l.cout * l.cin * l.k * l.kw);
+  const char *sel = std::getenv("PNVO_CONV");
+  const bool lds3 = conv3_lds_supported(a) && !(sel && std::strcmp(sel, "generic") == 0);
+  if (lds3) {                    // 3x3 stride-1 residual-stage conv: input patch staged in LDS
+    int nt = (l.coutp / 32) % 2 == 0 ? 2 : 1;
+    if (const char *e = std::getenv("PNVO_CONV3_NT")) nt = std::atoi(e) == 1 ? 1 : nt;
+    a.slots = conv3_lds_slots(a);
+    {
+      Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
+      HIPCHK(m, launch_conv3_lds(a, nt, s));
+    }
+    if (ss) {
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0],
+                                   ss[1], s, a.slots, mu_out, rstd_out));
+    }
+    return PNVO_OK;
+  }
   {
     Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
     HIPCHK(m, launch_conv(a, s));
@@ -765,10 +806,20 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
       if ((rc = run_conv(m, c1, B, cur, nullptr, nullptr, m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s)) != PNVO_OK)
         return rc;
-      if ((rc = run_conv(m, c2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s)) !=
-          PNVO_OK)
-        return rc;
       const long P = (long)c2.hout * c2.wout;
+      if (!layer_on_lds(c2, nullptr) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20)) {
+        // small deep stage on the generic kernel: its per-tap GroupNorm+ReLU prologue costs more than one streaming
+        // pass over the (L2-sized) tensor, so normalise once and run the conv on final activations
+        {
+          Timed t(m, s, "gn_relu_apply", 0.0, 8.0 * B * P * c2.cinp);
+          HIPCHK(m, launch_apply_ss_relu(m->rawA, m->ssA[0], m->ssA[1], B, P, c2.cinp, m->rawD, s));
+        }
+        if ((rc = run_conv(m, c2, B, m->rawD, nullptr, nullptr, m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s)) != PNVO_OK)
+          return rc;
+      } else if ((rc = run_conv(m, c2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0,
+                                s)) != PNVO_OK) {
+        return rc;
+      }
       if (ds) {
         const Layer &cd = m->convs[li++];
         if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK)

@@ -77,6 +77,11 @@ int conv_slots(int P, int MT);                       // stats slots per sample f
 void choose_tile(long M, int COUTP, int *MT, int *NT);
 hipError_t launch_conv(const ConvArgs &a, hipStream_t s);
 
+// LDS-staged 3x3 stride-1 kernel (conv3_lds.hip): same arguments / packing / epilogue contract as launch_conv.
+bool conv3_lds_supported(const ConvArgs &a);
+int conv3_lds_slots(const ConvArgs &a);                       // statistics slots per sample (tiles x waves)
+hipError_t launch_conv3_lds(const ConvArgs &a, int nt, hipStream_t s);
+
 size_t packed_conv_floats(int cout, int cin, int kh, int kw);
 void pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, float *out);
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     for (int c = wave; c < SLICE_B / 1024; c += NTHREADS / 64) {
       const char *gc = g + c * 1024;
       const unsigned lc = tab_lds + (unsigned)(buf * SLICE_B + c * 1024);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gc), "s"(lc) : "m0", "memory");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gc), "s"(lc) : "memory");   // (m0 is not tracked by the compiler in this kernel)
     }
   };
 
