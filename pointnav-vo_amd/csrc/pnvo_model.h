@@ -64,6 +64,22 @@ struct pnvo_model_s {
 
   void *train = nullptr;             // TrainState (pnvo_train_api.hip), present after pnvo_train_attach
 
+  // Opt-in (PNVO_GRAPH=1): the whole forward (~60 launches) captured once per (batch, tensor addresses, kernel
+  // selection) into a hipGraph and replayed (see pnvo_forward for the measurement that keeps it off by default).
+  struct GraphEntry {
+    const void *key[8];
+    int B;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    unsigned long long stamp;
+  };
+  std::vector<GraphEntry> graphs;
+  std::vector<GraphEntry> seen;      // call shapes met once (captured when they come back: no capture for one-off calls)
+  float *out_ws = nullptr;           // [cap, out_dim]: the graph's output (copied to the caller's tensor after replay)
+  hipStream_t cap_stream = nullptr;
+  int graph_mode = -1;               // -1: read PNVO_GRAPH on first use; 0 off; 1 on
+  unsigned long long graph_clock = 0;
+
   int timing = 0;
   std::vector<pnvo_kernel_time> tentries;
   std::map<std::string, int> tindex;
@@ -83,6 +99,7 @@ void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
 int pnvo_fail(pnvo_handle h, int code, const std::string &msg);
 void pnvo_free_dev(float *&p);
 int pnvo_ensure_workspace(pnvo_handle m, int B);
+void pnvo_drop_graphs(pnvo_handle m);   // forget the captured forward graphs (their kernel arguments went stale)
 
 #define HIPCHK(h, expr)                                                                                   \
   do {                                                                                                    \
