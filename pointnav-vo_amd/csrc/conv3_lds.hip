@@ -16,6 +16,8 @@
 //   * input channels beyond 32 are walked in chunks with the next chunk's global loads in flight during the MFMAs of
 //     the current one (double-buffered LDS, one barrier per chunk).
 // Statistics slot = (tile, wave): one writer per (sample, slot, channel), fixed summation order in gn_finalize.
+#include <cstdlib>
+
 #include "pnvo_internal.h"
 
 namespace pnvo {
@@ -35,8 +37,12 @@ __host__ __device__ constexpr int patch_pitch(int blk, int pwr) { return (blk &&
 
 // BLK 0: wave block = 4 rows x 8 cols (lane i -> x = i&7, y = i>>3); BLK 1: 8 rows x 4 cols (y = i&7, x = i>>3).
 // WY x WX wave blocks per workgroup.  MODE 0: x holds final activations; MODE 1: relu(x*scale+shift) while staging.
+// Workgroups are PERSISTENT: each walks work items (tile, n-tile group, channel chunk) with a grid stride; the global
+// loads of item q+1 are in flight during the MFMAs of item q and land in the other LDS buffer (one barrier per item), so
+// staging never idles the matrix pipe and there is no per-tile launch / drain.
 template <int BLK, int WY, int WX, int NT, int MODE>
-__global__ __launch_bounds__(64 * WY * WX) void conv3_lds_kernel(const ConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(64 * WY * WX) void conv3_lds_kernel(const ConvArgs p, int tiles_x, int tiles_y, int ngroups,
+                                                                 int nwork) {
   constexpr int BH = BLK ? 8 : 4, BW = BLK ? 4 : 8;
   constexpr int TH = BH * WY, TW = BW * WX, PH = TH + 2, PWR = TW + 2, PWP = patch_pitch(BLK, PWR);
   constexpr int BUF = PH * PWP * PP;                 // floats per LDS buffer
@@ -50,48 +56,62 @@ __global__ __launch_bounds__(64 * WY * WX) void conv3_lds_kernel(const ConvArgs 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  int bid = blockIdx.x;
-  const int tx = bid % tiles_x;
-  bid /= tiles_x;
-  const int ty = bid % tiles_y;
-  const int n = bid / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW;
   const int CIN = p.CIN, J = CIN >> 3, NCH = CIN >> 5;
-  const int H = p.H, W = p.W;
-
-  // ---- staging plan of this thread (the same for every channel chunk)
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.x + (long)n * H * W * CIN), 0, (unsigned)((long)H * W * CIN * 4), 0x00020000);
-  unsigned goff[NIT];   // byte offset of the item's 16 B in the sample (chunk 0) or OOB (zero padding / no item)
-  int loff[NIT];        // float offset in an LDS buffer or -1
+  const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
   const int g = tid & 7;
+
+  // work item w (a tile of one sample for one group of NT n-tiles) -> coordinates; consecutive w = adjacent tiles
+  struct Item {
+    int n, y0, x0, ntg0, tile;
+  };
+  auto decode = [&](int w) -> Item {
+    Item it;
+    it.ntg0 = (w % ngroups) * NT;
+    int t = w / ngroups;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    it.n = t / tiles_y;
+    it.y0 = ty * TH;
+    it.x0 = tx * TW;
+    it.tile = ty * tiles_x + tx;
+    return it;
+  };
+
+  // ---- staging: patch pixel/slot of this thread per pass is fixed; the image offset depends on the tile
+  int ppr[NIT], ppc[NIT], loff[NIT];
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
-    const int it = tid + k * NTHR;
-    const int pix = it >> 3;
-    const int pr = pix / PWR, pc = pix - pr * PWR;
-    const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
-    const bool item = it < ITEMS;
-    const bool inimg = item && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-    goff[k] = inimg ? (unsigned)(((yy * W + xx) * CIN + 4 * g) * 4) : OOB;
-    loff[k] = item ? (pr * PWP + pc) * PP + 4 * g : -1;
+    const int itx = tid + k * NTHR;
+    const int pix = itx >> 3;
+    ppr[k] = pix / PWR;
+    ppc[k] = pix - ppr[k] * PWR;
+    loff[k] = itx < ITEMS ? (ppr[k] * PWP + ppc[k]) * PP + 4 * g : -1;
   }
-  auto gload = [&](int c, f32x4 (&v)[NIT]) {
+  auto gload = [&](const Item &it, int c, f32x4 (&v)[NIT], unsigned &inmask) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.x + (long)it.n * H * W * CIN), 0, (unsigned)((long)H * W * CIN * 4), 0x00020000);
+    inmask = 0;
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) v[k] = bload4(rx, goff[k], (unsigned)c * 128u);
+    for (int k = 0; k < NIT; ++k) {
+      const int yy = it.y0 - 1 + ppr[k], xx = it.x0 - 1 + ppc[k];
+      const bool in = loff[k] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      inmask |= (in ? 1u : 0u) << k;
+      v[k] = bload4(rx, in ? (unsigned)(((yy * W + xx) * CIN + 4 * g) * 4) : OOB, (unsigned)c * 128u);
+    }
   };
-  auto lstore = [&](int c, float *buf, f32x4 (&v)[NIT]) {
+  auto lstore = [&](const Item &it, int c, float *buf, f32x4 (&v)[NIT], unsigned inmask) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
-      sc = *reinterpret_cast<const f32x4 *>(p.in_scale + (long)n * CIN + 32 * c + 4 * g);
-      sh = *reinterpret_cast<const f32x4 *>(p.in_shift + (long)n * CIN + 32 * c + 4 * g);
+      sc = *reinterpret_cast<const f32x4 *>(p.in_scale + (long)it.n * CIN + 32 * c + 4 * g);
+      sh = *reinterpret_cast<const f32x4 *>(p.in_shift + (long)it.n * CIN + 32 * c + 4 * g);
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (loff[k] >= 0) {
         f32x4 t = v[k];
         if (MODE == 1) {
-          const bool in = goff[k] != OOB;            // zero padding is applied AFTER the producer's GroupNorm + ReLU
+          const bool in = (inmask >> k) & 1u;        // zero padding is applied AFTER the producer's GroupNorm + ReLU
 #pragma unroll
           for (int e = 0; e < 4; ++e) t[e] = in ? fmaxf(__builtin_fmaf(t[e], sc[e], sh[e]), 0.f) : 0.f;
         }
@@ -105,20 +125,18 @@ __global__ __launch_bounds__(64 * WY * WX) void conv3_lds_kernel(const ConvArgs 
   const int ly = BLK ? (i & 7) : (i >> 3), lx = BLK ? (i >> 3) : (i & 7);
   const int lane_base = ((wy * BH + ly) * PWP + (wx * BW + lx)) * PP + 4 * h;
   const int T = 9, SJ = T * J;
-  const int ntg0 = blockIdx.y * NT;
   const unsigned w_nt_bytes = (unsigned)SJ * 1024u;
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.wpk + (long)ntg0 * SJ * 256), 0, (unsigned)NT * w_nt_bytes, 0x00020000);
   const unsigned wlane = (unsigned)lane * 16u;
 
-  f32x16 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  // NT == 1: two accumulators (even / odd k-steps) so that consecutive MFMAs never share one — an instruction issued
+  // between two MFMAs on the SAME accumulator costs ~43 cycles (MI355X_MICROARCH.md), on different ones ~6
+  constexpr int NA = NT == 1 ? 2 : NT;
+  f32x16 acc[NA];
 
   // one chunk = 36 stages (tap, 8-channel group): A one stage ahead (LDS), B two stages ahead (L2)
-  auto compute = [&](int c, const float *L) {
+  auto compute = [&](int ntg0, int c, const float *L) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.wpk + (long)ntg0 * SJ * 256), 0, (unsigned)NT * w_nt_bytes, 0x00020000);
     const float *la = L + lane_base;
     auto lda = [&](int s) -> f32x4 {
       const int tap = s >> 2, j = s & 3;
@@ -141,62 +159,89 @@ __global__ __launch_bounds__(64 * WY * WX) void conv3_lds_kernel(const ConvArgs 
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][t], b[s % 3][nt][t], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          const int ai = NT == 1 ? (t & 1) : nt;
+          acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][t], b[s % 3][nt][t], acc[ai], 0, 0, 0);
+        }
     }
   };
 
-  {
-    f32x4 sv[NIT];
-    gload(0, sv);
-    lstore(0, lds, sv);
-    __syncthreads();
-    for (int c = 0; c < NCH; ++c) {
-      const bool more = c + 1 < NCH;
-      if (more) gload(c + 1, sv);                    // in flight while the matrix cores work on chunk c
-      compute(c, lds + (c & 1) * BUF);
-      if (more) lstore(c + 1, lds + ((c + 1) & 1) * BUF, sv);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  const int Ho = p.Ho, Wo = p.Wo;
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(p.y + (long)n * Ho * Wo * p.y_cstride), 0, (unsigned)((long)Ho * Wo * p.y_cstride * 4), 0x00020000);
-  bool rok[16];
-  unsigned roff[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int ry_ = BLK ? (row & 7) : (row >> 3), rx_ = BLK ? (row >> 3) : (row & 7);
-    const int oy = y0 + wy * BH + ry_, ox = x0 + wx * BW + rx_;
-    rok[r] = oy < Ho && ox < Wo;
-    roff[r] = (unsigned)((oy * Wo + ox) * p.y_cstride) * 4u;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = (ntg0 + nt) * 32 + i;
-    const bool cvalid = co < p.y_cstride;
-    float s1 = 0.f, s2 = 0.f;
+  // ---- epilogue of one work item: raw output + GroupNorm partials.
+  //      C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  auto epilogue = [&](const Item &it) {
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.y + (long)it.n * Ho * Wo * p.y_cstride), 0, (unsigned)((long)Ho * Wo * p.y_cstride * 4), 0x00020000);
+    unsigned roff[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float v = rok[r] ? acc[nt][r] : 0.f;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry,
-                                            (rok[r] && cvalid) ? roff[r] + (unsigned)co * 4u : OOB, 0, 0);
-      s1 += v;
-      s2 = __builtin_fmaf(v, v, s2);
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ry_ = BLK ? (row & 7) : (row >> 3), rx_ = BLK ? (row >> 3) : (row & 7);
+      const int oy = it.y0 + wy * BH + ry_, ox = it.x0 + wx * BW + rx_;
+      roff[r] = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * p.y_cstride) * 4u : OOB;
     }
-    if (p.stats != nullptr) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        const int slot = (ty * tiles_x + tx) * (WY * WX) + wave;
-        float *dst = p.stats + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = (it.ntg0 + nt) * 32 + i;
+      const bool cvalid = co < p.y_cstride;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = roff[r] != OOB;
+        const float v = ok ? (NT == 1 ? acc[0][r] + acc[1][r] : acc[nt][r]) : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry,
+                                              (ok && cvalid) ? roff[r] + (unsigned)co * 4u : OOB, 0, 0);
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+      if (p.stats != nullptr) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) {
+          const int slot = it.tile * (WY * WX) + wave;
+          float *dst = p.stats + (((long)it.n * p.slots + slot) * p.COUTP + co) * 2;
+          dst[0] = s1;
+          dst[1] = s2;
+        }
       }
     }
+  };
+
+  // ---- the pipeline over (work item, channel chunk)
+  int w = blockIdx.x;
+  if (w >= nwork) return;
+  Item cur = decode(w);
+  int c = 0, buf = 0;
+  f32x4 sv[NIT];
+  unsigned inm;
+  gload(cur, 0, sv, inm);
+  lstore(cur, 0, lds, sv, inm);
+  __syncthreads();
+  for (;;) {
+    // what comes after (cur, c)?
+    int nc = c + 1, nw = w;
+    if (nc == NCH) {
+      nc = 0;
+      nw = w + gridDim.x;
+    }
+    const bool more = nw < nwork;
+    Item nxt = cur;
+    if (more && nw != w) nxt = decode(nw);
+    if (more) gload(nxt, nc, sv, inm);               // in flight while the matrix cores work on (cur, c)
+    if (c == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NA; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    }
+    compute(cur.ntg0, c, lds + buf * BUF);
+    if (c == NCH - 1) epilogue(cur);
+    if (!more) break;
+    lstore(nxt, nc, lds + (buf ^ 1) * BUF, sv, inm);
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
+    w = nw;
+    c = nc;
   }
 }
 
@@ -228,12 +273,26 @@ template <int BLK, int WY, int WX, int NT>
 hipError_t launch_cfg(const ConvArgs &a, int tiles_x, int tiles_y, hipStream_t s) {
   constexpr int BH = BLK ? 8 : 4, BW = BLK ? 4 : 8;
   constexpr int PH = BH * WY + 2, PWR = BW * WX + 2, PWP = patch_pitch(BLK, PWR);
-  const size_t lds = (size_t)PH * PWP * PP * 4 * (a.CIN > 32 ? 2 : 1);
-  dim3 grid((unsigned)((long)a.B * tiles_x * tiles_y), (unsigned)(a.COUTP / 32 / NT));
+  const size_t lds = (size_t)PH * PWP * PP * 4 * 2;
+  const int ngroups = a.COUTP / 32 / NT;
+  const long nwork = (long)a.B * tiles_x * tiles_y * ngroups;
+  // persistent grid: as many workgroups as fit (LDS-limited), rounded so that every workgroup gets the same item count
+  long resident = 256L * (long)((160 * 1024) / lds);
+  static int cap = -1;
+  if (cap < 0) {
+    const char *e = std::getenv("PNVO_CONV3_WGS");     // experiment knob: workgroups per CU
+    cap = e ? std::atoi(e) : 0;
+  }
+  if (cap > 0) resident = 256L * cap;
+  const long rounds = (nwork + resident - 1) / resident;
+  const long grid_x = (nwork + rounds - 1) / rounds;
+  dim3 grid((unsigned)grid_x);
   if (a.in_scale != nullptr)
-    hipLaunchKernelGGL((conv3_lds_kernel<BLK, WY, WX, NT, 1>), grid, dim3(64 * WY * WX), lds, s, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3_lds_kernel<BLK, WY, WX, NT, 1>), grid, dim3(64 * WY * WX), lds, s, a, tiles_x, tiles_y,
+                       ngroups, (int)nwork);
   else
-    hipLaunchKernelGGL((conv3_lds_kernel<BLK, WY, WX, NT, 0>), grid, dim3(64 * WY * WX), lds, s, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3_lds_kernel<BLK, WY, WX, NT, 0>), grid, dim3(64 * WY * WX), lds, s, a, tiles_x, tiles_y,
+                       ngroups, (int)nwork);
   return hipGetLastError();
 }
 }  // namespace

@@ -203,10 +203,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     //      row, both frames) + the 3 MFMAs of tap (kh,kw) for output channels 16*HP..  Blocks are written as inline asm:
     //      left to itself the compiler hoists every gather of a kernel row above the adds and spills them to scratch.
     //      In-order issue does the overlap: 8 ds_reads go out, the 3 MFMAs cover their latency, then the 8 adds.
-    f32x4 acc[NT16];
+    // one accumulator per (n-tile, k-step): the MFMAs of a block are independent, so neither the 40-cycle dependent
+    // latency of 16x16x4 nor the same-accumulator issue cliff (MI355X_MICROARCH.md) sits between them
+    f32x4 acc3[NT16][3];
     float gacc[16];
 #pragma unroll
-    for (int nt = 0; nt < NT16; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc3[nt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 16; ++q) gacc[q] = 0.f;
     const float *abase = dense + (3 * kq) * NPIX + (2 * wave) * PW + 2 * i;      // MFMA A: pixel i, channels 3kq..3kq+2
@@ -263,18 +267,18 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
                   [o6] "v"(o[12]), [o7] "v"(o[14]), [imm] "i"(BUF * SLICE_B));
           if (kw < 6) {                                                 // MFMAs of this block + gathers of the next one
             asm volatile(
-                "v_mfma_f32_16x16x4_f32 %[c], %[a0], %[b0], %[c]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c0], %[a0], %[b0], %[c0]\n\t"
                 "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
                 "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
                 "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
                 "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
-                "v_mfma_f32_16x16x4_f32 %[c], %[a1], %[b1], %[c]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c1], %[a1], %[b1], %[c1]\n\t"
                 "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
                 "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
                 "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
                 "ds_read_b32 %[t7], %[o7] offset:%[imm]\n\t"
-                "v_mfma_f32_16x16x4_f32 %[c], %[a2], %[b2], %[c]"
-                : [c] "+v"(acc[HP]), [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3]),
+                "v_mfma_f32_16x16x4_f32 %[c2], %[a2], %[b2], %[c2]"
+                : [c0] "+v"(acc3[HP][0]), [c1] "+v"(acc3[HP][1]), [c2] "+v"(acc3[HP][2]), [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3]),
                   [t4] "=&v"(tn[4]), [t5] "=&v"(tn[5]), [t6] "=&v"(tn[6]), [t7] "=&v"(tn[7])
                 : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 3]), [o2] "v"(o[kw + 5]), [o3] "v"(o[kw + 7]),
                   [o4] "v"(o[kw + 9]), [o5] "v"(o[kw + 11]), [o6] "v"(o[kw + 13]), [o7] "v"(o[kw + 15]),
@@ -282,10 +286,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
                   [b2] "v"(bq[0][2]), [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
           } else {
             asm volatile(
-                "v_mfma_f32_16x16x4_f32 %[c], %[a0], %[b0], %[c]\n\t"
-                "v_mfma_f32_16x16x4_f32 %[c], %[a1], %[b1], %[c]\n\t"
-                "v_mfma_f32_16x16x4_f32 %[c], %[a2], %[b2], %[c]"
-                : [c] "+v"(acc[HP])
+                "v_mfma_f32_16x16x4_f32 %[c0], %[a0], %[b0], %[c0]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c1], %[a1], %[b1], %[c1]\n\t"
+                "v_mfma_f32_16x16x4_f32 %[c2], %[a2], %[b2], %[c2]"
+                : [c0] "+v"(acc3[HP][0]), [c1] "+v"(acc3[HP][1]), [c2] "+v"(acc3[HP][2])
                 : [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]), [a2] "v"(a_cur[2]), [b0] "v"(bq[0][0]), [b1] "v"(bq[0][1]),
                   [b2] "v"(bq[0][2]));
           }
@@ -337,6 +341,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     //      partials.  Fixed order: mfma + (prev-frame row + cur-frame row).  The exchange lives in table buffer 1 (free
     //      since the barrier after kernel row 5), so no barrier is needed here: a wave only reads back its own rows.
     static_assert(TH * 16 * GP + TH * COUT * 2 <= SLICE_F, "exchange area must fit one table buffer");
+    f32x4 acc[NT16];
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt) acc[nt] = (acc3[nt][0] + acc3[nt][1]) + acc3[nt][2];   // fixed order
     float *gx = tab + SLICE_F;                              // [8 rows][16 pixels][GP]
     float *red = gx + TH * 16 * GP;
 #pragma unroll
