@@ -141,6 +141,8 @@ struct WgradArgs {
   int mode;                 // 0 plain, 1 producer GN+ReLU recomputed, 2 gathered+whitened observation tensors
   int TG, groups, ci_tiles, pairs, chunks;
   long pix_per_chunk;
+  // LDS-staged path (wgrad3_lds_kernel: 3x3 stride-1 convs with 32-channel multiples), chosen by wgrad_plan
+  int lds3, TH, TW, tiles_x, tiles_y, tiles_per_chunk;
 };
 void wgrad_plan(WgradArgs &a);
 size_t wgrad_partial_floats(const WgradArgs &a);

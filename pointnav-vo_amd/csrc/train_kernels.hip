@@ -5,6 +5,9 @@
 //   moments behind RunningMeanAndVar's train-mode update.
 // Backward-DATA of the convs reuses conv_mfma_kernel (flipped/transposed packed weights, `up` = forward stride).
 // Reductions have one writer per partial and a fixed summation order: gradients are bit-reproducible.
+#include <cstdlib>
+#include <cstring>
+
 #include "pnvo_internal.h"
 
 namespace pnvo {
@@ -166,25 +169,160 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
-// grad[map(co, ci, tap)] = sum over chunks (fixed order) of partial[chunk, pair, grp][t][ci_row][co_col]
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-staged weight gradient of the 3x3 stride-1 convs (every residual-stage conv but the three strided ones):
+//   dW[tap][ci][co] = sum_pix X[pix + tap][ci] * dY[pix][co]
+// A persistent workgroup owns one (ci-tile, co-tile) pair and a chunk of spatial tiles (TH x TW output pixels of one
+// sample).  Per tile it stages the (TH+2) x (TW+2) input patch (32 channels; the producer's GroupNorm+ReLU and the zero
+// padding applied while staging) and the TH x TW slab of dY (32 channels) into LDS with coalesced 16-byte loads; its 9
+// waves are the 9 taps: wave (kh,kw) runs D[ci][co] += X[pix+(kh,kw)][ci] * dY[pix][co] over the tile's pixels, two
+// pixels per v_mfma_f32_32x32x2_f32, both operands one conflict-free ds_read_b32 (32 consecutive channels per half
+// wave).  The accumulators live in registers across all tiles of the chunk; the per-chunk partials are summed in a
+// fixed order by wgrad_reduce_kernel (same layout as wgrad_kernel with TG = 9, one tap group).
+template <int MODE>
+__global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
+  constexpr int PP = 36;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int TH = p.TH, TW = p.TW, PH = TH + 2, PWR = TW + 2;
+  float *xs = lds;                         // [PH*PWR][PP]
+  float *ds = lds + PH * PWR * PP;         // [TH*TW][PP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = tap
+  const int i = lane & 31, h = lane >> 5;
+  const int kh = wave / 3, kw = wave - 3 * kh;
+  const int unit = blockIdx.x;
+  const int pair = unit / p.chunks, chunk = unit - pair * p.chunks;
+  const int cit = pair % p.ci_tiles, cot = pair / p.ci_tiles;
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  const int g = tid & 7;                   // 576 % 8 == 0: a thread keeps its 16-byte slot
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+
+  // staging through registers: the global loads of tile t+1 are in flight during the MFMAs of tile t
+  constexpr int NX = 4, ND = 3;            // 16-byte items per thread: patch <= 10x26 pixels, slab <= 8x24 (wgrad_plan)
+  f32x4 vx[NX], vd[ND];
+  auto gload = [&](int t) {
+    int q = t;
+    const int tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty = q % p.tiles_y;
+    const int n = q / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float *xb = p.x + ((long)n * p.H * p.W) * p.CIN + cit * 32 + 4 * g;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+      sc = *reinterpret_cast<const f32x4 *>(p.in_scale + (long)n * p.CIN + cit * 32 + 4 * g);
+      sh = *reinterpret_cast<const f32x4 *>(p.in_shift + (long)n * p.CIN + cit * 32 + 4 * g);
+    }
+    bool inx[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int pix = (tid + k * 576) >> 3;
+      const int pr = pix / PWR, pc = pix - pr * PWR;
+      const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+      inx[k] = pix < PH * PWR && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      vx[k] = inx[k] ? *reinterpret_cast<const f32x4 *>(xb + ((long)yy * p.W + xx) * p.CIN) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float *db = p.dy + ((long)n * p.Ho * p.Wo) * p.DYC + cot * 32 + 4 * g;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int pix = (tid + k * 576) >> 3;
+      const int qy = pix / TW, qx = pix - qy * TW;
+      const int oy = y0 + qy, ox = x0 + qx;
+      const bool in = pix < TH * TW && oy < p.Ho && ox < p.Wo;       // pixels outside the image contribute nothing
+      vd[k] = in ? *reinterpret_cast<const f32x4 *>(db + ((long)oy * p.Wo + ox) * p.DYC) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (MODE == 1) {                        // zero padding AFTER the input transform
+#pragma unroll
+      for (int k = 0; k < NX; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vx[k][e] = inx[k] ? fmaxf(__builtin_fmaf(vx[k][e], sc[e], sh[e]), 0.f) : 0.f;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int pix = (tid + k * 576) >> 3;
+      if (pix < PH * PWR) *reinterpret_cast<f32x4 *>(xs + pix * PP + 4 * g) = vx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int pix = (tid + k * 576) >> 3;
+      if (pix < TH * TW) *reinterpret_cast<f32x4 *>(ds + pix * PP + 4 * g) = vd[k];
+    }
+  };
+
+  int t0 = chunk * p.tiles_per_chunk, t1 = t0 + p.tiles_per_chunk;
+  if (t1 > ntiles) t1 = ntiles;
+  const float *xa = xs + (kh * PWR + kw + h) * PP + i;
+  const float *da = ds + h * PP + i;
+  const int half_w = TW >> 1;
+  if (t0 < t1) gload(t0);
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();                       // the previous tile's readers are done
+    lstore();
+    __syncthreads();
+    if (t + 1 < t1) gload(t + 1);
+    // K loop of this tap: pixel pairs (2s, 2s+1) of each tile row; lane half h takes pixel 2s+h
+    for (int qy = 0; qy < TH; ++qy) {
+      const float *xr = xa + qy * PWR * PP, *dr = da + qy * TW * PP;
+      int sx = 0;
+      for (; sx + 2 <= half_w; sx += 2) {
+        const float a0 = xr[(2 * sx) * PP], b0 = dr[(2 * sx) * PP];
+        const float a1 = xr[(2 * sx + 2) * PP], b1 = dr[(2 * sx + 2) * PP];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
+      }
+      if (sx < half_w) {
+        const float a0 = xr[(2 * sx) * PP], b0 = dr[(2 * sx) * PP];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout: col j (= co) = lane&31, row i (= ci) = (r&3) + 8*(r>>2) + 4*(lane>>5); fixed order acc0 + acc1
+  float *dst = p.partial + (((long)unit * 9 + wave) * 32) * 32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    dst[(long)row * 32 + i] = acc0[r] + acc1[r];
+  }
+}
+
+// grad[map(co, ci, tap)] = sum over chunks (fixed order) of partial[chunk, pair, grp][t][ci_row][co_col].
+// One block per (pair, tap, ci row): 32 output channels x 8 chunk lanes; lane k sums chunks k, k+8, ... in fp64
+// (coalesced 128-B reads), the 8 lane sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p, int TG, float *grad, const int *ci_perm,
                                                          int cin_out) {
+  __shared__ double red[8][32];
   const int T = p.KH * p.KW;
-  const long total = (long)p.COUT * p.CIN * T;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int tap = (int)(e % T);
-  const int ci = (int)((e / T) % p.CIN);
-  const int co = (int)(e / ((long)T * p.CIN));
-  const int cit = ci >> 5, cot = co >> 5, grp = tap / TG, t = tap - grp * TG;
-  const int pair = cot * p.ci_tiles + cit;
+  int b = blockIdx.x;
+  const int row = b & 31;
+  b >>= 5;
+  const int tap = b % T;
+  const int pair = b / T;
+  const int cit = pair % p.ci_tiles, cot = pair / p.ci_tiles;
+  const int col = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int grp = tap / TG, t = tap - grp * TG;
   double acc = 0.0;
-  for (int c = 0; c < p.chunks; ++c) {
+  for (int c = cl; c < p.chunks; c += 8) {
     const long unit = ((long)grp * p.pairs + pair) * p.chunks + c;
-    acc += (double)p.partial[(((unit * TG) + t) * 32 + (ci & 31)) * 32 + (co & 31)];
+    acc += (double)p.partial[(((unit * TG) + t) * 32 + row) * 32 + col];
   }
-  const int cio = ci_perm ? ci_perm[ci] : ci;       // stem: kernel channel order -> reference channel order
-  if (cio >= 0 && cio < cin_out) grad[((long)co * cin_out + cio) * T + tap] = (float)acc;
+  red[cl][col] = acc;
+  __syncthreads();
+  if (cl == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][col];
+    const int ci = cit * 32 + row, co = cot * 32 + col;
+    if (ci < p.CIN && co < p.COUT) {
+      const int cio = ci_perm ? ci_perm[ci] : ci;     // stem: kernel channel order -> reference channel order
+      if (cio >= 0 && cio < cin_out) grad[((long)co * cin_out + cio) * T + tap] = (float)s;
+    }
+  }
 }
 
 template <int TG>
@@ -201,6 +339,28 @@ static hipError_t launch_wgrad_t(const WgradArgs &a, hipStream_t s) {
 }
 
 void wgrad_plan(WgradArgs &a) {
+  a.lds3 = 0;
+  static const bool no_lds = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "generic") == 0;
+  if (!no_lds && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.CIN % 32 == 0 &&
+      a.COUT % 32 == 0 && a.DYC % 4 == 0 && a.H == a.Ho && a.W == a.Wo) {
+    a.lds3 = 1;
+    a.TG = 9;
+    a.groups = 1;
+    a.ci_tiles = a.CIN / 32;
+    a.pairs = a.ci_tiles * (a.COUT / 32);
+    a.tiles_x = (a.W + 23) / 24;
+    a.TW = ((a.W + a.tiles_x - 1) / a.tiles_x + 1) / 2 * 2;
+    a.tiles_y = (a.H + 7) / 8;
+    a.TH = (a.H + a.tiles_y - 1) / a.tiles_y;
+    const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+    long chunks = 512 / a.pairs;                      // 2 persistent workgroups per CU
+    if (chunks < 1) chunks = 1;
+    if (chunks > ntiles) chunks = ntiles;
+    a.tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
+    a.chunks = (int)((ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk);
+    a.pix_per_chunk = 0;
+    return;
+  }
   const int T = a.KH * a.KW;
   a.TG = T >= 9 ? (T % 9 == 0 ? 9 : (T % 7 == 0 ? 7 : (T % 6 == 0 ? 6 : 9))) : (T >= 3 ? 3 : 1);
   if (T == 1) a.TG = 1;
@@ -221,6 +381,19 @@ size_t wgrad_partial_floats(const WgradArgs &a) { return (size_t)a.chunks * a.pa
 
 hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int cin_out, hipStream_t s) {
   hipError_t e;
+  if (a.lds3) {
+    const size_t lds = (size_t)((a.TH + 2) * (a.TW + 2) + a.TH * a.TW) * 36 * 4;
+    dim3 grid((unsigned)(a.pairs * a.chunks));
+    if (a.mode == 1)
+      hipLaunchKernelGGL((wgrad3_lds_kernel<1>), grid, dim3(576), lds, s, a);
+    else
+      hipLaunchKernelGGL((wgrad3_lds_kernel<0>), grid, dim3(576), lds, s, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.pairs * 9 * 32)), dim3(256), 0, s, a, a.TG, grad, ci_perm,
+                       cin_out);
+    return hipGetLastError();
+  }
   switch (a.TG) {
     case 9: e = launch_wgrad_t<9>(a, s); break;
     case 7: e = launch_wgrad_t<7>(a, s); break;
@@ -230,9 +403,8 @@ hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  const long total = (long)a.COUT * a.CIN * a.KH * a.KW;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, a.TG, grad, ci_perm,
-                     cin_out);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.pairs * a.KH * a.KW * 32)), dim3(256), 0, s, a, a.TG, grad,
+                     ci_perm, cin_out);
   return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--detail", action="store_true", help="also print every timed kernel")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     lr = int(os.environ.get("LOCAL_RANK", 0))
@@ -42,20 +43,29 @@ def main():
     tgt = (torch.rand((a.batch, 3), device=dev) - 0.5) * 0.5
     for _ in range(a.warmup):
         ts.step(obs, tgt)
-    model.timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         _, loss = ts.step(obs, tgt)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    model.timing(True)                    # per-kernel breakdown: a separate pass (event pairs serialise the launches)
+    for _ in range(a.steps):
+        ts.step(obs, tgt)
+    torch.cuda.synchronize()
     kt = model.timing_read()
+    model.timing(False)
     if rank == 0:
         flops = 3 * 2.0 * ms.macs_per_pair(model.cfg) * a.batch
         agg = {}
         for k in kt:
             key = k["name"].split(":")[0]
             agg[key] = agg.get(key, 0.0) + k["total_ms"] / a.steps
+        if a.detail:
+            for k in sorted(kt, key=lambda k: -k["total_ms"]):
+                ms_ = k["total_ms"] / a.steps
+                tf = k["flops"] / a.steps / (ms_ * 1e-3) / 1e12 if k["flops"] else 0.0
+                print(f"  {k['name'][-52:]:52s} {ms_:8.3f} ms  {tf:6.1f} TF  x{k['launches'] // a.steps}", file=sys.stderr)
         print(json.dumps({"metric": "VO training step (fwd+bwd+Adam) frame-pairs/s", "value": world * a.batch / dt,
                           "ms_per_step": dt * 1e3, "pairs_per_gpu": a.batch, "n_gpus": world, "loss": float(loss),
                           "tflops_3x_fwd": flops / dt / 1e12, "ms_by_kernel_class": agg}))
