@@ -234,9 +234,10 @@ void free_train_ws(TrainState *t) {
 }
 
 // weight-gradient launch descriptor of conv `l` for batch B (input geometry = the forward conv's)
-WgradArgs wgrad_args(const Layer &l, int B, int cin_kernel, int dyc) {
+WgradArgs wgrad_args(const Layer &l, int B, int cin_kernel, int dyc, int mode = 0) {
   WgradArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.mode = mode;                 // wgrad_plan picks the kernel by mode
   a.B = B;
   a.H = l.hin;
   a.W = l.win;
@@ -272,7 +273,7 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
     }
     if ((rc = dmalloc(m, (void **)&s.mu, (size_t)B * l.groups * 4)) != PNVO_OK) return rc;
     if ((rc = dmalloc(m, (void **)&s.rstd, (size_t)B * l.groups * 4)) != PNVO_OK) return rc;
-    WgradArgs a = wgrad_args(l, B, li == 0 ? 32 : l.cin, l.coutp);
+    WgradArgs a = wgrad_args(l, B, li == 0 ? 32 : l.cin, l.coutp, li == 0 ? 2 : 0);
     wgmax = std::max(wgmax, wgrad_partial_floats(a));
   }
   {
@@ -664,9 +665,8 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     const Layer &l = m->convs[0];
     HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
     if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
-    WgradArgs a = wgrad_args(l, B, 32, l.coutp);
+    WgradArgs a = wgrad_args(l, B, 32, l.coutp, 2);
     a.dy = t->dStem;
-    a.mode = 2;
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
     std::vector<float> sc(m->CPL), sh(m->CPL);
     // the whitening constants are on the device (stem_sc/sh); the kernel wants them per lane: read them back once per

@@ -14,6 +14,7 @@ namespace pnvo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define PNVO_OOB 0x80000000u
 
@@ -291,6 +292,127 @@ __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-staged weight gradient of the 7x7 stride-2 stem (mode 2: input gathered from the observation tensors and whitened):
+//   dW[kh][kw][c][co] = sum_pix X[2*pix + (kh,kw) - 3][c] * dY[pix][co],   49 taps x (32 x 32) = 49 MFMA accumulators.
+// One persistent workgroup per CU, 7 waves = the 7 kernel rows; wave kh keeps the 7 accumulators of its row (independent
+// MFMA chains).  Per 4x16-pixel output tile the 13x37 input patch (whitened, zero padded AFTER whitening) and the dY
+// slab go to LDS; the global loads of tile t+1 are issued before the K loop of tile t and parked in registers (the K loop
+// itself touches only LDS, so nothing waits on them).  K loop: two pixels per v_mfma_f32_32x32x2_f32, operands are
+// conflict-free ds_read_b32 (32 consecutive channels per half wave), 8 reads per 7 MFMAs.
+__global__ __launch_bounds__(448) void wgrad_stem_lds_kernel(const WgradArgs p) {
+  constexpr int TH = 4, TW = 16, PH = 2 * TH + 5, PWR = 2 * TW + 5, NPIX = PH * PWR, PP = 36, NTHR = 448;
+  constexpr int PXP = NTHR / 16;                      // pixels per staging pass (16 channel pairs per pixel)
+  constexpr int NXP = (NPIX + PXP - 1) / PXP;         // 18 passes
+  constexpr int NDP = (TH * TW * 8 + NTHR - 1) / NTHR;   // 2 passes of 16-byte dY items
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *xs = lds;                                    // [NPIX][PP]
+  float *ds = lds + NPIX * PP;                        // [TH*TW][PP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kh = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int chunk = blockIdx.x;
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+
+  // staging role: channel pair pq of pixel pp0 + 28*k
+  const int pq = tid & 15, pp0 = tid >> 4;
+  const SrcLane s0 = p.src[2 * pq], s1 = p.src[2 * pq + 1];
+  const float sc0 = p.in_scale ? p.in_scale[2 * pq] : s0.sc, sh0 = p.in_shift ? p.in_shift[2 * pq] : s0.sh;
+  const float sc1 = p.in_scale ? p.in_scale[2 * pq + 1] : s1.sc, sh1 = p.in_shift ? p.in_shift[2 * pq + 1] : s1.sh;
+  const int g8 = tid & 7;
+
+  f32x2 vx[NXP];
+  f32x4 vd[NDP];
+  unsigned okm = 0;
+  auto gload = [&](int t) {
+    int q = t;
+    const int tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty = q % p.tiles_y;
+    const int n = q / p.tiles_y;
+    const int hb = 2 * ty * TH - 3, wb = 2 * tx * TW - 3;
+    okm = 0;
+#pragma unroll
+    for (int k = 0; k < NXP; ++k) {
+      const int pix = pp0 + k * PXP;
+      const int pr = pix / PWR, pc = pix - pr * PWR;
+      const int hi = hb + pr, wi = wb + pc;
+      const bool ok = pix < NPIX && s0.base != nullptr && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      okm |= (ok ? 1u : 0u) << k;
+      const float *addr = ok ? s0.base + (((long)n * p.H + hi) * p.W + wi) * s0.nch + s0.choff : p.zero_page;
+      vx[k] = *reinterpret_cast<const f32x2 *>(addr);
+    }
+    const float *db = p.dy + ((long)n * p.Ho * p.Wo) * p.DYC + 4 * g8;
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) {
+      const int pix = (tid + k * NTHR) >> 3;
+      const int qy = pix / TW, qx = pix - qy * TW;
+      const int oy = ty * TH + qy, ox = tx * TW + qx;
+      const bool in = pix < TH * TW && oy < p.Ho && ox < p.Wo;
+      vd[k] = in ? *reinterpret_cast<const f32x4 *>(db + ((long)oy * p.Wo + ox) * p.DYC) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int k = 0; k < NXP; ++k) {
+      const int pix = pp0 + k * PXP;
+      if (pix < NPIX) {
+        const bool ok = (okm >> k) & 1u;              // zero padding (and pad channels) AFTER the whitening
+        f32x2 v;
+        v[0] = ok ? __builtin_fmaf(vx[k][0], sc0, sh0) : 0.f;
+        v[1] = ok ? __builtin_fmaf(vx[k][1], sc1, sh1) : 0.f;
+        *reinterpret_cast<f32x2 *>(xs + pix * PP + 2 * pq) = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) {
+      const int pix = (tid + k * NTHR) >> 3;
+      if (pix < TH * TW) *reinterpret_cast<f32x4 *>(ds + pix * PP + 4 * g8) = vd[k];
+    }
+  };
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kw][r] = 0.f;
+
+  int t0 = chunk * p.tiles_per_chunk, t1 = t0 + p.tiles_per_chunk;
+  if (t1 > ntiles) t1 = ntiles;
+  const float *xa = xs + (kh * PWR + 2 * h) * PP + i;     // pixel (2*qy + kh, 2*(2*sx + h) + kw)
+  const float *da = ds + h * PP + i;
+  if (t0 < t1) gload(t0);
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();                                  // the previous tile's readers are done
+    lstore();
+    __syncthreads();
+    if (t + 1 < t1) gload(t + 1);                     // lands during the K loop (which only touches LDS)
+    for (int qy = 0; qy < TH; ++qy) {
+      const float *xr = xa + (2 * qy) * PWR * PP, *dr = da + qy * TW * PP;
+#pragma unroll 2
+      for (int sx = 0; sx < TW / 2; ++sx) {
+        const float b = dr[(2 * sx) * PP];
+        float a[7];
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) a[kw] = xr[(4 * sx + kw) * PP];
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kw], b, acc[kw], 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout: col j (= co) = lane&31, row i (= channel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int kw = 0; kw < 7; ++kw) {
+    float *dst = p.partial + ((((long)kh * p.chunks + chunk) * 7 + kw) * 32) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[(long)row * 32 + i] = acc[kw][r];
+    }
+  }
+}
+
 // grad[map(co, ci, tap)] = sum over chunks (fixed order) of partial[chunk, pair, grp][t][ci_row][co_col].
 // One block per (pair, tap, ci row): 32 output channels x 8 chunk lanes; lane k sums chunks k, k+8, ... in fp64
 // (coalesced 128-B reads), the 8 lane sums are combined in a fixed order.
@@ -361,6 +483,24 @@ void wgrad_plan(WgradArgs &a) {
     a.pix_per_chunk = 0;
     return;
   }
+  if (!no_lds && a.mode == 2 && a.KH == 7 && a.KW == 7 && a.stride == 2 && a.pad == 3 && a.CIN <= 32 && a.COUT == 32 &&
+      a.DYC % 4 == 0) {                                  // the stem: wgrad_stem_lds_kernel, one workgroup per CU
+    a.lds3 = 2;
+    a.TG = 7;
+    a.groups = 7;
+    a.ci_tiles = 1;
+    a.pairs = 1;
+    a.TH = 4;
+    a.TW = 16;
+    a.tiles_x = (a.Wo + 15) / 16;
+    a.tiles_y = (a.Ho + 3) / 4;
+    const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+    long chunks = ntiles < 256 ? ntiles : 256;
+    a.tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
+    a.chunks = (int)((ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk);
+    a.pix_per_chunk = 0;
+    return;
+  }
   const int T = a.KH * a.KW;
   a.TG = T >= 9 ? (T % 9 == 0 ? 9 : (T % 7 == 0 ? 7 : (T % 6 == 0 ? 6 : 9))) : (T >= 3 ? 3 : 1);
   if (T == 1) a.TG = 1;
@@ -381,6 +521,14 @@ size_t wgrad_partial_floats(const WgradArgs &a) { return (size_t)a.chunks * a.pa
 
 hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int cin_out, hipStream_t s) {
   hipError_t e;
+  if (a.lds3 == 2) {
+    const size_t lds = (size_t)(13 * 37 + 64) * 36 * 4;
+    hipLaunchKernelGGL(wgrad_stem_lds_kernel, dim3((unsigned)a.chunks), dim3(448), lds, s, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(49 * 32)), dim3(256), 0, s, a, a.TG, grad, ci_perm, cin_out);
+    return hipGetLastError();
+  }
   if (a.lds3) {
     const size_t lds = (size_t)((a.TH + 2) * (a.TW + 2) + a.TH * a.TW) * 36 * 4;
     dim3 grid((unsigned)(a.pairs * a.chunks));
