@@ -321,7 +321,7 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
   }
   if ((rc = dmalloc(m, (void **)&t->gn_part, (size_t)B * 65 * maxc * 2 * 4)) != PNVO_OK) return rc;   // 64 chunks + [B][C][2]
   if ((rc = dmalloc(m, (void **)&t->gn_coef, (size_t)B * maxg * 2 * 4)) != PNVO_OK) return rc;
-  if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 256 * 8)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 512 * 8)) != PNVO_OK) return rc;
   t->capB = B;
   return PNVO_OK;
 }
