@@ -621,21 +621,35 @@ __global__ __launch_bounds__(256) void gn_bwd_sum_chunks_kernel(const float *par
   nc[e * 2 + 1] = (float)a2;
 }
 
-// stage B: per (n, group): c1 = S1/N, c2 = S2/N;  per channel: dgamma, dbeta (sum over n in a fixed order, fp64)
+// stage B: per (n, group): c1 = S1/N, c2 = S2/N;  per channel: dgamma, dbeta (sum over n in a fixed order, fp64).
+// Blocks [0, nb_coef) do the coefficients (one thread per (n, group)); the following blocks take one channel per WAVE:
+// lane l sums samples l, l+64, ... and a fixed xor-shuffle tree combines the lanes.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, int B, int C, int Creal, int G, long P,
-                                                            const float *gamma, float *coef, float *dgamma, float *dbeta) {
+                                                            const float *gamma, float *coef, float *dgamma, float *dbeta,
+                                                            int nb_coef) {
   const int cpg = Creal / G;
+  if ((int)blockIdx.x >= nb_coef) {               // per-channel parameter gradients
+    const int c = ((int)blockIdx.x - nb_coef) * 4 + (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= Creal) return;
+    double dg = 0.0, db = 0.0;
+    for (int n = lane; n < B; n += 64) {
+      db += (double)nc[((long)n * C + c) * 2];
+      dg += (double)nc[((long)n * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      db += __shfl_xor(db, o);
+      dg += __shfl_xor(dg, o);
+    }
+    if (lane == 0) {
+      dgamma[c] = (float)dg;
+      dbeta[c] = (float)db;
+    }
+    return;
+  }
   const double N = (double)cpg * (double)P;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < Creal) {                               // per-channel parameter gradients
-    double dg = 0.0, db = 0.0;
-    for (int n = 0; n < B; ++n) {
-      db += (double)nc[((long)n * C + e) * 2];
-      dg += (double)nc[((long)n * C + e) * 2 + 1];
-    }
-    dgamma[e] = (float)dg;
-    dbeta[e] = (float)db;
-  }
   if (e < B * G) {                               // per-(sample, group) coefficients
     const int n = e / G, g = e % G;
     double S1 = 0.0, S2 = 0.0;
@@ -649,25 +663,39 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, i
   }
 }
 
+// dx for 4 consecutive channels per thread (C % 4 == 0; the 4 channels may straddle groups when C/G < 4)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, const float *dout, const float *scale,
                                                          const float *shift, const float *mu, const float *rstd,
                                                          const float *gamma, const float *coef, int C, int Creal, int G,
-                                                         long P, long total, int mask, float *dx) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int c = (int)(e % C);
+                                                         long P, long total4, int mask, float *dx) {
+  const long e4 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e4 >= total4) return;
+  const long e = e4 * 4;
+  const int c0 = (int)(e % C);
   const int n = (int)(e / (P * C));
-  float out = 0.f;
-  if (c < Creal) {
-    const int cpg = Creal / G, g = c / cpg;
-    const float xv = x[e];
-    float gd = dout[e];
-    if (mask && !(__builtin_fmaf(xv, scale[(long)n * C + c], shift[(long)n * C + c]) > 0.f)) gd = 0.f;
-    const float r_ = rstd[n * G + g];
-    const float xh = (xv - mu[n * G + g]) * r_;
-    out = r_ * (gamma[c] * gd - coef[((long)n * G + g) * 2] - xh * coef[((long)n * G + g) * 2 + 1]);
+  const int cpg = Creal / G;
+  const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + e), gv = *reinterpret_cast<const f32x4 *>(dout + e);
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (mask) {
+    sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + c0);
+    sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + c0);
   }
-  dx[e] = out;     // channel-pad lanes (compression 31 -> 32) get 0
+  f32x4 out;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = c0 + t;
+    float o = 0.f;
+    if (c < Creal) {
+      const int g = c / cpg;
+      float gd = gv[t];
+      if (mask && !(__builtin_fmaf(xv[t], sc[t], sh[t]) > 0.f)) gd = 0.f;
+      const float r_ = rstd[n * G + g];
+      const float xh = (xv[t] - mu[n * G + g]) * r_;
+      o = r_ * (gamma[c] * gd - coef[((long)n * G + g) * 2] - xh * coef[((long)n * G + g) * 2 + 1]);
+    }
+    out[t] = o;                                   // channel-pad lanes (compression 31 -> 32) get 0
+  }
+  *reinterpret_cast<f32x4 *>(dx + e) = out;
 }
 
 hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
@@ -682,12 +710,12 @@ hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, 
   float *nc = part + (size_t)B * chunks * C * 2;     // [B][C][2] right behind the chunk partials
   hipLaunchKernelGGL(gn_bwd_sum_chunks_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, s, part, B, C, chunks,
                      nc);
-  const int work = (B * G > Creal) ? B * G : Creal;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, nc, B, C, Creal, G, P,
-                     gamma, coef, dgamma, dbeta);
-  const long total = (long)B * P * C;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dout, scale, shift, mu,
-                     rstd, gamma, coef, C, Creal, G, P, total, mask, dx);
+  const int nb_coef = (B * G + 255) / 256;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)(nb_coef + (Creal + 3) / 4)), dim3(256), 0, s, nc, B, C, Creal,
+                     G, P, gamma, coef, dgamma, dbeta, nb_coef);
+  const long total4 = (long)B * P * C / 4;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, dout, scale, shift, mu,
+                     rstd, gamma, coef, C, Creal, G, P, total4, mask, dx);
   return hipGetLastError();
 }
 
