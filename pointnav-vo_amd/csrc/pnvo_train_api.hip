@@ -358,7 +358,10 @@ int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw,
   choose_tile(M, a.COUTP, &a.MT, &a.NT);
   a.slots = conv_slots(l.hin * l.win, a.MT);
   PnvoTimed tm(m, s, "dgrad:" + l.name, 2.0 * (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw, 0.0);
-  HIPCHK(m, launch_conv(a, s));
+  if (conv3_lds_supported(a))         // backward-data of a 3x3 stride-1 conv is a 3x3 stride-1 conv: LDS-staged kernel
+    HIPCHK(m, launch_conv3_lds(a, (a.COUTP / 32) % 2 == 0 ? 2 : 1, s));
+  else
+    HIPCHK(m, launch_conv(a, s));
   return PNVO_OK;
 }
 
