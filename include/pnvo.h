@@ -137,6 +137,16 @@ int pnvo_input_moments(pnvo_handle h, const float *rgb, const float *depth, cons
  * NULL) and dLoss/dPred into grad [B,D] (may be NULL). */
 int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, void *stream);
 
+/* nn.Dropout(p) of the two places the reference has one — before visual_fc's Linear and before output_head's Linear
+ * (pointnav_vo/vo/models/vo_cnn.py:216-227) — for the train-mode forward/backward.  torch's RNG stream cannot be
+ * reproduced; the mask is a counter-based hash of (seed, forward count, layer, element): keep with probability 1-p,
+ * kept values scaled by 1/(1-p), the same mask in the backward pass.  p = 0 (default) disables it. */
+int pnvo_train_set_dropout(pnvo_handle h, float p, uint64_t seed);
+
+/* The scaled mask (0 or 1/(1-p)) the LAST pnvo_train_forward used: layer 0 -> [B, fh*fw, compression channels padded to a multiple of 32]
+ * (the kernel's NHWC order of the flattened feature), layer 1 -> [B, hidden].  For checkers. */
+int pnvo_train_dropout_mask(pnvo_handle h, int layer, float *out, void *stream);
+
 /* torch.optim.Adam(weight_decay=0, amsgrad=False) on flat device buffers; step counts from 1. */
 int pnvo_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, void *stream);

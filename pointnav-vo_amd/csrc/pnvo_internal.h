@@ -159,6 +159,10 @@ hipError_t launch_maxpool_bwd(const float *dpool, const unsigned char *idx, int 
                               hipStream_t s);
 hipError_t launch_colsum(const float *x, int rows, int cols, int ld, float *out, hipStream_t s);
 hipError_t launch_padcopy(const float *src, int rows, int cols, int ldd, float *dst, hipStream_t s);
+// y = [relu(x*scale[n,c]+shift[n,c]) or x] * keep/(1-p); keep = hash(seed, step, layer, element) >= p.  x viewed as
+// [B][row] with row = P*C elements (C = channel count for the scale index); x == nullptr writes the bare scaled mask.
+hipError_t launch_dropout(const float *x, const float *scale, const float *shift, int B, long P, int C, float p,
+                          uint64_t seed, uint64_t step, int layer, float *y, hipStream_t s);
 hipError_t launch_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, hipStream_t s);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps,
                        int step, hipStream_t s);

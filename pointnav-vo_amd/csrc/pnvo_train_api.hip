@@ -53,6 +53,10 @@ struct TrainState {
   float *gn_part = nullptr, *gn_coef = nullptr, *wg_partial = nullptr;
   size_t wg_partial_floats = 0;
   double *mom_part = nullptr;
+  // dropout (pnvo_train_set_dropout): p, seed, forward counter; dropped activations of the last forward
+  float drop_p = 0.f;
+  uint64_t drop_seed = 0, drop_step = 0;
+  float *zdrop = nullptr, *hdrop = nullptr, *dmask = nullptr;
 };
 
 TrainState *TS(pnvo_handle m) { return reinterpret_cast<TrainState *>(m->train); }
@@ -230,6 +234,9 @@ void free_train_ws(TrainState *t) {
   dfree(t->gn_coef);
   dfree(t->wg_partial);
   dfree(t->mom_part);
+  dfree(t->zdrop);
+  dfree(t->hdrop);
+  dfree(t->dmask);
   t->capB = 0;
 }
 
@@ -321,6 +328,12 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
   }
   if ((rc = dmalloc(m, (void **)&t->gn_part, (size_t)B * 65 * maxc * 2 * 4)) != PNVO_OK) return rc;   // 64 chunks + [B][C][2]
   if ((rc = dmalloc(m, (void **)&t->gn_coef, (size_t)B * maxg * 2 * 4)) != PNVO_OK) return rc;
+  {
+    const size_t zf = (size_t)B * m->fh * m->fw * m->comp_cp, hf = (size_t)B * c.hidden;
+    if ((rc = dmalloc(m, (void **)&t->zdrop, zf * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&t->hdrop, hf * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&t->dmask, (zf > hf ? zf : hf) * 4)) != PNVO_OK) return rc;
+  }
   if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 512 * 8)) != PNVO_OK) return rc;
   t->capB = B;
   return PNVO_OK;
@@ -514,6 +527,20 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
     if ((rc = pnvo_run_conv(m, comp, B, t->y[8], nullptr, nullptr, sc.raw, comp.coutp, sc.ss, nullptr, nullptr, 0, s, nullptr,
                             sc.mu, sc.rstd)) != PNVO_OK)
       return rc;
+    ++t->drop_step;
+    if (t->drop_p > 0.f) {            // Dropout -> Linear -> ReLU -> Dropout -> Linear (vo_cnn.py:216-227), masks by hash
+      HIPCHK(m, launch_dropout(sc.raw, sc.ss[0], sc.ss[1], B, (long)m->fh * m->fw, m->comp_cp, t->drop_p, t->drop_seed,
+                               t->drop_step, 0, t->zdrop, s));
+      if ((rc = pnvo_run_conv(m, m->fc, B, t->zdrop, nullptr, nullptr, t->hid, c.hidden, nullptr, m->fc_bias, nullptr, 1, s,
+                              nullptr, nullptr, nullptr)) != PNVO_OK)
+        return rc;
+      HIPCHK(m, launch_dropout(t->hid, nullptr, nullptr, B, 1, c.hidden, t->drop_p, t->drop_seed, t->drop_step, 1, t->hdrop,
+                               s));
+      if ((rc = pnvo_run_conv(m, m->head, B, t->hdrop, nullptr, nullptr, out, c.out_dim, nullptr, m->head_bias, nullptr, 0,
+                              s, nullptr, nullptr, nullptr)) != PNVO_OK)
+        return rc;
+      return PNVO_OK;
+    }
     if ((rc = pnvo_run_conv(m, m->fc, B, sc.raw, sc.ss[0], sc.ss[1], t->hid, c.hidden, nullptr, m->fc_bias, nullptr, 1, s,
                             nullptr, nullptr, nullptr)) != PNVO_OK)
       return rc;
@@ -541,7 +568,7 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     if (!gb) return rc;
     HIPCHK(m, launch_colsum(grad_out, B, c.out_dim, c.out_dim, gb, s));
     WgradArgs a = wgrad_args(m->head, B, c.hidden, 8);
-    a.x = t->hid;
+    a.x = t->drop_p > 0.f ? t->hdrop : t->hid;
     a.dy = t->dout8;
     a.mode = 0;
     if ((rc = run_wgrad(m, t, a, "output_head.1.weight", nullptr, c.hidden, s)) != PNVO_OK) return rc;
@@ -566,6 +593,9 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
   // ---- hidden layer: hid = relu(z . W1^T + b1)
   const size_t icomp = m->convs.size() - 1;
   {
+    if (t->drop_p > 0.f) {            // dropout backward: the same mask, then the ReLU mask of the un-dropped activation
+      HIPCHK(m, launch_dropout(t->dh, nullptr, nullptr, B, 1, c.hidden, t->drop_p, t->drop_seed, t->drop_step, 1, t->dh, s));
+    }
     HIPCHK(m, launch_relu_mask(t->dh, t->hid, nullptr, (long)B * c.hidden, t->gh, s));
     float *gb = gradp(m, t, m->fc.name + ".bias", &rc);
     if (!gb) return rc;
@@ -578,6 +608,11 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     a.in_shift = sc.ss[1];
     a.dy = t->gh;
     a.mode = 1;
+    if (t->drop_p > 0.f) {            // the Linear saw the dropped, already activated feature
+      a.x = t->zdrop;
+      a.in_scale = a.in_shift = nullptr;
+      a.mode = 0;
+    }
     // the activation tensor is channel-padded: tell the kernel the real row pitch through H/W/CIN = (fh, fw, comp_cp)
     a.CIN = m->comp_cp;
     wgrad_plan(a);
@@ -600,6 +635,9 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     d.slots = conv_slots(1, d.MT);
     HIPCHK(m, launch_conv(d, s));
   }
+  if (t->drop_p > 0.f)
+    HIPCHK(m, launch_dropout(t->dz, nullptr, nullptr, B, (long)m->fh * m->fw, m->comp_cp, t->drop_p, t->drop_seed,
+                             t->drop_step, 0, t->dz, s));
   // ---- compression conv + GroupNorm(1) + ReLU
   float *dY = t->dYa, *dX = t->dYb;
   {
@@ -686,6 +724,30 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     a.in_shift = m->stem_sh;
     if ((rc = run_wgrad(m, t, a, l.name + ".weight", t->d_ciperm, l.cin, s)) != PNVO_OK) return rc;
   }
+  return PNVO_OK;
+}
+
+int pnvo_train_set_dropout(pnvo_handle m, float p, uint64_t seed) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  if (!(p >= 0.f && p < 1.f)) return pnvo_fail(m, PNVO_ERR_ARG, "dropout p must be in [0, 1)");
+  TrainState *t = TS(m);
+  t->drop_p = p;
+  t->drop_seed = seed;
+  return PNVO_OK;
+}
+
+int pnvo_train_dropout_mask(pnvo_handle m, int layer, float *out, void *stream) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  TrainState *t = TS(m);
+  if (t->lastB <= 0 || !out || (layer != 0 && layer != 1)) return pnvo_fail(m, PNVO_ERR_ARG, "bad argument / no forward yet");
+  const pnvo_config &c = m->cfg;
+  const float p = t->drop_p;
+  if (layer == 0)
+    HIPCHK(m, launch_dropout(nullptr, nullptr, nullptr, t->lastB, (long)m->fh * m->fw, m->comp_cp, p, t->drop_seed,
+                             t->drop_step, 0, out, (hipStream_t)stream));
+  else
+    HIPCHK(m, launch_dropout(nullptr, nullptr, nullptr, t->lastB, 1, c.hidden, p, t->drop_seed, t->drop_step, 1, out,
+                             (hipStream_t)stream));
   return PNVO_OK;
 }
 

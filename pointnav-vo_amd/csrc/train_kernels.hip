@@ -720,6 +720,45 @@ hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Dropout with a counter-based mask (splitmix64 finaliser of (seed, step, layer, element)): reproducible, stateless, the
+// backward pass recomputes the same mask.
+__device__ __forceinline__ unsigned dropout_bits(uint64_t seed, uint64_t step, int layer, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + 0xD1B54A32D192ED03ull * (step * 2 + (uint64_t)layer + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float *x, const float *scale, const float *shift, long total,
+                                                    long row, int C, unsigned thresh, float inv_keep, uint64_t seed,
+                                                    uint64_t step, int layer, float *y) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const float keep = dropout_bits(seed, step, layer, (uint64_t)e) >= thresh ? inv_keep : 0.f;
+  float v = 1.f;
+  if (x != nullptr) {
+    v = x[e];
+    if (scale != nullptr) {
+      const long n = e / row;
+      const int c = (int)(e % C);
+      v = fmaxf(__builtin_fmaf(v, scale[n * C + c], shift[n * C + c]), 0.f);
+    }
+  }
+  y[e] = v * keep;
+}
+
+hipError_t launch_dropout(const float *x, const float *scale, const float *shift, int B, long P, int C, float p,
+                          uint64_t seed, uint64_t step, int layer, float *y, hipStream_t s) {
+  const long total = (long)B * P * C;
+  double th = (double)p * 4294967296.0;
+  if (th > 4294967295.0) th = 4294967295.0;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, total, P * C, C,
+                     (unsigned)th, 1.0f / (1.0f - p), seed, step, layer, y);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // g = dy * (y > 0)   (ReLU backward on a materialised activation);  optionally  g += add
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *dy, const float *y, const float *add, long n4,
                                                       float *g) {

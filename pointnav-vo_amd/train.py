@@ -10,8 +10,9 @@ Mirrors, for one action model, the body of the reference's training iteration
 Forward, backward, loss and Adam are HIP kernels behind the C ABI (pnvo_train_*); this class only owns the flat
 device buffers and performs the collectives the reference semantics call for when torch.distributed is initialised:
 RunningMeanAndVar's three all-reduces (running_mean_and_var.py:27-38) and ONE all-reduce of the flat gradient buffer
-(RCCL over xGMI on the GPU box; 15.85 MB for the default model).  Dropout must be 0 (the reference's 0.2 uses torch's
-RNG stream, which cannot be reproduced; hash-based dropout is future work).
+(RCCL over xGMI on the GPU box; 15.85 MB for the default model).  Dropout (the reference trains with p = 0.2 before both
+Linear layers) uses a counter-based hash mask instead of torch's RNG stream — same distribution and arithmetic, a different
+but reproducible random draw (pnvo_train_set_dropout; `dropout_masks()` returns the masks of the last step for checkers).
 """
 import ctypes as C
 
@@ -21,16 +22,22 @@ import torch.distributed as dist
 from . import _lib, parallel
 
 
+def ms_feature_hw(cfg):
+    """Spatial size of the compressed feature map: 5 stride-2 stages, ceil at each (resnet.py:156-212)."""
+    h, w = cfg.height, cfg.width
+    for _ in range(5):
+        h, w = (h + 1) // 2, (w + 1) // 2
+    return h, w
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
 class VOTrainStep:
-    def __init__(self, model, lr=2.5e-4, eps=1e-8, betas=(0.9, 0.999)):
+    def __init__(self, model, lr=2.5e-4, eps=1e-8, betas=(0.9, 0.999), dropout_seed=0):
         if model.cfg.act_embed:
             raise NotImplementedError("training of act_embed variants is not built")
-        if getattr(model, "dropout_p", 0.0) != 0.0:
-            raise NotImplementedError("training needs dropout_p = 0 (torch's dropout RNG stream cannot be reproduced)")
         self.model = model
         self.lr, self.eps, self.betas = float(lr), float(eps), betas
         ref = next(model.parameters())
@@ -64,6 +71,9 @@ class VOTrainStep:
         self._toc = toc
         _lib.check(_lib.lib.pnvo_train_attach(model._handle, _ptr(self.flat), _ptr(self.grad), total, toc, len(named)),
                    model._handle)
+        self.dropout_p = float(getattr(model, "dropout_p", 0.0) or 0.0)
+        _lib.check(_lib.lib.pnvo_train_set_dropout(model._handle, C.c_float(self.dropout_p), C.c_uint64(int(dropout_seed))),
+                   model._handle)
         self.step_count = 0
         enc = model.visual_encoder
         self.rmv = getattr(enc, "running_mean_and_var", None) if model.cfg.normalize else None
@@ -71,6 +81,19 @@ class VOTrainStep:
         self._m1 = torch.empty(Cc, device=self.dev)
         self._m2 = torch.empty(Cc, device=self.dev)
         self._loss = torch.zeros(1, device=self.dev)
+
+    def dropout_masks(self, batch):
+        """Scaled masks (0 or 1/(1-p)) of the last forward: (m0 [B, fh*fw, Cpad] in the kernel's NHWC order with the
+        compression channels padded to a multiple of 32, m1 [B, hidden])."""
+        cfg = self.model.cfg
+        fh, fw = ms_feature_hw(cfg)
+        cpad = (cfg.fc_in // (fh * fw) + 31) // 32 * 32
+        m0 = torch.empty((batch, fh * fw, cpad), device=self.dev, dtype=torch.float32)
+        m1 = torch.empty((batch, cfg.hidden), device=self.dev, dtype=torch.float32)
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(_lib.lib.pnvo_train_dropout_mask(self.model._handle, 0, _ptr(m0), C.c_void_p(s)), self.model._handle)
+        _lib.check(_lib.lib.pnvo_train_dropout_mask(self.model._handle, 1, _ptr(m1), C.c_void_p(s)), self.model._handle)
+        return m0, m1
 
     # ------------------------------------------------------------------ pieces
     def _obs_ptrs(self, obs):

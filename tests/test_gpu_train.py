@@ -13,12 +13,12 @@ from pointnav_vo_amd.train import VOTrainStep
 pytestmark = pytest.mark.gpu
 
 
-def build(rec):
+def build(rec, dropout_p=0.0):
     cfg, sd, obs, _ = golden_case(rec)
     space = str(rec["obs_space"]).split(",")
     model = baseline_registry.get_vo_model(str(rec["model"]))(
         observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
-        normalize_visual_inputs=True, output_dim=3, dropout_p=0.0, discretized_depth_channels=int(rec["dd_bins"]))
+        normalize_visual_inputs=True, output_dim=3, dropout_p=dropout_p, discretized_depth_channels=int(rec["dd_bins"]))
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to("cuda:0")
     tobs = {k: torch.from_numpy(v).to("cuda:0") for k, v in obs.items()}
@@ -81,3 +81,48 @@ def test_two_steps_reduce_loss_on_a_fixed_batch():
     target = torch.from_numpy(rec["target"]).to("cuda:0")
     losses = [ts.step(tobs, target)[1].item() for _ in range(6)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_dropout_step_matches_checker_given_the_same_masks():
+    """The reference trains with nn.Dropout(0.2) before both Linear layers (vo_cnn.py:216-227).  torch's random draw
+    cannot be reproduced, so the HIP step draws its masks from a counter-based hash; given THOSE masks the forward, the
+    loss and every gradient must equal the checker's, the masks must be i.i.d.-looking Bernoulli(1-p)/(1-p), and the
+    draw must change from step to step but not from run to run."""
+    rec = load_golden("train_default_96x64_b3_f32.npz")
+    p = 0.2
+    model, cfg, sd, obs, tobs = build(rec, dropout_p=p)
+    ts = VOTrainStep(model, lr=float(rec["lr"]), eps=float(rec["eps"]), dropout_seed=1234)
+    target = torch.from_numpy(rec["target"]).to("cuda:0")
+    B = target.shape[0]
+    out, loss = ts.forward_backward(tobs, target=target)
+    m0k, m1 = ts.dropout_masks(B)
+    torch.cuda.synchronize()
+    g_first = ts.grad.clone()
+    # kernel order [B, fh*fw, 32] -> the reference's NCHW flatten [B, C*fh*fw] (C = 31 real channels)
+    Cc = cfg.fc_in // m0k.shape[1]
+    m0 = m0k[:, :, :Cc].permute(0, 2, 1).reshape(B, -1).cpu()
+    vals = torch.unique(torch.cat([m0.reshape(-1), m1.cpu().reshape(-1)]))
+    assert set(np.round(vals.numpy(), 5).tolist()) <= {0.0, round(1 / (1 - p), 5)}
+    keep = float((m0 > 0).float().mean()), float((m1 > 0).float().mean())
+    assert abs(keep[0] - (1 - p)) < 0.02 and abs(keep[1] - (1 - p)) < 0.04, keep
+    chk = ref.train_step(sd, obs, rec["target"], ngroups=cfg.ngroups, lr=float(rec["lr"]), eps=float(rec["eps"]),
+                         dtype=torch.float64, drop_masks=(m0.double(), m1.cpu().double()))
+    np.testing.assert_allclose(out.cpu().numpy(), chk["out"].numpy(), rtol=2e-4, atol=2e-5)
+    assert abs(loss.item() - float(chk["loss"])) < 1e-4 * max(1.0, abs(float(chk["loss"])))
+    bad = []
+    for name, (off, n) in ts.offsets.items():
+        g = ts.grad[off:off + n].cpu().double().numpy()
+        gr = chk["grads"][name].reshape(-1).numpy()
+        err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
+        if err > 2e-3:
+            bad.append((name, err))
+    assert not bad, bad
+    # a second forward draws a different mask; a fresh trainer with the same seed repeats the first one bit for bit
+    ts.forward_backward(tobs, target=target)
+    m0b, _ = ts.dropout_masks(B)
+    assert not torch.equal(m0b, m0k)
+    model2, *_ = build(rec, dropout_p=p)
+    ts2 = VOTrainStep(model2, lr=float(rec["lr"]), eps=float(rec["eps"]), dropout_seed=1234)
+    ts2.forward_backward(tobs, target=target)
+    torch.cuda.synchronize()
+    assert torch.equal(ts2.grad, g_first)

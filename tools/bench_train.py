@@ -34,7 +34,7 @@ def main():
     torch.cuda.set_device(dev)
     model = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
         observation_space=bench.SPACE, observation_size=(bench.W, bench.H), hidden_size=512, backbone="resnet18",
-        normalize_visual_inputs=True, output_dim=3, dropout_p=0.0, discretized_depth_channels=bench.BINS)
+        normalize_visual_inputs=True, output_dim=3, dropout_p=0.2, discretized_depth_channels=bench.BINS)   # reference p
     sd = synth.make_state_dict(ms.state_dict_spec(model.cfg), seed=0)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to(dev)
