@@ -135,6 +135,21 @@ class VOTrainStep:
         rmv._mean = (rmv._count * rmv._mean + new_count * new_mean) / (rmv._count + new_count)
         rmv._count += new_count
 
+    def forward_train(self, obs_pairs):
+        """model.train(); out = model(obs_pairs): RunningMeanAndVar update + dropout, activations kept for a backward."""
+        h = self.model._handle
+        ptrs, keep, B = self._obs_ptrs(obs_pairs)
+        out = torch.empty((B, self.model.cfg.out_dim), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev), torch.no_grad():
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            mean = var = None
+            if self.rmv is not None:
+                self._update_running_stats(ptrs, B, stream)
+                mean = self.rmv._mean.reshape(-1).contiguous()
+                var = self.rmv._var.reshape(-1).contiguous()
+            _lib.check(_lib.lib.pnvo_train_forward(h, *ptrs, int(B), _ptr(mean), _ptr(var), _ptr(out), stream), h)
+        return out
+
     def forward_backward(self, obs_pairs, target=None, grad_out=None):
         """Train-mode forward + backward.  Either `target` [B,3] (the reference's regression loss) or an explicit
         `grad_out` = dLoss/dOut [B,3] (e.g. from the geometric-invariance loss computed on the [B,3] outputs).

@@ -29,7 +29,10 @@ class AttrDict(dict):
             v = self[k]
         except KeyError as e:
             raise AttributeError(k) from e
-        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+            self[k] = v                  # keep the wrapped node: attribute assignment on it must persist
+        return v
 
     __setattr__ = dict.__setitem__
 
@@ -226,9 +229,10 @@ class BaseRLTrainerWithVO:
         if getattr(self, "_dd_flag", None) is not None:
             assert self._dd_flag.item() == 0, "depth must lie in [0, 1]"
         out = np.zeros((n, 3), dtype=np.float32)
+        std = np.zeros((n, 3), dtype=np.float32)
         rm = self.config.VO.REGRESS_MODEL
-        if rm.mode != "det":
-            raise NotImplementedError("VO.REGRESS_MODEL.mode == 'rnd' (dropout sampling, :295-308) is not provided")
+        if rm.mode not in ("det", "rnd"):
+            raise NotImplementedError(f"VO.REGRESS_MODEL.mode == {rm.mode!r}")
         keys = ["all"] * n if rm.regress_type == "unified_act" else [ACT_IDX2NAME[a] for a in acts]
         with torch.no_grad():
             for key in sorted(set(keys)):
@@ -236,17 +240,25 @@ class BaseRLTrainerWithVO:
                 sel = torch.as_tensor(idx, device=self.device)
                 sub = obs_pairs if len(idx) == n else {k: v.index_select(0, sel) for k, v in obs_pairs.items()}
                 model = self.vo_model[key]
-                model.eval()
-                if "act_embed" in rm.name:
-                    a = torch.as_tensor([acts[i] for i in idx], dtype=torch.long, device=self.device)
-                    res = model(sub, a)
-                else:
-                    res = model(sub)
-                out[idx] = res.cpu().numpy()
+                if rm.mode == "det":                      # :285-294
+                    model.eval()
+                    if "act_embed" in rm.name:
+                        a = torch.as_tensor([acts[i] for i in idx], dtype=torch.long, device=self.device)
+                        res = model(sub, a)
+                    else:
+                        res = model(sub)
+                    out[idx] = res.cpu().numpy()
+                else:                                     # 'rnd', :295-308: rnd_mode_n train-mode (dropout) forwards
+                    model.train()
+                    samples = np.stack([model(sub).cpu().numpy() for _ in range(int(rm.rnd_mode_n))])
+                    out[idx] = samples.mean(axis=0)
+                    std[idx] = samples.std(axis=0)
+        self._last_std = std
         return out
 
     def _compute_local_delta_states_from_vo(self, prev_obs, cur_obs, act, vis_video=False):
-        """(prev_obs, cur_obs, act) -> (list of 3 np.float32, [0,0,0], extra_infos)  (:169-314, mode 'det')."""
+        """(prev_obs, cur_obs, act) -> (list of 3 np.float32, std list, extra_infos)  (:169-314; std is [0,0,0] in mode
+        'det' and the per-component standard deviation of the rnd_mode_n dropout samples in mode 'rnd')."""
         if getattr(self, "_vo_obs_transformer", None) is not None:
             raise NotImplementedError
         deltas = self.compute_local_delta_states_batch([prev_obs], [cur_obs], [act])
@@ -254,4 +266,5 @@ class BaseRLTrainerWithVO:
         if vis_video and "top_down" in self.config.VO.REGRESS_MODEL.name:
             d = torch.from_numpy(np.ascontiguousarray(cur_obs["depth"], dtype=np.float32)).to(self.device)
             extra_infos["ego_top_down_map"] = self._top_down_view_generator.gen_top_down_view(d)
-        return list(deltas[0]), [0, 0, 0], extra_infos
+        stds = [0, 0, 0] if self.config.VO.REGRESS_MODEL.mode == "det" else list(self._last_std[0])
+        return list(deltas[0]), stds, extra_infos

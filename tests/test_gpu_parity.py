@@ -256,3 +256,28 @@ def test_compute_local_delta_states_from_vo_matches_reference():
     # batched sibling: same numbers in one call
     batch = t.compute_local_delta_states_batch(prevs, curs, acts)
     assert pair_rel_err(batch, rec["deltas"]).max() < TOL
+
+
+def test_rnd_mode_samples_dropout_and_updates_running_stats():
+    """VO.REGRESS_MODEL.mode == 'rnd' (base_trainer_with_vo.py:295-308): rnd_mode_n forwards with the model in train()
+    mode — dropout active, and (a quirk the reference has and a drop-in must keep) RunningMeanAndVar updated by every
+    one of them.  Returns the sample mean and a non-zero per-component std."""
+    rec = load_golden("boundary.npz")
+    t = make_trainer(rec)
+    t.config.VO.REGRESS_MODEL.mode = "rnd"
+    t.config.VO.REGRESS_MODEL.rnd_mode_n = 6
+    H, W = int(rec["height"]), int(rec["width"])
+    pi, ci, act, zb = rec["steps"][0]
+    prev = synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(pi), zero_border=int(zb))
+    cur = synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(ci), zero_border=int(zb))
+    from pointnav_vo_amd.common_vars import ACT_IDX2NAME
+    model = t.vo_model[ACT_IDX2NAME[int(act)]]
+    cnt0 = float(model.visual_encoder.running_mean_and_var._count)
+    deltas, std, extra = t._compute_local_delta_states_from_vo(prev, cur, int(act))
+    assert len(deltas) == 3 and len(std) == 3 and np.isfinite(deltas).all()
+    assert min(std) > 0.0                                   # six different dropout draws
+    assert float(model.visual_encoder.running_mean_and_var._count) == cnt0 + 6   # 6 train-mode forwards of 1 pair
+    # and the deterministic mode still works on the same trainer afterwards (eval forward, no dropout)
+    t.config.VO.REGRESS_MODEL.mode = "det"
+    d2, s2, _ = t._compute_local_delta_states_from_vo(prev, cur, int(act))
+    assert s2 == [0, 0, 0] and np.isfinite(d2).all()

@@ -58,11 +58,13 @@ def test_constructor_asserts_mirror_reference():
                                                         **dict(KW, backbone="resnet101"))
 
 
-def test_forward_refuses_cpu_and_train_mode():
+def test_forward_refuses_cpu():
+    """No CPU fallback in either mode: the train-mode forward ('rnd' mode / training) and the eval forward both need the
+    HIP library and a model on the GPU."""
     m = baseline_registry.get_vo_model("vo_cnn")(observation_space=["rgb", "depth"], **KW)
     obs = {"rgb": torch.zeros(1, 192, 341, 6), "depth": torch.zeros(1, 192, 341, 2)}
-    with pytest.raises(RuntimeError, match="eval"):
-        m(obs)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(obs)                                              # nn.Module default: training mode
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.eval()(obs)
 
