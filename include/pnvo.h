@@ -154,6 +154,44 @@ int pnvo_adam_step(float *params, const float *grads, float *exp_avg, float *exp
 /* Free everything owned by the handle. */
 int pnvo_destroy(pnvo_handle h);
 
+/* ---- the navigation policy's per-step forward: PointNavResNetPolicy.act
+ * (pointnav_vo/rl/policies/policy.py:29-46, resnet_policy.py:26-58 and 177-282) for the depth-only configuration of
+ * configs/rl/ddppo_pointnav.yaml (resnet18 backbone, 2-layer LSTM, normalize_visual_inputs False, no obs transform). ---- */
+typedef struct {
+  int32_t width, height;      /* depth frame W, H (341, 192); the encoder sees (W/2, H/2) after avg_pool2d(2) */
+  int32_t baseplanes;         /* resnet_baseplanes (32) */
+  int32_t hidden;             /* hidden_size (512) */
+  int32_t n_actions;          /* action_space.n (4) */
+  int32_t rnn_layers;         /* num_recurrent_layers (2, LSTM) */
+  int32_t flat_size;          /* after_compression_flat_size (2048) */
+} pnvo_policy_config;
+
+typedef struct pnvo_policy_s *pnvo_policy_handle;
+
+/* policy_cls(observation_space=..., action_space=..., ...).to(device) — ddppo_trainer.py:115-133. */
+int pnvo_policy_create(const pnvo_policy_config *cfg, int device, pnvo_policy_handle *out);
+
+/* actor_critic.load_state_dict(...) — ddppo_trainer.py:140-146; tensor names exactly as PointNavResNetPolicy.state_dict()
+ * spells them ("net.visual_encoder.backbone.conv1.0.weight", "net.state_encoder.rnn.weight_ih_l0",
+ * "action_distribution.linear.weight", "critic.fc.weight", ...).  blob is HOST memory. */
+int pnvo_policy_load_weights(pnvo_policy_handle h, const float *blob, size_t n_floats, const pnvo_tensor_desc *toc,
+                             int ntoc);
+
+/* features, rnn_hidden_states = net(observations, rnn_hidden_states, prev_actions, masks); logits / value of the two
+ * heads (policy.py:32-36).  All pointers are DEVICE memory:
+ *   depth [B,H,W,1] in 0..1 (observations["depth"]);  goal [B,2] = pointgoal_with_gps_compass (rho, phi);
+ *   prev_actions [B] int64;  masks [B] (0 at an episode start);  hidden_in / hidden_out [2*rnn_layers, B, hidden]
+ *   (h of every layer, then c of every layer: rnn_state_encoder.py:47-61);  features [B,hidden], logits [B,n_actions],
+ *   value [B] may each be NULL.  Sampling / argmax over the logits stays with the caller (policy.py:38-43). */
+int pnvo_policy_act(pnvo_policy_handle h, const float *depth, const float *goal, const int64_t *prev_actions,
+                    const float *masks, const float *hidden_in, int B, float *hidden_out, float *features, float *logits,
+                    float *value, void *stream);
+
+int pnvo_policy_destroy(pnvo_policy_handle h);
+
+/* F.avg_pool2d(x, 2) of 1-channel NHWC frames [N,H,W,1] -> [N,H/2,W/2,2] with channel 1 = 0 (resnet_policy.py:168). */
+int pnvo_avgpool2(const float *depth, int N, int H, int W, float *out, void *stream);
+
 /* Message of the last failing call on this handle (or of the last failing handle-less call if h is NULL). */
 const char *pnvo_last_error(pnvo_handle h);
 
@@ -174,6 +212,11 @@ typedef struct {
   double flops;               /* algorithmic FLOPs of those launches (2*MACs), 0 for non-GEMM kernels */
   double bytes;               /* algorithmic bytes of those launches (tensor reads + writes, once each) */
 } pnvo_kernel_time;
+/* The same forward stopped after visual_fc's Linear + ReLU: hidden_out [B, hidden] (device).  This is the visual
+ * feature the navigation policy consumes (rl/policies/resnet_policy.py:243-250) — see pnvo_policy_* below. */
+int pnvo_forward_features(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                          const int64_t *actions, int B, float *hidden_out, void *stream);
+
 /* The discretised-depth observation must be one-hot per frame — what _discretize_depth_func produces and asserts
  * (pointnav_vo/rl/common/base_trainer_with_vo.py:163); the fused stem exploits it.  A forward that meets a depth pixel
  * that is not exactly one 1 and zeros raises a host-visible flag: pnvo_check_inputs returns PNVO_ERR_INPUT once that

@@ -165,22 +165,10 @@ def linear(x, w, b, relu):
 
 
 # ----------------------------------------------------------------------------- whole forward
-def forward(sd, obs, *, ngroups, dtype=np.float32, actions=None, taps=None):
-    """Reference forward on CPU.  sd: reference state_dict as dict name -> ndarray.
-    ngroups = resnet_baseplanes // 2 (vo_cnn.py:206).  actions: int array [B] for the act_embed variants.
-    taps: optional dict that receives the intermediate activations (NHWC) by name."""
-    dtype = np.dtype(dtype)
+def encoder_(sd, x, ngroups, pre="visual_encoder.", taps=None):
+    """GroupNorm-ResNet18 backbone + compression block on an NHWC input (resnet.py:153-212; vo_cnn.py:85-95 /
+    rl/policies/resnet_policy.py:118-127).  Returns the compressed feature map, NHWC."""
     g = lambda k: np.asarray(sd[k])
-    pre = "visual_encoder."
-    has_norm = (pre + "running_mean_and_var._mean") in sd
-    x = assemble_whiten(
-        obs,
-        g(pre + "running_mean_and_var._mean") if has_norm else None,
-        g(pre + "running_mean_and_var._var") if has_norm else None,
-        dtype=dtype,
-    )
-    if taps is not None:
-        taps["input"] = x.copy()
     bb = pre + "backbone."
     x = conv2d(x, g(bb + "conv1.0.weight"), 2, 3)                       # resnet.py:156-163
     if taps is not None:
@@ -211,6 +199,26 @@ def forward(sd, obs, *, ngroups, dtype=np.float32, actions=None, taps=None):
     groupnorm_(x, 1, g(pre + "compression.1.weight"), g(pre + "compression.1.bias"), True)
     if taps is not None:
         taps["compression"] = x.copy()
+    return x
+
+
+def forward(sd, obs, *, ngroups, dtype=np.float32, actions=None, taps=None):
+    """Reference forward on CPU.  sd: reference state_dict as dict name -> ndarray.
+    ngroups = resnet_baseplanes // 2 (vo_cnn.py:206).  actions: int array [B] for the act_embed variants.
+    taps: optional dict that receives the intermediate activations (NHWC) by name."""
+    dtype = np.dtype(dtype)
+    g = lambda k: np.asarray(sd[k])
+    pre = "visual_encoder."
+    has_norm = (pre + "running_mean_and_var._mean") in sd
+    x = assemble_whiten(
+        obs,
+        g(pre + "running_mean_and_var._mean") if has_norm else None,
+        g(pre + "running_mean_and_var._var") if has_norm else None,
+        dtype=dtype,
+    )
+    if taps is not None:
+        taps["input"] = x.copy()
+    x = encoder_(sd, x, ngroups, pre, taps)
     feats = flatten_nchw(x)                                            # vo_cnn.py:217
     if "action_embedding.weight" in sd:                                # vo_cnn_act_embed.py:63-72
         emb = g("action_embedding.weight").astype(dtype)[np.asarray(actions).astype(np.int64)]

@@ -65,6 +65,14 @@ _SIGNATURES = {
     "pnvo_set_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "pnvo_tap_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
     "pnvo_check_inputs": (C.c_int, [C.c_void_p]),
+    "pnvo_forward_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    "pnvo_policy_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "pnvo_policy_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "pnvo_policy_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_policy_destroy": (C.c_int, [C.c_void_p]),
+    "pnvo_avgpool2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pnvo_timing_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pnvo_timing_read": (C.c_int, [C.c_void_p, C.POINTER(pnvo_kernel_time), C.c_int, C.POINTER(C.c_int)]),
     "pnvo_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

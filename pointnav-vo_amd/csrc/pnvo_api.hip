@@ -936,12 +936,35 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
                      c.act_embed ? actions : nullptr, 1, s)) != PNVO_OK)
     return rc;
   if ((rc = maybe_tap(m, "hidden", m->hid, (size_t)B * c.hidden, s)) != PNVO_OK) return rc;
+  if (m->features_only) {                          // pnvo_forward_features: `out` receives the hidden vector
+    HIPCHK(m, hipMemcpyAsync(out, m->hid, (size_t)B * c.hidden * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PNVO_OK;
+  }
   if ((rc = run_conv(m, m->head, B, m->hid, nullptr, nullptr, out, c.out_dim, nullptr, m->head_bias, nullptr, 0, s)) !=
       PNVO_OK)
     return rc;
   return PNVO_OK;
 }
 }  // namespace
+
+int pnvo_forward_features(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                          const int64_t *actions, int B, float *hidden_out, void *stream) {
+  if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
+  if (!m->loaded) return fail(m, PNVO_ERR_STATE, "pnvo_forward_features before pnvo_load_weights");
+  if (B <= 0 || !hidden_out) return fail(m, PNVO_ERR_ARG, "bad batch / null output");
+  const pnvo_config &c = m->cfg;
+  if ((c.n_rgb > 0) != (rgb != nullptr) || (c.n_depth > 0) != (depth != nullptr) || (c.n_dd > 0) != (dd != nullptr) ||
+      (c.n_tdv > 0) != (tdv != nullptr))
+    return fail(m, PNVO_ERR_ARG, "observation tensors do not match the model's observation_space");
+  if (int rc0 = pnvo_check_inputs(m)) return rc0;
+  HIPCHK(m, hipSetDevice(m->device));
+  int rc = ensure_workspace(m, B);
+  if (rc != PNVO_OK) return rc;
+  m->features_only = true;
+  rc = forward_body(m, rgb, depth, dd, tdv, actions, B, hidden_out, (hipStream_t)stream);
+  m->features_only = false;
+  return rc;
+}
 
 int pnvo_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
                           int64_t out_stride, int32_t *err_flag, void *stream) {

@@ -62,6 +62,7 @@ struct pnvo_model_s {
   float *tap_dst = nullptr;
   size_t tap_cap = 0;
 
+  bool features_only = false;        // pnvo_forward_features: stop after the hidden layer
   void *train = nullptr;             // TrainState (pnvo_train_api.hip), present after pnvo_train_attach
 
   // Opt-in (PNVO_GRAPH=1): the whole forward (~60 launches) captured once per (batch, tensor addresses, kernel

@@ -32,6 +32,15 @@ class BaselineRegistry:
         return cls._get_impl("vo_model", name)
 
     @classmethod
+    def register_policy(cls, to_register=None, *, name: Optional[str] = None):
+        """baseline_registry.py: register_policy / get_policy (ddppo_trainer.py:115)."""
+        return cls._register_impl("policy", to_register, name)
+
+    @classmethod
+    def get_policy(cls, name):
+        return cls._get_impl("policy", name)
+
+    @classmethod
     def register_vo_engine(cls, to_register=None, *, name: Optional[str] = None):
         return cls._register_impl("vo_engine", to_register, name)
 
@@ -48,3 +57,6 @@ def install_into(other_registry):
     (the reference's ``pointnav_vo.utils.baseline_registry.baseline_registry``), overriding the stock classes."""
     for name, cls_ in BaselineRegistry.mapping.get("vo_model", {}).items():
         other_registry.register_vo_model(cls_, name=name)
+    if hasattr(other_registry, "register_policy"):
+        for name, cls_ in BaselineRegistry.mapping.get("policy", {}).items():
+            other_registry.register_policy(cls_, name=name)

@@ -125,3 +125,22 @@ def make_raw_obs(H, W, seed=0, index=0, zero_border=0):
         d[:, :zero_border] = 0
         d[:, -2 * zero_border:] = 0
     return {"rgb": rgb, "depth": d}
+
+
+def make_policy_inputs(H, W, B, steps, seed):
+    """Per-step inputs of the navigation policy for `steps` consecutive act() calls of B environments:
+    list of (depth [B,H,W,1] float32 in [0,1], goal [B,2] = (rho, phi), prev_actions [B] int64, masks [B] float32).
+    Step 0 starts every episode (mask 0); at step 2 environment 1 % B resets."""
+    out = []
+    for t in range(steps):
+        depth = np.stack([make_raw_obs(H, W, seed=seed, index=100 * t + b)["depth"] for b in range(B)])
+        goal = np.stack([uniform(seed, f"goal{t}", (B,), 0.2, 6.0), uniform(seed, f"phi{t}", (B,), -3.0, 3.0)],
+                        axis=-1).astype(np.float32)
+        prev = (bits(seed, f"act{t}", B) % np.uint64(4)).astype(np.int64)
+        mask = np.ones(B, dtype=np.float32)
+        if t == 0:
+            mask[:] = 0.0
+        if t == 2:
+            mask[1 % B] = 0.0
+        out.append((depth, goal, prev, mask))
+    return out
