@@ -49,6 +49,7 @@ typedef struct {
   int32_t n_acts;             /* embedding rows - 1 (N_ACTS = 4) */
   int32_t flat_size;          /* after_compression_flat_size (2048) */
   int32_t max_batch;          /* workspace sizing hint; the workspace grows on demand */
+  int32_t backbone_depth;     /* 0 or 18: resnet18 (BasicBlock); 50 / 101: Bottleneck [3,4,6,3] / [3,4,23,3] (resnet.py:226-241) */
 } pnvo_config;
 
 /* One entry of the reference state_dict: name exactly as model.state_dict() spells it,

@@ -181,6 +181,24 @@ def encoder_(sd, x, ngroups, pre="visual_encoder.", taps=None):
         bi = 0
         while (bb + f"layer{li}.{bi}.convs.0.weight") in sd:
             p = bb + f"layer{li}.{bi}."
+            if (p + "convs.6.weight") in sd:                            # Bottleneck, resnet.py:58-69,93-117
+                stride = 2 if (li > 1 and bi == 0) else 1
+                out = conv2d(x, g(p + "convs.0.weight"), 1, 0)
+                groupnorm_(out, ngroups, g(p + "convs.1.weight"), g(p + "convs.1.bias"), True)
+                out = conv2d(out, g(p + "convs.3.weight"), stride, 1)
+                groupnorm_(out, ngroups, g(p + "convs.4.weight"), g(p + "convs.4.bias"), True)
+                out = conv2d(out, g(p + "convs.6.weight"), 1, 0)
+                groupnorm_(out, ngroups, g(p + "convs.7.weight"), g(p + "convs.7.bias"), False)
+                if (p + "downsample.0.weight") in sd:
+                    res = conv2d(x, g(p + "downsample.0.weight"), stride, 0)
+                    groupnorm_(res, ngroups, g(p + "downsample.1.weight"), g(p + "downsample.1.bias"), False)
+                else:
+                    res = x
+                x = add_relu_(out, np.ascontiguousarray(res))
+                if taps is not None:
+                    taps[f"layer{li}.{bi}"] = x.copy()
+                bi += 1
+                continue
             stride = 2 if (p + "downsample.0.weight") in sd else 1
             out = conv2d(x, g(p + "convs.0.weight"), stride, 1)         # BasicBlock, resnet.py:37-43
             groupnorm_(out, ngroups, g(p + "convs.1.weight"), g(p + "convs.1.bias"), True)

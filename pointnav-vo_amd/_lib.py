@@ -24,7 +24,7 @@ class PnvoError(RuntimeError):
 class pnvo_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "n_rgb", "n_depth", "n_dd", "n_tdv", "baseplanes", "hidden", "out_dim", "normalize",
-        "act_embed", "n_acts", "flat_size", "max_batch")]
+        "act_embed", "n_acts", "flat_size", "max_batch", "backbone_depth")]
 
 
 class pnvo_tensor_desc(C.Structure):

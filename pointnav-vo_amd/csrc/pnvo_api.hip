@@ -93,11 +93,29 @@ void build_plan(pnvo_model_s *m) {
   m->convs.clear();
   m->convs.push_back(make_layer(bb + "conv1.0", bb + "conv1.1", m->C, c.baseplanes, 7, 2, 3, c.height, c.width, g));
   int h = m->Hp, w = m->Wp, cin = c.baseplanes;
+  const bool bott = c.backbone_depth == 50 || c.backbone_depth == 101;
+  const int nblk[4] = {bott ? 3 : 2, bott ? 4 : 2, bott ? (c.backbone_depth == 101 ? 23 : 6) : 2, bott ? 3 : 2};
+  m->bottleneck = bott;
+  m->nblocks.assign(nblk, nblk + 4);
   for (int li = 1; li <= 4; ++li) {
     const int planes = c.baseplanes << (li - 1);
-    for (int bi = 0; bi < 2; ++bi) {
+    for (int bi = 0; bi < nblk[li - 1]; ++bi) {
       const std::string p = bb + "layer" + std::to_string(li) + "." + std::to_string(bi) + ".";
       const int stride = (li > 1 && bi == 0) ? 2 : 1;
+      if (bott) {                                    // Bottleneck: 1x1 -> 3x3 (stride) -> 1x1 (x4), resnet.py:58-69
+        Layer b1 = make_layer(p + "convs.0", p + "convs.1", cin, planes, 1, 1, 0, h, w, g);
+        Layer b2 = make_layer(p + "convs.3", p + "convs.4", planes, planes, 3, stride, 1, h, w, g);
+        Layer b3 = make_layer(p + "convs.6", p + "convs.7", planes, planes * 4, 1, 1, 0, b2.hout, b2.wout, g);
+        m->convs.push_back(b1);
+        m->convs.push_back(b2);
+        m->convs.push_back(b3);
+        if (stride != 1 || cin != planes * 4)
+          m->convs.push_back(make_layer(p + "downsample.0", p + "downsample.1", cin, planes * 4, 1, stride, 0, h, w, g));
+        h = b2.hout;
+        w = b2.wout;
+        cin = planes * 4;
+        continue;
+      }
       Layer c1 = make_layer(p + "convs.0", p + "convs.1", cin, planes, 3, stride, 1, h, w, g);
       m->convs.push_back(c1);
       m->convs.push_back(make_layer(p + "convs.3", p + "convs.4", planes, planes, 3, 1, 1, c1.hout, c1.wout, g));
@@ -217,6 +235,7 @@ void free_workspace(pnvo_model_s *m) {
   free_dev(m->rawA);
   free_dev(m->rawB);
   free_dev(m->rawD);
+  free_dev(m->rawC);
   free_dev(m->comp_raw);
   free_dev(m->hid);
   free_dev(m->stats);
@@ -266,7 +285,11 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   free_workspace(m);
   const pnvo_config &c = m->cfg;
   const size_t npix = (size_t)B * c.height * c.width;
-  const size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes;   // largest residual-stage tensor
+  size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes;          // largest residual-stage tensor
+  for (size_t k = 1; k < m->convs.size(); ++k) {
+    const size_t need = (size_t)B * m->convs[k].hout * m->convs[k].wout * m->convs[k].coutp;
+    if (need > act) act = need;
+  }
   int maxc = m->comp_cp;
   size_t st = (size_t)B * stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs) * m->convs[0].coutp * 2;   // LDS-staged stem
   for (const Layer &l : m->convs) {
@@ -282,6 +305,7 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   HIPCHK(m, alloc(m->rawA, act));
   HIPCHK(m, alloc(m->rawB, act));
   HIPCHK(m, alloc(m->rawD, act));
+  if (m->bottleneck) HIPCHK(m, alloc(m->rawC, act));
   HIPCHK(m, alloc(m->comp_raw, (size_t)B * m->fh * m->fw * m->comp_cp));
   HIPCHK(m, alloc(m->hid, (size_t)B * c.hidden));
   HIPCHK(m, alloc(m->out_ws, (size_t)B * c.out_dim));
@@ -887,7 +911,36 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
 
   // (a8) residual stages
   for (int stage = 1; stage <= 4; ++stage) {
-    for (int bi = 0; bi < 2; ++bi) {
+    for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
+      if (m->bottleneck) {                           // conv1x1 -> GN -> ReLU -> conv3x3(s) -> GN -> ReLU -> conv1x1 -> GN
+        const Layer &b1 = m->convs[li++];
+        const Layer &b2 = m->convs[li++];
+        const Layer &b3 = m->convs[li++];
+        const bool dsb = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
+        if ((rc = run_conv(m, b1, B, cur, nullptr, nullptr, m->rawA, b1.coutp, m->ssA, nullptr, nullptr, 0, s)) != PNVO_OK)
+          return rc;
+        if ((rc = run_conv(m, b2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawC, b2.coutp, m->ssB, nullptr, nullptr, 0, s)) !=
+            PNVO_OK)
+          return rc;
+        if ((rc = run_conv(m, b3, B, m->rawC, m->ssB[0], m->ssB[1], m->rawB, b3.coutp, m->ssA, nullptr, nullptr, 0, s)) !=
+            PNVO_OK)
+          return rc;
+        const long Pb = (long)b3.hout * b3.wout;
+        if (dsb) {
+          const Layer &cd = m->convs[li++];
+          if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK)
+            return rc;
+          Timed t(m, s, "residual", 0.0, 12.0 * B * Pb * b3.coutp);
+          HIPCHK(m, launch_residual(m->rawB, m->ssA[0], m->ssA[1], m->rawD, m->ssD[0], m->ssD[1], B, Pb, b3.coutp, nxt, s));
+        } else {
+          Timed t(m, s, "residual", 0.0, 12.0 * B * Pb * b3.coutp);
+          HIPCHK(m, launch_residual(m->rawB, m->ssA[0], m->ssA[1], cur, nullptr, nullptr, B, Pb, b3.coutp, nxt, s));
+        }
+        std::swap(cur, nxt);
+        const std::string tnb = "layer" + std::to_string(stage) + "." + std::to_string(bi);
+        if ((rc = maybe_tap(m, tnb.c_str(), cur, (size_t)B * Pb * b3.coutp, s)) != PNVO_OK) return rc;
+        continue;
+      }
       const Layer &c1 = m->convs[li++];
       const Layer &c2 = m->convs[li++];
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);

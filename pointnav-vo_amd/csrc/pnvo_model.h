@@ -52,7 +52,10 @@ struct pnvo_model_s {
 
   int cap = 0;                       // batch the workspace is sized for
   float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
-  float *rawA = nullptr, *rawB = nullptr, *rawD = nullptr, *comp_raw = nullptr, *hid = nullptr, *stats = nullptr;
+  float *rawA = nullptr, *rawB = nullptr, *rawD = nullptr, *rawC = nullptr, *comp_raw = nullptr, *hid = nullptr,
+        *stats = nullptr;
+  bool bottleneck = false;           // resnet50 / resnet101 backbone
+  std::vector<int> nblocks;          // residual blocks per stage
   float *ssA[2] = {nullptr, nullptr}, *ssB[2] = {nullptr, nullptr}, *ssD[2] = {nullptr, nullptr},
         *ssC[2] = {nullptr, nullptr};
   float *tapbuf = nullptr;

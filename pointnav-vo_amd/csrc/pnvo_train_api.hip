@@ -425,6 +425,7 @@ void pnvo_train_free(pnvo_handle m) {
 extern "C" {
 
 int pnvo_train_attach(pnvo_handle m, float *params, float *grads, size_t n_floats, const pnvo_tensor_desc *toc, int ntoc) {
+  if (m && m->bottleneck) return pnvo_fail(m, PNVO_ERR_ARG, "training of the Bottleneck backbones (vo_cnn_deeper) is not built");
   if (!m || !params || !grads || !toc) return pnvo_fail(m, PNVO_ERR_ARG, "null argument");
   if (!m->loaded) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach before pnvo_load_weights");
   if (n_floats >= (1u << 24)) return pnvo_fail(m, PNVO_ERR_ARG, "flat parameter buffer too large for the index maps");

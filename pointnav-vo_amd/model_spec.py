@@ -39,6 +39,8 @@ class VOConfig:
     n_acts: int = N_ACTS
     after_compression_flat_size: int = 2048
     blocks: Tuple[int, int, int, int] = (2, 2, 2, 2)   # resnet18, resnet.py:226-229
+    bottleneck: bool = False                           # resnet50 / resnet101: Bottleneck blocks, expansion 4 (:93-117)
+    backbone_depth: int = 18
 
     @property
     def ngroups(self):        # vo_cnn.py:206
@@ -90,9 +92,11 @@ def config_from_kwargs(*, observation_space, observation_size, hidden_size=512, 
                        n_acts=N_ACTS) -> VOConfig:
     """Same keyword contract as the reference constructors (vo_cnn.py:183-198; called at
     rl/common/base_trainer_with_vo.py:68-80).  dropout_p is accepted and irrelevant in eval()."""
-    if backbone != "resnet18":
-        raise NotImplementedError(
-            f"backbone {backbone!r}: only the resnet18/BasicBlock path is built (SURVEY.md §8(f) rank 4)")
+    depths = {"resnet18": (18, (2, 2, 2, 2), False), "resnet50": (50, (3, 4, 6, 3), True),
+              "resnet101": (101, (3, 4, 23, 3), True)}               # resnet.py:226-241
+    if backbone not in depths:
+        raise NotImplementedError(f"backbone {backbone!r}: resnet18 / resnet50 / resnet101 are built (no SE / ResNeXt)")
+    depth, blocks, bottleneck = depths[backbone]
     w, h = observation_size
     return VOConfig(
         width=int(w), height=int(h),
@@ -102,7 +106,8 @@ def config_from_kwargs(*, observation_space, observation_size, hidden_size=512, 
         n_tdv=top_down_view_pair_channel if "top_down_view" in observation_space else 0,
         baseplanes=int(resnet_baseplanes), hidden=int(hidden_size), out_dim=int(output_dim),
         normalize=bool(normalize_visual_inputs), act_embed=bool(act_embed), n_acts=int(n_acts),
-        after_compression_flat_size=int(after_compression_flat_size),
+        after_compression_flat_size=int(after_compression_flat_size), blocks=blocks, bottleneck=bottleneck,
+        backbone_depth=depth,
     )
 
 
@@ -143,6 +148,15 @@ def conv_plan(cfg: VOConfig) -> List[ConvDesc]:
         for bi in range(cfg.blocks[li - 1]):
             p = bb + f"layer{li}.{bi}."
             stride = 2 if (li > 1 and bi == 0) else 1
+            if cfg.bottleneck:                                  # 1x1 -> 3x3 (stride) -> 1x1 (x4), resnet.py:58-69
+                b1 = ConvDesc(p + "convs.0", p + "convs.1", cin, planes, 1, 1, 0, h, w, g)
+                b2 = ConvDesc(p + "convs.3", p + "convs.4", planes, planes, 3, stride, 1, h, w, g)
+                b3 = ConvDesc(p + "convs.6", p + "convs.7", planes, planes * 4, 1, 1, 0, b2.hout, b2.wout, g)
+                plan += [b1, b2, b3]
+                if stride != 1 or cin != planes * 4:            # resnet.py:190-195
+                    plan.append(ConvDesc(p + "downsample.0", p + "downsample.1", cin, planes * 4, 1, stride, 0, h, w, g))
+                h, w, cin = b2.hout, b2.wout, planes * 4
+                continue
             c1 = ConvDesc(p + "convs.0", p + "convs.1", cin, planes, 3, stride, 1, h, w, g)
             plan.append(c1)
             plan.append(ConvDesc(p + "convs.3", p + "convs.4", planes, planes, 3, 1, 1, c1.hout, c1.wout, g))

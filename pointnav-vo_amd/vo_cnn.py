@@ -102,7 +102,8 @@ class VisualOdometryCNNBase(nn.Module):
         cc = _lib.pnvo_config(width=c.width, height=c.height, n_rgb=c.n_rgb, n_depth=c.n_depth, n_dd=c.n_dd,
                               n_tdv=c.n_tdv, baseplanes=c.baseplanes, hidden=c.hidden, out_dim=c.out_dim,
                               normalize=int(c.normalize), act_embed=int(c.act_embed), n_acts=c.n_acts,
-                              flat_size=c.after_compression_flat_size, max_batch=0)
+                              flat_size=c.after_compression_flat_size, max_batch=0,
+                              backbone_depth=c.backbone_depth)
         h = C.c_void_p()
         _lib.check(_lib.lib.pnvo_create(C.byref(cc), int(device.index or 0), C.byref(h)))
         self._handle, self._handle_dev, self._loaded_sig = h, device.index, None
@@ -236,7 +237,7 @@ def _variant(name, *, base=VisualOdometryCNNBase, need=(), forbid=(), dd_zero=Fa
     """Build and register one reference variant; the asserts are the reference's own (vo_cnn.py:252-255 etc.)."""
 
     def __init__(self, *, observation_space, observation_size, hidden_size=512, resnet_baseplanes=32,
-                 backbone="resnet18", normalize_visual_inputs=False, output_dim=DEFAULT_DELTA_STATE_SIZE,
+                 backbone=backbone_req, normalize_visual_inputs=False, output_dim=DEFAULT_DELTA_STATE_SIZE,
                  dropout_p=0.2, discretized_depth_channels=default_dd,
                  top_down_view_pair_channel=TOP_DOWN_VIEW_PAIR_CHANNEL, n_acts=N_ACTS):
         assert backbone == backbone_req
@@ -261,7 +262,7 @@ VisualOdometryCNN = _variant("vo_cnn", forbid=(DD, TDV), dd_zero=True)          
 VisualOdometryCNNRGB = _variant("vo_cnn_rgb", forbid=("depth", DD, TDV), dd_zero=True)                   # :269
 VisualOdometryCNNWider = _variant("vo_cnn_wider", forbid=(DD, TDV), dd_zero=True, widen=2)               # :303
 VisualOdometryCNNDeeper = _variant("vo_cnn_deeper", forbid=(DD, TDV), dd_zero=True,
-                                   backbone_req="resnet101")                                             # :339 (raises: resnet101 is SURVEY §8(f) rank 4)
+                                   backbone_req="resnet101")                                             # :339 (Bottleneck [3,4,23,3])
 VisualOdometryCNNDiscretizedDepth = _variant("vo_cnn_rgb_d_dd", need=(DD,), forbid=(TDV,), default_dd=10)  # :373
 VisualOdometryCNN_RGB_D_TopDownView = _variant("vo_cnn_rgb_d_top_down", need=("rgb", "depth", TDV), forbid=(DD,))  # :408
 VisualOdometryCNN_RGB_DD_TopDownView = _variant("vo_cnn_rgb_dd_top_down", need=("rgb", DD, TDV), forbid=("depth",),

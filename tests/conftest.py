@@ -35,7 +35,8 @@ def golden_case(rec):
     cfg = ms.config_from_kwargs(
         observation_space=obs_space, observation_size=(int(rec["width"]), int(rec["height"])),
         hidden_size=512, resnet_baseplanes=int(rec["baseplanes"]), normalize_visual_inputs=True, output_dim=3,
-        discretized_depth_channels=bins, act_embed=bool(int(rec["act_embed"])))
+        discretized_depth_channels=bins, act_embed=bool(int(rec["act_embed"])),
+        backbone=str(rec["backbone"]) if "backbone" in rec else "resnet18")
     sd = synth.make_state_dict(ms.state_dict_spec(cfg), seed=int(rec["seed"]))
     obs = synth.make_obs_pairs(int(rec["batch"]), cfg.height, cfg.width, observation_space=obs_space,
                                dd_bins=max(bins, 1), seed=int(rec["seed"]))
@@ -49,6 +50,7 @@ MODEL_FIXTURES = [
     "model_vo_cnn_64x48_b2.npz",
     "model_rgb_d_dd_70x40_b2.npz",
     "model_wider_64x48_b2.npz",
+    "model_deeper_64x48_b2.npz",
     "model_act_embed_64x48_b3.npz",
     "model_d_dd_tdv_66x34_b2.npz",
 ]

@@ -171,7 +171,8 @@ def model_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, full
     out64 = run_ref(model, obs, torch.float64, actions, taps64)
     out32 = run_ref(model, obs, torch.float32, actions)
     rec = dict(model=name, obs_space=",".join(obs_space), width=W, height=H, batch=B, dd_bins=dd_bins, seed=seed,
-               baseplanes=cfg.baseplanes, act_embed=int(cfg.act_embed), out64=out64, out32=out32)
+               baseplanes=cfg.baseplanes, act_embed=int(cfg.act_embed), out64=out64, out32=out32,
+               backbone="resnet%d" % cfg.backbone_depth)
     if actions is not None:
         rec["actions"] = actions
     for k, v in taps64.items():
@@ -372,12 +373,18 @@ def main():
     torch.set_num_threads(8)
     registry, geo = import_reference()
     full = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    if len(sys.argv) > 1 and sys.argv[1] == "deeper":        # regenerate just the resnet101 fixture
+        model_fixture(registry, "model_deeper_64x48_b2.npz", "vo_cnn_deeper", ["rgb", "depth"], (64, 48), 2, 0, 8, False,
+                      extra={"backbone": "resnet101"})
+        return
     model_fixture(registry, "model_default_341x192_b2.npz", "vo_cnn_rgb_d_dd_top_down", full, (341, 192), 2, 10, 0, False)
     model_fixture(registry, "model_default_45x37_b3.npz", "vo_cnn_rgb_d_dd_top_down", full, (45, 37), 3, 10, 1, True)
     model_fixture(registry, "model_vo_cnn_64x48_b2.npz", "vo_cnn", ["rgb", "depth"], (64, 48), 2, 0, 2, False)
     model_fixture(registry, "model_rgb_d_dd_70x40_b2.npz", "vo_cnn_rgb_d_dd", ["rgb", "depth", "discretized_depth"],
                   (70, 40), 2, 10, 3, False)
     model_fixture(registry, "model_wider_64x48_b2.npz", "vo_cnn_wider", ["rgb", "depth"], (64, 48), 2, 0, 4, False)
+    model_fixture(registry, "model_deeper_64x48_b2.npz", "vo_cnn_deeper", ["rgb", "depth"], (64, 48), 2, 0, 8, False,
+                  extra={"backbone": "resnet101"})
     model_fixture(registry, "model_act_embed_64x48_b3.npz", "vo_cnn_act_embed", ["rgb", "depth"], (64, 48), 3, 0, 5, False)
     model_fixture(registry, "model_d_dd_tdv_66x34_b2.npz", "vo_cnn_d_dd_top_down",
                   ["depth", "discretized_depth", "top_down_view"], (66, 34), 2, 10, 6, False)

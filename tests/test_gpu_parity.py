@@ -29,8 +29,9 @@ def dev():
 def build(rec):
     cfg, sd, obs, actions = golden_case(rec)
     space = str(rec["obs_space"]).split(",")
-    kw = dict(observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
-              normalize_visual_inputs=True, output_dim=3, dropout_p=0.2)
+    kw = dict(observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512,
+              backbone=str(rec["backbone"]) if "backbone" in rec else "resnet18", normalize_visual_inputs=True,
+              output_dim=3, dropout_p=0.2)
     if int(rec["dd_bins"]):
         kw["discretized_depth_channels"] = int(rec["dd_bins"])
     model = baseline_registry.get_vo_model(str(rec["model"]))(**kw)

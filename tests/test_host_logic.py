@@ -53,9 +53,11 @@ def test_constructor_asserts_mirror_reference():
         baseline_registry.get_vo_model("vo_cnn")(observation_space=FULL, **KW)
     with pytest.raises(AssertionError):     # vo_cnn.py:501
         baseline_registry.get_vo_model("vo_cnn_d_dd_top_down")(observation_space=FULL, discretized_depth_channels=10, **KW)
-    with pytest.raises(NotImplementedError):  # resnet101 backbone is outside the built path
-        baseline_registry.get_vo_model("vo_cnn_deeper")(observation_space=["rgb", "depth"],
-                                                        **dict(KW, backbone="resnet101"))
+    with pytest.raises(AssertionError):     # vo_cnn.py:355: the deeper variant is resnet101 only
+        baseline_registry.get_vo_model("vo_cnn_deeper")(observation_space=["rgb", "depth"], **KW)
+    deeper = baseline_registry.get_vo_model("vo_cnn_deeper")(observation_space=["rgb", "depth"],
+                                                             **dict(KW, backbone="resnet101"))
+    assert sum(k.endswith("convs.6.weight") for k in deeper.state_dict()) == 3 + 4 + 23 + 3   # Bottleneck blocks
 
 
 def test_forward_refuses_cpu():
