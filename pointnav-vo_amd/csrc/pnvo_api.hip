@@ -481,8 +481,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
   int rc = PNVO_OK;
   const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
   const char *sel = std::getenv("PNVO_STEM");
-  if (m->dd_ok && m->train == nullptr && !(sel && std::strcmp(sel, "dense") == 0)) {
-    // one-hot-aware stem.  (The training path keeps the dense kernel: its operands are re-packed by pure gathers.)
+  if (m->dd_ok && !(sel && std::strcmp(sel, "dense") == 0)) {
+    // one-hot-aware stem (in training its operands are rebuilt on the device every step: refresh_stem_dd)
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
     StemDDArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -513,8 +513,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     if (const char *e = std::getenv("PNVO_STEM_DBG")) a.dbg = std::atoi(e);
     if (a.dbg == 9) {
       if (!m->dd_prof) {
-        HIPCHK(m, hipMalloc((void **)&m->dd_prof, 32));
-        HIPCHK(m, hipMemset(m->dd_prof, 0, 32));
+        HIPCHK(m, hipMalloc((void **)&m->dd_prof, 64));
+        HIPCHK(m, hipMemset(m->dd_prof, 0, 64));
       }
       a.prof = m->dd_prof;
     }
@@ -1064,11 +1064,12 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
   if (m->dd_prof) {
-    unsigned long long pr[4] = {0, 0, 0, 0};
-    (void)hipMemcpy(pr, m->dd_prof, 32, hipMemcpyDeviceToHost);
-    std::fprintf(stderr, "[pnvo] stem_dd phases (cycles per tile, workgroup thread 0): staging %.0f  k-loop %.0f  epilogue %.0f  (%llu tiles)\n",
-                 (double)pr[0] / (double)(pr[3] ? pr[3] : 1), (double)pr[1] / (double)(pr[3] ? pr[3] : 1),
-                 (double)pr[2] / (double)(pr[3] ? pr[3] : 1), pr[3]);
+    unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpy(pr, m->dd_prof, 64, hipMemcpyDeviceToHost);
+    const double nt_ = (double)(pr[3] ? pr[3] : 1);
+    std::fprintf(stderr, "[pnvo] stem_dd phases (cycles per tile, workgroup thread 0): staging %.0f  k-loop %.0f (of which "
+                 "row barriers %.0f)  epilogue %.0f  (%llu tiles)\n", (double)pr[0] / nt_, (double)pr[1] / nt_,
+                 (double)pr[4] / nt_, (double)pr[2] / nt_, pr[3]);
     (void)hipFree(m->dd_prof);
   }
   free_dev(m->zero_page);

@@ -72,6 +72,9 @@ bool stem_dd_supported(int bins);
 int stem_dd_slots(int Ho, int Wo);                  // GroupNorm partial-sum slots per sample (tiles)
 void pack_stem_dd_weight(const float *w_o12t, int cout, float *out);
 hipError_t launch_stem_dd(const StemDDArgs &a, hipStream_t s);
+hipError_t launch_stem_dd_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *dense_ref,
+                                 const int *dense_new, int nd, const int *dd_ref, const int *dd_new, int bins,
+                                 float *table, float *wpk, float *sc12, float *sh12, hipStream_t s);
 
 int conv_slots(int P, int MT);                       // stats slots per sample for a given wave tile
 void choose_tile(long M, int COUTP, int *MT, int *NT);

@@ -39,6 +39,9 @@ struct TrainState {
   std::vector<float *> dgrad_w;     // per conv of m->convs (nullptr for the stem: no input gradient)
   float *fc_t = nullptr, *head_t = nullptr;
   int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
+  int *d_ddmaps = nullptr;          // one-hot stem: [dense_ref 12 | dense_new 12 | dd_ref 2*bins | dd_new 2*bins]
+  int dd_nd = 0;
+  size_t stem_w_off = 0;            // offset of the OIHW stem weight in the flat parameter buffer
   // saved activations (sized for capB)
   int capB = 0;
   int lastB = 0;
@@ -204,6 +207,44 @@ int build_maps(pnvo_handle m, TrainState *t) {
   HIPCHK(m, hipMemcpy(t->d_ref_of_new, ron.data(), m->CPL * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(m, hipMemcpy(t->d_tensor_of_new, ton.data(), m->CPL * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(m, hipMemcpy(t->d_ciperm, perm.data(), 32 * sizeof(int), hipMemcpyHostToDevice));
+  if (m->dd_ok) {                  // the one-hot-aware stem's operands are rebuilt on the device after every step
+    const int bins = m->dd_bins;
+    std::vector<int> mp(24 + 4 * bins, -1);
+    auto find_new = [&](int tensor, int ch) {
+      for (int nc = 0; nc < m->CP; ++nc)
+        if (m->stem_tensor_of_new[nc] == tensor && m->stem_ch_of_new[nc] == ch && m->stem_ref_of_new[nc] >= 0) return nc;
+      return -1;
+    };
+    int nd = 0;
+    for (int d = 0; d < 12; ++d) {
+      if (m->dd_dense_tensor[d] < 0) continue;
+      const int nc = find_new(m->dd_dense_tensor[d], m->dd_dense_ch[d]);
+      mp[d] = m->stem_ref_of_new[nc];
+      mp[12 + d] = nc;
+      nd = d + 1;
+    }
+    for (int k = 0; k < 2 * bins; ++k) {
+      const int nc = find_new(2, k);
+      mp[24 + k] = m->stem_ref_of_new[nc];
+      mp[24 + 2 * bins + k] = nc;
+    }
+    t->dd_nd = nd;
+    if ((rc = dmalloc(m, (void **)&t->d_ddmaps, mp.size() * sizeof(int))) != PNVO_OK) return rc;
+    HIPCHK(m, hipMemcpy(t->d_ddmaps, mp.data(), mp.size() * sizeof(int), hipMemcpyHostToDevice));
+    auto it = t->toc.find(m->convs[0].name + ".weight");
+    if (it == t->toc.end()) return pnvo_fail(m, PNVO_ERR_WEIGHTS, "stem weight missing from the parameter table");
+    t->stem_w_off = it->second.off;
+  }
+  return PNVO_OK;
+}
+
+// Rebuild the one-hot-aware stem's operands from the flat parameters and the current whitening tables.
+int refresh_stem_dd(pnvo_handle m, TrainState *t, hipStream_t s) {
+  if (!m->dd_ok) return PNVO_OK;
+  const int bins = m->dd_bins;
+  HIPCHK(m, launch_stem_dd_repack(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_ddmaps,
+                                  t->d_ddmaps + 12, t->dd_nd, t->d_ddmaps + 24, t->d_ddmaps + 24 + 2 * bins, bins,
+                                  m->dd_table, m->dd_wpk, m->dd_sc, m->dd_sh, s));
   return PNVO_OK;
 }
 
@@ -416,6 +457,7 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->fc_t);
   dfree(t->head_t);
   dfree(t->d_ref_of_new);
+  dfree(t->d_ddmaps);
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
   delete t;
@@ -460,7 +502,7 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
   HIPCHK(m, hipSetDevice(m->device));
   TrainState *t = TS(m);
   for (const PackMap &pm : t->maps) HIPCHK(m, launch_gather(t->params, pm.map, pm.n, pm.dst, (hipStream_t)stream));
-  return PNVO_OK;
+  return refresh_stem_dd(m, t, (hipStream_t)stream);
 }
 
 int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
@@ -484,6 +526,7 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
   t->src[3] = tdv;
   if (c.normalize)   // RunningMeanAndVar buffers live on the device and change every step (running_mean_and_var.py:54-60)
     HIPCHK(m, launch_whiten_table(run_mean, run_var, t->d_ref_of_new, t->d_tensor_of_new, m->CPL, m->stem_sc, m->stem_sh, s));
+  if ((rc = refresh_stem_dd(m, t, s)) != PNVO_OK) return rc;   // W/std table, indicator weights: both move every step
 
   size_t li = 0;
   {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     }
   };
 
-  long long pt[4] = {0, 0, 0, 0};
+  long long pt[5] = {0, 0, 0, 0, 0};
   const int ntiles = p.B * p.tiles_x * p.tiles_y;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int bid = tile;
@@ -321,9 +321,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
         }
       }
     };
+    long long tbar = 0;
     auto row_end = [&](int kh) {                  // slice kh+1 has landed for everyone; slice kh's buffer is free
+      const long long b0 = PROF ? clock64() : 0;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (PROF) tbar += clock64() - b0;
       if (kh + 2 < 7) dma_slice(kh + 2, kh & 1);
     };
     using C0 = std::integral_constant<int, 0>;
@@ -400,10 +403,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
       pt[1] += tp2 - tp1;
       pt[2] += tp3 - tp2;
       pt[3] += 1;
+      pt[4] += tbar;
     }
   }
   if (PROF && threadIdx.x == 0 && p.prof != nullptr)
-    for (int k = 0; k < 4; ++k) atomicAdd(p.prof + k, (unsigned long long)pt[k]);
+    for (int k = 0; k < 5; ++k) atomicAdd(p.prof + k, (unsigned long long)pt[k]);
 }
 
 int stem_dd_slice_floats(int bins) { return slice_floats_c(bins); }
@@ -421,6 +425,64 @@ void pack_stem_dd_weight(const float *w, int cout, float *out) {
         for (int n = 0; n < 16; ++n)
           for (int t = 0; t < 3; ++t)
             out[(((size_t)tap * (cout / 16) + nt) * 64 + kq * 16 + n) * 3 + t] = w[((size_t)(nt * 16 + n) * CD + 3 * kq + t) * 49 + tap];
+}
+
+// Training: rebuild the kernel's operands (table, packed dense + indicator weights, dense whitening) ON THE DEVICE from
+// the current OIHW stem weight (inside the flat parameter buffer) and the current whitening tables sc/sh of the dense
+// stem (new channel order; sc = 1/(div*std), sh = -mean/std) — both change every optimisation step.  Same arithmetic as
+// the host-side construction in pnvo_load_weights (double, rounded to float once).
+__global__ __launch_bounds__(256) void stem_dd_repack_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
+                                                           const int *dense_ref, const int *dense_new, int nd,
+                                                           const int *dd_ref, const int *dd_new, int bins, int slice,
+                                                           float *table, float *wpk, float *sc12, float *sh12) {
+  const int brows = bins + 1;
+  const int n_tab = 49 * bins * 2 * 32, n_pk = 49 * NT16 * 64 * 3;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n_tab) {                                   // table[kh][kw][b][f][o] = W[o][ref(f,b)][tap] / std
+    const int o = e & 31;
+    int r = e >> 5;
+    const int f = r & 1;
+    r >>= 1;
+    const int b = r % bins;
+    const int tap = r / bins;
+    const int kh = tap / 7, kw = tap - 7 * kh;
+    const int k = f * bins + b;
+    const double inv_std = (double)sc_new[dd_new[k]];            // div = 1 for the depth modalities
+    table[(long)kh * slice + (((long)kw * brows + b) * 2 + f) * 32 + o] =
+        (float)((double)w[((long)o * cin + dd_ref[k]) * 49 + tap] * inv_std);
+  } else if (e < n_tab + n_pk) {                     // packed dense + indicator weights
+    int r = e - n_tab;
+    const int t = r % 3;
+    r /= 3;
+    const int lane = r & 63;
+    r >>= 6;
+    const int nt = r % NT16;
+    const int tap = r / NT16;
+    const int co = nt * 16 + (lane & 15), d = 3 * (lane >> 4) + t;
+    float v = 0.f;
+    if (d < nd) {
+      v = w[((long)co * cin + dense_ref[d]) * 49 + tap];
+    } else if (d == nd) {                            // "inside the image" indicator: -sum_c W * mean_c / std_c
+      double ind = 0.0;
+      for (int k = 0; k < 2 * bins; ++k)
+        ind += (double)w[((long)co * cin + dd_ref[k]) * 49 + tap] * (double)sh_new[dd_new[k]];   // sh = -mean/std
+      v = (float)ind;
+    }
+    wpk[e - n_tab] = v;
+  } else if (e < n_tab + n_pk + CD) {
+    const int d = e - n_tab - n_pk;
+    sc12[d] = d < nd ? sc_new[dense_new[d]] : 0.f;
+    sh12[d] = d < nd ? sh_new[dense_new[d]] : (d == nd ? 1.f : 0.f);
+  }
+}
+
+hipError_t launch_stem_dd_repack(const float *w, int cin, const float *sc_new, const float *sh_new, const int *dense_ref,
+                                 const int *dense_new, int nd, const int *dd_ref, const int *dd_new, int bins,
+                                 float *table, float *wpk, float *sc12, float *sh12, hipStream_t s) {
+  const int total = 49 * bins * 2 * 32 + 49 * NT16 * 64 * 3 + CD;
+  hipLaunchKernelGGL(stem_dd_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cin, sc_new, sh_new,
+                     dense_ref, dense_new, nd, dd_ref, dd_new, bins, stem_dd_slice_floats(bins), table, wpk, sc12, sh12);
+  return hipGetLastError();
 }
 
 hipError_t launch_stem_dd(const StemDDArgs &a, hipStream_t s) {
