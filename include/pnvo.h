@@ -138,6 +138,20 @@ int pnvo_input_moments(pnvo_handle h, const float *rgb, const float *depth, cons
  * NULL) and dLoss/dPred into grad [B,D] (may be NULL). */
 int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, void *stream);
 
+/* The regression loss in its general form: loss = sum_e coef[e] (target[e] - pred[e])^2 over n = B*D elements, grad =
+ * dLoss/dPred.  coef carries everything _compute_loss multiplies by (vo_cnn_engine.py:146-194: loss_weights["dx"|"dz"|"dyaw"],
+ * dz_regress_masks) and the 1/len(subset) of the per-data-type means the geometric-invariance engine takes
+ * (vo_cnn_regression_geo_invariance_engine.py:690-740); the host builds it (pointnav-vo_amd/train.py regression_coef). */
+int pnvo_mse_loss_coef(const float *pred, const float *target, const float *coef, int n, float *loss, float *grad,
+                       void *stream);
+
+/* _compute_geo_invariance_inverse_loss (vo_cnn_regression_geo_invariance_engine.py:367-449).  deltas [n_entries,3] in the
+ * alternating order the reference asserts (cur_rel_to_prev_0, prev_rel_to_cur_0, ...); actions [n_entries] int32 (the even
+ * rows are read; rows equal to move_forward drop the dz constraint).  out4 (device, may be NULL) = {weight * loss,
+ * abs_diff_rot, abs_diff_pos[0], abs_diff_pos[1]}; grad (may be NULL) = weight * dLoss/dDeltas [n_entries,3]. */
+int pnvo_geo_inverse_loss(const float *deltas, const int32_t *actions, int n_entries, int move_forward, float weight,
+                          float *out4, float *grad, void *stream);
+
 /* nn.Dropout(p) of the two places the reference has one — before visual_fc's Linear and before output_head's Linear
  * (pointnav_vo/vo/models/vo_cnn.py:216-227) — for the train-mode forward/backward.  torch's RNG stream cannot be
  * reproduced; the mask is a counter-based hash of (seed, forward count, layer, element): keep with probability 1-p,

@@ -56,6 +56,9 @@ _SIGNATURES = {
     "pnvo_input_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p]),
     "pnvo_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_mse_loss_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_geo_inverse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "pnvo_train_set_dropout": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
     "pnvo_train_dropout_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "pnvo_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,

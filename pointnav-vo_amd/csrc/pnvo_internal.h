@@ -167,6 +167,10 @@ hipError_t launch_padcopy(const float *src, int rows, int cols, int ldd, float *
 hipError_t launch_dropout(const float *x, const float *scale, const float *shift, int B, long P, int C, float p,
                           uint64_t seed, uint64_t step, int layer, float *y, hipStream_t s);
 hipError_t launch_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, hipStream_t s);
+hipError_t launch_mse_loss_coef(const float *pred, const float *target, const float *coef, int n, float *loss, float *grad,
+                                hipStream_t s);
+hipError_t launch_geo_inverse_loss(const float *deltas, const int *actions, int P, int move_forward, float weight, float *out,
+                                   float *grad, hipStream_t s);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps,
                        int step, hipStream_t s);
 hipError_t launch_gather(const float *src, const int *map, long n, float *dst, hipStream_t s);

@@ -833,6 +833,21 @@ int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *l
   return PNVO_OK;
 }
 
+int pnvo_mse_loss_coef(const float *pred, const float *target, const float *coef, int n, float *loss, float *grad,
+                       void *stream) {
+  if (!pred || !target || !coef || n <= 0) return pnvo_fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  HIPCHK(nullptr, launch_mse_loss_coef(pred, target, coef, n, loss, grad, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_geo_inverse_loss(const float *deltas, const int32_t *actions, int n_entries, int move_forward, float weight,
+                          float *out4, float *grad, void *stream) {
+  if (!deltas || !actions || n_entries <= 0 || (n_entries & 1))
+    return pnvo_fail(nullptr, PNVO_ERR_ARG, "deltas must hold an even number of alternating (cur_rel_to_prev, prev_rel_to_cur) rows");
+  HIPCHK(nullptr, launch_geo_inverse_loss(deltas, actions, n_entries / 2, move_forward, weight, out4, grad, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
 int pnvo_adam_step(float *p, const float *g, float *mom, float *var, size_t n, float lr, float beta1, float beta2, float eps,
                    int step, void *stream) {
   if (!p || !g || !mom || !var || step < 1) return pnvo_fail(nullptr, PNVO_ERR_ARG, "bad argument");

@@ -472,10 +472,12 @@ void wgrad_plan(WgradArgs &a) {
     a.pairs = a.ci_tiles * (a.COUT / 32);
     a.tiles_x = (a.W + 23) / 24;
     a.TW = ((a.W + a.tiles_x - 1) / a.tiles_x + 1) / 2 * 2;
-    a.tiles_y = (a.H + 7) / 8;
+    static const int th_max = std::getenv("PNVO_WGRAD_TH") ? std::atoi(std::getenv("PNVO_WGRAD_TH")) : 8;
+    static const int wg_cu = std::getenv("PNVO_WGRAD_WGS") ? std::atoi(std::getenv("PNVO_WGRAD_WGS")) : 2;
+    a.tiles_y = (a.H + th_max - 1) / th_max;
     a.TH = (a.H + a.tiles_y - 1) / a.tiles_y;
     const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
-    long chunks = 512 / a.pairs;                      // 2 persistent workgroups per CU
+    long chunks = 256L * wg_cu / a.pairs;             // persistent workgroups per CU
     if (chunks < 1) chunks = 1;
     if (chunks > ntiles) chunks = ntiles;
     a.tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
@@ -930,6 +932,86 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float *pred, const 
 
 hipError_t launch_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, hipStream_t s) {
   hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, s, pred, target, B, D, loss, grad);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Regression loss with per-element coefficients: loss = sum_e coef[e] (target[e] - pred[e])^2, grad = -2 coef (t - p).
+// coef folds everything _compute_loss multiplies or divides by (vo_cnn_engine.py:146-194: loss_weights, dz_regress_masks,
+// 1/len of the data-type subset the mean is taken over, ...geo_invariance_engine.py:690-740).
+__global__ __launch_bounds__(256) void mse_loss_coef_kernel(const float *pred, const float *target, const float *coef, int n,
+                                                          float *loss, float *grad) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const float d = target[e] - pred[e];
+    const float c = coef[e];
+    a += (double)c * (double)d * (double)d;
+    if (grad) grad[e] = -2.0f * c * d;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss) *loss = (float)red[0];
+}
+
+hipError_t launch_mse_loss_coef(const float *pred, const float *target, const float *coef, int n, float *loss, float *grad,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(mse_loss_coef_kernel, dim3(1), dim3(256), 0, s, pred, target, coef, n, loss, grad);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// _compute_geo_invariance_inverse_loss (vo_cnn_regression_geo_invariance_engine.py:367-449).  deltas [2P,3] alternate
+// a = cur_rel_to_prev_i, b = prev_rel_to_cur_i; with R(yaw_b) = [[cos, sin], [-sin, cos]]:
+//   L = mean_i (yaw_a + yaw_b)^2 + mean_{i,k} m_ik (pos_b + R pos_a)_k^2,   m_i1 = 0 when action_i == MOVE_FORWARD.
+// out[0] = weight * L; out[1] = mean |yaw_a + yaw_b|; out[2..3] = mean_i sqrt(m d^2) per column (the three logged values);
+// grad [2P,3] = weight * dL/ddeltas.  One block, fixed-order fp64 reduction.
+__global__ __launch_bounds__(256) void geo_inverse_loss_kernel(const float *deltas, const int *actions, int P, int move_forward,
+                                                             float weight, float *out, float *grad) {
+  __shared__ double red[4][256];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float ip = 1.f / (float)P;
+  for (int i = threadIdx.x; i < P; i += 256) {
+    const float *a = deltas + (size_t)(2 * i) * 3, *b = a + 3;
+    const float xa = a[0], za = a[1], ya = a[2], xb = b[0], zb = b[1], yb = b[2];
+    const float m = actions[2 * i] == move_forward ? 0.f : 1.f;
+    const float c = cosf(yb), s = sinf(yb);
+    const float r = ya + yb;
+    const float d0 = xb + (c * xa + s * za);
+    const float d1 = zb + (-s * xa + c * za);
+    acc[0] += (double)r * r + 0.5 * ((double)d0 * d0 + (double)m * d1 * d1);
+    acc[1] += fabs((double)r);
+    acc[2] += fabs((double)d0);
+    acc[3] += (double)m * fabs((double)d1);
+    if (grad) {
+      const float g0 = weight * d0 * ip, g1 = weight * m * d1 * ip, gr = weight * 2.f * r * ip;
+      float *ga = grad + (size_t)(2 * i) * 3, *gb = ga + 3;
+      ga[0] = g0 * c - g1 * s;
+      ga[1] = g0 * s + g1 * c;
+      ga[2] = gr;
+      gb[0] = g0;
+      gb[1] = g1;
+      gb[2] = gr + g0 * (-s * xa + c * za) + g1 * (-c * xa - s * za);
+    }
+  }
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4 && out)
+    out[threadIdx.x] = (float)((threadIdx.x == 0 ? (double)weight : 1.0) * red[threadIdx.x][0] / (double)P);
+}
+
+hipError_t launch_geo_inverse_loss(const float *deltas, const int *actions, int P, int move_forward, float weight, float *out,
+                                   float *grad, hipStream_t s) {
+  hipLaunchKernelGGL(geo_inverse_loss_kernel, dim3(1), dim3(256), 0, s, deltas, actions, P, move_forward, weight, out, grad);
   return hipGetLastError();
 }
 

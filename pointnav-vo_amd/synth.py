@@ -144,3 +144,20 @@ def make_policy_inputs(H, W, B, steps, seed):
             mask[1 % B] = 0.0
         out.append((depth, goal, prev, mask))
     return out
+
+
+def make_joint_batch(P, H, W, observation_space, dd_bins=10, seed=0):
+    """The batch layout "inverse_joint_train" produces (vo/dataset/regression_geo_invariance_iter_dataset.py:342-386): P turn
+    samples, each followed by its channel-swapped (cur, prev) entry for the opposite action.  Returns (obs dict [2P,...],
+    actions [2P] in {2 (left), 3 (right)}, data_types [2P] alternating 0 / 1)."""
+    base = make_obs_pairs(P, H, W, observation_space=observation_space, dd_bins=dd_bins, seed=seed)
+    acts = (bits(seed, "joint_acts", P) % np.uint64(2)).astype(np.int64) + 2
+
+    def swap(a):
+        h = a.shape[-1] // 2
+        return np.concatenate([a[..., h:], a[..., :h]], axis=-1)
+
+    obs = {k: np.stack([x for i in range(P) for x in (v[i], swap(v[i]))]) for k, v in base.items()}
+    actions = np.stack([x for i in range(P) for x in (acts[i], 5 - acts[i])]).astype(np.int64)
+    data_types = np.tile(np.array([0, 1], dtype=np.int64), P)
+    return obs, actions, data_types

@@ -15,6 +15,7 @@ Linear layers) uses a counter-based hash mask instead of torch's RNG stream — 
 but reproducible random draw (pnvo_train_set_dropout; `dropout_masks()` returns the masks of the last step for checkers).
 """
 import ctypes as C
+import math
 
 import torch
 import torch.distributed as dist
@@ -177,6 +178,14 @@ class VOTrainStep:
             _lib.check(_lib.lib.pnvo_train_backward(h, _ptr(grad_out), stream), h)
         return out, loss
 
+    def backward(self, grad_out):
+        """loss.backward() for the LAST forward_train of this model given dLoss/dOut [B,3]."""
+        h = self.model._handle
+        grad_out = grad_out.to(device=self.dev, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.dev), torch.no_grad():
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            _lib.check(_lib.lib.pnvo_train_backward(h, _ptr(grad_out), stream), h)
+
     def optimizer_step(self):
         """All-reduce (mean) of the flat gradient buffer across ranks, Adam, re-pack of the kernel operands."""
         h = self.model._handle
@@ -194,3 +203,121 @@ class VOTrainStep:
         out, loss = self.forward_backward(obs_pairs, target=target)
         self.optimizer_step()
         return out, loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+CUR_REL_TO_PREV, PREV_REL_TO_CUR = 0, 1            # pointnav_vo/vo/common/common_vars.py
+MOVE_FORWARD, TURN_LEFT, TURN_RIGHT = 1, 2, 3      # pointnav_vo/utils/misc_utils.py ACT_NAME2IDX values
+
+
+NO_NOISE_DELTAS = {MOVE_FORWARD: (0.0, -0.25, 0.0), TURN_LEFT: (0.0, 0.0, math.radians(10.0)),
+                   TURN_RIGHT: (0.0, 0.0, -math.radians(10.0))}     # common_vars.py (x, z, yaw)
+
+
+def compute_loss_weights(actions, targets, multiplier=None, fixed=True):
+    """VOCNNBaseEngine._compute_loss_weights (vo_cnn_engine.py:200-228): {"dx","dz","dyaw"} -> [M] float32 (host).  fixed
+    (configs/vo/vo_pointnav.yaml:41, the default): the constant multipliers.  Otherwise exp(mult_d * |noise-free delta_d of
+    the action - dx target|) — the reference passes the dx targets into all three exponents; kept as is."""
+    multiplier = multiplier or {"dx": 1.0, "dz": 1.0, "dyaw": 1.0}
+    t = torch.as_tensor(targets, dtype=torch.float32).reshape(-1, 3).cpu()
+    if fixed:
+        return {k: torch.full((t.shape[0],), float(multiplier[k])) for k in ("dx", "dz", "dyaw")}
+    nn = torch.tensor([NO_NOISE_DELTAS[int(a)] for a in torch.as_tensor(actions).reshape(-1).tolist()], dtype=torch.float32)
+    return {k: torch.exp(float(multiplier[k]) * torch.abs(nn[:, d] - t[:, 0])) for d, k in enumerate(("dx", "dz", "dyaw"))}
+
+
+def regression_coef(n, data_types=None, loss_weights=None, dz_regress_masks=None, device=None):
+    """coef [n,3] such that sum(coef * (gt - pred)^2) is what the reference adds up for one action model
+    (vo_cnn_regression_geo_invariance_engine.py:618-740 calling vo_cnn_engine.py:135-198): for every data type present
+    and every d in (dx, dz, dyaw): mean over that subset of (diff^2 [* dz_regress_mask for dz]) * loss_weights[d]."""
+    coef = torch.ones((n, 3), dtype=torch.float32)
+    if data_types is None:
+        coef /= float(n)
+    else:
+        dt = torch.as_tensor(data_types).reshape(-1).cpu()
+        for t in torch.unique(dt).tolist():
+            sel = dt == t
+            coef[sel] /= float(int(sel.sum()))
+    if loss_weights is not None:
+        for d, k in enumerate(("dx", "dz", "dyaw")):
+            coef[:, d] *= torch.as_tensor(loss_weights[k], dtype=torch.float32).reshape(-1).cpu()
+    if dz_regress_masks is not None:
+        coef[:, 1] *= torch.as_tensor(dz_regress_masks, dtype=torch.float32).reshape(-1).cpu()
+    return coef.to(device) if device is not None else coef
+
+
+class GeoInvarianceTrainStep:
+    """One training iteration of VOCNNRegressionGeometricInvarianceEngine for a dict of action models
+    (vo_cnn_regression_geo_invariance_engine.py:855-901 around _process_one_batch :451-807): every model sees the
+    entries of its action, the regression losses are per data type, and with "inverse_joint_train" the predictions of all
+    models, put back in batch order, are tied by the inverse-consistency loss (:367-449, weight
+    VO.GEOMETRY.loss_inv_weight).  Forward/backward/Adam of each model are the pnvo_train_* kernels; both losses and
+    their gradients are HIP kernels (pnvo_mse_loss_coef, pnvo_geo_inverse_loss); index bookkeeping stays on the host as
+    in the reference.
+
+    steps: {act: VOTrainStep} with act in {-1 (all actions), MOVE_FORWARD, TURN_LEFT, TURN_RIGHT}."""
+
+    def __init__(self, steps, invariance_types=("inverse_joint_train",), loss_inv_weight=1.0):
+        self.steps = dict(steps)
+        self.invariance_types = tuple(invariance_types)
+        self.loss_inv_weight = float(loss_inv_weight)
+        self.dev = next(iter(self.steps.values())).dev
+        self.last_logs = {}
+
+    def step(self, batch, actions, data_types, targets, loss_weights=None, dz_regress_masks=None):
+        """batch: dict of NHWC device tensors [M,...] (the model's observation_pairs); actions [M] int; data_types [M]
+        (CUR_REL_TO_PREV / PREV_REL_TO_CUR); targets [M,3] (dx, dz, dyaw).  Returns (total loss tensor [1], preds [M,3]
+        in batch order)."""
+        dev = self.dev
+        actions = torch.as_tensor(actions).reshape(-1).to("cpu", torch.int64)
+        data_types = torch.as_tensor(data_types).reshape(-1).to("cpu", torch.int64)
+        targets = torch.as_tensor(targets, dtype=torch.float32).reshape(-1, 3).to(dev)
+        M = actions.numel()
+        joint = "inverse_joint_train" in self.invariance_types
+        use_types = len(self.invariance_types) > 0
+        preds = torch.zeros((M, 3), device=dev, dtype=torch.float32)
+        idx_of, grads, total = {}, {}, torch.zeros(1, device=dev)
+        with torch.cuda.device(dev), torch.no_grad():
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for act, st in self.steps.items():
+                idx = torch.arange(M) if act == -1 else torch.nonzero(actions == act, as_tuple=True)[0]
+                if idx.numel() == 0:
+                    continue
+                di = idx.to(dev)
+                sub = {k: v.index_select(0, di).contiguous() for k, v in batch.items()}
+                out = st.forward_train(sub)
+                preds.index_copy_(0, di, out)
+                coef = regression_coef(
+                    idx.numel(), data_types[idx] if use_types else None,
+                    None if loss_weights is None else {k: torch.as_tensor(v).reshape(-1)[idx] for k, v in loss_weights.items()},
+                    None if dz_regress_masks is None else torch.as_tensor(dz_regress_masks).reshape(-1)[idx], device=dev)
+                g = torch.empty_like(out)
+                tgt = targets.index_select(0, di).contiguous()
+                _lib.check(_lib.lib.pnvo_mse_loss_coef(_ptr(out), _ptr(tgt), _ptr(coef), int(out.numel()), _ptr(st._loss),
+                                                       _ptr(g), stream))
+                total += st._loss
+                idx_of[act], grads[act] = di, g
+            if joint:
+                valid = torch.nonzero((actions == TURN_LEFT) | (actions == TURN_RIGHT), as_tuple=True)[0]
+                if valid.numel():
+                    vt = data_types[valid]
+                    if valid.numel() % 2 or not bool((vt[0::2] == CUR_REL_TO_PREV).all() and (vt[1::2] == PREV_REL_TO_CUR).all()):
+                        raise AssertionError("inverse_joint_train expects alternating (cur_rel_to_prev, prev_rel_to_cur) entries")
+                    dv = valid.to(dev)
+                    d = preds.index_select(0, dv).contiguous()
+                    a32 = actions[valid].to(dev, torch.int32).contiguous()
+                    out4 = torch.empty(4, device=dev)
+                    ginv = torch.empty_like(d)
+                    _lib.check(_lib.lib.pnvo_geo_inverse_loss(_ptr(d), _ptr(a32), int(d.shape[0]), MOVE_FORWARD,
+                                                              C.c_float(self.loss_inv_weight), _ptr(out4), _ptr(ginv), stream))
+                    total += out4[0:1]
+                    self.last_logs = {"abs_diff_geo_inverse_rot": out4[1], "abs_diff_geo_inverse_pos": out4[2:4]}
+                    full = torch.zeros_like(preds)
+                    full.index_copy_(0, dv, ginv)
+                    for act, di in idx_of.items():
+                        grads[act] += full.index_select(0, di)
+            for act, di in idx_of.items():
+                self.steps[act].backward(grads[act])
+            for act in idx_of:
+                self.steps[act].optimizer_step()
+        return total, preds

@@ -349,6 +349,111 @@ def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtyp
     print(f"{fname}: loss1={rec['loss1']:.6f} loss2={rec['loss2']:.6f}")
 
 
+def import_geo_engine():
+    """The reference's VOCNNRegressionGeometricInvarianceEngine class, unmodified; only absent third-party packages and the
+    modules that need them (HDF5 dataset, tensorboard writer, yacs config helpers) are stubbed."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    for n, pth in [("pointnav_vo.vo.engine", "/pointnav_vo/vo/engine"), ("pointnav_vo.vo.common", "/pointnav_vo/vo/common"),
+                   ("pointnav_vo.vo.dataset", "/pointnav_vo/vo/dataset")]:
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__path__ = [REF + pth]
+            sys.modules[n] = m
+    stub("h5py")
+    stub("yacs")
+    stub("yacs.config", CfgNode=dict)
+    stub("pointnav_vo.utils.tensorboard_utils", TensorboardWriter=object)
+    stub("pointnav_vo.utils.config_utils", update_config_log=None)
+    stub("pointnav_vo.vo.dataset.regression_geo_invariance_iter_dataset", StatePairRegressionDataset=object,
+         normal_collate_func=None, fast_collate_func=None)
+    mod = importlib.import_module("pointnav_vo.vo.engine.vo_cnn_regression_geo_invariance_engine")
+    return mod.VOCNNRegressionGeometricInvarianceEngine
+
+
+class _NS(dict):
+    """attribute + item access, `in` on keys (what the engine does with its yacs config)."""
+    __getattr__ = dict.__getitem__
+
+
+def joint_train_fixture(registry, fname, size, P, seed, fixed_weights):
+    """One training iteration of act_left_right_inv_joint (BASELINE config 3's model pair) through the reference engine's
+    own _process_one_batch with invariance_types = ["inverse_joint_train"] (…geo_invariance_engine.py:451-807): a
+    TURN_LEFT and a TURN_RIGHT model, P turn samples, each followed by its swapped prev_rel_to_cur entry for the opposite
+    action (dataset :342-386), regression losses per data type + the inverse-consistency loss, backward, Adam per action."""
+    Engine = import_geo_engine()
+    cv = importlib.import_module("pointnav_vo.vo.common.common_vars")
+    W, H = size
+    space = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    models, sds = {}, {}
+    for act, sd_seed in ((cv.TURN_LEFT, seed), (cv.TURN_RIGHT, seed + 1)):
+        m, cfg, sd = build_ref_model(registry, "vo_cnn_rgb_d_dd_top_down", space, size, 10, sd_seed, extra=dict(dropout_p=0.0))
+        models[act], sds[act] = m.double().train(), sd
+    base = synth.make_obs_pairs(P, H, W, observation_space=space, dd_bins=10, seed=seed)
+    acts = (synth.bits(seed, "joint_acts", P) % np.uint64(2)).astype(np.int64) + cv.TURN_LEFT
+
+    def swap(a):                                     # (prev, cur) -> (cur, prev): halves of the channel axis
+        h = a.shape[-1] // 2
+        return np.concatenate([a[..., h:], a[..., :h]], axis=-1)
+
+    obs = {k: np.stack([x for i in range(P) for x in (v[i], swap(v[i]))]) for k, v in base.items()}
+    actions = np.stack([x for i in range(P) for x in (acts[i], 5 - acts[i])]).astype(np.int64)
+    dtypes = np.tile(np.array([cv.CUR_REL_TO_PREV, cv.PREV_REL_TO_CUR], dtype=np.int64), P)
+    target = synth.uniform(seed, "joint_target", (2 * P, 3), -0.3, 0.3).astype(np.float32)
+    dzmask = np.ones((2 * P, 1), np.float32)
+    mult = {"dx": 1.0, "dz": 1.0, "dyaw": 1.0} if fixed_weights else {"dx": 2.0, "dz": 1.5, "dyaw": 3.0}
+
+    eng = object.__new__(Engine)
+    eng._config = _NS(VO=_NS(GEOMETRY=_NS(loss_inv_weight=0.7, invariance_types=["inverse_joint_train"]),
+                             TRAIN=_NS(loss_weight_fixed=fixed_weights, loss_weight_multiplier=mult),
+                             MODEL=_NS(name="vo_cnn_rgb_d_dd_top_down")))
+    eng._verbose = False
+    eng.device = torch.device("cpu")
+    eng._pin_memory_flag = False
+    eng._data_collate_mode = "normal"
+    eng._observation_space = space
+    eng._act_type = [cv.TURN_LEFT, cv.TURN_RIGHT]
+    eng._act_list = [cv.TURN_LEFT, cv.TURN_RIGHT]
+    eng.vo_model = models
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+    tg = t(target)
+    batch = (t(dtypes, torch.int64).unsqueeze(1), t(obs["rgb"]), t(obs["depth"]), t(obs["discretized_depth"]),
+             t(obs["top_down_view"]), t(actions, torch.int64).unsqueeze(1), tg[:, 0:1], torch.zeros_like(tg[:, 0:1]),
+             tg[:, 1:2], tg[:, 2:3], t(dzmask), torch.zeros(2 * P, 1), torch.zeros(2 * P, 1))
+    opts = {a: torch.optim.Adam(m.parameters(), lr=2.5e-4, eps=1e-8, weight_decay=0) for a, m in models.items()}
+    for o in opts.values():
+        o.zero_grad()
+    captured = {}
+    for a, m in models.items():
+        m.register_forward_hook(lambda _m, _i, o, a=a: captured.__setitem__(a, o.detach().clone()))
+    loss, bs, _, _, logs = eng._process_one_batch(batch, ["inverse_joint_train"], {}, {}, {}, train_flag=True)
+    loss.backward()
+    rec = dict(width=W, height=H, pairs=P, seed=seed, fixed_weights=int(fixed_weights), loss_inv_weight=0.7,
+               mult=np.array([mult["dx"], mult["dz"], mult["dyaw"]]), actions=actions, data_types=dtypes, target=target,
+               loss=loss.item(), abs_diff_geo_inverse_rot=float(logs[3]), abs_diff_geo_inverse_pos=logs[4].detach().numpy())
+    for a in models:
+        rec[f"pred{a}"] = captured[a].numpy()          # rows in the order of nonzero(actions == a)
+    for a, m in models.items():
+        for k, prm in m.named_parameters():
+            gflat = prm.grad.detach().reshape(-1).double().numpy()
+            idx = sample_idx("jgrad:" + k, gflat.size, 16)
+            rec[f"gidx/{k}"] = idx
+            rec[f"gval{a}/{k}"] = gflat[idx]
+            rec[f"gnorm{a}/{k}"] = np.linalg.norm(gflat)
+    for a, o in opts.items():
+        o.step()
+    for a, m in models.items():
+        for k, prm in m.named_parameters():
+            rec[f"pval{a}/{k}"] = prm.detach().reshape(-1).double().numpy()[rec[f"gidx/{k}"]]
+        for k, b in m.named_buffers():
+            rec[f"buf{a}/{k}"] = np.array(b.detach().double().numpy(), copy=True)
+    np.savez_compressed(os.path.join(HERE, fname), **rec)
+    print(f"{fname}: loss={rec['loss']:.6f} inv rot {rec['abs_diff_geo_inverse_rot']:.4f}")
+
+
 def geo_loss_fixture():
     meths = extract_methods(REF + "/pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py",
                             "VOCNNRegressionGeometricInvarianceEngine", ["_compute_geo_invariance_inverse_loss"])
@@ -373,6 +478,10 @@ def main():
     torch.set_num_threads(8)
     registry, geo = import_reference()
     full = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    if len(sys.argv) > 1 and sys.argv[1] == "joint":         # regenerate just the joint-training fixtures
+        joint_train_fixture(registry, "train_joint_64x48_p4.npz", (64, 48), 4, 41, True)
+        joint_train_fixture(registry, "train_joint_45x37_p3_w.npz", (45, 37), 3, 42, False)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "deeper":        # regenerate just the resnet101 fixture
         model_fixture(registry, "model_deeper_64x48_b2.npz", "vo_cnn_deeper", ["rgb", "depth"], (64, 48), 2, 0, 8, False,
                       extra={"backbone": "resnet101"})
@@ -393,6 +502,8 @@ def main():
     train_fixture(registry, "train_default_45x37_b4_f64.npz", "vo_cnn_rgb_d_dd_top_down", full, (45, 37), 4, 10, 31, torch.float64)
     train_fixture(registry, "train_default_96x64_b3_f32.npz", "vo_cnn_rgb_d_dd_top_down", full, (96, 64), 3, 10, 32, torch.float32)
     geo_loss_fixture()
+    joint_train_fixture(registry, "train_joint_64x48_p4.npz", (64, 48), 4, 41, True)
+    joint_train_fixture(registry, "train_joint_45x37_p3_w.npz", (45, 37), 3, 42, False)
 
 
 if __name__ == "__main__":

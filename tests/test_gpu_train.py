@@ -126,3 +126,85 @@ def test_dropout_step_matches_checker_given_the_same_masks():
     ts2.forward_backward(tobs, target=target)
     torch.cuda.synchronize()
     assert torch.equal(ts2.grad, g_first)
+
+
+@pytest.mark.parametrize("fname", ["train_joint_64x48_p4.npz", "train_joint_45x37_p3_w.npz"])
+def test_joint_inverse_train_step_matches_reference_engine(fname):
+    """act_left_right_inv_joint: two action models, per-data-type regression losses and the inverse-consistency loss, one
+    iteration — against the golden captured from the reference engine's own _process_one_batch and the fp64 checker."""
+    from pointnav_vo_amd import model_spec as ms, synth
+    from pointnav_vo_amd.train import GeoInvarianceTrainStep, compute_loss_weights
+    rec = load_golden(fname)
+    W, H, P, seed = int(rec["width"]), int(rec["height"]), int(rec["pairs"]), int(rec["seed"])
+    space = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    kw = dict(observation_space=space, observation_size=(W, H), hidden_size=512, backbone="resnet18",
+              normalize_visual_inputs=True, output_dim=3, dropout_p=0.0, discretized_depth_channels=10)
+    cfg = ms.config_from_kwargs(**kw)
+    spec = ms.state_dict_spec(cfg)
+    sds = {2: synth.make_state_dict(spec, seed=seed), 3: synth.make_state_dict(spec, seed=seed + 1)}
+    obs, actions, dtypes = synth.make_joint_batch(P, H, W, space, 10, seed)
+    steps = {}
+    for a, sd in sds.items():
+        m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(**kw)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        steps[a] = VOTrainStep(m.to("cuda:0"), lr=2.5e-4, eps=1e-8)
+    mult = {k: float(v) for k, v in zip(("dx", "dz", "dyaw"), rec["mult"])}
+    fixed = bool(rec["fixed_weights"])
+    js = GeoInvarianceTrainStep(steps, ("inverse_joint_train",), loss_inv_weight=float(rec["loss_inv_weight"]))
+    tobs = {k: torch.from_numpy(v).to("cuda:0") for k, v in obs.items()}
+    before = {a: st.flat.clone() for a, st in steps.items()}
+    grads = {}
+    orig = VOTrainStep.optimizer_step
+
+    def keep_grads(self):                      # capture the gradient buffers before Adam consumes them
+        grads[id(self)] = self.grad.clone()
+        orig(self)
+    VOTrainStep.optimizer_step = keep_grads
+    try:
+        loss, preds = js.step(tobs, actions, dtypes, rec["target"],
+                              loss_weights=compute_loss_weights(actions, rec["target"], mult, fixed))
+    finally:
+        VOTrainStep.optimizer_step = orig
+    torch.cuda.synchronize()
+    chk = ref.joint_train_step(sds, obs, actions, dtypes, rec["target"], ngroups=cfg.ngroups,
+                               loss_inv_weight=float(rec["loss_inv_weight"]), multiplier=mult, fixed=fixed)
+    assert abs(loss.item() - float(rec["loss"])) < 2e-4 * max(1.0, float(rec["loss"]))
+    np.testing.assert_allclose(float(js.last_logs["abs_diff_geo_inverse_rot"]), float(rec["abs_diff_geo_inverse_rot"]), rtol=1e-3)
+    np.testing.assert_allclose(js.last_logs["abs_diff_geo_inverse_pos"].cpu().numpy(), rec["abs_diff_geo_inverse_pos"], rtol=1e-3)
+    for a, st in steps.items():
+        idx = np.nonzero(actions == a)[0]
+        np.testing.assert_allclose(preds.cpu().numpy()[idx], rec[f"pred{a}"], rtol=2e-4, atol=2e-5)
+        bad = []
+        g_all = grads[id(st)]
+        for name, (off, n) in st.offsets.items():
+            g = g_all[off:off + n].cpu().double().numpy()
+            gr = chk["grads"][a][name].reshape(-1).numpy()
+            err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
+            gn = float(rec[f"gnorm{a}/{name}"])
+            if err > 2e-3 or abs(np.linalg.norm(g) - gn) > 5e-3 * max(gn, 1e-9):
+                bad.append((name, err, np.linalg.norm(g), gn))
+        assert not bad, (a, bad)
+        assert not torch.equal(before[a], st.flat)
+        for name, (off, n) in st.offsets.items():
+            gr = chk["grads"][a][name].reshape(-1).numpy()
+            pr = chk["params"][a][name].reshape(-1).numpy()
+            sel = np.abs(gr) > 1e-6 * max(np.abs(gr).max(), 1e-30)
+            np.testing.assert_allclose(st.flat[off:off + n].cpu().double().numpy()[sel], pr[sel], rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_geo_inverse_loss_kernel_matches_reference_golden():
+    import ctypes as C
+    from pointnav_vo_amd import _lib
+    rec = load_golden("train_geo_loss.npz")
+    d = torch.from_numpy(rec["deltas"]).float().to("cuda:0").contiguous()
+    a = torch.from_numpy(rec["actions"]).to("cuda:0", torch.int32).contiguous()
+    out4 = torch.zeros(4, device="cuda:0")
+    g = torch.zeros_like(d)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for w in (1.0, 0.3):
+        _lib.check(_lib.lib.pnvo_geo_inverse_loss(C.c_void_p(d.data_ptr()), C.c_void_p(a.data_ptr()), d.shape[0], 1, C.c_float(w),
+                                                  C.c_void_p(out4.data_ptr()), C.c_void_p(g.data_ptr()), s))
+        torch.cuda.synchronize()
+        assert abs(out4[0].item() - w * float(rec["loss"])) < 1e-5 * max(1.0, float(rec["loss"]))
+        np.testing.assert_allclose(g.cpu().numpy(), w * rec["grad"], rtol=1e-4, atol=1e-6)
+    assert _lib.lib.pnvo_geo_inverse_loss(C.c_void_p(d.data_ptr()), C.c_void_p(a.data_ptr()), 3, 1, C.c_float(1.0), None, None, s) != 0

@@ -48,3 +48,37 @@ def test_geo_inverse_loss_matches_reference():
     loss.backward()
     assert abs(loss.item() - float(rec["loss"])) < 1e-12
     np.testing.assert_allclose(d.grad.numpy(), rec["grad"], rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("fname", ["train_joint_64x48_p4.npz", "train_joint_45x37_p3_w.npz"])
+def test_joint_inverse_train_step_matches_reference_engine(fname):
+    """The fp64 checker's joint iteration == the reference engine's own _process_one_batch + backward + Adam.
+    Tolerances are 1e-6-ish, not 1e-10: the engine's _transfer_batch casts rgb with .float() (:335), so the reference
+    divides rgb by 255 in float32 even under a float64 model; the checker divides in float64."""
+    from pointnav_vo_amd import model_spec as ms, synth
+    rec = load_golden(fname)
+    W, H, P, seed = int(rec["width"]), int(rec["height"]), int(rec["pairs"]), int(rec["seed"])
+    space = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    cfg = ms.config_from_kwargs(observation_space=space, observation_size=(W, H), hidden_size=512, backbone="resnet18",
+                                normalize_visual_inputs=True, output_dim=3, dropout_p=0.0, discretized_depth_channels=10)
+    spec = ms.state_dict_spec(cfg)
+    sds = {2: synth.make_state_dict(spec, seed=seed), 3: synth.make_state_dict(spec, seed=seed + 1)}
+    obs, actions, dtypes = synth.make_joint_batch(P, H, W, space, 10, seed)
+    assert (actions == rec["actions"]).all() and (dtypes == rec["data_types"]).all()
+    m = rec["mult"]
+    r = ref.joint_train_step(sds, obs, actions, dtypes, rec["target"], ngroups=cfg.ngroups,
+                             loss_inv_weight=float(rec["loss_inv_weight"]), multiplier={"dx": m[0], "dz": m[1], "dyaw": m[2]},
+                             fixed=bool(rec["fixed_weights"]))
+    assert abs(float(r["loss"]) - float(rec["loss"])) < 1e-7 * max(1.0, float(rec["loss"]))
+    for a in (2, 3):
+        idx = np.nonzero(actions == a)[0]
+        np.testing.assert_allclose(r["preds"].numpy()[idx], rec[f"pred{a}"], rtol=1e-6, atol=1e-7)
+        for k, g in r["grads"][a].items():
+            gf = g.reshape(-1).numpy()
+            nrm = float(rec[f"gnorm{a}/{k}"])
+            assert abs(np.linalg.norm(gf) - nrm) <= 1e-5 * max(nrm, 1e-6), k
+            np.testing.assert_allclose(gf[rec[f"gidx/{k}"]], rec[f"gval{a}/{k}"], rtol=1e-4, atol=1e-6 * max(nrm, 1e-3), err_msg=k)
+            np.testing.assert_allclose(r["params"][a][k].reshape(-1).numpy()[rec[f"gidx/{k}"]], rec[f"pval{a}/{k}"],
+                                       rtol=0, atol=1e-8, err_msg=k)
+        for k, b in r["buffers"][a].items():
+            np.testing.assert_allclose(b.numpy().reshape(-1), rec[f"buf{a}/{k}"].reshape(-1), rtol=1e-6, atol=1e-9, err_msg=k)
