@@ -105,6 +105,33 @@ int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstrid
                       const float *consts, int rows_around_center, float *out, int64_t out_fstride,
                       int64_t out_pstride, void *work, void *stream);
 
+/* ---- VO dataset input pipeline on the device: what StatePairRegressionDataset._process_data
+ * does per sample on 20 CPU workers (pointnav_vo/vo/dataset/regression_geo_invariance_iter_dataset.py:205-454), per chunk
+ * on the GPU.  Reading the HDF5 file stays with the caller (h5py). ---- */
+
+/* The numpy twin of the top-down view, NormalizedDepth2TopDownViewHabitat.gen_top_down_view (geometry_utils.py:275-470),
+ * which the dataset uses (:247-262): same steps as pnvo_topdown_view with the projection in float64.
+ *   consts[7] (HOST doubles): inv(K)[0,0], inv(K)[0,2], min_x, x_range*(1+eps), max_depth-min_depth, (max_depth-min_depth)*(1+eps),
+ *   min_depth — computed by the caller with numpy as the reference does (pointnav-vo_amd/dataset.py). */
+int pnvo_topdown_view_f64(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                          const double *consts, int rows_around_center, float *out, int64_t out_fstride,
+                          int64_t out_pstride, void *work, void *stream);
+
+/* float16 bit patterns -> float32 (the HDF5 depth arrays, generate_datasets.py:272,290). */
+int pnvo_half_to_float(const uint16_t *src, int64_t n, float *dst, void *stream);
+
+/* Batch assembly for M entries from the N samples of a chunk (device pointers):
+ *   prev_rgb/cur_rgb [N,H*W*3] uint8, prev_depth/cur_depth [N,H*W] float16 bits, tdv_frames [2,N,H*W] float32 (top-down view of
+ *   the prev frames then the cur frames; NULL -> zeros), src[m] = sample of entry m, swap[m] != 0 -> the entry is (cur, prev)
+ *   (the geometric-inversion entry, :342-386).  Outputs (each may be NULL): rgb_pairs [M,H,W,6] (0..255), depth_pairs [M,H,W,2],
+ *   dd_pairs [M,H,W,2*bins] one-hot with the caller's HOST edges[bins+1] (the dataset compares float16 depth with
+ *   float16-rounded edges, regression_iter_dataset.py:32-69; NULL -> float32(i/bins)), tdv_pairs [M,H,W,2].
+ *   err_flag is set when a depth is outside [0,1] (the reference asserts, :33-34). */
+int pnvo_dataset_pairs(const uint8_t *prev_rgb, const uint8_t *cur_rgb, const uint16_t *prev_depth, const uint16_t *cur_depth,
+                       const float *tdv_frames, const int32_t *src, const int32_t *swap, int N, int M, int H, int W, int bins,
+                       const float *edges, float *rgb_pairs, float *depth_pairs, float *dd_pairs, float *tdv_pairs,
+                       int32_t *err_flag, void *stream);
+
 /* ---- training step (BASELINE config 4).  One optimisation step of one action model, replacing the body of the
  * reference's training iteration: zero_grad / forward in train mode / loss / backward / optimizer.step()
  * (pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py:855-901; loss vo_cnn_engine.py:135-198; Adam

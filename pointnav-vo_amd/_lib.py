@@ -45,6 +45,10 @@ _SIGNATURES = {
     "pnvo_discretize_depth": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
     "pnvo_topdown_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pnvo_topdown_view_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pnvo_half_to_float": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pnvo_dataset_pairs": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 7),
     "pnvo_topdown_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                     C.c_void_p]),

@@ -265,11 +265,13 @@ __global__ __launch_bounds__(256) void discretize_depth_kernel(const float *dept
 }
 
 hipError_t launch_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
-                                   int64_t out_stride, int32_t *err_flag, hipStream_t s) {
+                                   int64_t out_stride, int32_t *err_flag, hipStream_t s, const float *edges) {
   if (bins < 1 || bins > 64) return hipErrorInvalidValue;
   DepthEdges ed;
   for (int i = 0; i < bins; ++i) ed.e[i] = (float)((double)i * 1.0 / (double)bins);   // :105-115, rounded to fp32
   ed.e[bins] = 1.0f;
+  if (edges != nullptr)                                                               // caller-defined (HOST) edges
+    for (int i = 0; i <= bins; ++i) ed.e[i] = edges[i];
   hipLaunchKernelGGL(discretize_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, depth, (long)n,
                      (long)in_stride, bins, onehot, (long)out_stride, err_flag, ed);
   return hipGetLastError();
@@ -388,6 +390,160 @@ __global__ __launch_bounds__(256) void topdown_normalize_kernel(int H, int W, To
     if (mx > 0) v = fminf(div_rn((float)c[p], (float)mx), 1.0f);   // :543-554
     o[(long)p * opstride] = v;
   }
+}
+
+// The dataset-side twin NormalizedDepth2TopDownViewHabitat (numpy, geometry_utils.py:275-470) does the same projection
+// in float64: pixel centres (float16, exact for W < 1024) through np.linalg.inv(K) in double, true depth still in
+// float32 (:336-338: float32 array * python float), everything after it in double (:425-451).
+struct TopdownConsts64 {
+  double c[8];
+};
+
+__global__ __launch_bounds__(256) void topdown_project_f64_kernel(const float *depth, long fstride, long pstride, int H,
+                                                                int W, const TopdownConsts64 tc, int rows_around_center,
+                                                                TopdownWork *work, int *cnt) {
+  const int n = blockIdx.y;
+  const int r0 = work[n].bbox[0], r1 = work[n].bbox[1], c0 = work[n].bbox[2], c1 = work[n].bbox[3];
+  if (r1 < r0 || c1 < c0) return;              // all-zero frame (:296-297)
+  const int hc = r1 - r0 + 1, wc = c1 - c0 + 1;
+  const int half = (hc + 1) / 2;               // int(np.ceil(hc / 2)) (:371-378)
+  int b0 = half - rows_around_center;
+  if (b0 < 0) b0 = 0;
+  int b1 = half + rows_around_center;
+  if (b1 > hc) b1 = hc;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (b1 - b0) * wc) return;
+  const int j = b0 + t / wc, i = t % wc;
+  const int r = r0 + j, c = c0 + i;
+  const float *d = depth + (long)n * fstride;
+  const float m = blur_row(d, pstride, W, r, c, c0, c1);
+  const float u = r > r0 ? blur_row(d, pstride, W, r - 1, c, c0, c1) : 0.f;
+  const float dn = r < r1 ? blur_row(d, pstride, W, r + 1, c, c0, c1) : 0.f;
+  const float db = add_rn(mul_rn(m, 0.5f), mul_rn(add_rn(u, dn), 0.25f));
+  const double kinv00 = tc.c[0], kinv02 = tc.c[1], min_x = tc.c[2], x_den = tc.c[3], z_den = tc.c[5], min_depth = tc.c[6];
+  const float dscale = (float)tc.c[4], min_depth_f = (float)tc.c[6];
+  const double uu = (double)(i + c0) + 0.5;                              // :392-397
+  const double xc = kinv00 * uu + kinv02;                                // :405 (row 0 of inv(K) @ [u, v, 1])
+  const double z = (double)add_rn(mul_rn(db, dscale), min_depth_f);      // :336-338, :408
+  const double X = xc * z;                                               // :409
+  const double xn = (X - min_x) / x_den;                                 // :432
+  const double zn = (z - min_depth) / z_den;                             // :433-435
+  const double rf = (double)H - ceil((double)H * zn);                    // :443-445
+  const double cf = floor((double)W * xn);                               // :446
+  const long row = (long)rf, col = (long)cf;                             // .astype(np.int) (:448)
+  if (row >= 0 && row < H && col >= 0 && col < W) atomicAdd(&cnt[((long)n * H + row) * W + col], 1);
+}
+
+hipError_t launch_topdown_f64(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                              const double *consts, int rows_around_center, float *out, int64_t out_fstride,
+                              int64_t out_pstride, void *work, hipStream_t s) {
+  TopdownWork *tw = reinterpret_cast<TopdownWork *>(work);
+  int *cnt = reinterpret_cast<int *>(tw + N);
+  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N * H * W, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(topdown_bbox_kernel, dim3((unsigned)N), dim3(256), 0, s, depth, (long)in_fstride,
+                     (long)in_pstride, H, W, tw);
+  const int band = 2 * rows_around_center < H ? 2 * rows_around_center : H;
+  TopdownConsts64 tc;
+  for (int k = 0; k < 7; ++k) tc.c[k] = consts[k];   // HOST array
+  tc.c[7] = 0.0;
+  hipLaunchKernelGGL(topdown_project_f64_kernel, dim3((unsigned)((band * W + 255) / 256), (unsigned)N), dim3(256), 0, s,
+                     depth, (long)in_fstride, (long)in_pstride, H, W, tc, rows_around_center, tw, cnt);
+  hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)N), dim3(256), 0, s, H, W, tw, cnt, out,
+                     (long)out_fstride, (long)out_pstride);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Training-batch assembly from the arrays of one dataset chunk (StatePairRegressionDataset._process_data,
+// vo/dataset/regression_geo_invariance_iter_dataset.py:205-454): uint8 rgb and float16 depth frames as stored in the
+// HDF5 file -> the float32 NHWC observation pairs the model takes, for M entries; entry m reads sample src[m] and is
+// (prev, cur) or, when swap[m], (cur, prev) — the geometric-inversion entries (:342-386).  The one-hot depth uses the
+// caller's edges (the dataset compares float16 depth with float16-rounded edges, regression_iter_dataset.py:32-69).
+__device__ __forceinline__ float half_bits_to_float(unsigned short h) {
+  _Float16 v;
+  __builtin_memcpy(&v, &h, 2);
+  return (float)v;
+}
+
+struct DatasetPairsArgs {
+  const unsigned char *rgb[2];     // prev, cur: [N][H*W*3]
+  const unsigned short *depth[2];  // prev, cur: [N][H*W] float16 bits
+  const float *tdv;                // [2][N][H*W] (prev frames, then cur frames) or nullptr
+  const int *src, *swap;           // [M]
+  long npix;                       // H*W
+  long nsamples;                   // N
+  int bins;
+  float *o_rgb, *o_depth, *o_dd, *o_tdv;   // [M][npix][6 | 2 | 2*bins | 2], any may be nullptr
+  int *err_flag;
+  DepthEdges ed;
+};
+
+__global__ __launch_bounds__(256) void dataset_pairs_kernel(const DatasetPairsArgs a) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (p >= a.npix) return;
+  const int i = a.src[m];
+  const int sw = a.swap[m] != 0;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {                 // f: slot in the pair; which: 0 = prev frame, 1 = cur frame
+    const int which = f ^ sw;
+    const long e = ((long)m * a.npix + p);
+    if (a.o_rgb != nullptr) {
+      const unsigned char *r = a.rgb[which] + ((long)i * a.npix + p) * 3;
+      float *o = a.o_rgb + e * 6 + 3 * f;
+      o[0] = (float)r[0];
+      o[1] = (float)r[1];
+      o[2] = (float)r[2];
+    }
+    const float d = half_bits_to_float(a.depth[which][(long)i * a.npix + p]);
+    if (a.o_depth != nullptr) a.o_depth[e * 2 + f] = d;
+    if (a.o_dd != nullptr) {
+      if (!(d >= 0.f && d <= 1.f) && a.err_flag != nullptr) *a.err_flag = 1;
+      float *o = a.o_dd + e * (2 * a.bins) + (long)f * a.bins;
+      for (int k = 0; k < a.bins; ++k) {
+        const float lo = a.ed.e[k], hi = a.ed.e[k + 1];
+        o[k] = ((k == a.bins - 1) ? (d >= lo && d <= hi) : (d >= lo && d < hi)) ? 1.0f : 0.0f;
+      }
+    }
+    if (a.o_tdv != nullptr) a.o_tdv[e * 2 + f] = a.tdv != nullptr ? a.tdv[((long)which * a.nsamples + i) * a.npix + p] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void half_to_float_kernel(const unsigned short *src, long n, float *dst) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) dst[e] = half_bits_to_float(src[e]);
+}
+
+hipError_t launch_half_to_float(const unsigned short *src, long n, float *dst, hipStream_t s) {
+  hipLaunchKernelGGL(half_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, n, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_dataset_pairs(const unsigned char *prev_rgb, const unsigned char *cur_rgb, const unsigned short *prev_depth,
+                                const unsigned short *cur_depth, const float *tdv_frames, const int *src, const int *swap,
+                                int N, int M, int H, int W, int bins, const float *edges, float *o_rgb, float *o_depth,
+                                float *o_dd, float *o_tdv, int *err_flag, hipStream_t s) {
+  if (bins < 0 || bins > 64) return hipErrorInvalidValue;
+  DatasetPairsArgs a;
+  a.rgb[0] = prev_rgb;
+  a.rgb[1] = cur_rgb;
+  a.depth[0] = prev_depth;
+  a.depth[1] = cur_depth;
+  a.tdv = tdv_frames;
+  a.src = src;
+  a.swap = swap;
+  a.npix = (long)H * W;
+  a.nsamples = N;
+  a.bins = bins;
+  a.o_rgb = o_rgb;
+  a.o_depth = o_depth;
+  a.o_dd = bins > 0 ? o_dd : nullptr;
+  a.o_tdv = o_tdv;
+  a.err_flag = err_flag;
+  for (int k = 0; k <= bins; ++k) a.ed.e[k] = edges ? edges[k] : (k == bins ? 1.0f : (float)((double)k / (double)bins));
+  hipLaunchKernelGGL(dataset_pairs_kernel, dim3((unsigned)((a.npix + 255) / 256), (unsigned)M), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,

@@ -1040,6 +1040,37 @@ int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstrid
   return PNVO_OK;
 }
 
+int pnvo_topdown_view_f64(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                          const double *consts, int rows_around_center, float *out, int64_t out_fstride,
+                          int64_t out_pstride, void *work, void *stream) {
+  if (!depth || !out || !consts || !work || N < 0 || H <= 0 || W <= 0)
+    return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (N == 0) return PNVO_OK;
+  HIPCHK(nullptr, launch_topdown_f64(depth, N, H, W, in_fstride, in_pstride, consts, rows_around_center, out, out_fstride,
+                                     out_pstride, work, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_half_to_float(const uint16_t *src, int64_t n, float *dst, void *stream) {
+  if (!src || !dst || n < 0) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (n == 0) return PNVO_OK;
+  HIPCHK(nullptr, launch_half_to_float(src, (long)n, dst, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_dataset_pairs(const uint8_t *prev_rgb, const uint8_t *cur_rgb, const uint16_t *prev_depth, const uint16_t *cur_depth,
+                       const float *tdv_frames, const int32_t *src, const int32_t *swap, int N, int M, int H, int W, int bins,
+                       const float *edges, float *rgb_pairs, float *depth_pairs, float *dd_pairs, float *tdv_pairs,
+                       int32_t *err_flag, void *stream) {
+  if (!prev_depth || !cur_depth || !src || !swap || N <= 0 || M < 0 || H <= 0 || W <= 0 || bins < 0 || bins > 64)
+    return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (rgb_pairs && (!prev_rgb || !cur_rgb)) return fail(nullptr, PNVO_ERR_ARG, "rgb pairs requested without rgb frames");
+  if (M == 0) return PNVO_OK;
+  HIPCHK(nullptr, launch_dataset_pairs(prev_rgb, cur_rgb, prev_depth, cur_depth, tdv_frames, src, swap, N, M, H, W, bins, edges,
+                                       rgb_pairs, depth_pairs, dd_pairs, tdv_pairs, err_flag, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
 int pnvo_destroy(pnvo_handle m) {
   if (!m) return PNVO_OK;
   (void)hipSetDevice(m->device);

@@ -120,7 +120,15 @@ hipError_t launch_apply_ss_relu(const float *x, const float *s, const float *t, 
                                 hipStream_t st);
 
 hipError_t launch_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int bins, float *onehot,
-                                   int64_t out_stride, int32_t *err_flag, hipStream_t s);
+                                   int64_t out_stride, int32_t *err_flag, hipStream_t s, const float *edges = nullptr);
+hipError_t launch_topdown_f64(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
+                              const double *consts, int rows_around_center, float *out, int64_t out_fstride,
+                              int64_t out_pstride, void *work, hipStream_t s);
+hipError_t launch_half_to_float(const unsigned short *src, long n, float *dst, hipStream_t s);
+hipError_t launch_dataset_pairs(const unsigned char *prev_rgb, const unsigned char *cur_rgb, const unsigned short *prev_depth,
+                                const unsigned short *cur_depth, const float *tdv_frames, const int *src, const int *swap,
+                                int N, int M, int H, int W, int bins, const float *edges, float *o_rgb, float *o_depth,
+                                float *o_dd, float *o_tdv, int *err_flag, hipStream_t s);
 size_t topdown_workspace_bytes(int N, int H, int W);
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const float *consts_host, int rows_around_center, float *out, int64_t out_fstride,

@@ -161,3 +161,35 @@ def make_joint_batch(P, H, W, observation_space, dd_bins=10, seed=0):
     actions = np.stack([x for i in range(P) for x in (acts[i], 5 - acts[i])]).astype(np.int64)
     data_types = np.tile(np.array([0, 1], dtype=np.int64), P)
     return obs, actions, data_types
+
+
+def make_dataset_chunk(N, H, W, seed=0, bins=10):
+    """The arrays of one HDF5 chunk as generate_datasets.py stores them (:258-305): uint8 rgb vectors, float16 depth vectors,
+    uint8 actions, float16 poses.  Depth frames get a zero border of varying width (exercises the top-down view's crop),
+    exact float16 bin edges and their float16 neighbours (exercise the one-hot's float16 comparison), one all-zero frame."""
+    ch = {"actions": ((bits(seed, "ds_act", N) % np.uint64(3)) + np.uint64(1)).astype(np.uint8)}
+    edge = np.array([np.float16(i / bins) for i in range(bins + 1)], dtype=np.float16)
+    near = np.concatenate([edge, np.nextafter(edge[1:], np.float16(0)), np.nextafter(edge[:-1], np.float16(1))])
+    for k in ("prev", "cur"):
+        ch[f"{k}_rgbs"] = (bits(seed, f"ds_rgb_{k}", N * H * W * 3) & np.uint64(255)).astype(np.uint8).reshape(N, H * W * 3)
+        d = uniform(seed, f"ds_depth_{k}", (N, H, W), 0.0, 1.0).astype(np.float16)
+        pick = (bits(seed, f"ds_edge_{k}", N * H * W) % np.uint64(16)).reshape(N, H, W)
+        which = (bits(seed, f"ds_which_{k}", N * H * W) % np.uint64(near.size)).astype(np.int64).reshape(N, H, W)
+        d = np.where(pick == 0, near[which], d)
+        for n in range(N):
+            b = int(bits(seed, f"ds_border_{k}", N)[n] % np.uint64(4))
+            if b:
+                d[n, :b] = 0
+                d[n, H - 2 * b:] = 0
+                d[n, :, :2 * b] = 0
+                d[n, :, W - b:] = 0
+        if k == "cur" and N > 2:
+            d[N - 1] = 0
+        ch[f"{k}_depths"] = d.reshape(N, H * W)
+        yaw = uniform(seed, f"ds_yaw_{k}", (N,), -np.pi, np.pi)
+        ch[f"{k}_global_rotations"] = np.stack([0 * yaw, np.sin(yaw / 2), 0 * yaw, np.cos(yaw / 2)], 1).astype(np.float16)
+        ch[f"{k}_global_positions"] = uniform(seed, f"ds_pos_{k}", (N, 3), -3.0, 3.0).astype(np.float16)
+    dy = uniform(seed, "ds_dyaw", (N,), -0.3, 0.3)
+    ch["delta_rotations"] = np.stack([0 * dy, np.sin(dy / 2), 0 * dy, np.cos(dy / 2)], 1).astype(np.float16)
+    ch["delta_positions"] = uniform(seed, "ds_dpos", (N, 3), -0.3, 0.3).astype(np.float16)
+    return ch
