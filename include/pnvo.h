@@ -152,6 +152,10 @@ int pnvo_train_refresh(pnvo_handle h, void *stream);
 int pnvo_train_forward(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
                        const float *run_mean, const float *run_var, float *out, void *stream);
 
+/* act_embed variants (vo_cnn_act_embed.py:63-72): the actions [B] (DEVICE int64, values in [0, n_acts]) of the NEXT
+ * pnvo_train_forward / pnvo_train_backward pair; the caller keeps the buffer alive until the backward has run. */
+int pnvo_train_set_actions(pnvo_handle h, const int64_t *actions);
+
 /* loss.backward() given dLoss/dOut [B,out_dim]: fills the whole gradient buffer (overwrites; no accumulation). */
 int pnvo_train_backward(pnvo_handle h, const float *grad_out, void *stream);
 
@@ -186,7 +190,8 @@ int pnvo_geo_inverse_loss(const float *deltas, const int32_t *actions, int n_ent
 int pnvo_train_set_dropout(pnvo_handle h, float p, uint64_t seed);
 
 /* The scaled mask (0 or 1/(1-p)) the LAST pnvo_train_forward used: layer 0 -> [B, fh*fw, compression channels padded to a multiple of 32]
- * (the kernel's NHWC order of the flattened feature), layer 1 -> [B, hidden].  For checkers. */
+ * (the kernel's NHWC order of the flattened feature), layer 1 -> [B, hidden], layer 2 -> [B, 32] (the action-embedding
+ * columns of act_embed variants).  For checkers. */
 int pnvo_train_dropout_mask(pnvo_handle h, int layer, float *out, void *stream);
 
 /* torch.optim.Adam(weight_decay=0, amsgrad=False) on flat device buffers; step counts from 1. */

@@ -154,6 +154,7 @@ struct WgradArgs {
   long pix_per_chunk;
   // LDS-staged path (wgrad3_lds_kernel: 3x3 stride-1 convs with 32-channel multiples), chosen by wgrad_plan
   int lds3, TH, TW, tiles_x, tiles_y, tiles_per_chunk;
+  long grad_pitch;          // row pitch of the OIHW gradient tensor (0: cin_out * KH * KW)
 };
 void wgrad_plan(WgradArgs &a);
 size_t wgrad_partial_floats(const WgradArgs &a);
@@ -174,6 +175,12 @@ hipError_t launch_padcopy(const float *src, int rows, int cols, int ldd, float *
 // [B][row] with row = P*C elements (C = channel count for the scale index); x == nullptr writes the bare scaled mask.
 hipError_t launch_dropout(const float *x, const float *scale, const float *shift, int B, long P, int C, float p,
                           uint64_t seed, uint64_t step, int layer, float *y, hipStream_t s);
+hipError_t launch_embed_gather(const float *emb, const long long *actions, int B, int rows, float *out, int *err, hipStream_t s);
+hipError_t launch_embed_bias(const float *efeat, const float *w1, long pitch, int flat, const float *b1, int B, int hidden,
+                             float *bias, hipStream_t s);
+hipError_t launch_embed_backward(const float *gh, const float *efeat, const float *w1, long pitch, int flat, int B, int hidden,
+                                 float *dw1, float *dfeat, hipStream_t s);
+hipError_t launch_embed_scatter(const float *dfeat, const long long *actions, int B, int rows, float *demb, hipStream_t s);
 hipError_t launch_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, hipStream_t s);
 hipError_t launch_mse_loss_coef(const float *pred, const float *target, const float *coef, int n, float *loss, float *grad,
                                 hipStream_t s);

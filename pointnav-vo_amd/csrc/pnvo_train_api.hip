@@ -60,6 +60,13 @@ struct TrainState {
   float drop_p = 0.f;
   uint64_t drop_seed = 0, drop_step = 0;
   float *zdrop = nullptr, *hdrop = nullptr, *dmask = nullptr;
+  // action-embedding variants: the Linear's 32 embedding columns as per-sample bias rows (train_kernels.hip embed_*)
+  const long long *actions = nullptr;   // device [B], set by pnvo_train_set_actions for the next forward/backward
+  float *egath = nullptr, *efeat = nullptr, *biasB = nullptr, *dfeat = nullptr;
+  int64_t *iota = nullptr;
+  int *embed_err = nullptr;             // host-mapped flag: action outside the embedding table
+  size_t w1_off = 0, b1_off = 0, emb_off = 0;
+  long w1_pitch = 0;
 };
 
 TrainState *TS(pnvo_handle m) { return reinterpret_cast<TrainState *>(m->train); }
@@ -166,13 +173,30 @@ int build_maps(pnvo_handle m, TrainState *t) {
   if (!w2) return rc;
   const TocEnt *b2 = need(m, t, "output_head.1.bias", &rc);
   if (!b2) return rc;
-  if ((int)w1->shape[1] != flat) return pnvo_fail(m, PNVO_ERR_ARG, "training of act_embed variants is not built");
+  const int fc_in = flat + (c.act_embed ? 32 : 0);
+  if ((int)w1->shape[1] != fc_in) return pnvo_fail(m, PNVO_ERR_ARG, m->fc.name + ".weight has the wrong number of columns");
+  t->w1_off = w1->off;
+  t->w1_pitch = fc_in;
+  t->b1_off = b1->off;
+  if (c.act_embed) {
+    const TocEnt *emb = need(m, t, "action_embedding.weight", &rc);
+    if (!emb) return rc;
+    if (emb->shape.size() != 2 || emb->shape[0] != c.n_acts + 1 || emb->shape[1] != 32)
+      return pnvo_fail(m, PNVO_ERR_ARG, "action_embedding.weight must be [n_acts + 1, 32]");
+    t->emb_off = emb->off;
+    if (!t->embed_err) HIPCHK(m, hipHostMalloc((void **)&t->embed_err, sizeof(int), hipHostMallocMapped));
+    *t->embed_err = 0;
+  }
   {
-    const std::vector<float> i1 = index_tensor(*w1), i2 = index_tensor(*w2);
+    const std::vector<float> i1full = index_tensor(*w1), i2 = index_tensor(*w2);
+    std::vector<float> i1((size_t)c.hidden * flat);          // the visual columns
+    for (int o = 0; o < c.hidden; ++o)
+      std::memcpy(&i1[(size_t)o * flat], &i1full[(size_t)o * fc_in], sizeof(float) * (size_t)flat);
     std::vector<float> pk;
     pnvo_pack_conv_weight_cinp(i1.data(), c.hidden, m->comp_c, m->comp_cp, m->fh, m->fw, pk);
     if ((rc = add_map(m, t, m->fc.wpk, pk)) != PNVO_OK) return rc;
-    if ((rc = add_map(m, t, m->fc_bias, index_tensor(*b1))) != PNVO_OK) return rc;
+    if (!c.act_embed)        // act-embed: the per-action bias rows are rebuilt by refresh_embed_bias
+      if ((rc = add_map(m, t, m->fc_bias, index_tensor(*b1))) != PNVO_OK) return rc;
     pnvo_pack_conv_weight_cinp(i2.data(), c.out_dim, c.hidden, c.hidden, 1, 1, pk);
     if ((rc = add_map(m, t, m->head.wpk, pk)) != PNVO_OK) return rc;
     if ((rc = add_map(m, t, m->head_bias, index_tensor(*b2))) != PNVO_OK) return rc;
@@ -278,6 +302,11 @@ void free_train_ws(TrainState *t) {
   dfree(t->zdrop);
   dfree(t->hdrop);
   dfree(t->dmask);
+  dfree(t->egath);
+  dfree(t->efeat);
+  dfree(t->biasB);
+  dfree(t->dfeat);
+  dfree(t->iota);
   t->capB = 0;
 }
 
@@ -376,6 +405,17 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
     if ((rc = dmalloc(m, (void **)&t->dmask, (zf > hf ? zf : hf) * 4)) != PNVO_OK) return rc;
   }
   if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 512 * 8)) != PNVO_OK) return rc;
+  if (c.act_embed) {
+    const int rows = std::max(B, c.n_acts + 1);
+    if ((rc = dmalloc(m, (void **)&t->egath, (size_t)rows * 32 * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&t->efeat, (size_t)rows * 32 * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&t->dfeat, (size_t)rows * 32 * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&t->biasB, (size_t)rows * c.hidden * 4)) != PNVO_OK) return rc;
+    if ((rc = dmalloc(m, (void **)&t->iota, (size_t)rows * 8)) != PNVO_OK) return rc;
+    std::vector<int64_t> io(rows);
+    for (int k = 0; k < rows; ++k) io[k] = k;
+    HIPCHK(m, hipMemcpy(t->iota, io.data(), (size_t)rows * 8, hipMemcpyHostToDevice));
+  }
   t->capB = B;
   return PNVO_OK;
 }
@@ -460,6 +500,7 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->d_ddmaps);
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
+  if (t->embed_err) (void)hipHostFree(t->embed_err);
   delete t;
   m->train = nullptr;
 }
@@ -502,6 +543,15 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
   HIPCHK(m, hipSetDevice(m->device));
   TrainState *t = TS(m);
   for (const PackMap &pm : t->maps) HIPCHK(m, launch_gather(t->params, pm.map, pm.n, pm.dst, (hipStream_t)stream));
+  if (m->cfg.act_embed) {      // eval-mode bias rows bias[a][o] = b1[o] + W1[o][flat:] . emb[a]  (pnvo_load_weights does this on the host)
+    const pnvo_config &c = m->cfg;
+    const int rows = c.n_acts + 1, flat = m->comp_c * m->fh * m->fw;
+    int rc = ensure_train_ws(m, t, t->capB > 0 ? t->capB : 1);
+    if (rc != PNVO_OK) return rc;
+    HIPCHK(m, launch_embed_gather(t->params + t->emb_off, nullptr, rows, rows, t->egath, nullptr, (hipStream_t)stream));
+    HIPCHK(m, launch_embed_bias(t->egath, t->params + t->w1_off, t->w1_pitch, flat, t->params + t->b1_off, rows, c.hidden,
+                                m->fc_bias, (hipStream_t)stream));
+  }
   return refresh_stem_dd(m, t, (hipStream_t)stream);
 }
 
@@ -519,6 +569,7 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
   int rc = ensure_train_ws(m, t, B);
   if (rc != PNVO_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (c.act_embed && !t->actions) return pnvo_fail(m, PNVO_ERR_ARG, "act_embed model: pnvo_train_set_actions first");
   t->lastB = B;
   t->src[0] = rgb;
   t->src[1] = depth;
@@ -572,10 +623,24 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
                             sc.mu, sc.rstd)) != PNVO_OK)
       return rc;
     ++t->drop_step;
+    const float *fcb = m->fc_bias;
+    const int64_t *fcrow = nullptr;
+    if (c.act_embed) {                // the embedding columns of the Linear as per-sample bias rows (vo_cnn_act_embed.py:63-72)
+      const int flat = m->comp_c * m->fh * m->fw;
+      HIPCHK(m, launch_embed_gather(t->params + t->emb_off, t->actions, B, c.n_acts + 1, t->egath, t->embed_err, s));
+      if (t->drop_p > 0.f)            // nn.Dropout acts on the concatenated [visual | embedding] vector: mask "layer" 2
+        HIPCHK(m, launch_dropout(t->egath, nullptr, nullptr, B, 1, 32, t->drop_p, t->drop_seed, t->drop_step, 2, t->efeat, s));
+      else
+        HIPCHK(m, hipMemcpyAsync(t->efeat, t->egath, (size_t)B * 32 * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(m, launch_embed_bias(t->efeat, t->params + t->w1_off, t->w1_pitch, flat, t->params + t->b1_off, B, c.hidden,
+                                  t->biasB, s));
+      fcb = t->biasB;
+      fcrow = t->iota;
+    }
     if (t->drop_p > 0.f) {            // Dropout -> Linear -> ReLU -> Dropout -> Linear (vo_cnn.py:216-227), masks by hash
       HIPCHK(m, launch_dropout(sc.raw, sc.ss[0], sc.ss[1], B, (long)m->fh * m->fw, m->comp_cp, t->drop_p, t->drop_seed,
                                t->drop_step, 0, t->zdrop, s));
-      if ((rc = pnvo_run_conv(m, m->fc, B, t->zdrop, nullptr, nullptr, t->hid, c.hidden, nullptr, m->fc_bias, nullptr, 1, s,
+      if ((rc = pnvo_run_conv(m, m->fc, B, t->zdrop, nullptr, nullptr, t->hid, c.hidden, nullptr, fcb, fcrow, 1, s,
                               nullptr, nullptr, nullptr)) != PNVO_OK)
         return rc;
       HIPCHK(m, launch_dropout(t->hid, nullptr, nullptr, B, 1, c.hidden, t->drop_p, t->drop_seed, t->drop_step, 1, t->hdrop,
@@ -585,7 +650,7 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
         return rc;
       return PNVO_OK;
     }
-    if ((rc = pnvo_run_conv(m, m->fc, B, sc.raw, sc.ss[0], sc.ss[1], t->hid, c.hidden, nullptr, m->fc_bias, nullptr, 1, s,
+    if ((rc = pnvo_run_conv(m, m->fc, B, sc.raw, sc.ss[0], sc.ss[1], t->hid, c.hidden, nullptr, fcb, fcrow, 1, s,
                             nullptr, nullptr, nullptr)) != PNVO_OK)
       return rc;
     if ((rc = pnvo_run_conv(m, m->head, B, t->hid, nullptr, nullptr, out, c.out_dim, nullptr, m->head_bias, nullptr, 0, s,
@@ -660,6 +725,15 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     // the activation tensor is channel-padded: tell the kernel the real row pitch through H/W/CIN = (fh, fw, comp_cp)
     a.CIN = m->comp_cp;
     wgrad_plan(a);
+    if (c.act_embed) {                // gradient rows are [flat | 32] wide; the embedding columns and rows come from embed_*
+      const int flat = m->comp_c * m->fh * m->fw;
+      a.grad_pitch = t->w1_pitch;
+      HIPCHK(m, launch_embed_backward(t->gh, t->efeat, t->params + t->w1_off, t->w1_pitch, flat, B, c.hidden,
+                                      t->grads + t->w1_off, t->dfeat, s));
+      if (t->drop_p > 0.f)
+        HIPCHK(m, launch_dropout(t->dfeat, nullptr, nullptr, B, 1, 32, t->drop_p, t->drop_seed, t->drop_step, 2, t->dfeat, s));
+      HIPCHK(m, launch_embed_scatter(t->dfeat, t->actions, B, c.n_acts + 1, t->grads + t->emb_off, s));
+    }
     if ((rc = run_wgrad(m, t, a, m->fc.name + ".weight", nullptr, m->comp_c, s)) != PNVO_OK) return rc;
     ConvArgs d;
     std::memset(&d, 0, sizeof(d));
@@ -780,13 +854,27 @@ int pnvo_train_set_dropout(pnvo_handle m, float p, uint64_t seed) {
   return PNVO_OK;
 }
 
+int pnvo_train_set_actions(pnvo_handle m, const int64_t *actions) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  TrainState *t = TS(m);
+  if (t->embed_err && *t->embed_err) {
+    *t->embed_err = 0;
+    return pnvo_fail(m, PNVO_ERR_INPUT, "an action of the previous step was outside the embedding table");
+  }
+  t->actions = reinterpret_cast<const long long *>(actions);
+  return PNVO_OK;
+}
+
 int pnvo_train_dropout_mask(pnvo_handle m, int layer, float *out, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   TrainState *t = TS(m);
-  if (t->lastB <= 0 || !out || (layer != 0 && layer != 1)) return pnvo_fail(m, PNVO_ERR_ARG, "bad argument / no forward yet");
+  if (t->lastB <= 0 || !out || layer < 0 || layer > 2) return pnvo_fail(m, PNVO_ERR_ARG, "bad argument / no forward yet");
   const pnvo_config &c = m->cfg;
   const float p = t->drop_p;
-  if (layer == 0)
+  if (layer == 2)
+    HIPCHK(m, launch_dropout(nullptr, nullptr, nullptr, t->lastB, 1, 32, p, t->drop_seed, t->drop_step, 2, out,
+                             (hipStream_t)stream));
+  else if (layer == 0)
     HIPCHK(m, launch_dropout(nullptr, nullptr, nullptr, t->lastB, (long)m->fh * m->fw, m->comp_cp, p, t->drop_seed,
                              t->drop_step, 0, out, (hipStream_t)stream));
   else

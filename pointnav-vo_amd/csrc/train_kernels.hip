@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs p, in
     const int ci = cit * 32 + row, co = cot * 32 + col;
     if (ci < p.CIN && co < p.COUT) {
       const int cio = ci_perm ? ci_perm[ci] : ci;     // stem: kernel channel order -> reference channel order
-      if (cio >= 0 && cio < cin_out) grad[((long)co * cin_out + cio) * T + tap] = (float)s;
+      if (cio >= 0 && cio < cin_out)
+        grad[(long)co * (p.grad_pitch ? p.grad_pitch : (long)cin_out * T) + (long)cio * T + tap] = (float)s;
     }
   }
 }
@@ -757,6 +758,91 @@ hipError_t launch_dropout(const float *x, const float *scale, const float *shift
   if (th > 4294967295.0) th = 4294967295.0;
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, total, P * C, C,
                      (unsigned)th, 1.0f / (1.0f - p), seed, step, layer, y);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Action-embedding variants (vo_cnn_act_embed.py:56-72): hidden = relu(Linear([visual | emb[action]])).  The visual columns
+// run as the fh x fw "conv"; the 32 embedding columns are a per-sample bias row
+//   bias[n][o] = b1[o] + sum_e W1[o][flat + e] * efeat[n][e],   efeat = dropout(emb[action_n])
+// and their backward is three tiny kernels (dW1 columns, d efeat, scatter into the embedding rows; fixed summation order).
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float *emb, const long long *actions, int B, int rows,
+                                                         float *out, int *err) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * 32) return;
+  const int n = e >> 5;
+  const long long a = actions ? actions[n] : (long long)n;        // actions == nullptr: the table itself (rows = B)
+  if (a < 0 || a >= rows) {
+    if (err) *err = 1;
+    out[e] = 0.f;
+    return;
+  }
+  out[e] = emb[a * 32 + (e & 31)];
+}
+
+__global__ __launch_bounds__(256) void embed_bias_kernel(const float *efeat, const float *w1, long pitch, int flat,
+                                                       const float *b1, int B, int hidden, float *bias) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * hidden) return;
+  const int n = e / hidden, o = e - n * hidden;
+  const float *w = w1 + (long)o * pitch + flat, *f = efeat + (long)n * 32;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) acc += (double)w[k] * (double)f[k];
+  bias[e] = (float)(acc + (double)b1[o]);
+}
+
+// dW1[o][flat + e] = sum_n gh[n][o] * efeat[n][e]
+__global__ __launch_bounds__(256) void embed_wgrad_kernel(const float *gh, const float *efeat, int B, int hidden, long pitch,
+                                                        int flat, float *dw1) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= hidden * 32) return;
+  const int o = t >> 5, e = t & 31;
+  double acc = 0.0;
+  for (int n = 0; n < B; ++n) acc += (double)gh[(long)n * hidden + o] * (double)efeat[(long)n * 32 + e];
+  dw1[(long)o * pitch + flat + e] = (float)acc;
+}
+
+// d efeat[n][e] = sum_o gh[n][o] * W1[o][flat + e]
+__global__ __launch_bounds__(256) void embed_dfeat_kernel(const float *gh, const float *w1, long pitch, int flat, int B,
+                                                        int hidden, float *dfeat) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * 32) return;
+  const int n = t >> 5, e = t & 31;
+  double acc = 0.0;
+  for (int o = 0; o < hidden; ++o) acc += (double)gh[(long)n * hidden + o] * (double)w1[(long)o * pitch + flat + e];
+  dfeat[t] = (float)acc;
+}
+
+// demb[a][e] = sum over the samples with action a, in sample order (torch's embedding backward sums duplicates)
+__global__ __launch_bounds__(32) void embed_scatter_kernel(const float *dfeat, const long long *actions, int B, float *demb) {
+  const int a = blockIdx.x, e = threadIdx.x;
+  double acc = 0.0;
+  for (int n = 0; n < B; ++n)
+    if (actions[n] == a) acc += (double)dfeat[(long)n * 32 + e];
+  demb[a * 32 + e] = (float)acc;
+}
+
+hipError_t launch_embed_gather(const float *emb, const long long *actions, int B, int rows, float *out, int *err, hipStream_t s) {
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((B * 32 + 255) / 256)), dim3(256), 0, s, emb, actions, B, rows, out, err);
+  return hipGetLastError();
+}
+hipError_t launch_embed_bias(const float *efeat, const float *w1, long pitch, int flat, const float *b1, int B, int hidden,
+                             float *bias, hipStream_t s) {
+  hipLaunchKernelGGL(embed_bias_kernel, dim3((unsigned)(((long)B * hidden + 255) / 256)), dim3(256), 0, s, efeat, w1, pitch, flat,
+                     b1, B, hidden, bias);
+  return hipGetLastError();
+}
+hipError_t launch_embed_backward(const float *gh, const float *efeat, const float *w1, long pitch, int flat, int B, int hidden,
+                                 float *dw1, float *dfeat, hipStream_t s) {
+  hipLaunchKernelGGL(embed_wgrad_kernel, dim3((unsigned)((hidden * 32 + 255) / 256)), dim3(256), 0, s, gh, efeat, B, hidden, pitch,
+                     flat, dw1);
+  hipLaunchKernelGGL(embed_dfeat_kernel, dim3((unsigned)((B * 32 + 255) / 256)), dim3(256), 0, s, gh, w1, pitch, flat, B, hidden,
+                     dfeat);
+  return hipGetLastError();
+}
+hipError_t launch_embed_scatter(const float *dfeat, const long long *actions, int B, int rows, float *demb, hipStream_t s) {
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)rows), dim3(32), 0, s, dfeat, actions, B, demb);
   return hipGetLastError();
 }
 

@@ -37,8 +37,6 @@ def _ptr(t):
 
 class VOTrainStep:
     def __init__(self, model, lr=2.5e-4, eps=1e-8, betas=(0.9, 0.999), dropout_seed=0):
-        if model.cfg.act_embed:
-            raise NotImplementedError("training of act_embed variants is not built")
         self.model = model
         self.lr, self.eps, self.betas = float(lr), float(eps), betas
         ref = next(model.parameters())
@@ -88,12 +86,16 @@ class VOTrainStep:
         compression channels padded to a multiple of 32, m1 [B, hidden])."""
         cfg = self.model.cfg
         fh, fw = ms_feature_hw(cfg)
-        cpad = (cfg.fc_in // (fh * fw) + 31) // 32 * 32
+        cpad = (cfg.comp_channels + 31) // 32 * 32
         m0 = torch.empty((batch, fh * fw, cpad), device=self.dev, dtype=torch.float32)
         m1 = torch.empty((batch, cfg.hidden), device=self.dev, dtype=torch.float32)
         s = torch.cuda.current_stream(self.dev).cuda_stream
         _lib.check(_lib.lib.pnvo_train_dropout_mask(self.model._handle, 0, _ptr(m0), C.c_void_p(s)), self.model._handle)
         _lib.check(_lib.lib.pnvo_train_dropout_mask(self.model._handle, 1, _ptr(m1), C.c_void_p(s)), self.model._handle)
+        if cfg.act_embed:                     # the embedding columns of the concatenated feature the Dropout acts on
+            m2 = torch.empty((batch, 32), device=self.dev, dtype=torch.float32)
+            _lib.check(_lib.lib.pnvo_train_dropout_mask(self.model._handle, 2, _ptr(m2), C.c_void_p(s)), self.model._handle)
+            return m0, m1, m2
         return m0, m1
 
     # ------------------------------------------------------------------ pieces
@@ -136,10 +138,24 @@ class VOTrainStep:
         rmv._mean = (rmv._count * rmv._mean + new_count * new_mean) / (rmv._count + new_count)
         rmv._count += new_count
 
-    def forward_train(self, obs_pairs):
-        """model.train(); out = model(obs_pairs): RunningMeanAndVar update + dropout, activations kept for a backward."""
+    def _set_actions(self, actions, B):
+        """act_embed variants: hand the [B] int64 actions of this step to the library (kept alive until the backward)."""
+        if not self.model.cfg.act_embed:
+            return
+        if actions is None:
+            raise TypeError("act_embed model: actions are required")
+        a = torch.as_tensor(actions).to(device=self.dev, dtype=torch.int64).contiguous().reshape(-1)
+        if a.numel() != B:
+            raise ValueError(f"actions has {a.numel()} entries for a batch of {B}")
+        self._actions = a
+        _lib.check(_lib.lib.pnvo_train_set_actions(self.model._handle, _ptr(a)), self.model._handle)
+
+    def forward_train(self, obs_pairs, actions=None):
+        """model.train(); out = model(obs_pairs[, actions]): RunningMeanAndVar update + dropout, activations kept for a
+        backward."""
         h = self.model._handle
         ptrs, keep, B = self._obs_ptrs(obs_pairs)
+        self._set_actions(actions, B)
         out = torch.empty((B, self.model.cfg.out_dim), device=self.dev, dtype=torch.float32)
         with torch.cuda.device(self.dev), torch.no_grad():
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -151,12 +167,13 @@ class VOTrainStep:
             _lib.check(_lib.lib.pnvo_train_forward(h, *ptrs, int(B), _ptr(mean), _ptr(var), _ptr(out), stream), h)
         return out
 
-    def forward_backward(self, obs_pairs, target=None, grad_out=None):
+    def forward_backward(self, obs_pairs, target=None, grad_out=None, actions=None):
         """Train-mode forward + backward.  Either `target` [B,3] (the reference's regression loss) or an explicit
         `grad_out` = dLoss/dOut [B,3] (e.g. from the geometric-invariance loss computed on the [B,3] outputs).
         Returns (out, loss or None); gradients are left in self.grad (not yet all-reduced)."""
         h = self.model._handle
         ptrs, keep, B = self._obs_ptrs(obs_pairs)
+        self._set_actions(actions, B)
         out = torch.empty((B, self.model.cfg.out_dim), device=self.dev, dtype=torch.float32)
         with torch.cuda.device(self.dev), torch.no_grad():
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -198,9 +215,9 @@ class VOTrainStep:
                                                self.step_count, stream))
             _lib.check(_lib.lib.pnvo_train_refresh(h, stream), h)
 
-    def step(self, obs_pairs, target):
+    def step(self, obs_pairs, target, actions=None):
         """zero_grad / forward / loss / backward / all-reduce / Adam — returns (out [B,3], loss tensor)."""
-        out, loss = self.forward_backward(obs_pairs, target=target)
+        out, loss = self.forward_backward(obs_pairs, target=target, actions=actions)
         self.optimizer_step()
         return out, loss
 
@@ -285,7 +302,7 @@ class GeoInvarianceTrainStep:
                     continue
                 di = idx.to(dev)
                 sub = {k: v.index_select(0, di).contiguous() for k, v in batch.items()}
-                out = st.forward_train(sub)
+                out = st.forward_train(sub, actions[idx] if st.model.cfg.act_embed else None)
                 preds.index_copy_(0, di, out)
                 coef = regression_coef(
                     idx.numel(), data_types[idx] if use_types else None,

@@ -144,14 +144,14 @@ class VisualOdometryCNNBase(nn.Module):
         if self.training:
             # train-mode forward (the reference's 'rnd' mode calls it at inference, base_trainer_with_vo.py:295-308):
             # dropout active AND RunningMeanAndVar updated by the batch, exactly as nn.Module.train() implies there
-            if self.cfg.act_embed:
-                raise NotImplementedError("train-mode forward of act_embed variants is not built")
+            if self.cfg.act_embed and actions is None:
+                raise TypeError("forward() missing required argument 'actions' (act_embed model)")
             ts = getattr(self, "_train_step", None)
             if ts is None:
                 from .train import VOTrainStep
                 ts = VOTrainStep(self)
                 object.__setattr__(self, "_train_step", ts)
-            return ts.forward_train(observation_pairs)
+            return ts.forward_train(observation_pairs, actions)
         ref = next(self.parameters())
         if ref.device.type != "cuda":
             raise RuntimeError("pointnav_vo_amd VO models run on an MI355X only: move the model with .to('cuda') "

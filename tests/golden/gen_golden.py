@@ -304,7 +304,7 @@ def boundary_fixture(registry, geo):
 
 
 # ----------------------------------------------------------------------------- training-step fixtures (a14)
-def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtype):
+def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtype, actions=None):
     """model.train() forward (RunningMeanAndVar update), the reference's own _compute_loss for dx/dz/dyaw
     (vo/engine/vo_cnn_engine.py:135-198), backward, torch.optim.Adam(lr=2.5e-4, eps=1e-8) as the engine sets it up
     (vo_cnn_regression_geo_invariance_engine.py:122-133; configs/vo/vo_pointnav.yaml:35-45).  dropout_p = 0 so the step
@@ -321,12 +321,15 @@ def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtyp
     exec(meths["_compute_loss"], nsd)
     opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-8, weight_decay=0)
     rec = dict(model=name, obs_space=",".join(obs_space), width=W, height=H, batch=B, dd_bins=dd_bins, seed=seed,
-               baseplanes=cfg.baseplanes, act_embed=0, target=target, lr=2.5e-4, eps=1e-8)
+               baseplanes=cfg.baseplanes, act_embed=int(actions is not None), target=target, lr=2.5e-4, eps=1e-8)
+    if actions is not None:
+        rec["actions"] = np.asarray(actions, dtype=np.int64)
     tgt = torch.from_numpy(target).to(dtype)
     tgts = (tgt[:, 0:1], tgt[:, 1:2], tgt[:, 2:3])
     for step in (1, 2):
         opt.zero_grad()
-        out = model({k: torch.from_numpy(v).to(dtype) for k, v in obs.items()})
+        tobs = {k: torch.from_numpy(v).to(dtype) for k, v in obs.items()}
+        out = model(tobs) if actions is None else model(tobs, torch.as_tensor(actions, dtype=torch.long))
         loss = 0
         for d, dt in enumerate(["dx", "dz", "dyaw"]):
             loss = loss + nsd["_compute_loss"](None, out[:, d:d + 1], tgts, d_type=dt)[0]
@@ -478,6 +481,10 @@ def main():
     torch.set_num_threads(8)
     registry, geo = import_reference()
     full = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    if len(sys.argv) > 1 and sys.argv[1] == "actembed":      # regenerate just the act-embed training fixture
+        train_fixture(registry, "train_act_embed_64x48_b5_f64.npz", "vo_cnn_act_embed", ["rgb", "depth"], (64, 48), 5, 0, 33,
+                      torch.float64, actions=[1, 3, 2, 3, 1])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "joint":         # regenerate just the joint-training fixtures
         joint_train_fixture(registry, "train_joint_64x48_p4.npz", (64, 48), 4, 41, True)
         joint_train_fixture(registry, "train_joint_45x37_p3_w.npz", (45, 37), 3, 42, False)
@@ -501,6 +508,8 @@ def main():
     boundary_fixture(registry, geo)
     train_fixture(registry, "train_default_45x37_b4_f64.npz", "vo_cnn_rgb_d_dd_top_down", full, (45, 37), 4, 10, 31, torch.float64)
     train_fixture(registry, "train_default_96x64_b3_f32.npz", "vo_cnn_rgb_d_dd_top_down", full, (96, 64), 3, 10, 32, torch.float32)
+    train_fixture(registry, "train_act_embed_64x48_b5_f64.npz", "vo_cnn_act_embed", ["rgb", "depth"], (64, 48), 5, 0, 33,
+                  torch.float64, actions=[1, 3, 2, 3, 1])
     geo_loss_fixture()
     joint_train_fixture(registry, "train_joint_64x48_p4.npz", (64, 48), 4, 41, True)
     joint_train_fixture(registry, "train_joint_45x37_p3_w.npz", (45, 37), 3, 42, False)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def build(rec, dropout_p=0.0):
-    cfg, sd, obs, _ = golden_case(rec)
+    cfg, sd, obs, _acts = golden_case(rec)
     space = str(rec["obs_space"]).split(",")
     model = baseline_registry.get_vo_model(str(rec["model"]))(
         observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
@@ -208,3 +208,56 @@ def test_geo_inverse_loss_kernel_matches_reference_golden():
         assert abs(out4[0].item() - w * float(rec["loss"])) < 1e-5 * max(1.0, float(rec["loss"]))
         np.testing.assert_allclose(g.cpu().numpy(), w * rec["grad"], rtol=1e-4, atol=1e-6)
     assert _lib.lib.pnvo_geo_inverse_loss(C.c_void_p(d.data_ptr()), C.c_void_p(a.data_ptr()), 3, 1, C.c_float(1.0), None, None, s) != 0
+
+
+@pytest.mark.parametrize("dropout_p", [0.0, 0.2])
+def test_act_embed_train_step_matches_reference(dropout_p):
+    """vo_cnn_act_embed (vo_cnn_act_embed.py:17-75): the Linear's embedding columns run as per-sample bias rows; their
+    gradients (Linear columns, embedding rows incl. duplicates and never-used rows) against the golden / the fp64 checker."""
+    rec = load_golden("train_act_embed_64x48_b5_f64.npz")
+    model, cfg, sd, obs, tobs = build(rec, dropout_p=dropout_p)
+    actions = torch.from_numpy(rec["actions"])
+    ts = VOTrainStep(model, lr=float(rec["lr"]), eps=float(rec["eps"]), dropout_seed=11)
+    target = torch.from_numpy(rec["target"]).to("cuda:0")
+    out, loss = ts.forward_backward(tobs, target=target, actions=actions)
+    torch.cuda.synchronize()
+    masks = None
+    if dropout_p > 0:
+        m0, m1, m2 = ts.dropout_masks(out.shape[0])
+        B = out.shape[0]
+        fh, fw = cfg.final_hw
+        cc = cfg.comp_channels
+        vis = m0.reshape(B, fh, fw, -1)[..., :cc].permute(0, 3, 1, 2).reshape(B, -1)       # kernel NHWC -> NCHW flatten
+        masks = (torch.cat([vis, m2], dim=1).cpu().double(), m1.cpu().double())
+        keep = float((masks[0] > 0).double().mean())
+        assert 0.6 < keep < 0.95
+    chk = ref.train_step(sd, obs, rec["target"], ngroups=cfg.ngroups, lr=float(rec["lr"]), eps=float(rec["eps"]),
+                         dtype=torch.float64, actions=rec["actions"], drop_masks=masks)
+    if dropout_p == 0:
+        np.testing.assert_allclose(out.cpu().numpy(), rec["out1"], rtol=2e-4, atol=2e-5)
+        assert abs(loss.item() - float(rec["loss1"])) < 1e-4 * max(1.0, abs(float(rec["loss1"])))
+    np.testing.assert_allclose(out.cpu().numpy(), chk["out"].numpy(), rtol=2e-4, atol=2e-5)
+    bad = []
+    for name, (off, n) in ts.offsets.items():
+        g = ts.grad[off:off + n].cpu().double().numpy()
+        gr = chk["grads"][name].reshape(-1).numpy()
+        err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
+        if err > 2e-3:
+            bad.append((name, err, np.linalg.norm(g), np.linalg.norm(gr)))
+        if dropout_p == 0:
+            gn = float(rec[f"g1norm/{name}"])
+            assert abs(np.linalg.norm(g) - gn) <= 5e-3 * max(gn, 1e-9), name
+    assert not bad, bad
+    emb = ts.grad[ts.offsets["action_embedding.weight"][0]:][:5 * 32].reshape(5, 32).cpu()
+    assert not emb[0].any() and not emb[4].any() and emb[1].any() and emb[3].any()      # rows of unused actions stay zero
+    # after the step the eval-mode forward (per-action bias rows rebuilt on the device) matches the checker's new parameters
+    ts.optimizer_step()
+    torch.cuda.synchronize()
+    if dropout_p == 0:
+        from oracle import oracle
+        newsd = {**{k: v.numpy() for k, v in chk["params"].items()}, **{k: v.numpy() for k, v in chk["buffers"].items()}}
+        want = oracle.forward(newsd, obs, ngroups=cfg.ngroups, dtype=np.float64, actions=rec["actions"])
+        with torch.no_grad():
+            got = model.eval()(tobs, actions.to("cuda:0")).cpu().numpy()
+        err = np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-2)
+        assert err.max() < 5e-3, err

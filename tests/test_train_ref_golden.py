@@ -9,12 +9,12 @@ from oracle import torch_train_ref as ref
 
 
 def run_steps(rec, dtype, nsteps):
-    cfg, sd, obs, _ = golden_case(rec)
+    cfg, sd, obs, actions = golden_case(rec)
     cur = {k: np.array(v) for k, v in sd.items()}
     state, res = None, []
     for step in range(1, nsteps + 1):
         r = ref.train_step(cur, obs, rec["target"], ngroups=cfg.ngroups, lr=float(rec["lr"]), eps=float(rec["eps"]),
-                           dtype=dtype, state=state, step=step)
+                           dtype=dtype, state=state, step=step, actions=actions)
         res.append(r)
         state = r["state"]
         cur = {**{k: v.numpy() for k, v in r["params"].items()}, **{k: v.numpy() for k, v in r["buffers"].items()}}
@@ -22,6 +22,7 @@ def run_steps(rec, dtype, nsteps):
 
 
 @pytest.mark.parametrize("fname,dtype,tol", [("train_default_45x37_b4_f64.npz", torch.float64, 1e-9),
+                                             ("train_act_embed_64x48_b5_f64.npz", torch.float64, 1e-9),
                                              ("train_default_96x64_b3_f32.npz", torch.float32, 2e-3)])
 def test_train_step_matches_reference(fname, dtype, tol):
     rec = load_golden(fname)
