@@ -120,7 +120,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   // ---- loader state: the (kh, kw, j) of the next stage to fetch and the byte offsets of its tap
-  int l_kh = 0, l_kw = 0, l_j = 0, l_s = 0;
+  const int S_all = SJ / JC;             // pipeline stages of the whole reduction
+  int s_begin = 0, s_end = S_all;
+  if (p.ksplit > 1) {                    // split-K (linear layers with few output tiles): this z-slice's stages
+    const int per = (S_all + p.ksplit - 1) / p.ksplit;
+    s_begin = (int)blockIdx.z * per;
+    s_end = s_begin + per < S_all ? s_begin + per : S_all;
+  }
+  int l_s = s_begin * JC, l_j = l_s % J;
+  int l_kh = (l_s / J) / p.KW, l_kw = (l_s / J) % p.KW;
   unsigned toff[MT];
   auto set_tap = [&]() {
 #pragma unroll
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     unsigned ok0 = 0, ok1 = 0;
     int j0 = 0, j1 = 0;
     fetch(a0, b0, ok0, j0);
-    const int S = SJ / JC;               // pipeline stages
+    const int S = s_end - s_begin;       // pipeline stages (>= 1)
     int s = 0;
     for (; s + 2 <= S - 1; s += 2) {     // invariant: stage s is in buffer 0, stages s+1, s+2 exist
       fetch(a1, b1, ok1, j1);
@@ -249,8 +257,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   {
     long rows = M - m_base;
     if (rows > WM) rows = WM;
+    float *ybase = p.ksplit > 1 ? p.kpart + (long)blockIdx.z * M * p.y_cstride : p.y;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.y + m_base * p.y_cstride), 0, clamp_records(rows * p.y_cstride * 4), 0x00020000);
+        (void *)(ybase + m_base * p.y_cstride), 0, clamp_records(rows * p.y_cstride * 4), 0x00020000);
     const unsigned rstride = (unsigned)p.y_cstride * 4u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -344,8 +353,13 @@ template <int MT, int NT>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
   const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
   const int WM = MT * 32;
-  dim3 grid((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)(a.COUTP / 32 / NT));
+  dim3 grid((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)(a.COUTP / 32 / NT), (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
   ConvArgs p = a;
+  if (a.ksplit > 1) {            // raw partials: bias and ReLU belong to the reduce
+    p.bias = nullptr;
+    p.bias_row = nullptr;
+    p.relu_out = 0;
+  }
   size_t lds_bytes = 0;
   // 32-channel stages where the register file allows 2 waves/SIMD; the GN-prologue variant of the 4-accumulator
   // tiles (2x2, 1x4) only fits 16-channel stages
@@ -375,6 +389,44 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
     else
       hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0, 1>), grid, dim3(256), 0, s, p);
   }
+  return hipGetLastError();
+}
+
+// Split-K pays when a linear layer has too few output tiles to fill the chip and a long reduction (the 6x11 "conv" of the
+// FC: 32 workgroups x 66 stages at 256 pairs).  Only for plain linear epilogues (no statistics, no accumulate).
+int conv_ksplit(const ConvArgs &a) {
+  if (a.kpart == nullptr || a.stats != nullptr || a.accum || a.src_mode) return 1;
+  const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
+  const long wgs = ((M + 4L * a.MT * 32 - 1) / (4L * a.MT * 32)) * (a.COUTP / 32 / a.NT);
+  int jc = 1;                          // channel groups per pipeline stage, as launch_t picks them
+  if (a.MT != 4 && a.CIN % 32 == 0) jc = (a.in_scale != nullptr && a.MT * a.NT >= 4) ? 2 : 4;
+  const int S = a.KH * a.KW * (a.CIN / 8) / jc;
+  if (wgs >= 128 || S < 16) return 1;
+  int k = (int)(512 / wgs);
+  if (k > S / 4) k = S / 4;
+  if (k > 32) k = 32;
+  if (k < 2) return 1;
+  const int per = (S + k - 1) / k;
+  return (S + per - 1) / per;        // every slice non-empty
+}
+
+__global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *part, int ks, long M, int C, const float *bias,
+                                                          const int64_t *bias_row, int COUT, long P, int relu, float *y) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * C) return;
+  const long m = e / C;
+  const int c = (int)(e - m * C);
+  float v = 0.f;
+  for (int z = 0; z < ks; ++z) v += part[(long)z * M * C + e];      // fixed order
+  if (bias != nullptr && c < COUT) v += bias[(bias_row ? bias_row[m / P] : 0) * COUT + c];
+  if (relu) v = fmaxf(v, 0.f);
+  y[e] = v;
+}
+
+hipError_t launch_ksplit_reduce(const ConvArgs &a, hipStream_t s) {
+  const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
+  hipLaunchKernelGGL(ksplit_reduce_kernel, dim3((unsigned)((M * a.y_cstride + 255) / 256)), dim3(256), 0, s, a.kpart, a.ksplit,
+                     M, a.y_cstride, a.bias, a.bias_row, a.COUT, P, a.relu_out, a.y);
   return hipGetLastError();
 }
 

@@ -319,6 +319,15 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   }
   m->tapbuf_floats = (size_t)B * m->fh * m->fw * m->comp_cp;
   HIPCHK(m, alloc(m->tapbuf, m->tapbuf_floats));
+  {                                     // split-K partials of the linear layers: <= 32 slices of [B, hidden]
+    const size_t need = (size_t)32 * B * (size_t)std::max(c.hidden, 32);
+    if (need > m->kpart_floats) {
+      free_dev(m->kpart);
+      m->kpart_floats = 0;
+      HIPCHK(m, alloc(m->kpart, need));
+      m->kpart_floats = need;
+    }
+  }
   m->cap = B;
   return PNVO_OK;
 }
@@ -452,9 +461,28 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     }
     return PNVO_OK;
   }
+  if (bias != nullptr && !ss) {  // linear layer: split the reduction when the output tiles alone cannot fill the chip
+    a.kpart = reinterpret_cast<float *>(8);          // non-null: "scratch available" for the query
+    const int ks = conv_ksplit(a);
+    a.kpart = nullptr;
+    if (ks > 1) {
+      const size_t need = (size_t)ks * M * y_cstride;
+      if (need > m->kpart_floats) {
+        pnvo_drop_graphs(m);                         // captured launches point into the old scratch
+        if (m->kpart) (void)hipFree(m->kpart);
+        m->kpart = nullptr;
+        m->kpart_floats = 0;
+        HIPCHK(m, hipMalloc((void **)&m->kpart, need * sizeof(float)));
+        m->kpart_floats = need;
+      }
+      a.kpart = m->kpart;
+      a.ksplit = ks;
+    }
+  }
   {
     Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
     HIPCHK(m, launch_conv(a, s));
+    if (a.ksplit > 1) HIPCHK(m, launch_ksplit_reduce(a, s));
   }
   if (ss) {
     Timed t(m, s, "gn_finalize", 0.0, 0.0);
@@ -1104,6 +1132,7 @@ int pnvo_destroy(pnvo_handle m) {
     (void)hipFree(m->dd_prof);
   }
   free_dev(m->zero_page);
+  free_dev(m->kpart);
   for (auto &r : m->trecs) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);

@@ -34,6 +34,8 @@ struct ConvArgs {
   int up;                // 2: transposed (backward-data of a stride-2 conv): source = (pos - pad + k) / 2 when even; else 1
   int accum;             // epilogue adds into y instead of overwriting it
   const float *zero_page;            // >= 16 B of zeros (target of masked gathers)
+  int ksplit;            // > 1: blockIdx.z owns a slice of the (tap, channel-group) stages and writes a raw partial
+  float *kpart;          // [ksplit][M][y_cstride] partials (bias / ReLU / y are left to ksplit_reduce)
   SrcPiece pieces[8][2][2];          // [j][lane half h][q]: channels 8j+4h+2q, +1 of the stem's K order
 };
 
@@ -79,6 +81,9 @@ hipError_t launch_stem_dd_repack(const float *w_oihw, int cin, const float *sc_n
 int conv_slots(int P, int MT);                       // stats slots per sample for a given wave tile
 void choose_tile(long M, int COUTP, int *MT, int *NT);
 hipError_t launch_conv(const ConvArgs &a, hipStream_t s);
+// y = [relu](sum_z kpart[z] + bias[row]) for a split-K linear layer (a.ksplit > 1)
+hipError_t launch_ksplit_reduce(const ConvArgs &a, hipStream_t s);
+int conv_ksplit(const ConvArgs &a);   // how many K slices launch_conv would use for `a` when a.kpart is set (1: none)
 
 // LDS-staged 3x3 stride-1 kernel (conv3_lds.hip): same arguments / packing / epilogue contract as launch_conv.
 bool conv3_lds_supported(const ConvArgs &a);

@@ -40,6 +40,8 @@ struct pnvo_model_s {
   std::vector<int> stem_ref_of_new;  // new channel -> reference channel (vo_cnn.py:169-174 order), -1 = pad
   std::vector<int> stem_tensor_of_new, stem_ch_of_new;
   float *stem_sc = nullptr, *stem_sh = nullptr, *zero_page = nullptr;   // device: whitening table in the new order
+  float *kpart = nullptr;             // split-K partials of the linear layers (conv_mfma.hip conv_ksplit)
+  size_t kpart_floats = 0;
   float *stem_wpk16 = nullptr;       // stem weights packed for the LDS-staged 16x16x4 kernel
   int CPL = 0;                       // stem channels per pixel in LDS (C rounded up to 16)
   // one-hot-aware stem (stem_dd.hip): dense channels + indicator on the matrix cores, depth bins as a table gather
