@@ -324,7 +324,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     long long tbar = 0;
     auto row_end = [&](int kh) {                  // slice kh+1 has landed for everyone; slice kh's buffer is free
       const long long b0 = PROF ? clock64() : 0;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // vmcnt retires in order: "at most BD outstanding" leaves only the weight prefetches of the next BD blocks in
+      // flight — the table DMA of this row's start (>= 10 loads older) has landed.  vmcnt(0) would drain the prefetches
+      // (an L2 round trip) at every row end.
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BD) : "memory");
       __syncthreads();
       if (PROF) tbar += clock64() - b0;
       if (kh + 2 < 7) dma_slice(kh + 2, kh & 1);
