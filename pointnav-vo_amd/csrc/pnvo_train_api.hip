@@ -362,23 +362,28 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
   }
   t->wg_partial_floats = wgmax;
   if ((rc = dmalloc(m, (void **)&t->wg_partial, wgmax * 4)) != PNVO_OK) return rc;
-  // block outputs
-  t->y.assign(9, nullptr);
+  // block outputs: y[0] = pooled stem output, y[k] = output of residual block k (plan order)
+  size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes;
+  const size_t stem = (size_t)B * m->Hs * m->Ws * c.baseplanes;
   {
-    int h = m->Hp, w = m->Wp, ch = c.baseplanes;
-    if ((rc = dmalloc(m, (void **)&t->y[0], (size_t)B * h * w * ch * 4)) != PNVO_OK) return rc;
-    int k = 1;
-    for (int stage = 1; stage <= 4; ++stage) {
-      if (stage > 1) {
-        h = halve(h);
-        w = halve(w);
-        ch *= 2;
-      }
-      for (int bi = 0; bi < 2; ++bi, ++k)
-        if ((rc = dmalloc(m, (void **)&t->y[k], (size_t)B * h * w * ch * 4)) != PNVO_OK) return rc;
+    const int K = m->bottleneck ? 3 : 2;
+    const int nb = m->nblocks[0] + m->nblocks[1] + m->nblocks[2] + m->nblocks[3];
+    t->y.assign((size_t)nb + 1, nullptr);
+    if ((rc = dmalloc(m, (void **)&t->y[0], act * 4)) != PNVO_OK) return rc;
+    size_t li = 1;
+    for (int k = 1; k <= nb; ++k) {
+      const Layer &last = m->convs[li + K - 1];
+      const size_t n = (size_t)B * last.hout * last.wout * last.coutp;
+      if ((rc = dmalloc(m, (void **)&t->y[k], n * 4)) != PNVO_OK) return rc;
+      li += K;
+      if (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos) ++li;
+    }
+    for (size_t k = 1; k < m->convs.size(); ++k) {      // scratch gradients are as large as the largest activation
+      const Layer &l = m->convs[k];
+      act = std::max(act, (size_t)B * l.hout * l.wout * l.coutp);
+      act = std::max(act, (size_t)B * l.hin * l.win * l.cinp);
     }
   }
-  const size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes, stem = (size_t)B * m->Hs * m->Ws * c.baseplanes;
   if ((rc = dmalloc(m, (void **)&t->pool_idx, act)) != PNVO_OK) return rc;
   if ((rc = dmalloc(m, (void **)&t->hid, (size_t)B * c.hidden * 4)) != PNVO_OK) return rc;
   if ((rc = dmalloc(m, (void **)&t->dYa, act * 4)) != PNVO_OK) return rc;
@@ -508,7 +513,6 @@ void pnvo_train_free(pnvo_handle m) {
 extern "C" {
 
 int pnvo_train_attach(pnvo_handle m, float *params, float *grads, size_t n_floats, const pnvo_tensor_desc *toc, int ntoc) {
-  if (m && m->bottleneck) return pnvo_fail(m, PNVO_ERR_ARG, "training of the Bottleneck backbones (vo_cnn_deeper) is not built");
   if (!m || !params || !grads || !toc) return pnvo_fail(m, PNVO_ERR_ARG, "null argument");
   if (!m->loaded) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach before pnvo_load_weights");
   if (n_floats >= (1u << 24)) return pnvo_fail(m, PNVO_ERR_ARG, "flat parameter buffer too large for the index maps");
@@ -586,22 +590,27 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
     const Layer &stem = m->convs[li++];
     HIPCHK(m, launch_maxpool_train(cs.raw, cs.ss[0], cs.ss[1], B, m->Hs, m->Ws, stem.coutp, t->y[0], t->pool_idx, s));
   }
+  // residual blocks: a chain of K convs (BasicBlock K = 2, resnet.py:29-55; Bottleneck K = 3, :58-117) + the skip branch
+  const int K = m->bottleneck ? 3 : 2;
   int yk = 0;
   for (int stage = 1; stage <= 4; ++stage)
-    for (int bi = 0; bi < 2; ++bi) {
+    for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
       const float *xin = t->y[yk];
       float *yout = t->y[yk + 1];
-      const size_t i1 = li++, i2 = li++;
-      const Layer &c1 = m->convs[i1], &c2 = m->convs[i2];
+      size_t ik[3];
+      for (int k = 0; k < K; ++k) ik[k] = li++;
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
-      ConvSave &s1 = t->cs[i1], &s2 = t->cs[i2];
-      if ((rc = pnvo_run_conv(m, c1, B, xin, nullptr, nullptr, s1.raw, c1.coutp, s1.ss, nullptr, nullptr, 0, s, nullptr,
-                              s1.mu, s1.rstd)) != PNVO_OK)
-        return rc;
-      if ((rc = pnvo_run_conv(m, c2, B, s1.raw, s1.ss[0], s1.ss[1], s2.raw, c2.coutp, s2.ss, nullptr, nullptr, 0, s, nullptr,
-                              s2.mu, s2.rstd)) != PNVO_OK)
-        return rc;
-      const long P = (long)c2.hout * c2.wout;
+      for (int k = 0; k < K; ++k) {
+        const Layer &ck = m->convs[ik[k]];
+        ConvSave &sk = t->cs[ik[k]];
+        const ConvSave *sp = k ? &t->cs[ik[k - 1]] : nullptr;
+        if ((rc = pnvo_run_conv(m, ck, B, k ? sp->raw : xin, k ? sp->ss[0] : nullptr, k ? sp->ss[1] : nullptr, sk.raw, ck.coutp,
+                                sk.ss, nullptr, nullptr, 0, s, nullptr, sk.mu, sk.rstd)) != PNVO_OK)
+          return rc;
+      }
+      const Layer &cl = m->convs[ik[K - 1]];
+      ConvSave &sl = t->cs[ik[K - 1]];
+      const long P = (long)cl.hout * cl.wout;
       if (ds) {
         const size_t id = li++;
         const Layer &cd = m->convs[id];
@@ -609,17 +618,18 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
         if ((rc = pnvo_run_conv(m, cd, B, xin, nullptr, nullptr, sd.raw, cd.coutp, sd.ss, nullptr, nullptr, 0, s, nullptr,
                                 sd.mu, sd.rstd)) != PNVO_OK)
           return rc;
-        HIPCHK(m, launch_residual(s2.raw, s2.ss[0], s2.ss[1], sd.raw, sd.ss[0], sd.ss[1], B, P, c2.coutp, yout, s));
+        HIPCHK(m, launch_residual(sl.raw, sl.ss[0], sl.ss[1], sd.raw, sd.ss[0], sd.ss[1], B, P, cl.coutp, yout, s));
       } else {
-        HIPCHK(m, launch_residual(s2.raw, s2.ss[0], s2.ss[1], xin, nullptr, nullptr, B, P, c2.coutp, yout, s));
+        HIPCHK(m, launch_residual(sl.raw, sl.ss[0], sl.ss[1], xin, nullptr, nullptr, B, P, cl.coutp, yout, s));
       }
       ++yk;
     }
+  const int nblk_total = yk;
   {
     const size_t ic = li++;
     const Layer &comp = m->convs[ic];
     ConvSave &sc = t->cs[ic];
-    if ((rc = pnvo_run_conv(m, comp, B, t->y[8], nullptr, nullptr, sc.raw, comp.coutp, sc.ss, nullptr, nullptr, 0, s, nullptr,
+    if ((rc = pnvo_run_conv(m, comp, B, t->y[nblk_total], nullptr, nullptr, sc.raw, comp.coutp, sc.ss, nullptr, nullptr, 0, s, nullptr,
                             sc.mu, sc.rstd)) != PNVO_OK)
       return rc;
     ++t->drop_step;
@@ -670,6 +680,7 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   int rc = PNVO_OK;
 
+  const int nblk_total = m->nblocks[0] + m->nblocks[1] + m->nblocks[2] + m->nblocks[3];
   // ---- output head: out = hid . W2^T + b2
   HIPCHK(m, launch_padcopy(grad_out, B, c.out_dim, 8, t->dout8, s));
   {
@@ -762,7 +773,7 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     const Layer &l = m->convs[icomp];
     if ((rc = run_gn_bwd(m, t, icomp, B, t->dz, 1, t->dz, s)) != PNVO_OK) return rc;   // in place: dz -> dCompRaw
     WgradArgs a = wgrad_args(l, B, l.cin, l.coutp);
-    a.x = t->y[8];
+    a.x = t->y[nblk_total];
     a.dy = t->dz;
     a.mode = 0;
     if ((rc = run_wgrad(m, t, a, l.name + ".weight", nullptr, l.cin, s)) != PNVO_OK) return rc;
@@ -770,40 +781,43 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
   }
   // ---- residual blocks, last to first.  Conv indices: walk m->convs backwards from the compression layer.
   size_t li = icomp;
-  for (int blk = 8; blk >= 1; --blk) {
+  const int K = m->bottleneck ? 3 : 2;
+  for (int blk = nblk_total; blk >= 1; --blk) {
     const bool ds = m->convs[li - 1].name.find("downsample") != std::string::npos;
     const size_t id = ds ? li - 1 : 0;
-    const size_t i2 = ds ? li - 2 : li - 1, i1 = i2 - 1;
-    li = i1;
-    const Layer &c1 = m->convs[i1], &c2 = m->convs[i2];
-    const ConvSave &s1 = t->cs[i1];
+    size_t ik[3];
+    {
+      size_t last = ds ? li - 2 : li - 1;
+      for (int k = K - 1; k >= 0; --k) ik[k] = last - (size_t)(K - 1 - k);
+    }
+    li = ik[0];
+    const Layer &c1 = m->convs[ik[0]], &cl = m->convs[ik[K - 1]];
     const float *xin = t->y[blk - 1];
-    const long nout = (long)B * c2.hout * c2.wout * c2.coutp;
+    const long nout = (long)B * cl.hout * cl.wout * cl.coutp;
     const long nin = (long)B * c1.hin * c1.win * c1.cin;
     // G = dY * (y > 0)
     HIPCHK(m, launch_relu_mask(dY, t->y[blk], nullptr, nout, t->G, s));
-    // second conv: GN2 (no ReLU) <- G
-    if ((rc = run_gn_bwd(m, t, i2, B, t->G, 0, t->dRaw, s)) != PNVO_OK) return rc;
-    {
-      WgradArgs a = wgrad_args(c2, B, c2.cin, c2.coutp);
-      a.x = s1.raw;
-      a.in_scale = s1.ss[0];
-      a.in_shift = s1.ss[1];
+    // the chain, last conv first: GroupNorm (+ ReLU mask for every conv but the last) <- incoming gradient
+    const float *din = t->G;
+    for (int k = K - 1; k >= 0; --k) {
+      const Layer &ck = m->convs[ik[k]];
+      if ((rc = run_gn_bwd(m, t, ik[k], B, din, k == K - 1 ? 0 : 1, t->dRaw, s)) != PNVO_OK) return rc;
+      WgradArgs a = wgrad_args(ck, B, ck.cin, ck.coutp, k ? 1 : 0);
+      if (k) {                        // the conv saw relu(GN(raw of the previous conv)): recomputed in the fetch
+        const ConvSave &sp = t->cs[ik[k - 1]];
+        a.x = sp.raw;
+        a.in_scale = sp.ss[0];
+        a.in_shift = sp.ss[1];
+        a.mode = 1;
+      } else {
+        a.x = xin;
+        a.mode = 0;
+      }
       a.dy = t->dRaw;
-      a.mode = 1;
-      if ((rc = run_wgrad(m, t, a, c2.name + ".weight", nullptr, c2.cin, s)) != PNVO_OK) return rc;
+      if ((rc = run_wgrad(m, t, a, ck.name + ".weight", nullptr, ck.cin, s)) != PNVO_OK) return rc;
+      if ((rc = run_dgrad(m, t, ik[k], B, t->dRaw, k ? t->dA : dX, false, s)) != PNVO_OK) return rc;
+      din = t->dA;
     }
-    if ((rc = run_dgrad(m, t, i2, B, t->dRaw, t->dA, false, s)) != PNVO_OK) return rc;
-    // first conv: GN1 + ReLU <- dA
-    if ((rc = run_gn_bwd(m, t, i1, B, t->dA, 1, t->dRaw, s)) != PNVO_OK) return rc;
-    {
-      WgradArgs a = wgrad_args(c1, B, c1.cin, c1.coutp);
-      a.x = xin;
-      a.dy = t->dRaw;
-      a.mode = 0;
-      if ((rc = run_wgrad(m, t, a, c1.name + ".weight", nullptr, c1.cin, s)) != PNVO_OK) return rc;
-    }
-    if ((rc = run_dgrad(m, t, i1, B, t->dRaw, dX, false, s)) != PNVO_OK) return rc;
     // skip connection
     if (ds) {
       const Layer &cd = m->convs[id];

@@ -304,13 +304,13 @@ def boundary_fixture(registry, geo):
 
 
 # ----------------------------------------------------------------------------- training-step fixtures (a14)
-def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtype, actions=None):
+def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtype, actions=None, extra=None):
     """model.train() forward (RunningMeanAndVar update), the reference's own _compute_loss for dx/dz/dyaw
     (vo/engine/vo_cnn_engine.py:135-198), backward, torch.optim.Adam(lr=2.5e-4, eps=1e-8) as the engine sets it up
     (vo_cnn_regression_geo_invariance_engine.py:122-133; configs/vo/vo_pointnav.yaml:35-45).  dropout_p = 0 so the step
     is deterministic (torch's dropout RNG cannot be reproduced elsewhere)."""
     W, H = size
-    model, cfg, sd = build_ref_model(registry, name, obs_space, size, dd_bins, seed, extra=dict(dropout_p=0.0))
+    model, cfg, sd = build_ref_model(registry, name, obs_space, size, dd_bins, seed, extra=dict(extra or {}, dropout_p=0.0))
     model = model.double() if dtype == torch.float64 else model.float()
     model.train()
     obs = synth.make_obs_pairs(B, H, W, observation_space=obs_space, dd_bins=max(dd_bins, 1), seed=seed)
@@ -321,7 +321,8 @@ def train_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, dtyp
     exec(meths["_compute_loss"], nsd)
     opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-8, weight_decay=0)
     rec = dict(model=name, obs_space=",".join(obs_space), width=W, height=H, batch=B, dd_bins=dd_bins, seed=seed,
-               baseplanes=cfg.baseplanes, act_embed=int(actions is not None), target=target, lr=2.5e-4, eps=1e-8)
+               baseplanes=cfg.baseplanes, act_embed=int(actions is not None), target=target, lr=2.5e-4, eps=1e-8,
+               backbone=(extra or {}).get("backbone", "resnet18"))
     if actions is not None:
         rec["actions"] = np.asarray(actions, dtype=np.int64)
     tgt = torch.from_numpy(target).to(dtype)
@@ -481,6 +482,10 @@ def main():
     torch.set_num_threads(8)
     registry, geo = import_reference()
     full = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    if len(sys.argv) > 1 and sys.argv[1] == "traindeeper":   # regenerate just the Bottleneck training fixture
+        train_fixture(registry, "train_deeper_64x48_b2_f64.npz", "vo_cnn_deeper", ["rgb", "depth"], (64, 48), 2, 0, 34,
+                      torch.float64, extra={"backbone": "resnet101"})
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "actembed":      # regenerate just the act-embed training fixture
         train_fixture(registry, "train_act_embed_64x48_b5_f64.npz", "vo_cnn_act_embed", ["rgb", "depth"], (64, 48), 5, 0, 33,
                       torch.float64, actions=[1, 3, 2, 3, 1])
@@ -510,6 +515,8 @@ def main():
     train_fixture(registry, "train_default_96x64_b3_f32.npz", "vo_cnn_rgb_d_dd_top_down", full, (96, 64), 3, 10, 32, torch.float32)
     train_fixture(registry, "train_act_embed_64x48_b5_f64.npz", "vo_cnn_act_embed", ["rgb", "depth"], (64, 48), 5, 0, 33,
                   torch.float64, actions=[1, 3, 2, 3, 1])
+    train_fixture(registry, "train_deeper_64x48_b2_f64.npz", "vo_cnn_deeper", ["rgb", "depth"], (64, 48), 2, 0, 34,
+                  torch.float64, extra={"backbone": "resnet101"})
     geo_loss_fixture()
     joint_train_fixture(registry, "train_joint_64x48_p4.npz", (64, 48), 4, 41, True)
     joint_train_fixture(registry, "train_joint_45x37_p3_w.npz", (45, 37), 3, 42, False)

@@ -17,7 +17,8 @@ def build(rec, dropout_p=0.0):
     cfg, sd, obs, _acts = golden_case(rec)
     space = str(rec["obs_space"]).split(",")
     model = baseline_registry.get_vo_model(str(rec["model"]))(
-        observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
+        observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512,
+        backbone=str(rec["backbone"]) if "backbone" in rec else "resnet18",
         normalize_visual_inputs=True, output_dim=3, dropout_p=dropout_p, discretized_depth_channels=int(rec["dd_bins"]))
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to("cuda:0")
@@ -261,3 +262,27 @@ def test_act_embed_train_step_matches_reference(dropout_p):
             got = model.eval()(tobs, actions.to("cuda:0")).cpu().numpy()
         err = np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-2)
         assert err.max() < 5e-3, err
+
+
+def test_bottleneck_train_step_matches_reference():
+    """vo_cnn_deeper (resnet101 Bottleneck blocks, resnet.py:58-117): every parameter gradient of one training step."""
+    rec = load_golden("train_deeper_64x48_b2_f64.npz")
+    model, cfg, sd, obs, tobs = build(rec)
+    ts = VOTrainStep(model, lr=float(rec["lr"]), eps=float(rec["eps"]))
+    out, loss = ts.forward_backward(tobs, target=torch.from_numpy(rec["target"]).to("cuda:0"))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), rec["out1"], rtol=5e-4, atol=5e-5)
+    assert abs(loss.item() - float(rec["loss1"])) < 2e-4 * max(1.0, abs(float(rec["loss1"])))
+    chk = ref.train_step(sd, obs, rec["target"], ngroups=cfg.ngroups, lr=float(rec["lr"]), eps=float(rec["eps"]),
+                         dtype=torch.float64)
+    bad = []
+    for name, (off, n) in ts.offsets.items():
+        g = ts.grad[off:off + n].cpu().double().numpy()
+        gr = chk["grads"][name].reshape(-1).numpy()
+        err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
+        gn = float(rec[f"g1norm/{name}"])
+        if err > 5e-3 or abs(np.linalg.norm(g) - gn) > 1e-2 * max(gn, 1e-9):
+            bad.append((name, err, np.linalg.norm(g), gn))
+    assert not bad, bad[:8]
+    ts.optimizer_step()
+    torch.cuda.synchronize()

@@ -23,6 +23,7 @@ def run_steps(rec, dtype, nsteps):
 
 @pytest.mark.parametrize("fname,dtype,tol", [("train_default_45x37_b4_f64.npz", torch.float64, 1e-9),
                                              ("train_act_embed_64x48_b5_f64.npz", torch.float64, 1e-9),
+                                             ("train_deeper_64x48_b2_f64.npz", torch.float64, 1e-8),
                                              ("train_default_96x64_b3_f32.npz", torch.float32, 2e-3)])
 def test_train_step_matches_reference(fname, dtype, tol):
     rec = load_golden(fname)
