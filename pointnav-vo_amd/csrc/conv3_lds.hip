@@ -533,7 +533,10 @@ hipError_t launch_wave(const ConvArgs &a, hipStream_t s) {
   const int ngroups = a.COUTP / 32 / NT;
   const long nwork = (long)a.B * bx * by * ngroups;
   long wgs = 256L * (long)((160 * 1024) / lds);
-  if (wgs > 256L * 5) wgs = 256L * 5;                  // <= 20 waves per CU
+  // 3 workgroups per CU (12 waves): measured 112 vs 103 TFLOP/s against 4 on the 64-channel stage (8448 items: with 4096
+  // waves a quarter of the SIMDs end with one wave running a third item alone), equal on the 128-channel stage.
+  static const int cap = std::getenv("PNVO_WAVE_WGS") ? std::atoi(std::getenv("PNVO_WAVE_WGS")) : 3;
+  if (cap > 0 && wgs > 256L * cap) wgs = 256L * cap;
   if (wgs * 4 > nwork) wgs = (nwork + 3) / 4;
   if (a.in_scale != nullptr)
     hipLaunchKernelGGL((conv3_wave_kernel<BLK, NT, 1, MT>), dim3((unsigned)wgs), dim3(256), lds, s, a, bx, by, ngroups,

@@ -18,6 +18,7 @@
 //    for THIS layer's GroupNorm — no atomics, fixed summation order => bit-reproducible across runs and GPUs;
 //  * no barriers in the K loop: waves are independent, 2-3 waves/SIMD hide the load latency under the 64-cycle MFMAs.
 #include "pnvo_internal.h"
+#include <cmath>
 
 namespace pnvo {
 
@@ -336,15 +337,32 @@ int conv_slots(int P, int MT) {
 }
 
 void choose_tile(long M, int COUTP, int *MT, int *NT) {
+  // One 32-pixel tile per wave, 1 / 2 / 4 output-channel tiles.  Measured on every generic conv of the default model at 256
+  // pairs (PNVO_CONV_TILE sweep): what decides is how evenly the workgroups divide over the 256 CUs —
+  // 528 workgroups (2.06 per CU) lose to 1056 of half the size by 8 % despite the lower operand reuse — so: score =
+  // (workgroups per CU) / ceil(workgroups per CU) x a mild preference for more n-tiles per wave; larger pixel tiles
+  // (MT = 2, 4) lost everywhere.
   const int ntg = COUTP / 32;
-  int nt = (ntg % 4 == 0) ? 4 : ((ntg % 2 == 0) ? 2 : 1);   // instantiated n-tile counts: 1, 2, 4
-  int mt = 4 / nt;
-  if (mt < 1) mt = 1;
-  if (mt > 2) mt = 2;               // 32-channel pipeline stages need 16 VGPRs per pixel tile per buffer
-  auto waves = [&](int mt_, int nt_) { return ((M + mt_ * 32 - 1) / (mt_ * 32)) * (ntg / nt_); };
-  const long want = 256 * 8;        // >= 2 waves per SIMD over the whole chip
-  while (mt > 1 && waves(mt, nt) < want) mt >>= 1;
-  while (nt > 1 && waves(mt, nt) < want) nt >>= 1;
+  const long rows = (M + 127) / 128;                       // workgroups along M (4 waves x 32 pixels)
+  static const double reuse[5] = {0.0, 1.0, 1.08, 0.0, 1.12};
+  int best_nt = 1;
+  double best = -1.0;
+  for (int nt = 1; nt <= 4; nt *= 2) {
+    if (ntg % nt) continue;
+    const double per_cu = (double)(rows * (ntg / nt)) / 256.0;
+    const double balance = per_cu >= 1.0 ? per_cu / std::ceil(per_cu) : per_cu;
+    const double score = balance * reuse[nt];
+    if (score > best) {
+      best = score;
+      best_nt = nt;
+    }
+  }
+  int mt = 1, nt = best_nt;
+  static const int force = std::getenv("PNVO_CONV_TILE") ? std::atoi(std::getenv("PNVO_CONV_TILE")) : 0;   // experiment knob: 10*MT+NT
+  if (force > 0 && ntg % (force % 10) == 0 && M >= 8192) {
+    mt = force / 10;
+    nt = force % 10;
+  }
   *MT = mt;
   *NT = nt;
 }
