@@ -595,6 +595,10 @@ int conv3_lds_slots(const ConvArgs &a) {
 hipError_t launch_conv3_lds(const ConvArgs &a, int nt, hipStream_t s) {
   if (!conv3_lds_supported(a) || (nt != 1 && nt != 2) || (a.COUTP / 32) % nt != 0) return hipErrorInvalidValue;
   if (use_wave_kernel(a)) {
+    // one output-channel tile per item: twice the items of half the size divide more evenly over the 3072 waves (stage 3:
+    // 9216 items = exactly 3 each) — 115-119 vs 109-112 TFLOP/s with two (PNVO_WAVE_NT=2)
+    static const int wnt = std::getenv("PNVO_WAVE_NT") ? std::atoi(std::getenv("PNVO_WAVE_NT")) : 1;
+    if (wnt == 1) nt = 1;
     const int blk = wave_blk(a.Ho, a.Wo, nullptr);
     const int mt = wave_mt(a, blk);
     switch (blk * 100 + nt * 10 + mt) {
