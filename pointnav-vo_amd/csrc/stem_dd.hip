@@ -63,7 +63,8 @@ __device__ __forceinline__ f32x3 wload3(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 }  // namespace
 
-template <int BINS, bool PROF>   // PROF: per-phase s_memtime brackets into p.prof (PNVO_STEM_DBG=9)
+template <int BINS, bool PROF, int ABL>   // PROF: per-phase s_memtime brackets into p.prof (PNVO_STEM_DBG=9)
+                                          // ABL (timing experiments, wrong results): 1 = no gathers/adds, 2 = no MFMAs
 __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p) {
   constexpr int BROWS = BINS + 1;                 // + the all-zero row for padding pixels
   constexpr int KWB = BROWS * 256;                // bytes of one kernel-column block of the table
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     const float *abase = dense + (3 * kq) * NPIX + (2 * wave) * PW + 2 * i;      // MFMA A: pixel i, channels 3kq..3kq+2
     const unsigned *obase = reinterpret_cast<const unsigned *>(offs + ((lane >> 5) * PH + 2 * wave) * OW);   // this lane's frame
     const unsigned lane4 = tab_lds + (unsigned)lane * 4u;               // LDS address of (frame*32 + channel) in row 0
+    const unsigned abase_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)abase;
 
     auto ld_b = [&](int tap, int nt) -> f32x3 {                         // tap >= 49: out of range -> zeros
       return wload3(rw, wlane + (unsigned)nt * 768u, (unsigned)tap * SB);
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
 
     auto grow = [&](int kh, auto bufc) {
       constexpr int BUF = decltype(bufc)::value;
+      const unsigned arow = abase_lds + (unsigned)(kh * PW) * 4u;       // this kernel row of the dense patch
 #pragma unroll
       for (int HP = 0; HP < 2; ++HP) {
         unsigned o[21];
@@ -247,11 +250,21 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
         for (int kw = 0; kw < 7; ++kw) {
           const int x2 = HP * 7 + kw + BD, x1 = HP * 7 + kw + 1;      // blocks g+BD (weights) and g+1 (pixels)
           const f32x3 b_pre = ld_b((kh + x2 / 14) * 7 + (x2 % 14) % 7, (x2 % 14) / 7);
-          const f32x3 a_nxt = ld_a(kh + x1 / 14, (x1 % 14) % 7);
+          // the next block's MFMA A operands, issued from asm BEFORE this block's gathers: loaded by C++ they are ds_reads
+          // the compiler tracks, and its lgkmcnt(3) before the next MFMAs drained the 8 gathers in flight at every block
+          // (the gather latency was never hidden).  Being older than the gathers, the adds' lgkmcnt(8) covers them.
+          f32x3 a_nxt;
+          asm volatile("ds_read_b32 %[a0], %[ab] offset:%[i0]\n\t"
+                       "ds_read_b32 %[a1], %[ab] offset:%[i1]\n\t"
+                       "ds_read_b32 %[a2], %[ab] offset:%[i2]"
+                       : [a0] "=&v"(a_nxt[0]), [a1] "=&v"(a_nxt[1]), [a2] "=&v"(a_nxt[2])
+                       : [ab] "v"(arow), [i0] "i"((((x1 / 14) * PW + (x1 % 14) % 7)) * 4),
+                         [i1] "i"((((x1 / 14) * PW + (x1 % 14) % 7) + NPIX) * 4),
+                         [i2] "i"((((x1 / 14) * PW + (x1 % 14) % 7) + 2 * NPIX) * 4));
           float *g = gacc + 8 * HP;
           float(&tc)[8] = tg[kw & 1];                                   // this block's gathered rows
           float(&tn)[8] = tg[(kw & 1) ^ 1];                             // next block's (in flight)
-          if (kw == 0)                                                  // first block of the half-row: own gathers
+          if (kw == 0 && ABL != 1)                                      // first block of the half-row: own gathers
             asm volatile(
                 "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
                 "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
@@ -265,7 +278,22 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
                   [t5] "=&v"(tc[5]), [t6] "=&v"(tc[6]), [t7] "=&v"(tc[7])
                 : [o0] "v"(o[0]), [o1] "v"(o[2]), [o2] "v"(o[4]), [o3] "v"(o[6]), [o4] "v"(o[8]), [o5] "v"(o[10]),
                   [o6] "v"(o[12]), [o7] "v"(o[14]), [imm] "i"(BUF * SLICE_B));
-          if (kw < 6) {                                                 // MFMAs of this block + gathers of the next one
+          if (kw < 6 && ABL == 2) {                                     // ablation: the gathers alone
+            asm volatile(
+                "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
+                "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
+                "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
+                "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
+                "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
+                "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
+                "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
+                "ds_read_b32 %[t7], %[o7] offset:%[imm]"
+                : [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3]), [t4] "=&v"(tn[4]),
+                  [t5] "=&v"(tn[5]), [t6] "=&v"(tn[6]), [t7] "=&v"(tn[7])
+                : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 3]), [o2] "v"(o[kw + 5]), [o3] "v"(o[kw + 7]), [o4] "v"(o[kw + 9]),
+                  [o5] "v"(o[kw + 11]), [o6] "v"(o[kw + 13]), [o7] "v"(o[kw + 15]), [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
+          } else if (ABL == 2) {
+          } else if (kw < 6 && ABL == 0) {                              // MFMAs of this block + gathers of the next one
             asm volatile(
                 "v_mfma_f32_16x16x4_f32 %[c0], %[a0], %[b0], %[c0]\n\t"
                 "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
@@ -309,7 +337,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
                  [g6] "+v"(g[6]), [g7] "+v"(g[7])                                                                       \
                : [t0] "v"(tc[0]), [t1] "v"(tc[1]), [t2] "v"(tc[2]), [t3] "v"(tc[3]), [t4] "v"(tc[4]), [t5] "v"(tc[5]), \
                  [t6] "v"(tc[6]), [t7] "v"(tc[7]))
-          if (kw < 6)
+          if (ABL == 1) {
+          } else if (kw < 6)
             PNVO_DD_ADDS("s_waitcnt lgkmcnt(8)");
           else
             PNVO_DD_ADDS("s_waitcnt lgkmcnt(0)");
@@ -499,9 +528,13 @@ hipError_t launch_stem_dd(const StemDDArgs &a, hipStream_t s) {
   const long resident = (long)(160 * 1024 / lds) * 256;
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
   if (a.dbg == 9)
-    hipLaunchKernelGGL((stem_dd_kernel<10, true>), grid, dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL((stem_dd_kernel<10, true, 0>), grid, dim3(NTHREADS), lds, s, p);
+  else if (a.dbg == 11)
+    hipLaunchKernelGGL((stem_dd_kernel<10, false, 1>), grid, dim3(NTHREADS), lds, s, p);
+  else if (a.dbg == 12)
+    hipLaunchKernelGGL((stem_dd_kernel<10, false, 2>), grid, dim3(NTHREADS), lds, s, p);
   else
-    hipLaunchKernelGGL((stem_dd_kernel<10, false>), grid, dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL((stem_dd_kernel<10, false, 0>), grid, dim3(NTHREADS), lds, s, p);
   return hipGetLastError();
 }
 
