@@ -259,9 +259,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     long rows = M - m_base;
     if (rows > WM) rows = WM;
     float *ybase = p.ksplit > 1 ? p.kpart + (long)blockIdx.z * M * p.y_cstride : p.y;
+    const bool strided = (MODE == 0) && p.y_sh != 0;       // parity phase of a stride-2 backward-data conv
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(ybase + m_base * p.y_cstride), 0, clamp_records(rows * p.y_cstride * 4), 0x00020000);
+        (void *)(strided ? ybase : ybase + m_base * p.y_cstride), 0,
+        clamp_records(strided ? (long)p.B * p.y_H * p.y_W * p.y_cstride * 4 : rows * p.y_cstride * 4), 0x00020000);
     const unsigned rstride = (unsigned)p.y_cstride * 4u;
+    unsigned soff[MT][16];                                  // strided mode: byte offset of every output row of this lane
+    if (strided) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < M) {
+            const int n = (int)(m / P);
+            const int rem = (int)(m - (long)n * P);
+            const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+            soff[mt][r] = (unsigned)((((long)n * p.y_H + oi * p.y_sh + p.y_oh) * p.y_W + oj * p.y_sw + p.y_ow) * p.y_cstride) * 4u;
+          } else {
+            soff[mt][r] = PNVO_OOB;
+          }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = (ntg0 + nt) * 32 + i;
@@ -286,7 +305,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
             v += (co < p.COUT) ? p.bias[brow * p.COUT + co] : 0.f;
           }
           if (p.relu_out) v = fmaxf(v, 0.f);
-          const unsigned yo = cvalid ? vbase + (unsigned)row * rstride : PNVO_OOB;
+          unsigned yo = cvalid ? vbase + (unsigned)row * rstride : PNVO_OOB;
+          if (strided) yo = (cvalid && soff[mt][r] != PNVO_OOB) ? soff[mt][r] + (unsigned)co * 4u : PNVO_OOB;
           if (p.accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yo, 0, 0));   // y += conv
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yo, 0, 0);
         }

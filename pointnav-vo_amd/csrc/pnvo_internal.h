@@ -34,6 +34,8 @@ struct ConvArgs {
   int up;                // 2: transposed (backward-data of a stride-2 conv): source = (pos - pad + k) / 2 when even; else 1
   int accum;             // epilogue adds into y instead of overwriting it
   const float *zero_page;            // >= 16 B of zeros (target of masked gathers)
+  int y_sh, y_sw, y_oh, y_ow, y_H, y_W;   // y_sh != 0: output pixel (n,i,j) is stored at (n, i*y_sh + y_oh, j*y_sw + y_ow) of a
+                                          // [B, y_H, y_W, y_cstride] tensor (one parity phase of a stride-2 backward-data conv)
   int ksplit;            // > 1: blockIdx.z owns a slice of the (tap, channel-group) stages and writes a raw partial
   float *kpart;          // [ksplit][M][y_cstride] partials (bias / ReLU / y are left to ksplit_reduce)
   SrcPiece pieces[8][2][2];          // [j][lane half h][q]: channels 8j+4h+2q, +1 of the stem's K order

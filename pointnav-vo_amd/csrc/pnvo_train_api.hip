@@ -6,6 +6,7 @@
 //  vo_cnn_engine.py:135-198; Adam :122-133).  The flat parameter / gradient buffers are caller-owned device memory in
 // the reference's state_dict parameter order, so the data-parallel all-reduce is ONE collective on one buffer.
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 
@@ -37,6 +38,7 @@ struct TrainState {
   std::map<std::string, TocEnt> toc;
   std::vector<PackMap> maps;
   std::vector<float *> dgrad_w;     // per conv of m->convs (nullptr for the stem: no input gradient)
+  std::vector<std::array<float *, 4>> dgrad_wph;   // stride-2 3x3 convs: one sub-kernel per output parity phase (ph*2 + pw)
   float *fc_t = nullptr, *head_t = nullptr;
   int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
   int *d_ddmaps = nullptr;          // one-hot stem: [dense_ref 12 | dense_new 12 | dd_ref 2*bins | dd_new 2*bins]
@@ -126,6 +128,7 @@ int build_maps(pnvo_handle m, TrainState *t) {
   int rc = PNVO_OK;
   const pnvo_config &c = m->cfg;
   t->dgrad_w.assign(m->convs.size(), nullptr);
+  t->dgrad_wph.assign(m->convs.size(), std::array<float *, 4>{nullptr, nullptr, nullptr, nullptr});
   for (size_t li = 0; li < m->convs.size(); ++li) {
     Layer &l = m->convs[li];
     const TocEnt *w = need(m, t, l.name + ".weight", &rc);
@@ -155,6 +158,26 @@ int build_maps(pnvo_handle m, TrainState *t) {
       pnvo_pack_conv_weight_cinp(wt.data(), l.cin, l.cout, l.coutp, l.k, l.kw, pkt);
       if ((rc = dmalloc(m, (void **)&t->dgrad_w[li], pkt.size() * sizeof(float))) != PNVO_OK) return rc;
       if ((rc = add_map(m, t, t->dgrad_w[li], pkt)) != PNVO_OK) return rc;
+      if (l.stride == 2 && l.k == 3 && l.kw == 3 && l.pad == 1) {
+        // dX[2i+ph] = sum over the taps whose source row (2i+ph-1+kh)/2 is an integer: kh = 1 (ph = 0) or kh = 0, 2
+        // (ph = 1), reading dY rows i, or i and i+1 — a 1- or 2-tap stride-1 conv per parity phase, no masked taps
+        for (int ph = 0; ph < 2; ++ph)
+          for (int pw = 0; pw < 2; ++pw) {
+            const int th[2] = {ph ? 0 : 1, 2}, tw[2] = {pw ? 0 : 1, 2};
+            const int nh = ph ? 2 : 1, nw = pw ? 2 : 1;
+            std::vector<float> sub((size_t)l.cin * l.cout * nh * nw);
+            for (int ci = 0; ci < l.cin; ++ci)
+              for (int co = 0; co < l.cout; ++co)
+                for (int a = 0; a < nh; ++a)
+                  for (int b = 0; b < nw; ++b)
+                    sub[(((size_t)ci * l.cout + co) * nh + a) * nw + b] = wt[(((size_t)ci * l.cout + co) * 3 + th[a]) * 3 + tw[b]];
+            std::vector<float> pks;
+            pnvo_pack_conv_weight_cinp(sub.data(), l.cin, l.cout, l.coutp, nh, nw, pks);
+            float *&dst = t->dgrad_wph[li][ph * 2 + pw];
+            if ((rc = dmalloc(m, (void **)&dst, pks.size() * sizeof(float))) != PNVO_OK) return rc;
+            if ((rc = add_map(m, t, dst, pks)) != PNVO_OK) return rc;
+          }
+      }
     }
     const TocEnt *g = need(m, t, l.gn + ".weight", &rc);
     if (!g) return rc;
@@ -433,6 +456,44 @@ float *gradp(pnvo_handle m, TrainState *t, const std::string &name, int *rc) {
 // backward-data of conv `l`: dX[B, hin, win, cin] (+)= conv(dRaw[B, hout, wout, coutp], flipped/transposed weights)
 int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw, float *dx, bool accum, hipStream_t s) {
   const Layer &l = m->convs[li];
+  static const bool no_phase = std::getenv("PNVO_DGRAD") && std::strcmp(std::getenv("PNVO_DGRAD"), "masked") == 0;
+  if (t->dgrad_wph[li][0] != nullptr && !no_phase) {   // stride-2 3x3: four dense parity-phase convs instead of 9 taps, 3/4 masked
+    PnvoTimed tm(m, s, "dgrad:" + l.name, 2.0 * (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw, 0.0);
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.x = draw;
+        a.wpk = t->dgrad_wph[li][ph * 2 + pw];
+        a.y = dx;
+        a.B = B;
+        a.H = l.hout;
+        a.W = l.wout;
+        a.CIN = l.coutp;
+        a.Ho = (l.hin - ph + 1) / 2;
+        a.Wo = (l.win - pw + 1) / 2;
+        if (a.Ho <= 0 || a.Wo <= 0) continue;
+        a.COUT = l.cin;
+        a.COUTP = rup(l.cin, 32);
+        a.KH = ph ? 2 : 1;
+        a.KW = pw ? 2 : 1;
+        a.stride = 1;
+        a.pad = 0;
+        a.up = 1;
+        a.accum = accum ? 1 : 0;
+        a.y_cstride = l.cin;
+        a.y_sh = a.y_sw = 2;
+        a.y_oh = ph;
+        a.y_ow = pw;
+        a.y_H = l.hin;
+        a.y_W = l.win;
+        const long M = (long)B * a.Ho * a.Wo;
+        choose_tile(M, a.COUTP, &a.MT, &a.NT);
+        a.slots = conv_slots(a.Ho * a.Wo, a.MT);
+        HIPCHK(m, launch_conv(a, s));
+      }
+    return PNVO_OK;
+  }
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = draw;
@@ -499,6 +560,8 @@ void pnvo_train_free(pnvo_handle m) {
   free_train_ws(t);
   for (auto &pm : t->maps) dfree(pm.map);
   for (auto &p : t->dgrad_w) dfree(p);
+  for (auto &q : t->dgrad_wph)
+    for (auto &p : q) dfree(p);
   dfree(t->fc_t);
   dfree(t->head_t);
   dfree(t->d_ref_of_new);
