@@ -181,11 +181,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // pixels per v_mfma_f32_32x32x2_f32, both operands one conflict-free ds_read_b32 (32 consecutive channels per half
 // wave).  The accumulators live in registers across all tiles of the chunk; the per-chunk partials are summed in a
 // fixed order by wgrad_reduce_kernel (same layout as wgrad_kernel with TG = 9, one tap group).
-template <int MODE>
+template <int MODE, int S>                // S: stride of the forward conv (1 or 2); patch = (T - 1) * S + 3 input pixels per axis
 __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
   constexpr int PP = 36;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int TH = p.TH, TW = p.TW, PH = TH + 2, PWR = TW + 2;
+  const int TH = p.TH, TW = p.TW, PH = (TH - 1) * S + 3, PWR = (TW - 1) * S + 3;
   float *xs = lds;                         // [PH*PWR][PP]
   float *ds = lds + PH * PWR * PP;         // [TH*TW][PP]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
     q /= p.tiles_x;
     const int ty = q % p.tiles_y;
     const int n = q / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
+    const int y0 = ty * TH, x0 = tx * TW;      // output-tile origin; the input patch starts at (y0 * S - 1, x0 * S - 1)
     const float *xb = p.x + ((long)n * p.H * p.W) * p.CIN + cit * 32 + 4 * g;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
     for (int k = 0; k < NX; ++k) {
       const int pix = (tid + k * 576) >> 3;
       const int pr = pix / PWR, pc = pix - pr * PWR;
-      const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+      const int yy = y0 * S - 1 + pr, xx = x0 * S - 1 + pc;
       inx[k] = pix < PH * PWR && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       vx[k] = inx[k] ? *reinterpret_cast<const f32x4 *>(xb + ((long)yy * p.W + xx) * p.CIN) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
 
   int t0 = chunk * p.tiles_per_chunk, t1 = t0 + p.tiles_per_chunk;
   if (t1 > ntiles) t1 = ntiles;
-  const float *xa = xs + (kh * PWR + kw + h) * PP + i;
+  const float *xa = xs + (kh * PWR + kw + h * S) * PP + i;
   const float *da = ds + h * PP + i;
   const int half_w = TW >> 1;
   if (t0 < t1) gload(t0);
@@ -269,16 +269,16 @@ __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
     if (t + 1 < t1) gload(t + 1);
     // K loop of this tap: pixel pairs (2s, 2s+1) of each tile row; lane half h takes pixel 2s+h
     for (int qy = 0; qy < TH; ++qy) {
-      const float *xr = xa + qy * PWR * PP, *dr = da + qy * TW * PP;
+      const float *xr = xa + qy * S * PWR * PP, *dr = da + qy * TW * PP;
       int sx = 0;
       for (; sx + 2 <= half_w; sx += 2) {
-        const float a0 = xr[(2 * sx) * PP], b0 = dr[(2 * sx) * PP];
-        const float a1 = xr[(2 * sx + 2) * PP], b1 = dr[(2 * sx + 2) * PP];
+        const float a0 = xr[(2 * sx) * S * PP], b0 = dr[(2 * sx) * PP];
+        const float a1 = xr[(2 * sx + 2) * S * PP], b1 = dr[(2 * sx + 2) * PP];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
       }
       if (sx < half_w) {
-        const float a0 = xr[(2 * sx) * PP], b0 = dr[(2 * sx) * PP];
+        const float a0 = xr[(2 * sx) * S * PP], b0 = dr[(2 * sx) * PP];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
       }
     }
@@ -486,6 +486,28 @@ void wgrad_plan(WgradArgs &a) {
     a.pix_per_chunk = 0;
     return;
   }
+  if (!no_lds && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.CIN % 32 == 0 &&
+      a.COUT % 32 == 0 && a.DYC % 4 == 0) {
+    // strided 3x3: same kernel with a (2T+1)-pixel patch per axis; tiles of <= 4 x 12 outputs keep the patch at 9 x 25
+    // pixels (<= 4 sixteen-byte staging items per thread)
+    a.lds3 = 3;
+    a.TG = 9;
+    a.groups = 1;
+    a.ci_tiles = a.CIN / 32;
+    a.pairs = a.ci_tiles * (a.COUT / 32);
+    a.tiles_x = (a.Wo + 11) / 12;
+    a.TW = ((a.Wo + a.tiles_x - 1) / a.tiles_x + 1) / 2 * 2;
+    a.tiles_y = (a.Ho + 3) / 4;
+    a.TH = (a.Ho + a.tiles_y - 1) / a.tiles_y;
+    const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+    long chunks = 256L * 2 / a.pairs;
+    if (chunks < 1) chunks = 1;
+    if (chunks > ntiles) chunks = ntiles;
+    a.tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
+    a.chunks = (int)((ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk);
+    a.pix_per_chunk = 0;
+    return;
+  }
   if (!no_lds && a.mode == 2 && a.KH == 7 && a.KW == 7 && a.stride == 2 && a.pad == 3 && a.CIN <= 32 && a.COUT == 32 &&
       a.DYC % 4 == 0) {                                  // the stem: wgrad_stem_lds_kernel, one workgroup per CU
     a.lds3 = 2;
@@ -533,12 +555,17 @@ hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int
     return hipGetLastError();
   }
   if (a.lds3) {
-    const size_t lds = (size_t)((a.TH + 2) * (a.TW + 2) + a.TH * a.TW) * 36 * 4;
+    const int S = a.lds3 == 3 ? 2 : 1;
+    const size_t lds = (size_t)(((a.TH - 1) * S + 3) * ((a.TW - 1) * S + 3) + a.TH * a.TW) * 36 * 4;
     dim3 grid((unsigned)(a.pairs * a.chunks));
-    if (a.mode == 1)
-      hipLaunchKernelGGL((wgrad3_lds_kernel<1>), grid, dim3(576), lds, s, a);
+    if (S == 2 && a.mode == 1)
+      hipLaunchKernelGGL((wgrad3_lds_kernel<1, 2>), grid, dim3(576), lds, s, a);
+    else if (S == 2)
+      hipLaunchKernelGGL((wgrad3_lds_kernel<0, 2>), grid, dim3(576), lds, s, a);
+    else if (a.mode == 1)
+      hipLaunchKernelGGL((wgrad3_lds_kernel<1, 1>), grid, dim3(576), lds, s, a);
     else
-      hipLaunchKernelGGL((wgrad3_lds_kernel<0>), grid, dim3(576), lds, s, a);
+      hipLaunchKernelGGL((wgrad3_lds_kernel<0, 1>), grid, dim3(576), lds, s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.pairs * 9 * 32)), dim3(256), 0, s, a, a.TG, grad, ci_perm,
