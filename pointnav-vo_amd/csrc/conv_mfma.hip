@@ -46,7 +46,9 @@ __device__ __forceinline__ unsigned clamp_records(long bytes) {
 // JC = 8-channel groups fetched per pipeline stage.  JC = 4 makes a stage one (tap, 32-channel chunk): the four 16-B
 // loads of a lane hit ONE 128-B line back to back, so the line comes from L2 once per tap instead of once per 16-B
 // slice (measured 4x L2 over-fetch with JC = 1: profiles/r1_kernel_mfma_busy.md).
-template <int MT, int NT, int MODE, int JC>
+// FEAT (compile-time so that the common kernels carry none of it): 0 plain; 1 the 4 waves of a workgroup share one tile and
+// split its reduction (ConvArgs::wsplit); 2 strided output map (ConvArgs::y_sh, parity phases of a stride-2 backward-data conv).
+template <int MT, int NT, int MODE, int JC, int FEAT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   constexpr bool XF = (MODE != 0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -56,8 +58,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   const int i = lane & 31, h = lane >> 5;
   const long P = (long)p.Ho * p.Wo;
   const long M = (long)p.B * P;
-  const long wg_m0 = (long)blockIdx.x * (4 * WM);
-  const long m_base = wg_m0 + (long)wave * WM;
+  constexpr bool WS = FEAT == 1;                          // the 4 waves split the reduction of one tile (see ConvArgs)
+  const long wg_m0 = (long)blockIdx.x * (WS ? WM : 4 * WM);
+  const long m_base = WS ? wg_m0 : wg_m0 + (long)wave * WM;
   const int CIN = p.CIN;
   const int J = CIN >> 3;
   const long HWC = (long)p.H * p.W * CIN;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   int n_lo = 0, tab = 0;
   bool use_lds = false;
   if (XF) {
-    long last = wg_m0 + 4 * WM - 1;
+    long last = wg_m0 + (WS ? WM : 4 * WM) - 1;
     if (last > M - 1) last = M - 1;
     n_lo = (MODE == 2) ? 0 : (int)(wg_m0 / P);
     const int cnt = (MODE == 2) ? 1 : (int)(last / P) - n_lo + 1;
@@ -127,6 +130,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     const int per = (S_all + p.ksplit - 1) / p.ksplit;
     s_begin = (int)blockIdx.z * per;
     s_end = s_begin + per < S_all ? s_begin + per : S_all;
+  }
+  if (WS) {                              // this wave's quarter of the stages
+    const int per = (s_end - s_begin + 3) / 4;
+    s_begin += wave * per;
+    if (s_begin > s_end) s_begin = s_end;
+    if (s_begin + per < s_end) s_end = s_begin + per;
   }
   int l_s = s_begin * JC, l_j = l_s % J;
   int l_kh = (l_s / J) / p.KW, l_kw = (l_s / J) % p.KW;
@@ -236,22 +245,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     f32x4 a0[MT][JC], b0[NT][JC], a1[MT][JC], b1[NT][JC];
     unsigned ok0 = 0, ok1 = 0;
     int j0 = 0, j1 = 0;
-    fetch(a0, b0, ok0, j0);
-    const int S = s_end - s_begin;       // pipeline stages (>= 1)
-    int s = 0;
-    for (; s + 2 <= S - 1; s += 2) {     // invariant: stage s is in buffer 0, stages s+1, s+2 exist
-      fetch(a1, b1, ok1, j1);
-      compute(a0, b0, ok0, j0);
+    const int S = s_end - s_begin;       // pipeline stages (>= 1; 0 only for a trailing wave of a split tile)
+    if (!WS || S > 0) {
       fetch(a0, b0, ok0, j0);
-      compute(a1, b1, ok1, j1);
+      int s = 0;
+      for (; s + 2 <= S - 1; s += 2) {   // invariant: stage s is in buffer 0, stages s+1, s+2 exist
+        fetch(a1, b1, ok1, j1);
+        compute(a0, b0, ok0, j0);
+        fetch(a0, b0, ok0, j0);
+        compute(a1, b1, ok1, j1);
+      }
+      if (s + 1 <= S - 1) {              // two stages left: s (buffer 0) and s+1
+        fetch(a1, b1, ok1, j1);
+        compute(a0, b0, ok0, j0);
+        compute(a1, b1, ok1, j1);
+      } else {                           // one stage left
+        compute(a0, b0, ok0, j0);
+      }
     }
-    if (s + 1 <= S - 1) {                // two stages left: s (buffer 0) and s+1
-      fetch(a1, b1, ok1, j1);
-      compute(a0, b0, ok0, j0);
-      compute(a1, b1, ok1, j1);
-    } else {                             // one stage left
-      compute(a0, b0, ok0, j0);
+  }
+
+  // ---- split tile: waves 1..3 hand their partial accumulators to wave 0 through LDS; fixed summation order
+  if (WS) {
+    float *red = lds + p.lds_floats;     // [3][MT*NT*16][64], behind the input-transform tables
+    if (wave > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[(((wave - 1) * MT * NT + mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
     }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] += red[((w * MT * NT + mt * NT + nt) * 16 + r) * 64 + lane];
   }
 
   // ---- epilogue 1: store.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -259,28 +294,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
     long rows = M - m_base;
     if (rows > WM) rows = WM;
     float *ybase = p.ksplit > 1 ? p.kpart + (long)blockIdx.z * M * p.y_cstride : p.y;
-    const bool strided = (MODE == 0) && p.y_sh != 0;       // parity phase of a stride-2 backward-data conv
+    constexpr bool strided = FEAT == 2;                    // parity phase of a stride-2 backward-data conv
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(strided ? ybase : ybase + m_base * p.y_cstride), 0,
         clamp_records(strided ? (long)p.B * p.y_H * p.y_W * p.y_cstride * 4 : rows * p.y_cstride * 4), 0x00020000);
     const unsigned rstride = (unsigned)p.y_cstride * 4u;
-    unsigned soff[MT][16];                                  // strided mode: byte offset of every output row of this lane
-    if (strided) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long m = m_base + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < M) {
-            const int n = (int)(m / P);
-            const int rem = (int)(m - (long)n * P);
-            const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
-            soff[mt][r] = (unsigned)((((long)n * p.y_H + oi * p.y_sh + p.y_oh) * p.y_W + oj * p.y_sw + p.y_ow) * p.y_cstride) * 4u;
-          } else {
-            soff[mt][r] = PNVO_OOB;
-          }
-        }
-    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = (ntg0 + nt) * 32 + i;
@@ -306,7 +324,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
           }
           if (p.relu_out) v = fmaxf(v, 0.f);
           unsigned yo = cvalid ? vbase + (unsigned)row * rstride : PNVO_OOB;
-          if (strided) yo = (cvalid && soff[mt][r] != PNVO_OOB) ? soff[mt][r] + (unsigned)co * 4u : PNVO_OOB;
+          if (strided) {                     // rare path (backward-data phases): the address math stays out of the common one
+            const long m = m_base + mt * 32 + row + 4 * h;
+            const int n = (int)(m / P);
+            const int rem = (int)(m - (long)n * P);
+            const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+            const unsigned so = (unsigned)((((long)n * p.y_H + oi * p.y_sh + p.y_oh) * p.y_W + oj * p.y_sw + p.y_ow) * p.y_cstride) * 4u;
+            yo = (cvalid && m < M) ? so + (unsigned)co * 4u : PNVO_OOB;
+          }
           if (p.accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yo, 0, 0));   // y += conv
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, yo, 0, 0);
         }
@@ -387,12 +412,33 @@ void choose_tile(long M, int COUTP, int *MT, int *NT) {
   *NT = nt;
 }
 
+// Split the reduction of every tile over the 4 waves of its workgroup?  Pays when whole-tile items divide badly over the
+// SIMDs (stage 4 at 256 pairs: 4.125 wave items per SIMD run as 5; split, 16.5 quarter items run as 17) or do not fill the
+// chip at all (batch 1), and the reduction is long enough to quarter.
+int conv_wsplit(const ConvArgs &a) {
+  static const int force = std::getenv("PNVO_CONV_WSPLIT") ? std::atoi(std::getenv("PNVO_CONV_WSPLIT")) : -1;   // experiment knob
+  if (a.src_mode || a.ksplit > 1 || a.MT != 1 || a.NT > 2 || a.y_sh != 0) return 0;
+  const int jc = (a.MT != 4 && a.CIN % 32 == 0) ? ((a.in_scale != nullptr && a.MT * a.NT >= 4) ? 2 : 4) : 1;
+  const int S = a.KH * a.KW * (a.CIN / 8) / jc;
+  if (S < 16) return 0;
+  if (force >= 0) return force;
+  const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
+  const long WM = a.MT * 32, groups = a.COUTP / 32 / a.NT;
+  const double whole = (double)(((M + 4 * WM - 1) / (4 * WM)) * groups) / 256.0;      // 4-wave workgroups per CU = waves per SIMD
+  const double split = (double)(((M + WM - 1) / WM) * groups) / 256.0;                // quarter-size waves per SIMD
+  const double t_whole = std::ceil(whole), t_split = std::ceil(split) / 4.0;
+  return t_split < 0.88 * t_whole ? 1 : 0;      // the LDS hand-over and three idle epilogues cost ~8 % (measured: 33/4 vs 9 lost)
+}
+
 template <int MT, int NT>
 static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
   const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
   const int WM = MT * 32;
-  dim3 grid((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)(a.COUTP / 32 / NT), (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
   ConvArgs p = a;
+  p.wsplit = conv_wsplit(a);
+  const long wg_rows = p.wsplit ? WM : 4L * WM;
+  const size_t red_bytes = p.wsplit ? (size_t)3 * MT * NT * 16 * 64 * 4 : 0;
+  dim3 grid((unsigned)((M + wg_rows - 1) / wg_rows), (unsigned)(a.COUTP / 32 / NT), (unsigned)(a.ksplit > 1 ? a.ksplit : 1));
   if (a.ksplit > 1) {            // raw partials: bias and ReLU belong to the reduce
     p.bias = nullptr;
     p.bias_row = nullptr;
@@ -404,11 +450,26 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
   constexpr int JCF = (MT == 4) ? 1 : 4;
   constexpr int JCX = (MT == 4) ? 1 : ((MT * NT >= 4) ? 2 : 4);
   const bool wide = (JCF > 1) && (a.CIN % 32 == 0);
+  const int feat = p.wsplit ? 1 : (a.y_sh != 0 ? 2 : 0);
+  if (feat != 0 && (MT != 1 || NT > 2 + 2 * (feat == 2) || a.src_mode || (feat == 2 && a.in_scale != nullptr))) return hipErrorInvalidValue;
+#define PNVO_LAUNCH(MODE_, JC_, LDS_)                                                                                   \
+  do {                                                                                                                  \
+    if (feat == 0)                                                                                                      \
+      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, MODE_, JC_, 0>), grid, dim3(256), (LDS_), s, p);                     \
+    else if constexpr (MT == 1 && NT <= 2 && MODE_ != 2) {                                                              \
+      if (feat == 1)                                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, MODE_, JC_, 1>), grid, dim3(256), (LDS_) + red_bytes, s, p);       \
+      else if constexpr (MODE_ == 0)                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, MODE_, JC_, 2>), grid, dim3(256), (LDS_), s, p);                   \
+    } else if constexpr (MT == 1 && MODE_ == 0) {                                                                       \
+      if (feat == 2) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, MODE_, JC_, 2>), grid, dim3(256), (LDS_), s, p);     \
+    }                                                                                                                   \
+  } while (0)
   if (a.src_mode) {
     p.lds_floats = 2 * a.CIN;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 2, 1>), grid, dim3(256), (size_t)p.lds_floats * 4, s, p);
+    PNVO_LAUNCH(2, 1, (size_t)p.lds_floats * 4);
   } else if (a.in_scale != nullptr) {
-    const long cnt_max = (4L * WM + P - 2) / P + 1;
+    const long cnt_max = (wg_rows + P - 2) / P + 1;
     const long need = cnt_max * a.CIN * 2;
     if (need * 4 <= 48 * 1024) {
       p.lds_floats = (int)need;
@@ -417,16 +478,17 @@ static hipError_t launch_t(const ConvArgs &a, hipStream_t s) {
       p.lds_floats = 0;
     }
     if (wide)
-      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 1, JCX>), grid, dim3(256), lds_bytes, s, p);
+      PNVO_LAUNCH(1, JCX, lds_bytes);
     else
-      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 1, 1>), grid, dim3(256), lds_bytes, s, p);
+      PNVO_LAUNCH(1, 1, lds_bytes);
   } else {
     p.lds_floats = 0;
     if (wide)
-      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0, JCF>), grid, dim3(256), 0, s, p);
+      PNVO_LAUNCH(0, JCF, (size_t)0);
     else
-      hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, 0, 1>), grid, dim3(256), 0, s, p);
+      PNVO_LAUNCH(0, 1, (size_t)0);
   }
+#undef PNVO_LAUNCH
   return hipGetLastError();
 }
 

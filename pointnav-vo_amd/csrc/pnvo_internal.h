@@ -36,6 +36,8 @@ struct ConvArgs {
   const float *zero_page;            // >= 16 B of zeros (target of masked gathers)
   int y_sh, y_sw, y_oh, y_ow, y_H, y_W;   // y_sh != 0: output pixel (n,i,j) is stored at (n, i*y_sh + y_oh, j*y_sw + y_ow) of a
                                           // [B, y_H, y_W, y_cstride] tensor (one parity phase of a stride-2 backward-data conv)
+  int wsplit;            // 1: the 4 waves of a workgroup share ONE 32-pixel tile and split its reduction (summed through LDS in
+                         // a fixed order): 4x finer work items for layers whose grid divides badly over the 256 CUs
   int ksplit;            // > 1: blockIdx.z owns a slice of the (tap, channel-group) stages and writes a raw partial
   float *kpart;          // [ksplit][M][y_cstride] partials (bias / ReLU / y are left to ksplit_reduce)
   SrcPiece pieces[8][2][2];          // [j][lane half h][q]: channels 8j+4h+2q, +1 of the stem's K order
