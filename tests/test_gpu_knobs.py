@@ -1,0 +1,46 @@
+"""GPU (-m gpu): every experiment knob of libpnvo selects a different kernel or grid shape, never a different result.
+The knobs are read once per process, so each setting runs the golden check in a fresh interpreter."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import golden_case, load_golden
+from pointnav_vo_amd.registry import baseline_registry
+from pointnav_vo_amd import vo_cnn
+worst = 0.0
+for fname in ("model_default_341x192_b2.npz", "model_default_45x37_b3.npz", "model_wider_64x48_b2.npz"):
+    rec = load_golden(fname)
+    cfg, sd, obs, _ = golden_case(rec)
+    kw = dict(observation_space=str(rec["obs_space"]).split(","), observation_size=(cfg.width, cfg.height), hidden_size=512,
+              backbone="resnet18", normalize_visual_inputs=True, output_dim=3, dropout_p=0.2)
+    if int(rec["dd_bins"]):
+        kw["discretized_depth_channels"] = int(rec["dd_bins"])
+    m = baseline_registry.get_vo_model(str(rec["model"]))(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    with torch.no_grad():
+        out = m({k: torch.from_numpy(v).to("cuda:0") for k, v in obs.items()}).cpu().numpy().astype(np.float64)
+    ref = rec["out64"]
+    err = np.linalg.norm(out - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    worst = max(worst, float(err.max()))
+print("WORST", worst)
+assert worst < 1e-4, worst
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+KNOBS = [{}, {"PNVO_CONV_WSPLIT": "1"}, {"PNVO_CONV_WSPLIT": "0"}, {"PNVO_CONV_TILE": "12"}, {"PNVO_CONV_TILE": "22"},
+         {"PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {"PNVO_CONV3": "tile"}, {"PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"},
+         {"PNVO_STEM": "dense"}, {"PNVO_GRAPH": "1"}]
+
+
+@pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+def test_knob_keeps_parity(env):
+    r = subprocess.run([sys.executable, "-c", CHECK], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
