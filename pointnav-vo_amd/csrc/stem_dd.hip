@@ -207,16 +207,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     // one accumulator per (n-tile, k-step): the MFMAs of a block are independent, so neither the 40-cycle dependent
     // latency of 16x16x4 nor the same-accumulator issue cliff (MI355X_MICROARCH.md) sits between them
     f32x4 acc3[NT16][3];
-    float gacc[16];
+    f32x2 g2[8];                                                        // gathered sums: [half-row][pixel pair], 2 channels
 #pragma unroll
     for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc3[nt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 16; ++q) gacc[q] = 0.f;
+    for (int q = 0; q < 8; ++q) g2[q] = f32x2{0.f, 0.f};
     const float *abase = dense + (3 * kq) * NPIX + (2 * wave) * PW + 2 * i;      // MFMA A: pixel i, channels 3kq..3kq+2
-    const unsigned *obase = reinterpret_cast<const unsigned *>(offs + ((lane >> 5) * PH + 2 * wave) * OW);   // this lane's frame
-    const unsigned lane4 = tab_lds + (unsigned)lane * 4u;               // LDS address of (frame*32 + channel) in row 0
+    // gather lanes: lane = (pixel parity P, frame f, channel pair cp): one ds_read_b64 serves TWO pixels (lanes 0-31 / 32-63)
+    // and lands in an aligned register pair that v_pk_add_f32 accumulates -- half the VALU instructions of one channel per
+    // lane for the same LDS bytes (VALU and MFMA instructions of a SIMD do not overlap freely: tools/ubench/mfma_valu.hip)
+    const int gP = lane >> 5, gf = (lane >> 4) & 1, gcp = lane & 15;
+    const unsigned *obase = reinterpret_cast<const unsigned *>(offs + (gf * PH + 2 * wave) * OW) + gP;   // this lane's frame, +2 columns for P
+    const unsigned lane8 = tab_lds + (unsigned)(gf * 128 + gcp * 8);    // LDS address of (frame, channel pair) in row 0
     const unsigned abase_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)abase;
 
     auto ld_b = [&](int tap, int nt) -> f32x3 {                         // tap >= 49: out of range -> zeros
@@ -237,22 +241,22 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
       const unsigned arow = abase_lds + (unsigned)(kh * PW) * 4u;       // this kernel row of the dense patch
 #pragma unroll
       for (int HP = 0; HP < 2; ++HP) {
-        unsigned o[21];
-        float tg[2][8];
-        const unsigned *orow = obase + (kh * OW + 16 * HP) / 2;        // 11 dwords = 22 columns (21 used)
+        unsigned o[19];
+        f32x2 tg[2][4];
+        const unsigned *orow = obase + (kh * OW + 16 * HP) / 2;        // 10 dwords = 20 columns (19 used)
 #pragma unroll
-        for (int j = 0; j < 11; ++j) {
+        for (int j = 0; j < 10; ++j) {
           const unsigned pr = orow[j];
-          o[2 * j] = (pr & 0xffffu) + lane4;
-          if (2 * j + 1 < 21) o[2 * j + 1] = (pr >> 16) + lane4;
+          o[2 * j] = (pr & 0xffffu) + lane8;
+          if (2 * j + 1 < 19) o[2 * j + 1] = (pr >> 16) + lane8;
         }
 #pragma unroll
         for (int kw = 0; kw < 7; ++kw) {
           const int x2 = HP * 7 + kw + BD, x1 = HP * 7 + kw + 1;      // blocks g+BD (weights) and g+1 (pixels)
           const f32x3 b_pre = ld_b((kh + x2 / 14) * 7 + (x2 % 14) % 7, (x2 % 14) / 7);
           // the next block's MFMA A operands, issued from asm BEFORE this block's gathers: loaded by C++ they are ds_reads
-          // the compiler tracks, and its lgkmcnt(3) before the next MFMAs drained the 8 gathers in flight at every block
-          // (the gather latency was never hidden).  Being older than the gathers, the adds' lgkmcnt(8) covers them.
+          // the compiler tracks, and its lgkmcnt(3) before the next MFMAs drained the gathers in flight at every block
+          // (the gather latency was never hidden).  Being older than the gathers, the adds' lgkmcnt(4) covers them.
           f32x3 a_nxt;
           asm volatile("ds_read_b32 %[a0], %[ab] offset:%[i0]\n\t"
                        "ds_read_b32 %[a1], %[ab] offset:%[i1]\n\t"
@@ -261,57 +265,42 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
                        : [ab] "v"(arow), [i0] "i"((((x1 / 14) * PW + (x1 % 14) % 7)) * 4),
                          [i1] "i"((((x1 / 14) * PW + (x1 % 14) % 7) + NPIX) * 4),
                          [i2] "i"((((x1 / 14) * PW + (x1 % 14) % 7) + 2 * NPIX) * 4));
-          float *g = gacc + 8 * HP;
-          float(&tc)[8] = tg[kw & 1];                                   // this block's gathered rows
-          float(&tn)[8] = tg[(kw & 1) ^ 1];                             // next block's (in flight)
+          f32x2 *g = g2 + 4 * HP;
+          f32x2(&tc)[4] = tg[kw & 1];                                   // this block's gathered rows
+          f32x2(&tn)[4] = tg[(kw & 1) ^ 1];                             // next block's (in flight)
+          // pixel pair q of the half-row = pixels 2q + P: patch columns 4q + kw (+2 for P, folded into obase)
           if (kw == 0 && ABL != 1)                                      // first block of the half-row: own gathers
             asm volatile(
-                "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
-                "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
-                "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
-                "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
-                "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
-                "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
-                "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
-                "ds_read_b32 %[t7], %[o7] offset:%[imm]"
-                : [t0] "=&v"(tc[0]), [t1] "=&v"(tc[1]), [t2] "=&v"(tc[2]), [t3] "=&v"(tc[3]), [t4] "=&v"(tc[4]),
-                  [t5] "=&v"(tc[5]), [t6] "=&v"(tc[6]), [t7] "=&v"(tc[7])
-                : [o0] "v"(o[0]), [o1] "v"(o[2]), [o2] "v"(o[4]), [o3] "v"(o[6]), [o4] "v"(o[8]), [o5] "v"(o[10]),
-                  [o6] "v"(o[12]), [o7] "v"(o[14]), [imm] "i"(BUF * SLICE_B));
+                "ds_read_b64 %[t0], %[o0] offset:%[imm]\n\t"
+                "ds_read_b64 %[t1], %[o1] offset:%[imm]\n\t"
+                "ds_read_b64 %[t2], %[o2] offset:%[imm]\n\t"
+                "ds_read_b64 %[t3], %[o3] offset:%[imm]"
+                : [t0] "=&v"(tc[0]), [t1] "=&v"(tc[1]), [t2] "=&v"(tc[2]), [t3] "=&v"(tc[3])
+                : [o0] "v"(o[0]), [o1] "v"(o[4]), [o2] "v"(o[8]), [o3] "v"(o[12]), [imm] "i"(BUF * SLICE_B));
           if (kw < 6 && ABL == 2) {                                     // ablation: the gathers alone
             asm volatile(
-                "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
-                "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
-                "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
-                "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
-                "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
-                "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
-                "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
-                "ds_read_b32 %[t7], %[o7] offset:%[imm]"
-                : [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3]), [t4] "=&v"(tn[4]),
-                  [t5] "=&v"(tn[5]), [t6] "=&v"(tn[6]), [t7] "=&v"(tn[7])
-                : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 3]), [o2] "v"(o[kw + 5]), [o3] "v"(o[kw + 7]), [o4] "v"(o[kw + 9]),
-                  [o5] "v"(o[kw + 11]), [o6] "v"(o[kw + 13]), [o7] "v"(o[kw + 15]), [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
+                "ds_read_b64 %[t0], %[o0] offset:%[imm]\n\t"
+                "ds_read_b64 %[t1], %[o1] offset:%[imm]\n\t"
+                "ds_read_b64 %[t2], %[o2] offset:%[imm]\n\t"
+                "ds_read_b64 %[t3], %[o3] offset:%[imm]"
+                : [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3])
+                : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 5]), [o2] "v"(o[kw + 9]), [o3] "v"(o[kw + 13]),
+                  [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
           } else if (ABL == 2) {
           } else if (kw < 6 && ABL == 0) {                              // MFMAs of this block + gathers of the next one
             asm volatile(
                 "v_mfma_f32_16x16x4_f32 %[c0], %[a0], %[b0], %[c0]\n\t"
-                "ds_read_b32 %[t0], %[o0] offset:%[imm]\n\t"
-                "ds_read_b32 %[t1], %[o1] offset:%[imm]\n\t"
-                "ds_read_b32 %[t2], %[o2] offset:%[imm]\n\t"
-                "ds_read_b32 %[t3], %[o3] offset:%[imm]\n\t"
+                "ds_read_b64 %[t0], %[o0] offset:%[imm]\n\t"
+                "ds_read_b64 %[t1], %[o1] offset:%[imm]\n\t"
                 "v_mfma_f32_16x16x4_f32 %[c1], %[a1], %[b1], %[c1]\n\t"
-                "ds_read_b32 %[t4], %[o4] offset:%[imm]\n\t"
-                "ds_read_b32 %[t5], %[o5] offset:%[imm]\n\t"
-                "ds_read_b32 %[t6], %[o6] offset:%[imm]\n\t"
-                "ds_read_b32 %[t7], %[o7] offset:%[imm]\n\t"
+                "ds_read_b64 %[t2], %[o2] offset:%[imm]\n\t"
+                "ds_read_b64 %[t3], %[o3] offset:%[imm]\n\t"
                 "v_mfma_f32_16x16x4_f32 %[c2], %[a2], %[b2], %[c2]"
-                : [c0] "+v"(acc3[HP][0]), [c1] "+v"(acc3[HP][1]), [c2] "+v"(acc3[HP][2]), [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]), [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3]),
-                  [t4] "=&v"(tn[4]), [t5] "=&v"(tn[5]), [t6] "=&v"(tn[6]), [t7] "=&v"(tn[7])
-                : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 3]), [o2] "v"(o[kw + 5]), [o3] "v"(o[kw + 7]),
-                  [o4] "v"(o[kw + 9]), [o5] "v"(o[kw + 11]), [o6] "v"(o[kw + 13]), [o7] "v"(o[kw + 15]),
-                  [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]), [a2] "v"(a_cur[2]), [b0] "v"(bq[0][0]), [b1] "v"(bq[0][1]),
-                  [b2] "v"(bq[0][2]), [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
+                : [c0] "+v"(acc3[HP][0]), [c1] "+v"(acc3[HP][1]), [c2] "+v"(acc3[HP][2]), [t0] "=&v"(tn[0]), [t1] "=&v"(tn[1]),
+                  [t2] "=&v"(tn[2]), [t3] "=&v"(tn[3])
+                : [o0] "v"(o[kw + 1]), [o1] "v"(o[kw + 5]), [o2] "v"(o[kw + 9]), [o3] "v"(o[kw + 13]), [a0] "v"(a_cur[0]),
+                  [a1] "v"(a_cur[1]), [a2] "v"(a_cur[2]), [b0] "v"(bq[0][0]), [b1] "v"(bq[0][1]), [b2] "v"(bq[0][2]),
+                  [imm] "i"(BUF * SLICE_B + (kw + 1) * KWB));
           } else {
             asm volatile(
                 "v_mfma_f32_16x16x4_f32 %[c0], %[a0], %[b0], %[c0]\n\t"
@@ -321,25 +310,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
                 : [a0] "v"(a_cur[0]), [a1] "v"(a_cur[1]), [a2] "v"(a_cur[2]), [b0] "v"(bq[0][0]), [b1] "v"(bq[0][1]),
                   [b2] "v"(bq[0][2]));
           }
-          // this block's rows were requested one block ago: LDS returns in order, so "at most 8 outstanding" = landed
+          // this block's rows were requested one block ago: LDS returns in order, so "at most 4 outstanding" = landed
 #define PNVO_DD_ADDS(WAIT)                                                                                              \
   asm volatile(WAIT "\n\t"                                                                                              \
-               "v_add_f32 %[g0], %[g0], %[t0]\n\t"                                                                      \
-               "v_add_f32 %[g1], %[g1], %[t1]\n\t"                                                                      \
-               "v_add_f32 %[g2], %[g2], %[t2]\n\t"                                                                      \
-               "v_add_f32 %[g3], %[g3], %[t3]\n\t"                                                                      \
-               "v_add_f32 %[g4], %[g4], %[t4]\n\t"                                                                      \
-               "v_add_f32 %[g5], %[g5], %[t5]\n\t"                                                                      \
-               "v_add_f32 %[g6], %[g6], %[t6]\n\t"                                                                      \
-               "v_add_f32 %[g7], %[g7], %[t7]\n\t"                                                                      \
+               "v_pk_add_f32 %[g0], %[g0], %[t0]\n\t"                                                                   \
+               "v_pk_add_f32 %[g1], %[g1], %[t1]\n\t"                                                                   \
+               "v_pk_add_f32 %[g2], %[g2], %[t2]\n\t"                                                                   \
+               "v_pk_add_f32 %[g3], %[g3], %[t3]\n\t"                                                                   \
                "s_nop 1"                                                                                                \
-               : [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3]), [g4] "+v"(g[4]), [g5] "+v"(g[5]), \
-                 [g6] "+v"(g[6]), [g7] "+v"(g[7])                                                                       \
-               : [t0] "v"(tc[0]), [t1] "v"(tc[1]), [t2] "v"(tc[2]), [t3] "v"(tc[3]), [t4] "v"(tc[4]), [t5] "v"(tc[5]), \
-                 [t6] "v"(tc[6]), [t7] "v"(tc[7]))
+               : [g0] "+v"(g[0]), [g1] "+v"(g[1]), [g2] "+v"(g[2]), [g3] "+v"(g[3])                                   \
+               : [t0] "v"(tc[0]), [t1] "v"(tc[1]), [t2] "v"(tc[2]), [t3] "v"(tc[3]))
           if (ABL == 1) {
           } else if (kw < 6)
-            PNVO_DD_ADDS("s_waitcnt lgkmcnt(8)");
+            PNVO_DD_ADDS("s_waitcnt lgkmcnt(4)");
           else
             PNVO_DD_ADDS("s_waitcnt lgkmcnt(0)");
 #undef PNVO_DD_ADDS
@@ -382,11 +365,18 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_dd_kernel(const StemDDArgs p
     float *gx = tab + SLICE_F;                              // [8 rows][16 pixels][GP]
     float *red = gx + TH * 16 * GP;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {                           // v_permlane32_swap: lanes 0-31 <- pixel q, 32-63 <- pixel q+8
-      float lo = gacc[q], hi = gacc[q + 8];               // (inline asm: the builtin's second result was miscompiled)
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-      const float sgl = lo + hi;
-      gx[(wave * 16 + q + 8 * (lane >> 5)) * GP + (lane & 31)] = sgl;
+    for (int q = 0; q < 8; ++q) {                           // prev-frame + cur-frame rows: lanes 16 apart (ds_swizzle xor 0x10)
+      f32x2 v = g2[q];
+      float o0, o1;                                         // (inline asm: the compiler folded the two builtin swizzles of a
+      asm volatile("ds_swizzle_b32 %0, %2 offset:swizzle(SWAP,16)\n\t"    //  register pair into one and reused its result)
+                   "ds_swizzle_b32 %1, %3 offset:swizzle(SWAP,16)\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(o0), "=&v"(o1)
+                   : "v"(v[0]), "v"(v[1]));
+      if (gf == 0) {                                        // own = prev frame: prev + cur, as before
+        const int px = 8 * (q >> 2) + 2 * (q & 3) + gP;
+        *reinterpret_cast<f32x2 *>(gx + (wave * 16 + px) * GP + 2 * gcp) = f32x2{v[0] + o0, v[1] + o1};
+      }
     }
     {
       const int ho = ho0 + wave;
