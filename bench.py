@@ -32,7 +32,7 @@ W, H, BINS = 341, 192, 10
 SPACE = ["rgb", "depth", "discretized_depth", "top_down_view"]
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes of ONE stem launch at B=256 from rocprofv3 PMC passes (profiles/r1f_pmc.md; the dense stem:
+# HBM-side bytes of ONE stem launch at B=256 from rocprofv3 PMC passes (profiles/r1g_pmc.md; the dense stem:
 # profiles/r1_final_pmc_traffic.md): FETCH_SIZE in KiB (x2: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md
 # §HBM) + WRITE_SIZE in KiB.  Algorithmic bytes of that launch: 2.01 GB of observation tensors + 0.54 GB of stem output.
 STEM_TRAFFIC_B256 = {"onehot": (2 * 1.626e6 + 5.34e5) * 1024, "dense": (2 * 2.023e6 + 5.45e5) * 1024}
@@ -193,7 +193,7 @@ def main():
             "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                          "traffic": STEM_TRAFFIC_B256[stem_kind] if (B == 256 and is_stem) else None,
-                         "traffic_note": "bytes per launch, rocprofv3 PMC of this command (profiles/r1f_pmc.md)",
+                         "traffic_note": "bytes per launch, rocprofv3 PMC of this command (profiles/r1g_pmc.md)",
                          "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms,
                          "executed": executed},
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
