@@ -95,8 +95,8 @@ def cpu_baseline(sd, ngroups, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
