@@ -31,11 +31,36 @@ import ctypes as C  # noqa: E402
 W, H, BINS = 341, 192, 10
 SPACE = ["rgb", "depth", "discretized_depth", "top_down_view"]
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
+PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes of ONE stem launch at B=256 from rocprofv3 PMC passes (profiles/r1g_pmc.md; the dense stem:
-# profiles/r1_final_pmc_traffic.md): FETCH_SIZE in KiB (x2: gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md
-# §HBM) + WRITE_SIZE in KiB.  Algorithmic bytes of that launch: 2.01 GB of observation tensors + 0.54 GB of stem output.
-STEM_TRAFFIC_B256 = {"onehot": (2 * 1.626e6 + 5.34e5) * 1024, "dense": (2 * 2.023e6 + 5.45e5) * 1024}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/round_profile.sh (PMC passes)
+
+
+def source_hash():
+    """sha256[:12] over the kernel sources: a traffic record measured on other kernels is reported as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pointnav-vo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def measured_traffic(config, kernel, batch):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this command (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, MI355X_MICROARCH.md section HBM), as recorded by tools/round_profile.sh; None when no record matches
+    the current kernel sources, configuration and batch."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    e = rec.get(config, {}).get(kernel)
+    if not e or e.get("batch") != batch:
+        return None, "no PMC record for this kernel / batch"
+    if e.get("source_hash") != source_hash():
+        return None, f"stale PMC record (kernel sources changed since {e.get('source_hash')})"
+    return float(e["bytes_per_launch"]), f"rocprofv3 PMC, {e.get('file', 'profiles/')}"
 
 
 def build_model(dev, seed=0):
@@ -92,13 +117,72 @@ def cpu_baseline(sd, ngroups, budget_s=15.0):
                       f"best of several team sizes on a {cores}-core host)"}
 
 
+def preheat(step, dev, cap_s=2.0, tol=0.02):
+    """Run steps until three consecutive step times agree within `tol` (clock ramp / first-touch effects of a cold box
+    are over) or `cap_s` seconds have passed.  Reported as `preheat_s` / `preheat_steps`; never part of the timed region."""
+    t_start = time.perf_counter()
+    hist = []
+    while True:
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize(dev)
+        hist.append(time.perf_counter() - t0)
+        el = time.perf_counter() - t_start
+        if len(hist) >= 3 and max(hist[-3:]) <= (1.0 + tol) * min(hist[-3:]):
+            return el, len(hist), True
+        if el >= cap_s:
+            return el, len(hist), False
+
+
+def timed_steps(step, steps, sync_all, dev):
+    """EXACTLY `steps` calls between two (barrier + synchronize) brackets -> wall seconds; one event per step boundary on
+    the launch stream gives the per-step distribution without serialising anything."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sync_all()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    sync_all()
+    dt = time.perf_counter() - t0
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return dt, {"p50": per[len(per) // 2], "min": per[0], "max": per[-1]}
+
+
+def stem_executed(kt_entry, B, per_launch_ms):
+    """Work the stem kernels EXECUTE (not the algorithmic 30-channel conv): matrix-core FLOPs per launch against the
+    peak of the pipe they run on."""
+    ho, wo = (H + 1) // 2, (W + 1) // 2
+    px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128              # pixels of the 8x16 tiles, padding included
+    sel = os.environ.get("PNVO_STEM", "mx")
+    if sel == "mx":          # stem_mx.hip: 7 x v_mfma_f32_32x32x16_bf16 per tap and 32-pixel tile (3 weight pieces x 2
+        flops = px / 32 * 49 * 7 * (2.0 * 32 * 32 * 16)       #   K-chunks + 1 chunk of float-modality remainders)
+        peak, pipe = PEAK_BF16_TFLOPS, "bf16 MFMA (three exact bf16 weight pieces -> float32 results)"
+    elif sel == "dd":        # stem_dd.hip: K = 12 of 30 channels on the fp32 MFMA pipe, the rest gathered from LDS
+        flops = 2.0 * px * 32 * 12 * 49
+        peak, pipe = PEAK_FP32_TFLOPS, "fp32 MFMA at K = 12 (+ LDS gather of the one-hot channels)"
+    else:                    # stem_lds.hip: all 32 padded channels on the fp32 MFMA pipe
+        flops = 2.0 * px * 32 * 32 * 49
+        peak, pipe = PEAK_FP32_TFLOPS, "fp32 MFMA"
+    tf = flops / (per_launch_ms * 1e-3) / 1e12
+    return tf, peak, pipe
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step (BASELINE configs[1]: 256)")
+    ap.add_argument("--batch", type=int, default=None, help="frame pairs per GPU per step (default: the config's)")
+    ap.add_argument("--config", default="fwd_fp32", choices=["fwd_fp32", "dual_bf16", "train"],
+                    help="fwd_fp32 = BASELINE configs[1] (the headline); dual_bf16 = configs[2]; train = configs[3] shape")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N>1 launch (nccl = RCCL; gloo only exercises the host logic)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: run the N-rank control flow (barriers, max-over-ranks, JSON) with a stub step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-preheat", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,20 +191,33 @@ def main():
     dist = None
     if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: one process per GPU over RCCL
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, rank, world, dist)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-
-    model, sd = build_model(dev)
-    B = args.batch
-    obs = make_inputs(B, dev, rank)
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    if args.config == "dual_bf16":
+        from tools import bench_configs
+        return bench_configs.run_dual_bf16(args, rank, world, dist, dev, sync_all)
+    if args.config == "train":
+        from tools import bench_configs
+        return bench_configs.run_train(args, rank, world, dist, dev, sync_all)
+
+    model, sd = build_model(dev)
+    B = args.batch or 256
+    obs = make_inputs(B, dev, rank)
+    step = lambda: model(obs)                      # one pass of the product path as a caller makes it
 
     with torch.no_grad():
         # parity on the first pairs of this rank's batch (fp64 oracle on the same tensors)
@@ -135,19 +232,15 @@ def main():
             o = out[:nchk].cpu().numpy().astype(np.float64)
             rel = float((np.linalg.norm(o - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)).max())
 
+        pre = (0.0, 0, None) if args.no_preheat else preheat(step, dev)
         for _ in range(args.warmup):
-            model(obs)
-        sync_all()
-        t0 = time.perf_counter()                      # ---- the timed region: K calls of the product path as a caller
-        for _ in range(args.steps):                   #      makes them (plain asynchronous launches on torch's stream)
-            model(obs)
-        sync_all()
-        dt = time.perf_counter() - t0
+            step()
+        dt, per_step = timed_steps(step, args.steps, sync_all, dev)      # ---- the timed region
         # ---- the same K steps once more with a HIP-event pair around every launch (on the launch stream): per-kernel
         #      durations for `roofline` / `kernels`.  Not part of `value`: event pairs serialise the launches.
         model.timing(True)
         for _ in range(args.steps):
-            model(obs)
+            step()
         sync_all()
         kt = model.timing_read()
         model.timing(False)
@@ -161,24 +254,14 @@ def main():
         bytes_pair = float(ms.streaming_bytes_per_pair(model.cfg))
         dom = max((k for k in kt if k["name"].startswith("conv:")), key=lambda k: k["total_ms"])
         per_launch_ms = dom["total_ms"] / dom["launches"]
-        ach = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+        alg = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12      # algorithmic FLOPs of the layer
         total_kernel_ms = sum(k["total_ms"] for k in kt)
-        stem_kind = "dense" if os.environ.get("PNVO_STEM") == "dense" else "onehot"
         is_stem = dom["name"].endswith("conv1.0")
-        executed = None
-        if is_stem and stem_kind == "onehot":
-            # stem_dd.hip multiplies only the 10 dense channels + 1 indicator (K = 12 per tap) on the matrix cores and
-            # GATHERS the 20 one-hot channels from an LDS table: the algorithmic FLOPs (30 channels) exceed the executed
-            # ones, so `frac` (algorithmic / peak, the contract's definition) can pass 1.  The executed-work figures
-            # below are the ones the kernel is actually bounded by.
-            ho, wo = (H + 1) // 2, (W + 1) // 2
-            px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128          # pixels of the 8x16 tiles, padding included
-            mfma_tf = 2.0 * px * 32 * 12 * 49 / (per_launch_ms * 1e-3) / 1e12
-            lds_gbs = px * 49 * 256.0 / (per_launch_ms * 1e-3) / 1e9
-            executed = {"mfma_tflops": mfma_tf, "mfma_frac": mfma_tf / PEAK_FP32_TFLOPS,
-                        "lds_gather_GBps": lds_gbs, "lds_gather_frac": lds_gbs / (256 * 128 * 2.4),
-                        "note": "one-hot depth channels are gathered from an LDS weight table instead of multiplied; "
-                                "K = 12 of the 30 input channels run on the MFMA pipe (DESIGN.md section 4)"}
+        if is_stem:
+            ach, peak, pipe = stem_executed(dom, B, per_launch_ms)
+        else:                                       # every other conv executes exactly its algorithmic FLOPs (fp32 MFMA)
+            ach, peak, pipe = alg, PEAK_FP32_TFLOPS, "fp32 MFMA"
+        traffic, traffic_note = measured_traffic("fwd_fp32", dom["name"], B)
         res = {
             "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -186,16 +269,19 @@ def main():
             "config": {"workload": "BASELINE configs[1]: act_forward VO inference (vo_cnn_rgb_d_dd_top_down, 30 input "
                                    "channels), 341x192, fp32, seeded random weights", "pairs_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"dp{world} (independent pairs, no collective)"},
+            "ms_per_step_events": per_step,
+            "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
+            "kernel_ms_per_step": total_kernel_ms / args.steps,
             "pose_rel_err_vs_fp64_oracle": rel,
             "model_tflops": value * flops_pair / 1e12,
-            "frac_fp32_peak_whole_path": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
+            "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
-            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": STEM_TRAFFIC_B256[stem_kind] if (B == 256 and is_stem) else None,
-                         "traffic_note": "bytes per launch, rocprofv3 PMC of this command (profiles/r1g_pmc.md)",
-                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms,
-                         "executed": executed},
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "pipe": pipe,
+                         "definition": "EXECUTED matrix-core FLOPs per launch / HIP-event launch duration / peak of that pipe",
+                         "algorithmic_tflops": alg, "algorithmic_frac": alg / PEAK_FP32_TFLOPS,
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
                                 "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
@@ -204,6 +290,39 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)
         print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run(args, rank, world, dist):
+    """`--backend gloo --dry-run`: the N>1 control flow of this file (rendezvous, barrier brackets, max over ranks,
+    rank-0 JSON) with a stub in place of the GPU step, so the multi-process path runs where there is no GPU."""
+    cpu = torch.device("cpu")
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+
+    B = args.batch or 256
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))               # rank-dependent: the max over ranks must win
+    sync_all()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, cpu)
+    lo, hi = parallel.shard_bounds(world * B, rank, world)
+    mine = torch.full((hi - lo, 1), float(rank))
+    allr = parallel.gather_results(mine, world * B)          # the result gather of the sharded inference path
+    counts = [int((allr == r).sum()) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": world * B * args.steps / dt, "unit": "frame-pairs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "none", "config": {"workload": "dry run of the N-rank control flow", "backend": args.backend,
+                                                     "shard_counts": counts}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

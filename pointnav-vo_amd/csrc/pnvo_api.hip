@@ -22,8 +22,16 @@ int pnvo_fail(pnvo_handle h, int code, const std::string &msg) {
   return code;
 }
 
+// Sizes of the operand buffers upload() owns: a reload of same-sized data (every pnvo_load_weights after the first)
+// rewrites them in place, so device addresses cached elsewhere (the training step's re-pack maps, captured graphs)
+// stay valid across train -> eval -> train switches.
+static std::map<const void *, size_t> g_upload_floats;
+
 void pnvo_free_dev(float *&p) {
-  if (p) (void)hipFree(p);
+  if (p) {
+    g_upload_floats.erase(p);
+    (void)hipFree(p);
+  }
   p = nullptr;
 }
 
@@ -177,8 +185,12 @@ const float *find_tensor(pnvo_handle h, const Toc &t, const std::string &name, s
 }
 
 int upload(pnvo_handle h, float *&dst, const float *src, size_t n) {
-  free_dev(dst);
-  HIPCHK(h, hipMalloc((void **)&dst, n * sizeof(float)));
+  auto it = dst ? g_upload_floats.find(dst) : g_upload_floats.end();
+  if (it == g_upload_floats.end() || it->second != n) {
+    free_dev(dst);
+    HIPCHK(h, hipMalloc((void **)&dst, n * sizeof(float)));
+    g_upload_floats[dst] = n;
+  }
   HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyHostToDevice));
   return PNVO_OK;
 }
@@ -292,6 +304,10 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   }
   int maxc = m->comp_cp;
   size_t st = (size_t)B * stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs) * m->convs[0].coutp * 2;   // LDS-staged stem
+  {
+    const size_t st_mx = (size_t)B * stem_mx_slots(m->Hs, m->Ws) * m->convs[0].coutp * 2;
+    if (st_mx > st) st = st_mx;
+  }
   for (const Layer &l : m->convs) {
     if (l.coutp > maxc) maxc = l.coutp;
     const size_t s = stats_floats(l, B);
@@ -509,7 +525,53 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
   int rc = PNVO_OK;
   const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
   const char *sel = std::getenv("PNVO_STEM");
-  if (m->dd_ok && !(sel && std::strcmp(sel, "dense") == 0)) {
+  if (m->mx_ok && !m->in_train_forward && (!sel || std::strcmp(sel, "mx") == 0)) {
+    // bf16 matrix cores, three exact weight pieces: float32 results (stem_mx.hip).  The training step keeps the kernels
+    // below, whose operands it rebuilds on the device after every Adam step.
+    StemMXArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int k = 0; k < 4; ++k) a.src[k] = src[k];
+    a.units = m->mx_units;
+    a.zero_page = m->mx_pages;
+    a.xunit[0] = m->mx_xunit[0];
+    a.xunit[1] = m->mx_xunit[1];
+    a.wpk = m->mx_wpk3;
+    a.bad_input = m->dd_flag;
+    const int ntn = stem.cout / 32;
+    for (int g = 0; g < ntn; ++g) {
+      a.y[g] = y;
+      a.stats[g] = m->stats;
+      a.y_coff[g] = 32 * g;
+    }
+    a.y_cstride = stem.coutp;
+    a.stats_cstride = stem.coutp;
+    a.B = B;
+    a.H = c.height;
+    a.W = c.width;
+    a.Ho = m->Hs;
+    a.Wo = m->Ws;
+    a.slots = stem_mx_slots(m->Hs, m->Ws);
+    if (const char *e = std::getenv("PNVO_STEM_MXDBG")) a.dbg = std::atoi(e);
+    if (const char *e = std::getenv("PNVO_STEM_DBG"))
+      if (std::atoi(e) == 9) {
+        if (!m->mx_prof) {
+          HIPCHK(m, hipMalloc((void **)&m->mx_prof, 256));
+          HIPCHK(m, hipMemset(m->mx_prof, 0, 256));
+        }
+        a.prof = m->mx_prof;
+      }
+    const double M = (double)B * m->Hs * m->Ws;
+    {
+      Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
+              4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
+      HIPCHK(m, launch_stem_mx(a, 3, ntn, false, s));
+    }
+    {
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
+                                   stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
+    }
+  } else if (m->dd_ok && !(sel && std::strcmp(sel, "dense") == 0)) {
     // one-hot-aware stem (in training its operands are rebuilt on the device every step: refresh_stem_dd)
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
     StemDDArgs a;
@@ -756,6 +818,90 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
       }
     }
   }
+  {
+    // ---- stem on the bf16 matrix cores (stem_mx.hip): 16 two-channel units in observation-tensor order, unit 15 = indicator
+    Layer &st = h->convs[0];
+    const float *w = find_tensor(h, t, st.name + ".weight", {st.cout, st.cin, st.k, st.kw}, &rc);
+    if (!w) return rc;
+    h->mx_ok = false;
+    const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+    const int nunits = (c.n_rgb + c.n_depth + c.n_dd + c.n_tdv) / 2;
+    if (nunits <= 15 && c.n_depth <= 2 && c.n_tdv <= 2 && (st.cout == 32 || st.cout == 64) && st.k == 7) {
+      std::vector<StemMXUnit> units(16);
+      std::vector<int> slot_ref(32, -1), slot_ref_sw(32, -1), slot_tensor(32, -1);
+      for (int x = 0; x < 4; ++x) h->mx_xslot[x] = -1;
+      int u = 0, nx = 0;
+      h->mx_xunit[0] = h->mx_xunit[1] = -1;
+      for (int tn = 0; tn < 4; ++tn)
+        for (int ch = 0; ch < nsrc[tn]; ch += 2, ++u) {
+          StemMXUnit &ud = units[u];
+          std::memset(&ud, 0, sizeof(ud));
+          ud.tensor = tn;
+          ud.nch = nsrc[tn];
+          ud.choff = ch;
+          ud.kind = (tn == 1 || tn == 3) ? 1 : 0;
+          if (ud.kind == 1) {                              // remainder pair 0 -> bytes 0 / 8, pair 1 -> bytes 4 / 12
+            h->mx_xunit[nx] = u;
+            h->mx_xslot[2 * nx] = 2 * u;
+            h->mx_xslot[2 * nx + 1] = 2 * u + 1;
+            ++nx;
+          }
+          for (int e = 0; e < 2; ++e) {
+            int nc = -1, ncs = -1;                          // position in the stem's "new" (tensor-major) channel order
+            for (int k = 0; k < h->CP; ++k) {
+              if (h->stem_tensor_of_new[k] != tn) continue;
+              if (h->stem_ch_of_new[k] == ch + e) nc = k;
+              if (h->stem_ch_of_new[k] == (ch + e + nsrc[tn] / 2) % nsrc[tn]) ncs = k;   // the frame-swapped twin
+            }
+            slot_ref[2 * u + e] = h->stem_ref_of_new[nc];
+            slot_ref_sw[2 * u + e] = h->stem_ref_of_new[ncs];
+            slot_tensor[2 * u + e] = tn;
+          }
+        }
+      for (; u < 15; ++u) {
+        std::memset(&units[u], 0, sizeof(StemMXUnit));
+        units[u].kind = 3;
+      }
+      std::memset(&units[15], 0, sizeof(StemMXUnit));
+      units[15].kind = 2;
+      const int T = 49;
+      auto fold = [&](const std::vector<int> &ref, std::vector<float> &wk) {
+        wk.assign((size_t)st.cout * 32 * T, 0.f);
+        for (int o = 0; o < st.cout; ++o)
+          for (int tap = 0; tap < T; ++tap) {
+            double ind = 0.0;
+            for (int k = 0; k < 30; ++k) {
+              const int r = ref[k];
+              if (r < 0) continue;
+              const double wv = (double)w[((size_t)o * st.cin + r) * T + tap];
+              const double sd = (double)h->stdev[r], mu = (double)h->mean[r];
+              const double div = slot_tensor[k] == 0 ? 255.0 : 1.0;
+              wk[((size_t)o * 32 + k) * T + tap] = (float)(wv / (div * sd));
+              ind -= wv * mu / sd;
+            }
+            wk[((size_t)o * 32 + 30) * T + tap] = (float)ind;      // "inside the image" indicator
+          }
+      };
+      fold(slot_ref, h->mx_wk);
+      fold(slot_ref_sw, h->mx_wk_swapped);
+      std::vector<unsigned short> pk(stem_mx_packed_u16(3, st.cout / 32));
+      pack_stem_mx_weight(h->mx_wk.data(), st.cout, 3, h->mx_xslot, pk.data());
+      if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_wpk3), reinterpret_cast<const float *>(pk.data()), pk.size() / 2)) !=
+          PNVO_OK)
+        return rc;
+      if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_units), reinterpret_cast<const float *>(units.data()),
+                       units.size() * sizeof(StemMXUnit) / 4)) != PNVO_OK)
+        return rc;
+      {
+        std::vector<float> pages(64, 0.f);
+        for (int k = 32; k < 64; ++k) pages[k] = 1.f;
+        if ((rc = upload(h, h->mx_pages, pages.data(), pages.size())) != PNVO_OK) return rc;
+      }
+      if (!h->dd_flag) HIPCHK(h, hipHostMalloc((void **)&h->dd_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+      *(volatile int *)h->dd_flag = 0;
+      h->mx_ok = true;
+    }
+  }
   // Linear(flat[+embed] -> hidden): visual columns become the fh x fw "conv"; the embedding columns fold into a
   // per-action bias row:  bias[a][o] = b[o] + sum_e W[o][flat+e] * emb[a][e]   (vo_cnn_act_embed.py:63-72)
   const int flat = h->comp_c * h->fh * h->fw;
@@ -804,8 +950,9 @@ int pnvo_check_inputs(pnvo_handle m) {
   if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
   if (m->dd_flag && *(volatile int *)m->dd_flag != 0)
     return fail(m, PNVO_ERR_INPUT,
-                "an earlier forward met a discretised-depth pixel that is not one-hot (base_trainer_with_vo.py:163); "
-                "its outputs are invalid.  Feed one-hot depth, or set PNVO_STEM=dense for soft depth codes");
+                "an earlier forward met observation values outside the reference's contract — a discretised-depth pixel "
+                "that is not one-hot (base_trainer_with_vo.py:163) or an rgb value that is not an integer 0..255 — so its "
+                "outputs are invalid.  Feed contract inputs, or set PNVO_STEM=dense for soft depth codes / fractional rgb");
   return PNVO_OK;
 }
 
@@ -1117,11 +1264,24 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->stem_sc);
   free_dev(m->stem_sh);
   free_dev(m->stem_wpk16);
+  free_dev(reinterpret_cast<float *&>(m->mx_wpk3));
+  free_dev(reinterpret_cast<float *&>(m->mx_units));
+  free_dev(m->mx_pages);
   free_dev(m->dd_wpk);
   free_dev(m->dd_table);
   free_dev(m->dd_sc);
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
+  if (m->mx_prof) {
+    unsigned long long pr[32];
+    (void)hipMemcpy(pr, m->mx_prof, 256, hipMemcpyDeviceToHost);
+    for (int w = 0; w < 4; ++w) {
+      const double nt_ = (double)(pr[8 * w + 4] ? pr[8 * w + 4] : 1);
+      std::fprintf(stderr, "[pnvo] stem_mx wave %d (cycles per tile): staging %.0f  barrier %.0f  k-loop %.0f  reduce+epilogue %.0f  "
+                   "(%llu tiles)\n", w, pr[8 * w] / nt_, pr[8 * w + 1] / nt_, pr[8 * w + 2] / nt_, pr[8 * w + 3] / nt_, pr[8 * w + 4]);
+    }
+    (void)hipFree(m->mx_prof);
+  }
   if (m->dd_prof) {
     unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpy(pr, m->dd_prof, 64, hipMemcpyDeviceToHost);

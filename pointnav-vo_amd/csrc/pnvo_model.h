@@ -52,6 +52,18 @@ struct pnvo_model_s {
   int *dd_flag = nullptr;            // host-mapped: set when a depth pixel was not one-hot
   unsigned long long *dd_prof = nullptr;   // PNVO_STEM_DBG=9: {staging, K loop, epilogue} cycles, tiles
 
+  // stem on the bf16 matrix cores (stem_mx.hip): exact three-piece bf16 weights -> float32 results (inference default)
+  bool mx_ok = false;
+  pnvo::StemMXUnit *mx_units = nullptr;      // device [16]
+  unsigned short *mx_wpk3 = nullptr;         // device: three-piece packing (float32 results)
+  std::vector<float> mx_wk, mx_wk_swapped;   // host [cout][32 slots][49]: whitening-folded weights, as is / for the
+                                             //   (cur, prev) channel-swapped pair (geometric-invariance dual forward)
+  int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels
+  int mx_xunit[2] = {-1, -1};                // their units
+  float *mx_pages = nullptr;                 // device: 32 zeros, 32 ones
+  unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx
+  bool in_train_forward = false;             // set by pnvo_train_forward: its stem operands are rebuilt on the device
+
   int cap = 0;                       // batch the workspace is sized for
   float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
   float *rawA = nullptr, *rawB = nullptr, *rawD = nullptr, *rawC = nullptr, *comp_raw = nullptr, *hid = nullptr,

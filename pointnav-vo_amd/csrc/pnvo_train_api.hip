@@ -649,7 +649,10 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
   size_t li = 0;
   {
     ConvSave &cs = t->cs[li];
-    if ((rc = pnvo_run_stem(m, B, t->src, cs.raw, cs.ss, cs.mu, cs.rstd, s)) != PNVO_OK) return rc;
+    m->in_train_forward = true;
+    rc = pnvo_run_stem(m, B, t->src, cs.raw, cs.ss, cs.mu, cs.rstd, s);
+    m->in_train_forward = false;
+    if (rc != PNVO_OK) return rc;
     const Layer &stem = m->convs[li++];
     HIPCHK(m, launch_maxpool_train(cs.raw, cs.ss[0], cs.ss[1], B, m->Hs, m->Ws, stem.coutp, t->y[0], t->pool_idx, s));
   }

@@ -92,6 +92,22 @@ def _init(name, shape):
     return t
 
 
+class _NetHolder(_Holder):
+    """`policy.net` of the reference (PointNavResNetNet, resnet_policy.py:177-282) as far as its callers read it."""
+
+    @property
+    def num_recurrent_layers(self):
+        return self._layers * 2                            # LSTM: h and c (rnn_state_encoder.py:44-45)
+
+    @property
+    def output_size(self):
+        return self._hidden
+
+    @property
+    def is_blind(self):
+        return False                                       # a depth encoder is always present here
+
+
 @baseline_registry.register_policy(name="resnet_rnn_policy")
 class PointNavResNetPolicy(nn.Module):
     def __init__(self, *, observation_space, action_space, goal_sensor_uuid=GOAL_SENSOR, hidden_size=512,
@@ -120,11 +136,14 @@ class PointNavResNetPolicy(nn.Module):
                     mod.add_module(p, _Holder())
                 mod = getattr(mod, p)
             mod.register_parameter(parts[-1], nn.Parameter(_init(name, tuple(shape))))
+        # the reference trainers read these through policy.net (ppo_trainer.py:618, ddppo_trainer.py:279)
+        net = self.net
+        net.__class__ = _NetHolder
+        net._layers, net._hidden = self._layers, self._hidden
         self._handle = None
         self._handle_dev = None
         self._loaded_sig = None
 
-    # the reference exposes these through policy.net
     @property
     def num_recurrent_layers(self):
         return self._layers * 2                            # LSTM: h and c (rnn_state_encoder.py:44-45)

@@ -68,6 +68,8 @@ class VOTrainStep:
                 self.offsets[n] = (off, k)
                 off += k
         self._toc = toc
+        self._named = named
+        model._loaded_sig = None          # p.data now aliases the flat buffer: the eval path re-reads it on its next call
         _lib.check(_lib.lib.pnvo_train_attach(model._handle, _ptr(self.flat), _ptr(self.grad), total, toc, len(named)),
                    model._handle)
         self.dropout_p = float(getattr(model, "dropout_p", 0.0) or 0.0)
@@ -80,6 +82,65 @@ class VOTrainStep:
         self._m1 = torch.empty(Cc, device=self.dev)
         self._m2 = torch.empty(Cc, device=self.dev)
         self._loss = torch.zeros(1, device=self.dev)
+        self._psig = self._param_sig()
+
+    # ------------------------------------------------------------------ parameter / optimizer state
+    def _param_sig(self):
+        return tuple((p.data_ptr(), p._version) for _, p in self._named)
+
+    def _sync_params(self, stream):
+        """Parameters edited outside the HIP Adam step (model.load_state_dict on resume, an in-place torch edit) land in
+        the flat buffer but not in the packed kernel operands: re-pack before the next train-mode forward."""
+        sig = self._param_sig()
+        if sig == self._psig:
+            return
+        off = 0
+        with torch.no_grad():
+            for _, p in self._named:                      # a tensor re-pointed by the caller: alias it again
+                k = p.numel()
+                view = self.flat[off:off + k].view(p.shape)
+                if p.data_ptr() != view.data_ptr():
+                    view.copy_(p.detach())
+                    p.data = view
+                    p.grad = self.grad[off:off + k].view(p.shape)
+                off += k
+        _lib.check(_lib.lib.pnvo_train_refresh(self.model._handle, stream), self.model._handle)
+        self.model._loaded_sig = None
+        self._psig = self._param_sig()
+
+    def state_dict(self):
+        """Optimizer state in torch.optim.Adam's layout (the reference checkpoints `optim_states`,
+        vo_cnn_regression_geo_invariance_engine.py:1425-1433): per-parameter step / exp_avg / exp_avg_sq."""
+        state, off = {}, 0
+        for i, (_, p) in enumerate(self._named):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + k].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(self._named)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        self.lr, self.eps, self.betas = float(group["lr"]), float(group["eps"]), tuple(group["betas"])
+        off, steps = 0, set()
+        with torch.no_grad():
+            for i, (_, p) in enumerate(self._named):
+                k = p.numel()
+                st = sd["state"].get(i)
+                if st is None:
+                    self.exp_avg[off:off + k].zero_()
+                    self.exp_avg_sq[off:off + k].zero_()
+                else:
+                    self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(st["step"]))
+                off += k
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ; the HIP Adam keeps one step count for the model")
+        self.step_count = steps.pop() if steps else 0
 
     def dropout_masks(self, batch):
         """Scaled masks (0 or 1/(1-p)) of the last forward: (m0 [B, fh*fw, Cpad] in the kernel's NHWC order with the
@@ -159,6 +220,7 @@ class VOTrainStep:
         out = torch.empty((B, self.model.cfg.out_dim), device=self.dev, dtype=torch.float32)
         with torch.cuda.device(self.dev), torch.no_grad():
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            self._sync_params(stream)
             mean = var = None
             if self.rmv is not None:
                 self._update_running_stats(ptrs, B, stream)
@@ -177,6 +239,7 @@ class VOTrainStep:
         out = torch.empty((B, self.model.cfg.out_dim), device=self.dev, dtype=torch.float32)
         with torch.cuda.device(self.dev), torch.no_grad():
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            self._sync_params(stream)
             mean = var = None
             if self.rmv is not None:
                 self._update_running_stats(ptrs, B, stream)
@@ -214,6 +277,7 @@ class VOTrainStep:
                                                self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
                                                self.step_count, stream))
             _lib.check(_lib.lib.pnvo_train_refresh(h, stream), h)
+        self.model._loaded_sig = None     # operands only the eval path owns are rebuilt from the flat buffer on its next call
 
     def step(self, obs_pairs, target, actions=None):
         """zero_grad / forward / loss / backward / all-reduce / Adam — returns (out [B,3], loss tensor)."""

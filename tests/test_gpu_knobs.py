@@ -37,7 +37,7 @@ assert worst < 1e-4, worst
 
 KNOBS = [{}, {"PNVO_CONV_WSPLIT": "1"}, {"PNVO_CONV_WSPLIT": "0"}, {"PNVO_CONV_TILE": "12"}, {"PNVO_CONV_TILE": "22"},
          {"PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {"PNVO_CONV3": "tile"}, {"PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"},
-         {"PNVO_STEM": "dense"}, {"PNVO_GRAPH": "1"}]
+         {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")

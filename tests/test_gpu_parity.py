@@ -122,26 +122,47 @@ def test_full_batch_256_properties():
     np.testing.assert_array_equal(obs["top_down_view"][0, ..., 1].cpu().numpy(), oracle.topdown_view(d0[..., 1], c)[..., 0])
 
 
-def test_onehot_stem_agrees_with_dense_stem(monkeypatch):
-    """The default model's stem gathers the one-hot depth channels from a weight table (stem_dd.hip); PNVO_STEM=dense
-    selects the all-MFMA stem (stem_lds.hip).  Both compute the same products; they must agree to summation-order
-    noise at every output pixel, borders (zero padding after whitening) included, and both must match the reference."""
+def test_three_stems_agree(monkeypatch):
+    """The default model's stem runs on the bf16 matrix cores with the float32 weights split into three exact bf16
+    pieces (stem_mx.hip, the default); PNVO_STEM=dd selects the one-hot table-gather stem (stem_dd.hip), PNVO_STEM=dense
+    the all-fp32-MFMA stem (stem_lds.hip).  All three compute the same products exactly; they must agree to float32
+    summation-order noise at every output pixel, borders (zero padding after whitening) included, and match the reference."""
     rec = load_golden("model_default_341x192_b2.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
     with torch.no_grad():
+        out_mx, stem_mx = model.tap("stem_conv", tobs)
+        monkeypatch.setenv("PNVO_STEM", "dd")
         out_dd, stem_dd = model.tap("stem_conv", tobs)
         monkeypatch.setenv("PNVO_STEM", "dense")
         out_dense, stem_dense = model.tap("stem_conv", tobs)
         monkeypatch.delenv("PNVO_STEM")
-    a, b = stem_dd.cpu().numpy(), stem_dense.cpu().numpy()
-    assert a.shape == b.shape and np.abs(b).max() > 0.1
-    assert not np.array_equal(a, b), "PNVO_STEM=dense did not select a different kernel"
+        model.check_inputs()
+    a, d, b = stem_mx.cpu().numpy(), stem_dd.cpu().numpy(), stem_dense.cpu().numpy()
+    assert a.shape == b.shape == d.shape and np.abs(b).max() > 0.1
+    assert not np.array_equal(a, b) and not np.array_equal(d, b) and not np.array_equal(a, d), "knob did not select another kernel"
     assert np.abs(a - b).max() / np.abs(b).max() < 2e-6
+    assert np.abs(d - b).max() / np.abs(b).max() < 2e-6
     want = rec["tap/stem_conv"] if "tap/stem_conv" in rec else None
     if want is not None:
-        assert np.abs(a[..., : want.shape[-1]] - want).max() / np.abs(want).max() < 2e-5
-    assert pair_rel_err(out_dd.cpu().numpy(), rec["out64"]).max() < TOL
-    assert pair_rel_err(out_dense.cpu().numpy(), rec["out64"]).max() < TOL
+        for x in (a, d, b):
+            assert np.abs(x[..., : want.shape[-1]] - want).max() / np.abs(want).max() < 2e-5
+    for o in (out_mx, out_dd, out_dense):
+        assert pair_rel_err(o.cpu().numpy(), rec["out64"]).max() < TOL
+
+
+def test_fractional_rgb_is_reported_not_silently_wrong():
+    """The split-weight stem relies on rgb being uint8-valued (exact in bf16); a fractional value must raise
+    PNVO_ERR_INPUT, never a silently rounded result.  PNVO_STEM=dense accepts such input."""
+    rec = load_golden("model_default_45x37_b3.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    bad = dict(tobs)
+    bad["rgb"] = tobs["rgb"].clone()
+    bad["rgb"][0, 3, 4, 1] = 17.3
+    with torch.no_grad():
+        model(bad)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.PnvoError, match="contract"):
+            model.check_inputs()
 
 
 def test_non_onehot_depth_is_reported_not_silently_wrong():
