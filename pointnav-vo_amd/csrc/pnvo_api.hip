@@ -531,10 +531,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     StemMXArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int k = 0; k < 4; ++k) a.src[k] = src[k];
-    a.units = m->mx_units;
     a.zero_page = m->mx_pages;
-    a.xunit[0] = m->mx_xunit[0];
-    a.xunit[1] = m->mx_xunit[1];
     a.wpk = m->mx_wpk3;
     a.bad_input = m->dd_flag;
     const int ntn = stem.cout / 32;
@@ -819,51 +816,33 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     }
   }
   {
-    // ---- stem on the bf16 matrix cores (stem_mx.hip): 16 two-channel units in observation-tensor order, unit 15 = indicator
+    // ---- stem on the bf16 matrix cores (stem_mx.hip)
     Layer &st = h->convs[0];
     const float *w = find_tensor(h, t, st.name + ".weight", {st.cout, st.cin, st.k, st.kw}, &rc);
     if (!w) return rc;
     h->mx_ok = false;
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
-    const int nunits = (c.n_rgb + c.n_depth + c.n_dd + c.n_tdv) / 2;
-    if (nunits <= 15 && c.n_depth <= 2 && c.n_tdv <= 2 && (st.cout == 32 || st.cout == 64) && st.k == 7) {
-      std::vector<StemMXUnit> units(16);
+    // fixed K-slot layout of stem_mx.hip: 0-19 discretised depth | 20-25 rgb | 26-27 depth | 28-29 top-down view | 30 indicator
+    const bool shape_ok = (c.n_rgb == 0 || c.n_rgb == 6) && (c.n_depth == 0 || c.n_depth == 2) && (c.n_dd == 0 || c.n_dd == 20) &&
+                          (c.n_tdv == 0 || c.n_tdv == 2);
+    if (shape_ok && (st.cout == 32 || st.cout == 64) && st.k == 7) {
       std::vector<int> slot_ref(32, -1), slot_ref_sw(32, -1), slot_tensor(32, -1);
+      const int first_slot[4] = {20, 26, 0, 28};           // rgb, depth, dd, tdv
       for (int x = 0; x < 4; ++x) h->mx_xslot[x] = -1;
-      int u = 0, nx = 0;
-      h->mx_xunit[0] = h->mx_xunit[1] = -1;
+      if (c.n_depth) h->mx_xslot[0] = 26, h->mx_xslot[1] = 27;
+      if (c.n_tdv) h->mx_xslot[2] = 28, h->mx_xslot[3] = 29;
       for (int tn = 0; tn < 4; ++tn)
-        for (int ch = 0; ch < nsrc[tn]; ch += 2, ++u) {
-          StemMXUnit &ud = units[u];
-          std::memset(&ud, 0, sizeof(ud));
-          ud.tensor = tn;
-          ud.nch = nsrc[tn];
-          ud.choff = ch;
-          ud.kind = (tn == 1 || tn == 3) ? 1 : 0;
-          if (ud.kind == 1) {                              // remainder pair 0 -> bytes 0 / 8, pair 1 -> bytes 4 / 12
-            h->mx_xunit[nx] = u;
-            h->mx_xslot[2 * nx] = 2 * u;
-            h->mx_xslot[2 * nx + 1] = 2 * u + 1;
-            ++nx;
+        for (int ch = 0; ch < nsrc[tn]; ++ch) {
+          int nc = -1, ncs = -1;                            // position in the stem's "new" (tensor-major) channel order
+          for (int k = 0; k < h->CP; ++k) {
+            if (h->stem_tensor_of_new[k] != tn) continue;
+            if (h->stem_ch_of_new[k] == ch) nc = k;
+            if (h->stem_ch_of_new[k] == (ch + nsrc[tn] / 2) % nsrc[tn]) ncs = k;   // the frame-swapped twin
           }
-          for (int e = 0; e < 2; ++e) {
-            int nc = -1, ncs = -1;                          // position in the stem's "new" (tensor-major) channel order
-            for (int k = 0; k < h->CP; ++k) {
-              if (h->stem_tensor_of_new[k] != tn) continue;
-              if (h->stem_ch_of_new[k] == ch + e) nc = k;
-              if (h->stem_ch_of_new[k] == (ch + e + nsrc[tn] / 2) % nsrc[tn]) ncs = k;   // the frame-swapped twin
-            }
-            slot_ref[2 * u + e] = h->stem_ref_of_new[nc];
-            slot_ref_sw[2 * u + e] = h->stem_ref_of_new[ncs];
-            slot_tensor[2 * u + e] = tn;
-          }
+          slot_ref[first_slot[tn] + ch] = h->stem_ref_of_new[nc];
+          slot_ref_sw[first_slot[tn] + ch] = h->stem_ref_of_new[ncs];
+          slot_tensor[first_slot[tn] + ch] = tn;
         }
-      for (; u < 15; ++u) {
-        std::memset(&units[u], 0, sizeof(StemMXUnit));
-        units[u].kind = 3;
-      }
-      std::memset(&units[15], 0, sizeof(StemMXUnit));
-      units[15].kind = 2;
       const int T = 49;
       auto fold = [&](const std::vector<int> &ref, std::vector<float> &wk) {
         wk.assign((size_t)st.cout * 32 * T, 0.f);
@@ -889,12 +868,8 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
       if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_wpk3), reinterpret_cast<const float *>(pk.data()), pk.size() / 2)) !=
           PNVO_OK)
         return rc;
-      if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_units), reinterpret_cast<const float *>(units.data()),
-                       units.size() * sizeof(StemMXUnit) / 4)) != PNVO_OK)
-        return rc;
       {
         std::vector<float> pages(64, 0.f);
-        for (int k = 32; k < 64; ++k) pages[k] = 1.f;
         if ((rc = upload(h, h->mx_pages, pages.data(), pages.size())) != PNVO_OK) return rc;
       }
       if (!h->dd_flag) HIPCHK(h, hipHostMalloc((void **)&h->dd_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1265,7 +1240,6 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->stem_sh);
   free_dev(m->stem_wpk16);
   free_dev(reinterpret_cast<float *&>(m->mx_wpk3));
-  free_dev(reinterpret_cast<float *&>(m->mx_units));
   free_dev(m->mx_pages);
   free_dev(m->dd_wpk);
   free_dev(m->dd_table);

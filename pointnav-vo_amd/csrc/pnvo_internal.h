@@ -83,18 +83,10 @@ hipError_t launch_stem_dd_repack(const float *w_oihw, int cin, const float *sc_n
                                  float *table, float *wpk, float *sc12, float *sh12, hipStream_t s);
 
 // The stem on the bf16 matrix cores (stem_mx.hip): float32 results from exact three-piece bf16 weights, or native bf16.
-struct StemMXUnit {           // K-slots 2u, 2u+1 of the A operand = two adjacent channels of one observation tensor
-  int tensor;                 // 0 rgb, 1 depth, 2 discretised depth, 3 top-down view
-  int nch, choff;             // channels per pixel of that tensor, first channel of the pair
-  int kind;                   // 0: exact in bf16 by contract; 1: float modality (x = hi + mid + lo); 2: indicator; 3: unused
-  int pad_[4];
-};
 struct StemMXArgs {
   const float *src[4];        // rgb, depth, dd, tdv observation tensors (nullptr if absent)
-  const StemMXUnit *units;    // [16] device
   const unsigned short *wpk;  // pack_stem_mx_weight(): [49 taps][fragments][N-tiles][64 lanes][8 bf16]
-  const float *zero_page;     // 128 B of zeros followed by 128 B of 1.0f (targets of out-of-image / indicator reads)
-  int xunit[2];               // units of the (up to two) float modalities, -1 if absent: remainder pairs 0 / 1
+  const float *zero_page;     // >= 128 B of zeros (target of out-of-image reads)
   int *bad_input;             // host-visible flag: a value that must be exact in bf16 was not (PIECES = 3)
   void *y[4];                 // per N-tile (32 output channels): output tensor [B,Ho,Wo,y_cstride] float or bf16
   float *stats[4];            // per N-tile: [B,slots,stats_cstride,2]

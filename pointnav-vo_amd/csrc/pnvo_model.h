@@ -54,13 +54,11 @@ struct pnvo_model_s {
 
   // stem on the bf16 matrix cores (stem_mx.hip): exact three-piece bf16 weights -> float32 results (inference default)
   bool mx_ok = false;
-  pnvo::StemMXUnit *mx_units = nullptr;      // device [16]
   unsigned short *mx_wpk3 = nullptr;         // device: three-piece packing (float32 results)
   std::vector<float> mx_wk, mx_wk_swapped;   // host [cout][32 slots][49]: whitening-folded weights, as is / for the
                                              //   (cur, prev) channel-swapped pair (geometric-invariance dual forward)
   int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels
-  int mx_xunit[2] = {-1, -1};                // their units
-  float *mx_pages = nullptr;                 // device: 32 zeros, 32 ones
+  float *mx_pages = nullptr;                 // device: 64 zeros (out-of-image reads)
   unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx
   bool in_train_forward = false;             // set by pnvo_train_forward: its stem operands are rebuilt on the device
 

@@ -54,7 +54,6 @@ constexpr int PAR = 19 * PITCH;                   // odd-column plane of a patch
 constexpr int ROW = 3072;                         // patch row pitch (2 x 19 x 80 = 3040, padded: 2 rows = 0 mod 256 B)
 constexpr int PATCH_BYTES = PH * ROW;             // 64512
 constexpr int NTHREADS = 256;
-constexpr int RPR = 11;                           // staging: patch rows per round
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const bf16x2 r = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -105,96 +104,95 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   const bool prof = p.prof != nullptr && (blockIdx.x % 61) == 0;   // sampled: the atomics below perturb the memory pipe                  // PNVO_STEM_DBG=9: per-phase cycles of wave 0 (s_memtime)
   const unsigned long long tp0 = prof ? __builtin_readcyclecounter() : 0;
   // ---------------------------------------------------------------- staging: observation tensors -> bf16 patch in LDS
-  // Pass 1, thread = (unit u, pixel lane pl): patch columns pl, pl+16, pl+32 of all 21 rows, 63 x 8 B per thread in flight
-  // at once.  Instruction count is what bounds this phase (it shares the SIMDs with the other workgroup's MFMAs), so:
-  // no bounds branches (out-of-image addresses are redirected to a page of zeros; the indicator unit reads a page of
-  // ones), a pair is packed by one v_cvt_pk_bf16_f32 (exact by contract: any set low bit raises the flag), and the LDS
-  // address is one register per column group + an immediate per row.
+  // One thread per patch pixel (777 pixels: three full rounds + nine pixels for wave 0): the per-pixel work — index
+  // arithmetic, bounds, four tensor addresses — is paid once per 120 B of input instead of once per 8 B.  What bounds
+  // this phase is the INSTRUCTION COUNT (it shares the SIMDs with the other workgroup's MFMAs: measured ~4.5 cycles per
+  // instruction of either wave), not bytes: 16-byte loads, one v_cvt_pk_bf16_f32 per channel pair, 16-byte LDS writes.
+  // Fixed K-slot layout (absent modalities stay zero, their weights are zero):
+  //   slots 0-19 discretised depth | 20-25 rgb | 26-27 depth | 28-29 top-down view | 30-31 indicator
+  // Out-of-image pixels read a page of zeros (zero padding AFTER whitening); a value that must be exact in bf16 and is not
+  // (low 16 bits set) raises the host-visible flag.
   {
-    const int u = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const StemMXUnit ud = p.units[u];
-    const float *tb = ud.tensor == 0 ? p.src[0] : ud.tensor == 1 ? p.src[1] : ud.tensor == 2 ? p.src[2] : p.src[3];
     const float *zp = p.zero_page;
-    const float *img = ud.kind == 2 ? zp + 32 : ud.kind == 3 ? zp : tb + (long)n * p.H * p.W * ud.nch + ud.choff;
-    const int rowstep = ud.kind < 2 ? p.W * ud.nch : 0;                    // floats per image row of that tensor
-    const int colstep = ud.kind < 2 ? ud.nch : 0;
-    int coff[3];
-    unsigned loff[3];
-    bool cok[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int px = pl + 16 * j, wi = wi_base + px;
-      cok[j] = px < PW && wi >= 0 && wi < p.W;
-      coff[j] = wi * colstep;
-      loff[j] = (unsigned)((px & 1) * PAR + (px >> 1) * PITCH + 4 * u);
-    }
+    const float *b_rgb = p.src[0] ? p.src[0] + (long)n * p.H * p.W * 6 : nullptr;
+    const float *b_d = p.src[1] ? p.src[1] + (long)n * p.H * p.W * 2 : nullptr;
+    const float *b_dd = p.src[2] ? p.src[2] + (long)n * p.H * p.W * 20 : nullptr;
+    const float *b_t = p.src[3] ? p.src[3] + (long)n * p.H * p.W * 2 : nullptr;
     unsigned lowbits = 0;
-    int roff = hi_base * rowstep;
 #pragma unroll
-    for (int r0 = 0; r0 < PH; r0 += RPR) {                                 // two rounds (11 + 10 rows): <= 33 loads in flight
-      f32x2 v[RPR][3];
+    for (int r0 = 0; r0 < 4; r0 += 2) {
+      f32x4 vdd[2][5], vr4[2];
+      f32x2 vr2[2], vd[2], vt[2];
+      bool inb[2];
+      unsigned ldsoff[2];
 #pragma unroll
-      for (int k = 0; k < RPR; ++k) {
-        if (r0 + k >= PH) continue;
-        const int hi = hi_base + r0 + k;                                   // wave-uniform
-        const bool rok = hi >= 0 && hi < p.H;
+      for (int rr = 0; rr < 2; ++rr) {
+        const int pix = (r0 + rr) * NTHREADS + (int)threadIdx.x;
+        const int py = pix / PW, px = pix - py * PW;
+        const int hi = hi_base + py, wi = wi_base + px;
+        const bool in = pix < NPIX && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const int e = in ? hi * p.W + wi : 0;                          // pixel index inside the image
+        inb[rr] = in;
+        ldsoff[rr] = (unsigned)(py * ROW + (px & 1) * PAR + (px >> 1) * PITCH);
+        if (r0 + rr == 3 && wave != 0) continue;                       // the last nine pixels belong to wave 0
+        // absent modalities and out-of-image pixels read the zero page: no branches, no register initialisation
+        const float *a_dd = (in && b_dd) ? b_dd + (long)e * 20 : zp;
+        const float *a_rgb = (in && b_rgb) ? b_rgb + (long)e * 6 : zp;   // 24 B per pixel: 8-byte aligned
+        const float *a_d = (in && b_d) ? b_d + (long)e * 2 : zp;
+        const float *a_t = (in && b_t) ? b_t + (long)e * 2 : zp;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float *ad = (rok && cok[j] && !(p.dbg & 1)) ? img + (roff + coff[j]) : zp;
-          v[k][j] = *reinterpret_cast<const f32x2 *>(ad);
+        for (int c = 0; c < 5; ++c) vdd[rr][c] = *reinterpret_cast<const f32x4 *>(a_dd + 4 * c);
+        {
+          const f32x2 q0 = *reinterpret_cast<const f32x2 *>(a_rgb), q1 = *reinterpret_cast<const f32x2 *>(a_rgb + 2);
+          vr4[rr] = f32x4{q0[0], q0[1], q1[0], q1[1]};
+          vr2[rr] = *reinterpret_cast<const f32x2 *>(a_rgb + 4);
         }
-        roff += rowstep;
+        vd[rr] = *reinterpret_cast<const f32x2 *>(a_d);
+        vt[rr] = *reinterpret_cast<const f32x2 *>(a_t);
       }
 #pragma unroll
-      for (int k = 0; k < RPR; ++k) {
-        if (r0 + k >= PH) continue;
+      for (int rr = 0; rr < 2; ++rr) {
+        if (r0 + rr == 3 && wave != 0) continue;
+        const int pix = (r0 + rr) * NTHREADS + (int)threadIdx.x;
+        if (pix >= NPIX) continue;
+        unsigned w[16];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (j == 2 && pl + 32 >= PW) continue;
-          const float f0 = v[k][j][0], f1 = v[k][j][1];      // (bit_cast straight from a vector element misreads it)
+        for (int c = 0; c < 5; ++c) {
+          w[2 * c] = pack_bf16(vdd[rr][c][0], vdd[rr][c][1]);
+          w[2 * c + 1] = pack_bf16(vdd[rr][c][2], vdd[rr][c][3]);
+          if (EXTRA) {
+            const float f0 = vdd[rr][c][0], f1 = vdd[rr][c][1], f2 = vdd[rr][c][2], f3 = vdd[rr][c][3];
+            lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
+            lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
+          }
+        }
+        w[10] = pack_bf16(vr4[rr][0], vr4[rr][1]);
+        w[11] = pack_bf16(vr4[rr][2], vr4[rr][3]);
+        w[12] = pack_bf16(vr2[rr][0], vr2[rr][1]);
+        if (EXTRA) {
+          const float f0 = vr4[rr][0], f1 = vr4[rr][1], f2 = vr4[rr][2], f3 = vr4[rr][3], f4 = vr2[rr][0], f5 = vr2[rr][1];
           lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
-          const unsigned w0 = pack_bf16(v[k][j][0], v[k][j][1]);   // one v_cvt_pk_bf16_f32 (exact for contract inputs)
-          *reinterpret_cast<unsigned *>(lds + (r0 + k) * ROW + loff[j]) = w0;
+          lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
+          lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
+        }
+        w[13] = pack_bf16(vd[rr][0], vd[rr][1]);
+        w[14] = pack_bf16(vt[rr][0], vt[rr][1]);
+        w[15] = inb[rr] ? 0x3f803f80u : 0u;                            // indicator (two slots)
+        unsigned char *dst = lds + ldsoff[rr];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<u32x4 *>(dst + 16 * q) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        if (EXTRA) {                                                   // float modalities: x - hi = mid + lo (exact)
+          const float d0 = vd[rr][0] - bf16_lo(w[13]), d1 = vd[rr][1] - bf16_hi(w[13]);
+          const float t0 = vt[rr][0] - bf16_lo(w[14]), t1 = vt[rr][1] - bf16_hi(w[14]);
+          const unsigned md = pack_bf16(d0, d1), mt = pack_bf16(t0, t1);
+          const unsigned ld = pack_bf16(d0 - bf16_lo(md), d1 - bf16_hi(md));
+          const unsigned lt = pack_bf16(t0 - bf16_lo(mt), t1 - bf16_hi(mt));
+          *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{md, mt, ld, lt};
         }
       }
     }
-    // kind 0 (rgb, one-hot depth, by contract exact in bf16): a dropped low bit would be a silently rounded input.
-    // kind 1 (float modalities): the rounded-off bits are carried by the remainder pieces of pass 2 (PIECES = 3) or are
-    //         the bf16 rounding of the native bf16 mode.
-    if (EXTRA && ud.kind == 0 && (lowbits & 0xffffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
-  }
-  if (EXTRA) {
-    // Pass 2: remainders of the float modalities, x - hi = mid + lo (exact: <= 16 significant bits are left).
-    // thread = (s = which float unit, column, row parity); 11 iterations of 2 patch rows.
-    const int sx = threadIdx.x & 1, col = (threadIdx.x >> 1) & 63, rsub = threadIdx.x >> 7;
-    const StemMXUnit ud = p.units[p.xunit[sx] >= 0 ? p.xunit[sx] : 15];
-    const bool have = p.xunit[sx] >= 0;
-    const float *tb = ud.tensor == 1 ? p.src[1] : p.src[3];
-    const float *zp = p.zero_page;
-    const float *img = have ? tb + (long)n * p.H * p.W * ud.nch + ud.choff : zp;
-    const int wi = wi_base + col;
-    const bool cok = col < PW && wi >= 0 && wi < p.W && have;
-    const unsigned lo = (unsigned)((col & 1) * PAR + (col >> 1) * PITCH + 64 + 4 * sx);
-    f32x2 v[11];
-#pragma unroll
-    for (int it = 0; it < 11; ++it) {
-      const int k = 2 * it + rsub, hi = hi_base + k;
-      const bool ok = cok && k < PH && hi >= 0 && hi < p.H;
-      const float *ad = ok ? img + ((long)hi * p.W + wi) * ud.nch : zp;
-      v[it] = *reinterpret_cast<const f32x2 *>(ad);
-    }
-#pragma unroll
-    for (int it = 0; it < 11; ++it) {
-      const int k = 2 * it + rsub;
-      const unsigned w0 = pack_bf16(v[it][0], v[it][1]);           // the piece pass 1 stored
-      const float q0 = v[it][0] - bf16_lo(w0), q1 = v[it][1] - bf16_hi(w0);
-      const unsigned w1 = pack_bf16(q0, q1);
-      const unsigned w2 = pack_bf16(q0 - bf16_lo(w1), q1 - bf16_hi(w1));
-      if (col < PW && k < PH) {
-        *reinterpret_cast<unsigned *>(lds + k * ROW + lo) = w1;
-        *reinterpret_cast<unsigned *>(lds + k * ROW + lo + 8) = w2;
-      }
-    }
+    if (EXTRA && (lowbits & 0xffffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
   }
   const unsigned long long tp1 = prof ? __builtin_readcyclecounter() : 0;
   __syncthreads();
@@ -212,14 +210,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int rr = (lane & 31) >> 4, c = lane & 15, h = lane >> 5;
     const unsigned baseA = (unsigned)(2 * rr * ROW + c * PITCH + h * 16);
     const unsigned baseX = (unsigned)(2 * rr * ROW + c * PITCH + 64);
-    const u32x4 *wl = reinterpret_cast<const u32x4 *>(p.wpk) + lane;
     const int nfrag = NFT * ntg;                          // fragments per tap in the packed array
-    auto loadB = [&](int tap, u32x4 *b) {
-      const u32x4 *wt = wl + (long)tap * nfrag * 64;
+    auto loadB = [&](int tap, u32x4 *b) {                 // uniform base (SGPRs) + lane offset + immediates
+      const u32x4 *wt = reinterpret_cast<const u32x4 *>(p.wpk) + ((long)tap * nfrag + gy * NT) * 64;
 #pragma unroll
       for (int f = 0; f < NFT; ++f)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[f * NT + nt] = wt[(f * ntg + gy * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt) b[f * NT + nt] = wt[(f * ntg + nt) * 64 + lane];
     };
     auto tapoff = [&](int tap) {
       const int kh = tap / 7, kw = tap - 7 * kh;
@@ -266,16 +263,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     };
     loadB(wave, b0);
     loadA0(wave, a00);
-    for (int tap = wave; tap < 49; tap += 8) {
-      const int t1 = tap + 4 < 49 ? tap + 4 : tap;
+    // taps wave, wave+4, ...: six pairs for every wave, plus tap 48 for wave 0
+#pragma unroll 1
+    for (int it = 0; it < 6; ++it) {
+      const int tap = wave + 8 * it;
       loadA1(tap, a1, ax);
-      loadB(t1, b1);
-      loadA0(t1, a01);
+      loadB(tap + 4, b1);
+      loadA0(tap + 4, a01);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(a00, b0);
       __builtin_amdgcn_sched_barrier(0);
-      if (tap + 4 >= 49) break;
-      const int t2 = tap + 8 < 49 ? tap + 8 : tap;
+      const int t2 = tap + 8 < 49 ? tap + 8 : tap;         // (waves 1-3: the last prefetch is a harmless repeat)
       loadA1(tap + 4, a1, ax);
       loadB(t2, b0);
       loadA0(t2, a00);
@@ -283,76 +281,80 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       mfmas(a01, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (wave == 0) {
+      loadA1(48, a1, ax);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a00, b0);
+    }
   }
 
   const unsigned long long tp3 = prof ? __builtin_readcyclecounter() : 0;
   // ---------------------------------------------------------------- K-split reduction through LDS (fixed order) + epilogue
+  // Every wave publishes its partial sums of all four M-tiles (64 KB per N-tile: the patch is dead by now) and reduces
+  // M-tile `wave` in wave order 0,1,2,3 — no data-dependent register selection, bit-reproducible.
   const int rr16 = lane >> 5;                             // accumulator row = (r & 3) + 8 (r >> 2) + 4 rr16
+  const bool full = ho0 + TH <= p.Ho && wo0 + TW <= p.Wo; // the whole tile is inside the output (wave-uniform)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     __syncthreads();                                      // patch (or the previous N-tile's exchange) no longer read
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (m == wave) continue;
-      const int sp = wave - (wave > m ? 1 : 0);
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq)
-        *reinterpret_cast<f32x4 *>(lds + (((m * 3 + sp) * 4 + rq) * 64 + lane) * 16) =
+        *reinterpret_cast<f32x4 *>(lds + (((m * 4 + wave) * 4 + rq) * 64 + lane) * 16) =
             f32x4{acc[m][nt][4 * rq], acc[m][nt][4 * rq + 1], acc[m][nt][4 * rq + 2], acc[m][nt][4 * rq + 3]};
-    }
     __syncthreads();
     f32x16 tot;
-    {
-      // own tile: sum the four waves' partials in wave order 0,1,2,3
-      f32x16 own = acc[0][nt];
 #pragma unroll
-      for (int m = 1; m < 4; ++m)
-        if (m == wave) own = acc[m][nt];
-      bool first = true;
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        f32x16 part;
-        if (s == wave) {
-          part = own;
-        } else {
-          const int sp = s - (s > wave ? 1 : 0);
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + (((wave * 4 + s4) * 4 + rq) * 64 + lane) * 16);
 #pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(lds + (((wave * 3 + sp) * 4 + rq) * 64 + lane) * 16);
-            part[4 * rq] = t[0];
-            part[4 * rq + 1] = t[1];
-            part[4 * rq + 2] = t[2];
-            part[4 * rq + 3] = t[3];
-          }
-        }
-        if (first) {
-          tot = part;
-          first = false;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tot[r] += part[r];
-        }
+        for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? t[e] : tot[4 * rq + e] + t[e];
       }
-    }
     // epilogue of M-tile `wave`: rows 2*wave, 2*wave+1 of the tile; lane = output channel, registers = pixels
     const int g = gy * NT + nt;                           // N-tile of the launch
     const int co = p.y_coff[g] + (lane & 31);
+    const long rowpix = ((long)n * p.Ho + ho0 + 2 * wave) * p.Wo + wo0 + 4 * rr16;   // pixel of register 0
     float s1 = 0.f, s2 = 0.f;
+    if (full) {
+      if (BF16OUT) {
+        __bf16 *y0 = reinterpret_cast<__bf16 *>(p.y[g]) + rowpix * p.y_cstride + co;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16;
-      const int ho = ho0 + 2 * wave + (i >> 4), wo = wo0 + (i & 15);
-      const bool ok = ho < p.Ho && wo < p.Wo;
-      const float v = ok ? tot[r] : 0.f;
-      if (ok) {
-        const long off = (((long)n * p.Ho + ho) * p.Wo + wo) * p.y_cstride + co;
-        if (BF16OUT)
-          reinterpret_cast<__bf16 *>(p.y[g])[off] = (__bf16)v;
-        else
-          reinterpret_cast<float *>(p.y[g])[off] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int dpix = (r >> 3) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1);
+          y0[(long)dpix * p.y_cstride] = (__bf16)tot[r];
+          s1 += tot[r];
+          s2 = __builtin_fmaf(tot[r], tot[r], s2);
+        }
+      } else {
+        float *y0 = reinterpret_cast<float *>(p.y[g]) + rowpix * p.y_cstride + co;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dpix = (r >> 3) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1);
+          y0[(long)dpix * p.y_cstride] = tot[r];
+          s1 += tot[r];
+          s2 = __builtin_fmaf(tot[r], tot[r], s2);
+        }
       }
-      s1 += v;
-      s2 = __builtin_fmaf(v, v, s2);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16;
+        const int ho = ho0 + 2 * wave + (i >> 4), wo = wo0 + (i & 15);
+        const bool ok = ho < p.Ho && wo < p.Wo;
+        const float v = ok ? tot[r] : 0.f;
+        if (ok) {
+          const long off = (((long)n * p.Ho + ho) * p.Wo + wo) * p.y_cstride + co;
+          if (BF16OUT)
+            reinterpret_cast<__bf16 *>(p.y[g])[off] = (__bf16)v;
+          else
+            reinterpret_cast<float *>(p.y[g])[off] = v;
+        }
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
     }
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
