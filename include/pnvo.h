@@ -83,6 +83,26 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
 int pnvo_forward(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv,
                  const int64_t *actions, int B, float *out, void *stream);
 
+/*
+ * Arithmetic of pnvo_forward for this handle: 0 = float32 (default: exact-float32 products on the matrix cores), 1 = bfloat16
+ * (BASELINE config 3: bf16 operands and bf16 activations in HBM, float32 accumulation / GroupNorm statistics / Linear layers).
+ * The reference has no such switch (it would be model.bfloat16(), which also rounds the normalisation and the head);
+ * resnet18 BasicBlock models with 32 base planes only.  Takes effect at the next forward; no reload needed.
+ */
+int pnvo_set_precision(pnvo_handle h, int precision);
+
+/*
+ * Replaces: the geometric-invariance dual forward of the joint left/right training and evaluation
+ *   pred_a = vo_model[act_a](batch_pairs);  pred_b = vo_model[act_b](swapped batch_pairs)
+ * (pointnav_vo/vo/engine/vo_cnn_regression_geo_invariance_engine.py:569-602; the swapped (cur, prev) entries are built by
+ * pointnav_vo/vo/dataset/regression_geo_invariance_iter_dataset.py:342-386).  Both models run in every launch; model b sees
+ * each observation tensor with its [prev | cur] channel halves exchanged WITHOUT the caller materialising the swapped pair
+ * (a permutation of b's stem weights), so the observation tensors are read once.  Both handles must have the same
+ * architecture and precision 1 (bfloat16).  Tensor contract as pnvo_forward; out_a / out_b [B,out_dim].
+ */
+int pnvo_forward_dual(pnvo_handle ha, pnvo_handle hb, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                      int B, float *out_a, float *out_b, void *stream);
+
 /* Replaces: BaseRLTrainerWithVO._discretize_depth_func (base_trainer_with_vo.py:135-167), batched and strided so
  * that it writes straight into obs_pairs["discretized_depth"]:
  *   for p in [0,n): d = depth[p*in_stride];  onehot[p*out_stride + i] = (e_i <= d < e_{i+1}) for i in [0,bins)

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "pnvo_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(pnvo_tensor_desc), C.c_int]),
     "pnvo_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_void_p]),
+    "pnvo_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "pnvo_forward_dual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_discretize_depth": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
     "pnvo_topdown_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

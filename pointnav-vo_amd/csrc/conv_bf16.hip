@@ -1,0 +1,464 @@
+// conv_bf16.hip — the residual stages of the native-bf16 forward (BASELINE config 3), gfx950 only.
+//
+// Every conv after the stem (3x3 stride 1 / 2, 1x1 stride 2, the compression conv; resnet.py:29-55,189-212, vo_cnn.py:
+// 76-101) as an implicit GEMM on v_mfma_f32_32x32x16_bf16: bf16 activations in HBM (NHWC, channels a multiple of 32),
+// bf16 weights, fp32 accumulation, GroupNorm statistics taken from the fp32 accumulators and kept in fp32.  The whole
+// path is HBM/issue-bound at bf16 rates (the 3x3 blocks are 0.29 TFLOP per 256 pairs), so the kernel is built around
+// touching every activation once: a workgroup stages the input patch of its output tile in LDS, applying the producer's
+// GroupNorm + ReLU (MODE 1: relu(x*scale+shift), per-sample scale/shift from gn_finalize) ONCE per element while it
+// converts, and zero padding after that transform as the reference does.  Pixel pitch in LDS = channels*2 + 16 bytes
+// (an odd number of 16-byte units: the 16 lanes a ds_read_b128 serves per cycle hit all banks once).
+//
+// Workgroup = 4 waves, output tile = TR x TC pixels = MT 32-pixel M-tiles (row-major pixel order; a table in LDS maps a
+// tile pixel to its patch offset and output position, so ragged tiles such as 4x22 or 6x11 cost nothing per MFMA).
+// The waves form a WM x WN grid: wave = (M-tile group, N-tile group), MW x NW accumulators of 32x32 each; the B
+// fragments stream from L2 (uniform base + lane), A fragments from LDS, both double-buffered one (tap, k-chunk) step
+// ahead.  Input channels beyond CK are processed in chunks with the accumulators kept in registers.
+// blockIdx.z selects one of up to two models (the geometric-invariance dual forward runs both in every launch).
+#include <cstring>
+
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const bf16x2 r = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+}  // namespace
+
+template <int KS, int STRIDE, int MODE, bool F32OUT, int MW, int NW>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
+  constexpr int CS = KS == 1 ? 1 : STRIDE;         // patch pixels per output pixel
+  constexpr int PAD = KS / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int z = blockIdx.z;
+  const unsigned short *x = p.x[z];
+  const u32x4 *wpk = reinterpret_cast<const u32x4 *>(p.wpk[z]);
+
+  const int ntiles = p.B * p.tiles_r * p.tiles_c;
+  const int chunk = (ntiles + 7) >> 3;
+  int bid = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);     // consecutive tiles of an XCD are neighbours
+  if (bid >= ntiles) return;
+  const int tci = bid % p.tiles_c;
+  bid /= p.tiles_c;
+  const int tri = bid % p.tiles_r;
+  const int n = bid / p.tiles_r;
+  const int r0 = tri * p.TR, c0 = tci * p.TC;
+  const int hi0 = r0 * STRIDE - PAD, wi0 = c0 * STRIDE - PAD;
+  const int PR = p.PR, PC = p.PC, CK = p.CK;
+  const int pitch = CK * 2 + 16;
+  const int npix = p.TR * p.TC;
+  unsigned *qtab = reinterpret_cast<unsigned *>(lds + PR * PC * pitch);   // [MT*32]: patch offset | tr << 24 | tc << 16 ... see below
+  // pixel table: for tile pixel q (row-major): low 20 bits = patch byte offset of its top-left tap, bits 20-25 = tile row,
+  // bits 26-31 = tile column (rows / columns < 64)
+  if ((int)threadIdx.x < p.MT * 32) {
+    const int q = min((int)threadIdx.x, npix - 1);
+    const int tr = q / p.TC, tc = q - tr * p.TC;
+    qtab[threadIdx.x] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch) | ((unsigned)tr << 20) | ((unsigned)tc << 26);
+  }
+
+  const int wn = p.wn;                                                   // wave grid: (4 / wn) x wn
+  const int wave_m = wave / wn;
+  const int wave_n = (wave & (wn - 1)) + (int)blockIdx.y * (8 / NW);      // layers wider than 8 N-tiles: blockIdx.y = N group
+  const int ntt = p.COUTP >> 5, kct = p.CIN >> 4;                        // N-tiles, 16-channel k-chunks of the layer
+
+  f32x16 acc[MW][NW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging role: thread -> (pixel lane, 8-channel group); G groups per pixel, 256 / G pixels per step
+  const int G = CK >> 3;
+  const int cg = threadIdx.x & (G - 1), pl = threadIdx.x / G, PS = 256 / G;
+  const int dr = PS / PC, dc = PS - dr * PC;
+  const int nppix = PR * PC;
+
+  for (int ck0 = 0; ck0 < p.CIN; ck0 += CK) {
+    if (ck0 > 0) __syncthreads();                                        // the previous chunk's patch is no longer read
+    {
+      f32x4 sc0, sc1, sh0, sh1;
+      if (MODE == 1) {
+        const float *ps = p.in_scale[z] + (long)n * p.CIN + ck0 + 8 * cg;
+        const float *pt = p.in_shift[z] + (long)n * p.CIN + ck0 + 8 * cg;
+        sc0 = *reinterpret_cast<const f32x4 *>(ps);
+        sc1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+        sh0 = *reinterpret_cast<const f32x4 *>(pt);
+        sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+      }
+      int pr = pl / PC, pc = pl - pr * PC;
+      const unsigned short *xb = x + ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
+      for (int pix = pl; pix < nppix; pix += 4 * PS) {
+        u32x4 v[4];
+        unsigned off[4], inmask = 0;
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int hi = hi0 + pr * PSTEP, wi = wi0 + pc * PSTEP;
+          ok[k] = pix + k * PS < nppix;
+          const bool in = ok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+          off[k] = (unsigned)((pr * PC + pc) * pitch + 16 * cg);
+          v[k] = u32x4{0u, 0u, 0u, 0u};
+          if (in) v[k] = *reinterpret_cast<const u32x4 *>(xb + ((long)hi * p.W + wi) * p.CIN);
+          inmask |= (unsigned)in << k;                                   // outside the image: zero AFTER the transform
+          pr += dr;
+          pc += dc;
+          if (pc >= PC) {
+            pc -= PC;
+            pr += 1;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!ok[k]) continue;
+          u32x4 o = v[k];
+          if (MODE == 1) {
+            if (!((inmask >> k) & 1u)) {
+              o = u32x4{0u, 0u, 0u, 0u};
+            } else {
+              o[0] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][0]), sc0[0], sh0[0]), 0.f),
+                           fmaxf(__builtin_fmaf(hi_f(v[k][0]), sc0[1], sh0[1]), 0.f));
+              o[1] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][1]), sc0[2], sh0[2]), 0.f),
+                           fmaxf(__builtin_fmaf(hi_f(v[k][1]), sc0[3], sh0[3]), 0.f));
+              o[2] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][2]), sc1[0], sh1[0]), 0.f),
+                           fmaxf(__builtin_fmaf(hi_f(v[k][2]), sc1[1], sh1[1]), 0.f));
+              o[3] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][3]), sc1[2], sh1[2]), 0.f),
+                           fmaxf(__builtin_fmaf(hi_f(v[k][3]), sc1[3], sh1[3]), 0.f));
+            }
+          }
+          *reinterpret_cast<u32x4 *>(lds + off[k]) = o;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- compute: steps s = (tap, 16-channel chunk); fragments of step s+1 are fetched during the MFMAs of step s
+    unsigned aoff[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = min(wave_m * MW + i, p.MT - 1);
+      aoff[i] = (qtab[mt * 32 + (lane & 31)] & 0xfffffu) + (unsigned)((lane >> 5) * 16);
+    }
+    const int kcc = CK >> 4;                                             // k-chunks per staged chunk
+    const int nsteps = KS * KS * kcc;
+    const int kc_base = ck0 >> 4;
+    auto loadAB = [&](int s, u32x4 *a, u32x4 *b) {
+      const int tap = s / kcc, kc = s - tap * kcc;
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const unsigned toff = (unsigned)((kh * PC + kw) * pitch + kc * 32);
+#pragma unroll
+      for (int i = 0; i < MW; ++i) a[i] = *reinterpret_cast<const u32x4 *>(lds + aoff[i] + toff);
+      const u32x4 *wb = wpk + ((long)(tap * kct + kc_base + kc) * ntt + wave_n * NW) * 64;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int jj = min(wave_n * NW + j, ntt - 1) - wave_n * NW;      // (N-tiles past the layer's repeat the last one)
+        b[j] = wb[jj * 64 + lane];
+      }
+    };
+    auto mfmas = [&](const u32x4 *a, const u32x4 *b) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                              acc[i][j], 0, 0, 0);
+    };
+    u32x4 a0[MW], b0[NW], a1[MW], b1[NW];
+    loadAB(0, a0, b0);
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 2) {                                // nsteps is even for every supported shape
+      loadAB(s + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      loadAB(s + 2 < nsteps ? s + 2 : s, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot)
+  const int rr16 = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int mt = wave_m * MW + i;
+    if (mt >= p.MT) continue;
+    unsigned ent[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ent[r] = qtab[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * rr16];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int nt = wave_n * NW + j;
+      if (nt >= ntt) continue;
+      const int co = nt * 32 + (lane & 31);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * rr16;
+        const int tr = (ent[r] >> 20) & 63, tc = ent[r] >> 26;
+        const int ho = r0 + tr, wo = c0 + tc;
+        const bool ok = q < npix && ho < p.Ho && wo < p.Wo;
+        const float v = ok ? acc[i][j][r] : 0.f;
+        if (ok) {
+          const long o = (((long)n * p.Ho + ho) * p.Wo + wo) * p.COUTP + co;
+          if (F32OUT)
+            reinterpret_cast<float *>(p.y[z])[o] = v;
+          else
+            reinterpret_cast<__bf16 *>(p.y[z])[o] = (__bf16)v;
+        }
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32 && p.stats[z] != nullptr) {
+        const int slot = (tri * p.tiles_c + tci) * p.MT + mt;
+        float *dst = p.stats[z] + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host side: tile / wave-grid plan of one layer and the launch.
+namespace {
+template <int KS, int STRIDE>
+hipError_t launch_ks(const ConvBArgs &a, int mode, bool f32out, int mw, int nw, dim3 grid, size_t ldsb, hipStream_t s) {
+#define PNVO_CB(MODE_, F32_, MW_, NW_)                                                                          \
+  if (mode == MODE_ && f32out == F32_ && mw == MW_ && nw == NW_) {                                             \
+    hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, MODE_, F32_, MW_, NW_>), grid, dim3(256), ldsb, s, a);    \
+    return hipGetLastError();                                                                                  \
+  }
+  PNVO_CB(0, false, 1, 1) PNVO_CB(1, false, 1, 1) PNVO_CB(0, false, 2, 1) PNVO_CB(1, false, 2, 1)
+  PNVO_CB(0, false, 4, 1) PNVO_CB(1, false, 4, 1) PNVO_CB(0, false, 4, 2) PNVO_CB(1, false, 4, 2)
+  PNVO_CB(0, true, 1, 1) PNVO_CB(0, true, 2, 1) PNVO_CB(0, true, 4, 1) PNVO_CB(0, true, 4, 2)
+#undef PNVO_CB
+  return hipErrorInvalidValue;
+}
+}  // namespace
+
+// Fills the plan fields of `a` (TR, TC, tiles, PR, PC, CK, MT, wn, slots) from its shape fields; returns false when the
+// layer is outside what the kernel covers (the caller then refuses the bf16 mode for that model).
+bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes) {
+  if (a.CIN % 32 || a.COUTP % 32 || a.COUTP > 1024 || a.CIN > 256) return false;
+  if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 2))) return false;
+  const int ntt = a.COUTP / 32;
+  // output tile: <= 128 pixels; 8 x 16 for the wide stages, whole-width strips for the narrow ones
+  int TR, TC;
+  if (a.Wo >= 32) {
+    TR = 8;
+    TC = 16;
+  } else {
+    TC = a.Wo;
+    TR = 128 / TC;
+    if (TR > a.Ho) TR = a.Ho;
+    // balance the strips over the rows
+    const int nstr = (a.Ho + TR - 1) / TR;
+    TR = (a.Ho + nstr - 1) / nstr;
+  }
+  a.TR = TR;
+  a.TC = TC;
+  a.tiles_r = (a.Ho + TR - 1) / TR;
+  a.tiles_c = (a.Wo + TC - 1) / TC;
+  a.MT = (TR * TC + 31) / 32;
+  const int cs = ks == 1 ? 1 : stride;
+  a.PR = (TR - 1) * cs + ks;
+  a.PC = (TC - 1) * cs + ks;
+  // wave grid and accumulators per wave
+  if (ntt == 1) {
+    a.wn = 1;
+    *mw = 1;
+    *nw = 1;
+  } else if (ntt == 2) {
+    a.wn = 2;
+    *mw = 2;
+    *nw = 1;
+  } else if (ntt == 4) {
+    a.wn = 4;
+    *mw = 4;
+    *nw = 1;
+  } else {
+    a.wn = 4;
+    *mw = 4;
+    *nw = 2;
+  }
+  if ((4 / a.wn) * *mw < a.MT) return false;
+  // channel chunk: the largest power of two (<= CIN) whose patch fits 56 KB
+  int ck = a.CIN;
+  while (ck > 32 && (size_t)a.PR * a.PC * (ck * 2 + 16) > (size_t)56 * 1024) ck /= 2;
+  if ((size_t)a.PR * a.PC * (ck * 2 + 16) > (size_t)60 * 1024) return false;
+  if (a.CIN % ck) return false;
+  a.CK = ck;
+  a.slots = a.tiles_r * a.tiles_c * a.MT;
+  *lds_bytes = (size_t)a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4;
+  return true;
+}
+
+hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bool f32out, int mw, int nw, size_t lds_bytes,
+                            int nmodels, hipStream_t s) {
+  const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
+  dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((a.COUTP + 255) / 256)   /* groups of 8 N-tiles */, (unsigned)nmodels);
+  if (ks == 3 && stride == 1) return launch_ks<3, 1>(a, mode, f32out, mw, nw, grid, lds_bytes, s);
+  if (ks == 3 && stride == 2) return launch_ks<3, 2>(a, mode, f32out, mw, nw, grid, lds_bytes, s);
+  if (ks == 1 && stride == 2) return launch_ks<1, 2>(a, mode, f32out, mw, nw, grid, lds_bytes, s);
+  return hipErrorInvalidValue;
+}
+
+// B operand:  out[tap][k-chunk (cin/16)][N-tile (coutp/32)][lane = kh*32 + n][8 bf16] = W[N-tile*32 + n][16 kc + 8 kh + j][tap]
+void pack_conv_bf16_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh_, int kw_, unsigned short *out) {
+  const int T = kh_ * kw_, kct = cinp / 16, ntt = coutp / 32;
+  auto bf = [](float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  };
+  for (int tap = 0; tap < T; ++tap)
+    for (int kc = 0; kc < kct; ++kc)
+      for (int nt = 0; nt < ntt; ++nt)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
+            float v = 0.f;
+            if (co < cout && ci < cin) v = oihw[((size_t)co * cin + ci) * T + tap];
+            out[((((size_t)tap * kct + kc) * ntt + nt) * 64 + ln) * 8 + j] = bf(v);
+          }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// relu(gn(x)) then MaxPool 3x3 s2 p1 (resnet.py:165-168), bf16 in / bf16 out, 8 channels per thread.
+__global__ __launch_bounds__(256) void gn_relu_maxpool_bf16_kernel(const unsigned short *x0, const unsigned short *x1,
+                                                                 const float *sc0, const float *sc1, const float *sh0,
+                                                                 const float *sh1, int B, int H, int W, int C, int Ho, int Wo,
+                                                                 unsigned short *o0, unsigned short *o1) {
+  const int z = blockIdx.z;
+  const unsigned short *x = z ? x1 : x0;
+  const float *scale = z ? sc1 : sc0, *shift = z ? sh1 : sh0;
+  unsigned short *out = z ? o1 : o0;
+  const int Q = C >> 3;
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * Ho * Wo * Q;
+  if (g >= total) return;
+  const int q = (int)(g % Q);
+  long r = g / Q;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  float sc[8], sh[8], m[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    sc[t] = scale[(long)n * C + 8 * q + t];
+    sh[t] = shift[(long)n * C + 8 * q + t];
+    m[t] = 0.f;                                // every window holds >= 1 real pixel and relu(.) >= 0
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = 2 * ho - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = 2 * wo - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(x + (((long)n * H + hi) * W + wi) * C + 8 * q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        m[2 * t] = fmaxf(m[2 * t], __builtin_fmaf(lo_f(v[t]), sc[2 * t], sh[2 * t]));
+        m[2 * t + 1] = fmaxf(m[2 * t + 1], __builtin_fmaf(hi_f(v[t]), sc[2 * t + 1], sh[2 * t + 1]));
+      }
+    }
+  }
+  reinterpret_cast<u32x4 *>(out)[g] = u32x4{pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7])};
+}
+
+hipError_t launch_gn_relu_maxpool_bf16(const unsigned short *const *x, const float *const *scale, const float *const *shift,
+                                       int B, int H, int W, int C, unsigned short *const *out, int nmodels, hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(gn_relu_maxpool_bf16_kernel, dim3((unsigned)((total + 255) / 256), 1, (unsigned)nmodels), dim3(256), 0, s,
+                     x[0], x[nmodels - 1], scale[0], scale[nmodels - 1], shift[0], shift[nmodels - 1], B, H, W, C, Ho, Wo,
+                     out[0], out[nmodels - 1]);
+  return hipGetLastError();
+}
+
+// BasicBlock tail (resnet.py:47-55): y = relu(GN2(conv2) + residual), residual = x (final activations) or GN_d(conv1x1(x)).
+struct ResidualBArgs {
+  const unsigned short *a[2], *b[2];
+  const float *sa[2], *ta[2], *sb[2], *tb[2];
+  unsigned short *y[2];
+  long PC;
+  int C;
+  long total8;
+};
+__global__ __launch_bounds__(256) void residual_bf16_kernel(const ResidualBArgs p) {
+  const int z = blockIdx.z;
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= p.total8) return;
+  const long e = g * 8;
+  const int n = (int)(e / p.PC);
+  const int c = (int)(e % p.C);
+  const u32x4 va = reinterpret_cast<const u32x4 *>(p.a[z])[g];
+  const u32x4 vb = reinterpret_cast<const u32x4 *>(p.b[z])[g];
+  const float *sa = p.sa[z] + (long)n * p.C + c, *ta = p.ta[z] + (long)n * p.C + c;
+  float r[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    r[2 * t] = lo_f(vb[t]);
+    r[2 * t + 1] = hi_f(vb[t]);
+  }
+  if (p.sb[z] != nullptr) {
+    const float *sb = p.sb[z] + (long)n * p.C + c, *tb = p.tb[z] + (long)n * p.C + c;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) r[t] = __builtin_fmaf(r[t], sb[t], tb[t]);
+  }
+  float o[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    o[2 * t] = fmaxf(__builtin_fmaf(lo_f(va[t]), sa[2 * t], ta[2 * t]) + r[2 * t], 0.f);
+    o[2 * t + 1] = fmaxf(__builtin_fmaf(hi_f(va[t]), sa[2 * t + 1], ta[2 * t + 1]) + r[2 * t + 1], 0.f);
+  }
+  reinterpret_cast<u32x4 *>(p.y[z])[g] = u32x4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+}
+
+hipError_t launch_residual_bf16(const unsigned short *const *a, const float *const *sa, const float *const *ta,
+                                const unsigned short *const *b, const float *const *sb, const float *const *tb, int B, long P,
+                                int C, unsigned short *const *y, int nmodels, hipStream_t s) {
+  ResidualBArgs p;
+  for (int z = 0; z < 2; ++z) {
+    const int k = z < nmodels ? z : 0;
+    p.a[z] = a[k];
+    p.b[z] = b[k];
+    p.sa[z] = sa[k];
+    p.ta[z] = ta[k];
+    p.sb[z] = sb ? sb[k] : nullptr;
+    p.tb[z] = tb ? tb[k] : nullptr;
+    p.y[z] = y[k];
+  }
+  p.PC = P * C;
+  p.C = C;
+  p.total8 = (long)B * P * C / 8;
+  hipLaunchKernelGGL(residual_bf16_kernel, dim3((unsigned)((p.total8 + 255) / 256), 1, (unsigned)nmodels), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace pnvo

@@ -226,6 +226,7 @@ int load_conv(pnvo_handle h, const Toc &t, Layer &l, bool has_gn) {
   std::vector<float> pk;
   pack_conv_weight_cinp(w, l.cout, l.cin, l.cinp, l.k, l.kw, pk);
   if ((rc = upload(h, l.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
+  l.host_w.assign(w, w + (size_t)l.cout * l.cin * l.k * l.kw);
   if (has_gn) {
     const float *g = find_tensor(h, t, l.gn + ".weight", {l.cout}, &rc);
     if (!g) return rc;
@@ -918,7 +919,35 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     if ((rc = upload(h, h->head_bias, b2, c.out_dim)) != PNVO_OK) return rc;
   }
   h->loaded = true;
+  h->load_gen += 1;
   return PNVO_OK;
+}
+
+int pnvo_set_precision(pnvo_handle h, int precision) {
+  if (!h) return fail(h, PNVO_ERR_ARG, "null handle");
+  if (precision != 0 && precision != 1) return fail(h, PNVO_ERR_ARG, "precision must be 0 (float32) or 1 (bfloat16)");
+  h->precision = precision;
+  return PNVO_OK;
+}
+
+int pnvo_forward_dual(pnvo_handle ha, pnvo_handle hb, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                      int B, float *out_a, float *out_b, void *stream) {
+  if (!ha || !hb) return fail(ha, PNVO_ERR_ARG, "null handle");
+  if (!ha->loaded || !hb->loaded) return fail(ha, PNVO_ERR_STATE, "pnvo_forward_dual before pnvo_load_weights");
+  if (B <= 0 || !out_a || !out_b) return fail(ha, PNVO_ERR_ARG, "bad batch / null output");
+  if (ha->precision != 1 || hb->precision != 1)
+    return fail(ha, PNVO_ERR_STATE, "pnvo_forward_dual runs the bfloat16 path: call pnvo_set_precision(h, 1) on both models");
+  if (std::memcmp(&ha->cfg, &hb->cfg, sizeof(pnvo_config)) != 0 || ha->device != hb->device)
+    return fail(ha, PNVO_ERR_ARG, "the two models of a dual forward must share architecture and device");
+  const pnvo_config &c = ha->cfg;
+  if ((c.n_rgb > 0) != (rgb != nullptr) || (c.n_depth > 0) != (depth != nullptr) || (c.n_dd > 0) != (dd != nullptr) ||
+      (c.n_tdv > 0) != (tdv != nullptr))
+    return fail(ha, PNVO_ERR_ARG, "observation tensors do not match the model's observation_space");
+  if (int rc0 = pnvo_check_inputs(ha)) return rc0;
+  HIPCHK(ha, hipSetDevice(ha->device));
+  pnvo_handle hs[2] = {ha, hb};
+  float *outs[2] = {out_a, out_b};
+  return pnvo_forward_bf16(hs, 2, rgb, depth, dd, tdv, nullptr, B, outs, (hipStream_t)stream);
 }
 
 int pnvo_check_inputs(pnvo_handle m) {
@@ -949,6 +978,11 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
   if (c.act_embed && !actions) return fail(m, PNVO_ERR_ARG, "act_embed model needs actions");
   if (int rc0 = pnvo_check_inputs(m)) return rc0;
   HIPCHK(m, hipSetDevice(m->device));
+  if (m->precision == 1) {
+    pnvo_handle hs[1] = {m};
+    float *outs[1] = {out};
+    return pnvo_forward_bf16(hs, 1, rgb, depth, dd, tdv, actions, B, outs, (hipStream_t)stream);
+  }
   int rc = ensure_workspace(m, B);
   if (rc != PNVO_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1225,6 +1259,7 @@ int pnvo_destroy(pnvo_handle m) {
   if (!m) return PNVO_OK;
   (void)hipSetDevice(m->device);
   pnvo_train_free(m);
+  pnvo_bf16_free(m);
   free_workspace(m);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   for (Layer &l : m->convs) {

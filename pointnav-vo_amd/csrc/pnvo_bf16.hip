@@ -1,0 +1,319 @@
+// pnvo_bf16.hip — host side of the native-bf16 forward (BASELINE config 3: the geometric-invariance dual forward in
+// bf16).  pnvo_set_precision(h, 1) routes pnvo_forward here; pnvo_forward_dual runs TWO action models in every launch
+// (blockIdx.z / the stem's second N-tile), the second one on the channel-swapped (cur, prev) pair that the reference's
+// dataset builds for the opposite action (regression_geo_invariance_iter_dataset.py:342-386, engine :569-602) — here a
+// permutation of that model's stem weights, so the observation tensors are read from HBM once for both models.
+//
+// Numerics: bf16 operands on the matrix cores, fp32 accumulation; activations are stored in bf16 (raw conv outputs,
+// block outputs); GroupNorm statistics come from the fp32 accumulators and stay fp32 (scale/shift, whitening constants,
+// the compression output, both Linear layers).  Kernels: stem_mx.hip (PIECES = 1), conv_bf16.hip, the fp32 split-K
+// linear kernels of conv_mfma.hip for visual_fc / output_head.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pnvo_model.h"
+
+using namespace pnvo;
+
+namespace {
+
+struct BLayer {
+  ConvBArgs plan;               // shape + tile plan (pointers filled per launch)
+  int mw = 1, nw = 1;
+  size_t lds = 0;
+  unsigned short *wpk = nullptr;
+};
+
+struct Bf16State {
+  unsigned long long gen = 0;
+  std::vector<BLayer> layers;   // parallel to m->convs (index 0 unused: the stem)
+  unsigned short *stem_wpk = nullptr;        // PIECES = 1 packing, one N-tile group (this model on (prev, cur))
+  std::vector<unsigned short> stem_host, stem_host_sw;   // host copies: as is / for the swapped pair
+  unsigned short *dual_stem = nullptr;       // [tap][fragment][2 models][lane]: this model + a partner's swapped packing
+  const void *dual_partner = nullptr;
+  unsigned long long dual_partner_gen = 0, dual_self_gen = 0;
+  int cap = 0;
+  unsigned short *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr}, *rawA = nullptr, *rawB = nullptr, *rawD = nullptr;
+  float *comp_raw = nullptr, *hid = nullptr, *stats = nullptr;
+  float *ssA[2] = {nullptr, nullptr}, *ssB[2] = {nullptr, nullptr}, *ssD[2] = {nullptr, nullptr}, *ssC[2] = {nullptr, nullptr};
+};
+
+template <typename T>
+void dfree(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_ws(Bf16State *b) {
+  dfree(b->stem_raw);
+  dfree(b->bufY[0]);
+  dfree(b->bufY[1]);
+  dfree(b->rawA);
+  dfree(b->rawB);
+  dfree(b->rawD);
+  dfree(b->comp_raw);
+  dfree(b->hid);
+  dfree(b->stats);
+  for (int k = 0; k < 2; ++k) {
+    dfree(b->ssA[k]);
+    dfree(b->ssB[k]);
+    dfree(b->ssD[k]);
+    dfree(b->ssC[k]);
+  }
+  b->cap = 0;
+}
+
+int prepare(pnvo_handle m) {
+  Bf16State *b = static_cast<Bf16State *>(m->bf);
+  if (b && b->gen == m->load_gen) return PNVO_OK;
+  const pnvo_config &c = m->cfg;
+  if (m->bottleneck || c.baseplanes != 32 || !m->mx_ok || m->convs[0].cout != 32)
+    return pnvo_fail(m, PNVO_ERR_ARG, "the bfloat16 path covers the resnet18 (BasicBlock, baseplanes 32) models");
+  if (!b) {
+    b = new Bf16State();
+    m->bf = b;
+  }
+  if (b->layers.size() != m->convs.size()) {
+    for (BLayer &l : b->layers) dfree(l.wpk);
+    b->layers.assign(m->convs.size(), BLayer());
+  }
+  for (size_t li = 1; li < m->convs.size(); ++li) {
+    const Layer &l = m->convs[li];
+    BLayer &bl = b->layers[li];
+    std::memset(&bl.plan, 0, sizeof(bl.plan));
+    bl.plan.H = l.hin;
+    bl.plan.W = l.win;
+    bl.plan.CIN = rup(l.cin, 32);
+    bl.plan.Ho = l.hout;
+    bl.plan.Wo = l.wout;
+    bl.plan.COUTP = l.coutp;
+    if (!conv_bf16_plan(bl.plan, l.k, l.stride, &bl.mw, &bl.nw, &bl.lds))
+      return pnvo_fail(m, PNVO_ERR_ARG, "layer '" + l.name + "' is outside the bfloat16 conv kernel's shapes");
+    if (l.host_w.empty()) return pnvo_fail(m, PNVO_ERR_STATE, "weights of '" + l.name + "' were not loaded");
+    std::vector<unsigned short> pk((size_t)l.k * l.kw * bl.plan.CIN * l.coutp);
+    pack_conv_bf16_weight(l.host_w.data(), l.cout, l.cin, bl.plan.CIN, l.coutp, l.k, l.kw, pk.data());
+    if (!bl.wpk) HIPCHK(m, hipMalloc((void **)&bl.wpk, pk.size() * 2));
+    HIPCHK(m, hipMemcpy(bl.wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+  }
+  {
+    const size_t n = stem_mx_packed_u16(1, 1);
+    b->stem_host.resize(n);
+    b->stem_host_sw.resize(n);
+    pack_stem_mx_weight(m->mx_wk.data(), 32, 1, m->mx_xslot, b->stem_host.data());
+    pack_stem_mx_weight(m->mx_wk_swapped.data(), 32, 1, m->mx_xslot, b->stem_host_sw.data());
+    if (!b->stem_wpk) HIPCHK(m, hipMalloc((void **)&b->stem_wpk, n * 2));
+    HIPCHK(m, hipMemcpy(b->stem_wpk, b->stem_host.data(), n * 2, hipMemcpyHostToDevice));
+  }
+  b->gen = m->load_gen;
+  return PNVO_OK;
+}
+
+int ensure_ws(pnvo_handle m, int B) {
+  Bf16State *b = static_cast<Bf16State *>(m->bf);
+  if (B <= b->cap) return PNVO_OK;
+  free_ws(b);
+  const pnvo_config &c = m->cfg;
+  size_t act = (size_t)B * m->Hp * m->Wp * c.baseplanes, st = (size_t)B * stem_mx_slots(m->Hs, m->Ws) * 32 * 2;
+  int maxc = m->comp_cp;
+  for (size_t li = 1; li < m->convs.size(); ++li) {
+    const Layer &l = m->convs[li];
+    act = std::max(act, (size_t)B * l.hout * l.wout * l.coutp);
+    st = std::max(st, (size_t)B * b->layers[li].plan.slots * l.coutp * 2);
+    maxc = std::max(maxc, l.coutp);
+  }
+  HIPCHK(m, hipMalloc((void **)&b->stem_raw, (size_t)B * m->Hs * m->Ws * 32 * 2));
+  for (unsigned short **pp : {&b->bufY[0], &b->bufY[1], &b->rawA, &b->rawB, &b->rawD}) HIPCHK(m, hipMalloc((void **)pp, act * 2));
+  HIPCHK(m, hipMalloc((void **)&b->comp_raw, (size_t)B * m->fh * m->fw * m->comp_cp * 4));
+  HIPCHK(m, hipMalloc((void **)&b->hid, (size_t)B * c.hidden * 4));
+  HIPCHK(m, hipMalloc((void **)&b->stats, st * 4));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(m, hipMalloc((void **)&b->ssA[k], (size_t)B * maxc * 4));
+    HIPCHK(m, hipMalloc((void **)&b->ssB[k], (size_t)B * maxc * 4));
+    HIPCHK(m, hipMalloc((void **)&b->ssD[k], (size_t)B * maxc * 4));
+    HIPCHK(m, hipMalloc((void **)&b->ssC[k], (size_t)B * m->comp_cp * 4));
+    HIPCHK(m, hipMemset(b->ssC[k], 0, (size_t)B * m->comp_cp * 4));      // pad channels stay (0, 0)
+  }
+  b->cap = B;
+  return PNVO_OK;
+}
+
+// the stem's B operand for a dual launch: [tap][fragment][model 0 | model 1 on the swapped pair][lane]
+int dual_stem(pnvo_handle m0, pnvo_handle m1) {
+  Bf16State *b0 = static_cast<Bf16State *>(m0->bf), *b1 = static_cast<Bf16State *>(m1->bf);
+  if (b0->dual_stem && b0->dual_partner == m1 && b0->dual_partner_gen == m1->load_gen && b0->dual_self_gen == m0->load_gen)
+    return PNVO_OK;
+  const size_t n1 = stem_mx_packed_u16(1, 1);            // 49 taps x 2 fragments x 512 u16
+  std::vector<unsigned short> pk(2 * n1);
+  for (size_t tf = 0; tf < n1 / 512; ++tf) {
+    std::memcpy(&pk[(2 * tf) * 512], &b0->stem_host[tf * 512], 1024);
+    std::memcpy(&pk[(2 * tf + 1) * 512], &b1->stem_host_sw[tf * 512], 1024);
+  }
+  if (!b0->dual_stem) HIPCHK(m0, hipMalloc((void **)&b0->dual_stem, pk.size() * 2));
+  HIPCHK(m0, hipMemcpy(b0->dual_stem, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+  b0->dual_partner = m1;
+  b0->dual_partner_gen = m1->load_gen;
+  b0->dual_self_gen = m0->load_gen;
+  return PNVO_OK;
+}
+
+}  // namespace
+
+void pnvo_bf16_free(pnvo_handle m) {
+  Bf16State *b = static_cast<Bf16State *>(m->bf);
+  if (!b) return;
+  free_ws(b);
+  for (BLayer &l : b->layers) dfree(l.wpk);
+  dfree(b->stem_wpk);
+  dfree(b->dual_stem);
+  delete b;
+  m->bf = nullptr;
+}
+
+int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                      const int64_t *actions, int B, float *const *outs, hipStream_t s) {
+  pnvo_handle m = hs[0];
+  Bf16State *bs[2] = {nullptr, nullptr};
+  int rc;
+  for (int z = 0; z < nm; ++z) {
+    if ((rc = prepare(hs[z])) != PNVO_OK) return z == 0 ? rc : pnvo_fail(m, rc, hs[z]->err);
+    bs[z] = static_cast<Bf16State *>(hs[z]->bf);
+    if ((rc = ensure_ws(hs[z], B)) != PNVO_OK) return z == 0 ? rc : pnvo_fail(m, rc, hs[z]->err);
+  }
+  if (nm == 2 && (rc = dual_stem(hs[0], hs[1])) != PNVO_OK) return rc;
+  const pnvo_config &c = m->cfg;
+  const Layer &stem = m->convs[0];
+  auto each = [&](auto f) {                       // per-model pointer arrays for the batched launches
+    using T = decltype(f(0));
+    struct R { T v[2]; } r;
+    for (int z = 0; z < 2; ++z) r.v[z] = f(z < nm ? z : 0);
+    return r;
+  };
+
+  // (a4-a6) fused stem, one N-tile per model
+  {
+    StemMXArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.src[0] = rgb;
+    a.src[1] = depth;
+    a.src[2] = dd;
+    a.src[3] = tdv;
+    a.zero_page = m->mx_pages;
+    a.wpk = nm == 2 ? bs[0]->dual_stem : bs[0]->stem_wpk;
+    for (int z = 0; z < nm; ++z) {
+      a.y[z] = bs[z]->stem_raw;
+      a.stats[z] = bs[z]->stats;
+      a.y_coff[z] = 0;
+    }
+    a.y_cstride = 32;
+    a.stats_cstride = 32;
+    a.B = B;
+    a.H = c.height;
+    a.W = c.width;
+    a.Ho = m->Hs;
+    a.Wo = m->Ws;
+    a.slots = stem_mx_slots(m->Hs, m->Ws);
+    const double M = (double)B * m->Hs * m->Ws;
+    {
+      PnvoTimed t(m, s, "bf16:stem", 2.0 * nm * M * stem.cout * stem.cin * 49,
+                  4.0 * (double)B * c.height * c.width * stem.cin + 2.0 * nm * M * stem.cout);
+      HIPCHK(m, launch_stem_mx(a, 1, nm, true, s));
+    }
+    PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
+    for (int z = 0; z < nm; ++z)
+      HIPCHK(m, launch_gn_finalize(bs[z]->stats, B, a.slots, 32, 32, stem.groups, (long)m->Hs * m->Ws, 1, hs[z]->convs[0].gamma,
+                                   hs[z]->convs[0].beta, 1e-5f, bs[z]->ssA[0], bs[z]->ssA[1], s, a.slots, nullptr, nullptr));
+  }
+  // (a7) GN + ReLU + maxpool
+  int cur = 0;
+  {
+    auto x = each([&](int z) { return (const unsigned short *)bs[z]->stem_raw; });
+    auto sc = each([&](int z) { return (const float *)bs[z]->ssA[0]; });
+    auto sh = each([&](int z) { return (const float *)bs[z]->ssA[1]; });
+    auto o = each([&](int z) { return bs[z]->bufY[0]; });
+    PnvoTimed t(m, s, "bf16:gn_relu_maxpool", 0.0, 2.0 * nm * B * ((double)m->Hs * m->Ws + (double)m->Hp * m->Wp) * 32);
+    HIPCHK(m, launch_gn_relu_maxpool_bf16(x.v, sc.v, sh.v, B, m->Hs, m->Ws, 32, o.v, nm, s));
+  }
+
+  // one conv of the residual stages + its GroupNorm finalisation
+  auto conv = [&](size_t li, auto xin, auto yout, int ss_sel /*0 A, 1 B, 2 D, 3 C*/, int in_sel /*-1 none, 0 A*/, bool f32out) -> int {
+    const Layer &l = m->convs[li];
+    ConvBArgs a = bs[0]->layers[li].plan;
+    a.B = B;
+    for (int z = 0; z < 2; ++z) {
+      const int k = z < nm ? z : 0;
+      a.x[z] = xin(k);
+      a.wpk[z] = bs[k]->layers[li].wpk;
+      a.y[z] = yout(k);
+      a.stats[z] = bs[k]->stats;
+      a.in_scale[z] = in_sel == 0 ? bs[k]->ssA[0] : nullptr;
+      a.in_shift[z] = in_sel == 0 ? bs[k]->ssA[1] : nullptr;
+    }
+    const double macs = (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw;
+    {
+      PnvoTimed t(m, s, "bf16:conv:" + l.name, 2.0 * nm * macs,
+                  2.0 * nm * ((double)B * l.hin * l.win * l.cin + (double)B * l.hout * l.wout * l.cout));
+      HIPCHK(m, launch_conv_bf16(a, l.k, l.stride, in_sel == 0 ? 1 : 0, f32out, bs[0]->layers[li].mw, bs[0]->layers[li].nw,
+                                 bs[0]->layers[li].lds, nm, s));
+    }
+    PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
+    for (int z = 0; z < nm; ++z) {
+      float **ss = ss_sel == 0 ? bs[z]->ssA : ss_sel == 1 ? bs[z]->ssB : ss_sel == 2 ? bs[z]->ssD : bs[z]->ssC;
+      HIPCHK(m, launch_gn_finalize(bs[z]->stats, B, a.slots, l.coutp, l.cout, l.groups, (long)l.hout * l.wout, 1,
+                                   hs[z]->convs[li].gamma, hs[z]->convs[li].beta, 1e-5f, ss[0], ss[1], s, a.slots, nullptr,
+                                   nullptr));
+    }
+    return PNVO_OK;
+  };
+
+  // (a8) residual stages (BasicBlock: conv3x3(s) -> GN -> ReLU -> conv3x3 -> GN; + identity / conv1x1(s)+GN; ReLU)
+  size_t li = 1;
+  for (int stage = 1; stage <= 4; ++stage)
+    for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
+      const size_t l1 = li++, l2 = li++;
+      const bool ds = li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos;
+      const Layer &c2 = m->convs[l2];
+      auto xcur = [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; };
+      if ((rc = conv(l1, xcur, [&](int z) { return (void *)bs[z]->rawA; }, 0, -1, false)) != PNVO_OK) return rc;
+      if ((rc = conv(l2, [&](int z) { return (const unsigned short *)bs[z]->rawA; }, [&](int z) { return (void *)bs[z]->rawB; }, 1,
+                     0, false)) != PNVO_OK)
+        return rc;
+      const long P = (long)c2.hout * c2.wout;
+      auto a_ = each([&](int z) { return (const unsigned short *)bs[z]->rawB; });
+      auto sa = each([&](int z) { return (const float *)bs[z]->ssB[0]; });
+      auto ta = each([&](int z) { return (const float *)bs[z]->ssB[1]; });
+      auto y_ = each([&](int z) { return bs[z]->bufY[cur ^ 1]; });
+      if (ds) {
+        const size_t ld = li++;
+        if ((rc = conv(ld, xcur, [&](int z) { return (void *)bs[z]->rawD; }, 2, -1, false)) != PNVO_OK) return rc;
+        auto b_ = each([&](int z) { return (const unsigned short *)bs[z]->rawD; });
+        auto sb = each([&](int z) { return (const float *)bs[z]->ssD[0]; });
+        auto tb = each([&](int z) { return (const float *)bs[z]->ssD[1]; });
+        PnvoTimed t(m, s, "bf16:residual", 0.0, 6.0 * nm * B * P * c2.coutp);
+        HIPCHK(m, launch_residual_bf16(a_.v, sa.v, ta.v, b_.v, sb.v, tb.v, B, P, c2.coutp, y_.v, nm, s));
+      } else {
+        auto b_ = each([&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; });
+        PnvoTimed t(m, s, "bf16:residual", 0.0, 6.0 * nm * B * P * c2.coutp);
+        HIPCHK(m, launch_residual_bf16(a_.v, sa.v, ta.v, b_.v, nullptr, nullptr, B, P, c2.coutp, y_.v, nm, s));
+      }
+      cur ^= 1;
+    }
+  // (a10) compression conv + GroupNorm(1, C): fp32 output for the Linear layers
+  if ((rc = conv(li, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; }, [&](int z) { return (void *)bs[z]->comp_raw; }, 3,
+                 -1, true)) != PNVO_OK)
+    return rc;
+  // (a11) Flatten + Linear + ReLU + output head: the fp32 split-K linear kernels on each model
+  for (int z = 0; z < nm; ++z) {
+    pnvo_handle h = hs[z];
+    const int tm = h->timing;
+    h->timing = 0;                                  // (their event records belong to the fp32 path's table)
+    rc = pnvo_run_conv(h, h->fc, B, bs[z]->comp_raw, bs[z]->ssC[0], bs[z]->ssC[1], bs[z]->hid, c.hidden, nullptr, h->fc_bias,
+                       c.act_embed ? actions : nullptr, 1, s, nullptr, nullptr, nullptr);
+    if (rc == PNVO_OK)
+      rc = pnvo_run_conv(h, h->head, B, bs[z]->hid, nullptr, nullptr, outs[z], c.out_dim, nullptr, h->head_bias, nullptr, 0, s,
+                         nullptr, nullptr, nullptr);
+    h->timing = tm;
+    if (rc != PNVO_OK) return z == 0 ? rc : pnvo_fail(m, rc, h->err);
+  }
+  return PNVO_OK;
+}

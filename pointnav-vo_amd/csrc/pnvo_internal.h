@@ -101,6 +101,26 @@ size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
 
+// Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).
+struct ConvBArgs {
+  const unsigned short *x[2];        // [B,H,W,CIN] bf16 NHWC
+  const unsigned short *wpk[2];      // pack_conv_bf16_weight()
+  void *y[2];                        // [B,Ho,Wo,COUTP] raw output, bf16 (or float for the compression conv)
+  const float *in_scale[2], *in_shift[2];   // [B,CIN] MODE 1: relu(x*scale+shift) applied while staging
+  float *stats[2];                   // [B,slots,COUTP,2] GroupNorm partial sums
+  int B, H, W, CIN, Ho, Wo, COUTP;
+  int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_bf16_plan
+};
+bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
+hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bool f32out, int mw, int nw, size_t lds_bytes,
+                            int nmodels, hipStream_t s);
+void pack_conv_bf16_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);
+hipError_t launch_gn_relu_maxpool_bf16(const unsigned short *const *x, const float *const *scale, const float *const *shift,
+                                       int B, int H, int W, int C, unsigned short *const *out, int nmodels, hipStream_t s);
+hipError_t launch_residual_bf16(const unsigned short *const *a, const float *const *sa, const float *const *ta,
+                                const unsigned short *const *b, const float *const *sb, const float *const *tb, int B, long P,
+                                int C, unsigned short *const *y, int nmodels, hipStream_t s);
+
 int conv_slots(int P, int MT);                       // stats slots per sample for a given wave tile
 void choose_tile(long M, int COUTP, int *MT, int *NT);
 hipError_t launch_conv(const ConvArgs &a, hipStream_t s);

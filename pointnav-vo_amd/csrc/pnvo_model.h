@@ -17,6 +17,7 @@ struct Layer {
   int cin = 0, cinp = 0, cout = 0, coutp = 0, k = 1, kw = 1, stride = 1, pad = 0;
   int hin = 0, win = 0, hout = 0, wout = 0, groups = 1;
   float *wpk = nullptr, *gamma = nullptr, *beta = nullptr;   // device
+  std::vector<float> host_w;  // OIHW copy of the loaded weight (source of the bf16 packing, pnvo_bf16.hip)
 };
 
 struct TimingRec {
@@ -60,7 +61,10 @@ struct pnvo_model_s {
   int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels
   float *mx_pages = nullptr;                 // device: 64 zeros (out-of-image reads)
   unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx
-  bool in_train_forward = false;             // set by pnvo_train_forward: its stem operands are rebuilt on the device
+  bool in_train_forward = false;
+  int precision = 0;                         // pnvo_set_precision: 0 float32 (default), 1 bfloat16 (BASELINE config 3)
+  unsigned long long load_gen = 0;           // bumped by pnvo_load_weights (operands derived lazily are rebuilt)
+  void *bf = nullptr;                        // Bf16State (pnvo_bf16.hip)             // set by pnvo_train_forward: its stem operands are rebuilt on the device
 
   int cap = 0;                       // batch the workspace is sized for
   float *xin = nullptr, *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr};
@@ -112,6 +116,9 @@ void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, 
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
                   hipStream_t s);
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
+void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip
+int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                      const int64_t *actions, int B, float *const *outs, hipStream_t s);
 int pnvo_fail(pnvo_handle h, int code, const std::string &msg);
 void pnvo_free_dev(float *&p);
 int pnvo_ensure_workspace(pnvo_handle m, int B);

@@ -53,6 +53,8 @@ constexpr int PITCH = 80;                         // bytes per patch pixel: 64 (
 constexpr int PAR = 19 * PITCH;                   // odd-column plane of a patch row
 constexpr int ROW = 3072;                         // patch row pitch (2 x 19 x 80 = 3040, padded: 2 rows = 0 mod 256 B)
 constexpr int PATCH_BYTES = PH * ROW;             // 64512
+constexpr int XCHG_BYTES = 4 * 4 * 4096;          // K-split exchange: [M-tile][wave][4 KB], reuses the patch area
+constexpr int RED_OFF = XCHG_BYTES > PATCH_BYTES ? XCHG_BYTES : PATCH_BYTES;
 constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr bool EXTRA = PIECES == 3;
   constexpr int NFT = PIECES * 2 + (EXTRA ? 1 : 0);        // B fragments per (tap, N-tile)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  float *red = reinterpret_cast<float *>(lds + PATCH_BYTES);   // [4 waves][NT*32][2]
+  float *red = reinterpret_cast<float *>(lds + RED_OFF);       // [4 waves][NT*32][2]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -442,13 +444,13 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
   const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
   const unsigned gx = (unsigned)(((ntiles + 7) / 8) * 8);
   if (pieces == 3 && !bf16_out) {
-    const size_t ldsb = PATCH_BYTES + 4 * 1 * 32 * 2 * sizeof(float);
+    const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<3, 1, false>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
   } else if (pieces == 1 && bf16_out && ntiles_n % 2 == 0) {
-    const size_t ldsb = PATCH_BYTES + 4 * 2 * 32 * 2 * sizeof(float);
+    const size_t ldsb = RED_OFF + 4 * 2 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<1, 2, true>), dim3(gx, (unsigned)(ntiles_n / 2)), dim3(NTHREADS), ldsb, s, p);
   } else if (pieces == 1 && bf16_out) {
-    const size_t ldsb = PATCH_BYTES + 4 * 1 * 32 * 2 * sizeof(float);
+    const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<1, 1, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
   } else {
     return hipErrorInvalidValue;

@@ -87,8 +87,19 @@ class VisualOdometryCNNBase(nn.Module):
         self._handle = None
         self._handle_dev = None
         self._loaded_sig = None
+        self._precision = "float32"
 
     # ------------------------------------------------------------------ libpnvo plumbing
+    def set_precision(self, precision):
+        """"float32" (default) or "bfloat16" (BASELINE config 3: bf16 operands / activations, fp32 accumulation and
+        normalisation statistics; resnet18 models).  Applies to the eval-mode forward and to dual_forward()."""
+        if precision not in ("float32", "bfloat16"):
+            raise ValueError(precision)
+        self._precision = precision
+        if self._handle is not None:
+            _lib.check(_lib.lib.pnvo_set_precision(self._handle, int(precision == "bfloat16")), self._handle)
+        return self
+
     def _tensors(self):
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
@@ -107,6 +118,7 @@ class VisualOdometryCNNBase(nn.Module):
         h = C.c_void_p()
         _lib.check(_lib.lib.pnvo_create(C.byref(cc), int(device.index or 0), C.byref(h)))
         self._handle, self._handle_dev, self._loaded_sig = h, device.index, None
+        _lib.check(_lib.lib.pnvo_set_precision(h, int(self._precision == "bfloat16")), h)
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
@@ -225,6 +237,51 @@ class VisualOdometryCNNBase(nn.Module):
         _lib.check(_lib.lib.pnvo_timing_read(self._handle, ent, 128, C.byref(n)), self._handle)
         return [dict(name=ent[i].name.decode(), launches=int(ent[i].launches), total_ms=float(ent[i].total_ms),
                      flops=float(ent[i].flops), bytes=float(ent[i].bytes)) for i in range(min(n.value, 128))]
+
+
+def _obs_ptrs(model, observation_pairs, dev):
+    c = model.cfg
+    ptrs, B, keep = [], None, []
+    for key, n in (("rgb", c.n_rgb), ("depth", c.n_depth), ("discretized_depth", c.n_dd), ("top_down_view", c.n_tdv)):
+        if n == 0:
+            ptrs.append(None)
+            continue
+        t = observation_pairs[key]
+        if t.device != dev:
+            raise RuntimeError(f"observation '{key}' is on {t.device}, model on {dev}")
+        t = t.to(torch.float32).contiguous()
+        if t.dim() != 4 or t.shape[1] != c.height or t.shape[2] != c.width or t.shape[3] != n:
+            raise ValueError(f"observation '{key}' has shape {tuple(t.shape)}, expected [B,{c.height},{c.width},{n}]")
+        B = t.shape[0] if B is None else B
+        assert t.shape[0] == B
+        keep.append(t)
+        ptrs.append(C.c_void_p(t.data_ptr()))
+    return ptrs, B, keep
+
+
+def dual_forward(model_a, model_b, observation_pairs):
+    """The geometric-invariance dual forward (vo_cnn_regression_geo_invariance_engine.py:569-602): returns
+    (model_a(observation_pairs), model_b(swapped observation_pairs)) where the swapped pair exchanges the [prev | cur] halves
+    of every observation tensor (regression_geo_invariance_iter_dataset.py:342-386) — computed in ONE pass over the
+    observation tensors, both models in every launch, on the bfloat16 path (call set_precision("bfloat16") on both)."""
+    ref = next(model_a.parameters())
+    if ref.device.type != "cuda" or next(model_b.parameters()).device != ref.device:
+        raise RuntimeError("dual_forward: both models must be on the same MI355X (there is no CPU fallback)")
+    if model_a.training or model_b.training:
+        raise RuntimeError("dual_forward is the eval-mode forward of both models")
+    dev = ref.device
+    for m in (model_a, model_b):
+        m._ensure_handle(dev)
+        m._sync_weights()
+    ptrs, B, keep = _obs_ptrs(model_a, observation_pairs, dev)
+    oa = torch.empty((B, model_a.cfg.out_dim), device=dev, dtype=torch.float32)
+    ob = torch.empty_like(oa)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.pnvo_forward_dual(model_a._handle, model_b._handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(B),
+                                              C.c_void_p(oa.data_ptr()), C.c_void_p(ob.data_ptr()), C.c_void_p(stream)),
+                   model_a._handle)
+    return oa, ob
 
 
 class VisualOdometryCNNActEmbedBase(VisualOdometryCNNBase):
