@@ -250,6 +250,8 @@ hipError_t launch_ks(const ConvBArgs &a, int mode, bool f32out, int mw, int nw, 
   }
   PNVO_CB(0, false, 1, 1) PNVO_CB(1, false, 1, 1) PNVO_CB(0, false, 2, 1) PNVO_CB(1, false, 2, 1)
   PNVO_CB(0, false, 4, 1) PNVO_CB(1, false, 4, 1) PNVO_CB(0, false, 4, 2) PNVO_CB(1, false, 4, 2)
+  PNVO_CB(0, false, 3, 1) PNVO_CB(1, false, 3, 1) PNVO_CB(0, false, 3, 2) PNVO_CB(1, false, 3, 2) PNVO_CB(0, true, 3, 2)
+  PNVO_CB(0, true, 3, 1)
   PNVO_CB(0, true, 1, 1) PNVO_CB(0, true, 2, 1) PNVO_CB(0, true, 4, 1) PNVO_CB(0, true, 4, 2)
 #undef PNVO_CB
   return hipErrorInvalidValue;
@@ -301,6 +303,7 @@ bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *
     *mw = 4;
     *nw = 2;
   }
+  if (a.wn == 4 && a.MT < *mw) *mw = a.MT == 3 ? 3 : *mw;               // ragged strips: three M-tiles, fewer accumulators
   if ((4 / a.wn) * *mw < a.MT) return false;
   // channel chunk: the largest power of two (<= CIN) whose patch fits 56 KB
   int ck = a.CIN;

@@ -132,6 +132,65 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
   }
 }
 
+// Two models in one launch (the bf16 dual forward): blockIdx.y = model.
+struct GnFin2 {
+  const float *stats[2], *gamma[2], *beta[2];
+  float *scale[2], *shift[2];
+};
+// One 256-thread block per (sample, model): 256 / G threads per group read the per-slot partials (coalesced over the
+// channel pairs of a slot), fixed-order fp64 reduction through LDS.
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const GnFin2 q, int slots, int CP, int C, int G, long P, float eps) {
+  __shared__ double red[2][256];
+  const int z = blockIdx.y, n = blockIdx.x;
+  const int cpg = C / G, lpg = 256 / G;
+  const int g = threadIdx.x / lpg, l = threadIdx.x - g * lpg;
+  const float *stats = q.stats[z] + (long)n * slots * CP * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = l; k < slots * cpg; k += lpg) {
+    const int slot = k / cpg, c = g * cpg + k - slot * cpg;
+    const float2 v = *reinterpret_cast<const float2 *>(stats + ((long)slot * CP + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (l < cpg || l == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < lpg; ++k) {                     // every writer of the group sums in the same order
+      t1 += red[0][g * lpg + k];
+      t2 += red[1][g * lpg + k];
+    }
+    const double cnt = (double)P * cpg;
+    const double mu = t1 / cnt;
+    double var = t2 / cnt - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int k = l; k < cpg; k += lpg) {
+      const int c = g * cpg + k;
+      const double sc = rstd * (double)q.gamma[z][c];
+      q.scale[z][(long)n * CP + c] = (float)sc;
+      q.shift[z][(long)n * CP + c] = (float)((double)q.beta[z][c] - mu * sc);
+    }
+  }
+}
+
+hipError_t launch_gn_finalize2(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
+                               const float *const *beta, float eps, float *const *scale, float *const *shift, int nmodels,
+                               hipStream_t s) {
+  GnFin2 q;
+  for (int z = 0; z < 2; ++z) {
+    const int k = z < nmodels ? z : 0;
+    q.stats[z] = stats[k];
+    q.gamma[z] = gamma[k];
+    q.beta[z] = beta[k];
+    q.scale[z] = scale[k];
+    q.shift[z] = shift[k];
+  }
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3((unsigned)B, (unsigned)nmodels), dim3(256), 0, s, q, slots, CP, C, G, P, eps);
+  return hipGetLastError();
+}
+
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
                               hipStream_t s, int fixed_ns, float *mu_out, float *rstd_out) {

@@ -220,9 +220,12 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       HIPCHK(m, launch_stem_mx(a, 1, nm, true, s));
     }
     PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
-    for (int z = 0; z < nm; ++z)
-      HIPCHK(m, launch_gn_finalize(bs[z]->stats, B, a.slots, 32, 32, stem.groups, (long)m->Hs * m->Ws, 1, hs[z]->convs[0].gamma,
-                                   hs[z]->convs[0].beta, 1e-5f, bs[z]->ssA[0], bs[z]->ssA[1], s, a.slots, nullptr, nullptr));
+    auto st = each([&](int z) { return (const float *)bs[z]->stats; });
+    auto ga = each([&](int z) { return (const float *)hs[z]->convs[0].gamma; });
+    auto be = each([&](int z) { return (const float *)hs[z]->convs[0].beta; });
+    auto sc = each([&](int z) { return bs[z]->ssA[0]; });
+    auto sh = each([&](int z) { return bs[z]->ssA[1]; });
+    HIPCHK(m, launch_gn_finalize2(st.v, B, a.slots, 32, 32, stem.groups, (long)m->Hs * m->Ws, ga.v, be.v, 1e-5f, sc.v, sh.v, nm, s));
   }
   // (a7) GN + ReLU + maxpool
   int cur = 0;
@@ -257,12 +260,14 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
                                  bs[0]->layers[li].lds, nm, s));
     }
     PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
-    for (int z = 0; z < nm; ++z) {
-      float **ss = ss_sel == 0 ? bs[z]->ssA : ss_sel == 1 ? bs[z]->ssB : ss_sel == 2 ? bs[z]->ssD : bs[z]->ssC;
-      HIPCHK(m, launch_gn_finalize(bs[z]->stats, B, a.slots, l.coutp, l.cout, l.groups, (long)l.hout * l.wout, 1,
-                                   hs[z]->convs[li].gamma, hs[z]->convs[li].beta, 1e-5f, ss[0], ss[1], s, a.slots, nullptr,
-                                   nullptr));
-    }
+    auto ssof = [&](int z) { return ss_sel == 0 ? bs[z]->ssA : ss_sel == 1 ? bs[z]->ssB : ss_sel == 2 ? bs[z]->ssD : bs[z]->ssC; };
+    auto st = each([&](int z) { return (const float *)bs[z]->stats; });
+    auto ga = each([&](int z) { return (const float *)hs[z]->convs[li].gamma; });
+    auto be = each([&](int z) { return (const float *)hs[z]->convs[li].beta; });
+    auto sc = each([&](int z) { return ssof(z)[0]; });
+    auto sh = each([&](int z) { return ssof(z)[1]; });
+    HIPCHK(m, launch_gn_finalize2(st.v, B, a.slots, l.coutp, l.cout, l.groups, (long)l.hout * l.wout, ga.v, be.v, 1e-5f, sc.v, sh.v,
+                                  nm, s));
     return PNVO_OK;
   };
 

@@ -143,6 +143,10 @@ hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int 
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
                               hipStream_t s, int fixed_ns = 0, float *mu_out = nullptr, float *rstd_out = nullptr);
 
+hipError_t launch_gn_finalize2(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
+                               const float *const *beta, float eps, float *const *scale, float *const *shift, int nmodels,
+                               hipStream_t s);
+
 // Input assembly + whitening (vo_cnn.py:110-176) into channel-padded NHWC.
 struct AssembleArgs {
   const float *src[4];   // rgb, depth, dd, tdv (nullptr if absent)

@@ -174,12 +174,19 @@ class VOTrainStep:
             ptrs.append(_ptr(t))
         return ptrs, keep, B
 
-    def _update_running_stats(self, ptrs, B, stream):
-        """RunningMeanAndVar.forward, training branch (running_mean_and_var.py:23-60), statistics by HIP kernels."""
+    def _input_moments(self, ptrs, B, center, power, out, stream):
+        """Per-channel mean over (B, H, W) of (x - center)^power of the assembled input, by HIP kernels (one coalesced
+        pass per observation tensor).  The only device work of the RunningMeanAndVar update: tests of the host logic
+        substitute it."""
         h = self.model._handle
+        _lib.check(_lib.lib.pnvo_input_moments(h, *ptrs, int(B), _ptr(center), int(power), _ptr(out), stream), h)
+
+    def _update_running_stats(self, ptrs, B, stream):
+        """RunningMeanAndVar.forward, training branch (running_mean_and_var.py:23-60): batch statistics from
+        _input_moments, the three all-reduces of :27-38 when torch.distributed is initialised, Chan's merge :44-60."""
         rmv = self.rmv
         distributed = dist.is_available() and dist.is_initialized()
-        _lib.check(_lib.lib.pnvo_input_moments(h, *ptrs, int(B), None, 1, _ptr(self._m1), stream), h)
+        self._input_moments(ptrs, B, None, 1, self._m1, stream)
         new_mean = (self._m1 * B).view(1, -1, 1, 1)                 # = adaptive_avg_pool2d(x, 1).sum(0)
         new_count = torch.full_like(rmv._count, B)
         if distributed:
@@ -187,7 +194,7 @@ class VOTrainStep:
             dist.all_reduce(new_count)
         new_mean = new_mean / new_count
         ctr = new_mean.reshape(-1).contiguous()
-        _lib.check(_lib.lib.pnvo_input_moments(h, *ptrs, int(B), _ptr(ctr), 2, _ptr(self._m2), stream), h)
+        self._input_moments(ptrs, B, ctr, 2, self._m2, stream)
         new_var = (self._m2 * B).view(1, -1, 1, 1)
         if distributed:
             dist.all_reduce(new_var)

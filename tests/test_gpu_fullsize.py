@@ -1,0 +1,162 @@
+"""GPU (-m gpu): BASELINE-size runs (341x192; 128 pairs per training step = configs[3] per-GPU shape, 256 pairs per forward =
+configs[1]/[2]) checked through properties that do not need a CPU reference of that size, plus robustness of the
+train <-> eval hand-over and a multi-step Adam trajectory against the pinned fp64 checker."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case, load_golden
+from oracle import torch_train_ref as ref
+from pointnav_vo_amd import model_spec as ms, synth
+from pointnav_vo_amd.registry import baseline_registry
+from pointnav_vo_amd import vo_cnn  # noqa: F401
+from pointnav_vo_amd.train import VOTrainStep
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (synthetic BASELINE-size inputs generated on the device)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def default_model(normalize=True, dropout_p=0.2, seed=0, size=(341, 192)):
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=size, hidden_size=512, backbone="resnet18",
+        normalize_visual_inputs=normalize, output_dim=3, dropout_p=dropout_p, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=seed)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return m.to(DEV), sd
+
+
+def test_training_step_at_128_pairs_full_resolution():
+    """configs[3] per-GPU shape: finite loss, gradients bit-reproducible run to run, Adam moves every tensor."""
+    obs = bench.make_inputs(128, torch.device(DEV), 0)
+    tgt = (torch.rand((128, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) - 0.5) * 0.5
+    grads, losses = [], []
+    for _ in range(2):
+        model, _ = default_model()
+        ts = VOTrainStep(model, dropout_seed=5)
+        before = ts.flat.clone()
+        out, loss = ts.forward_backward(obs, target=tgt)
+        grads.append(ts.grad.clone())
+        losses.append(loss.item())
+        ts.optimizer_step()
+        torch.cuda.synchronize()
+        moved = [(n, bool((ts.flat[o:o + k] != before[o:o + k]).any())) for n, (o, k) in ts.offsets.items()]
+        assert all(mv for _, mv in moved), [n for n, mv in moved if not mv]
+        del ts, model
+    assert np.isfinite(losses).all() and torch.isfinite(grads[0]).all()
+    assert losses[0] == losses[1] and torch.equal(grads[0], grads[1])          # fixed-order reductions everywhere
+
+
+def test_gradients_are_additive_over_pairs_at_full_resolution():
+    """GroupNorm is per sample, so without batch-coupled pieces (RunningMeanAndVar off, dropout off) the gradient of the
+    mean loss over 8 pairs is the mean of the gradients over its two halves."""
+    obs = bench.make_inputs(8, torch.device(DEV), 3)
+    tgt = (torch.rand((8, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)) - 0.5) * 0.5
+    g = []
+    for sl in (slice(0, 8), slice(0, 4), slice(4, 8)):
+        model, _ = default_model(normalize=False, dropout_p=0.0)
+        ts = VOTrainStep(model)
+        ts.forward_backward({k: v[sl].contiguous() for k, v in obs.items()}, target=tgt[sl].contiguous())
+        g.append(ts.grad.clone())
+        offsets = ts.offsets
+        del ts, model
+    want = 0.5 * (g[1] + g[2])
+    bad = []
+    for name, (o, k) in offsets.items():
+        err = (g[0][o:o + k] - want[o:o + k]).norm() / want[o:o + k].norm().clamp_min(1e-20)
+        if err > 2e-4:
+            bad.append((name, float(err)))
+    assert not bad, bad
+
+
+def _small(rec_name="train_default_45x37_b4_f64.npz", dropout_p=0.0):
+    rec = load_golden(rec_name)
+    cfg, sd, obs, _ = golden_case(rec)
+    space = str(rec["obs_space"]).split(",")
+    model = baseline_registry.get_vo_model(str(rec["model"]))(
+        observation_space=space, observation_size=(cfg.width, cfg.height), hidden_size=512, backbone="resnet18",
+        normalize_visual_inputs=True, output_dim=3, dropout_p=dropout_p, discretized_depth_channels=int(rec["dd_bins"]))
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    tobs = {k: torch.from_numpy(v).to(DEV) for k, v in obs.items()}
+    return rec, cfg, sd, obs, model.to(DEV), tobs, torch.from_numpy(rec["target"]).to(DEV)
+
+
+def test_train_eval_train_round_trips_keep_the_kernel_operands_in_sync():
+    """An eval forward between optimisation steps reloads the packed operands.  The training step's device-side re-pack
+    maps must stay valid (same buffers): the eval result equals a fresh model loaded with the trained weights, and the
+    trajectory with eval forwards in between equals, bit for bit, the trajectory without them."""
+    def run(with_evals):
+        rec, cfg, sd, obs, model, tobs, tgt = _small()
+        ts = VOTrainStep(model, lr=1e-4)
+        losses, evals = [], []
+        for _ in range(3):
+            model.train()
+            losses.append(ts.step(tobs, tgt)[1].item())
+            if with_evals:
+                with torch.no_grad():
+                    evals.append(model.eval()(tobs).clone())
+        torch.cuda.synchronize()
+        return rec, cfg, model, tobs, ts.flat.clone(), losses, evals
+
+    rec, cfg, model, tobs, flat_a, loss_a, evals = run(True)
+    _, _, _, _, flat_b, loss_b, _ = run(False)
+    assert loss_a == loss_b and torch.equal(flat_a, flat_b), (loss_a, loss_b)
+    assert not torch.equal(evals[0], evals[1]) and not torch.equal(evals[1], evals[2])        # the weights keep moving
+    fresh = baseline_registry.get_vo_model(str(rec["model"]))(
+        observation_space=str(rec["obs_space"]).split(","), observation_size=(cfg.width, cfg.height), hidden_size=512,
+        backbone="resnet18", normalize_visual_inputs=True, output_dim=3, dropout_p=0.0, discretized_depth_channels=int(rec["dd_bins"]))
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        assert torch.equal(fresh.to(DEV).eval()(tobs), evals[2])
+
+
+def test_parameters_loaded_after_attach_are_used_by_the_next_training_forward():
+    """model.load_state_dict() after a VOTrainStep is attached (resume from a checkpoint) must reach the kernels."""
+    rec, cfg, sd, obs, model, tobs, tgt = _small()
+    ts = VOTrainStep(model, lr=1e-3)
+    for _ in range(3):
+        ts.step(tobs, tgt)
+    ckpt_model = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ckpt_optim = ts.state_dict()
+    out_next, loss_next = ts.step(tobs, tgt)                       # step 4 of the original run
+    # resume: new model, new step object, restore both states, repeat step 4
+    rec2, cfg2, sd2, obs2, model2, tobs2, tgt2 = _small()
+    ts2 = VOTrainStep(model2, lr=1e-3)
+    model2.load_state_dict(ckpt_model)                             # lands in the flat buffer, AFTER the attach
+    ts2.load_state_dict(ckpt_optim)
+    out_res, loss_res = ts2.step(tobs2, tgt2)
+    torch.cuda.synchronize()
+    assert ts2.step_count == 4
+    assert torch.equal(out_res, out_next) and loss_res.item() == loss_next.item()
+    assert torch.equal(ts2.flat, ts.flat) and torch.equal(ts2.exp_avg_sq, ts.exp_avg_sq)
+
+
+def test_five_step_adam_trajectory_follows_the_fp64_checker():
+    """Five optimisation steps on a fixed batch: loss curve and final parameters against the fp64 torch checker run with
+    the same Adam state.  Adam's normalised update makes an element whose gradient sign flips with rounding move the
+    other way (2 lr per step), so the parameter bound is stated per element class."""
+    rec, cfg, sd, obs, model, tobs, tgt = _small()
+    lr, nsteps = 2.5e-4, 5
+    ts = VOTrainStep(model, lr=lr)
+    losses = [ts.step(tobs, tgt)[1].item() for _ in range(nsteps)]
+    torch.cuda.synchronize()
+    cur, state, closs = dict(sd), None, []
+    for k in range(nsteps):
+        r = ref.train_step(cur, obs, rec["target"], ngroups=cfg.ngroups, lr=lr, dtype=torch.float64, state=state, step=k + 1)
+        closs.append(float(r["loss"]))
+        state = r["state"]
+        cur = {**{n: v for n, v in r["params"].items()}, **r["buffers"]}
+    np.testing.assert_allclose(losses, closs, rtol=2e-3)
+    worst, frac_off = 0.0, []
+    for name, (o, k) in ts.offsets.items():
+        d = (ts.flat[o:o + k].cpu().double() - cur[name].reshape(-1)).abs()
+        worst = max(worst, float(d.max()))
+        frac_off.append(float((d > 0.1 * lr).double().mean()))
+    assert worst <= 2 * nsteps * lr * 1.01, worst                   # nobody can be further than 2 lr per step
+    assert np.mean(frac_off) < 0.02, np.mean(frac_off)              # and almost every element is on the checker's path

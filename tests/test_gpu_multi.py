@@ -1,0 +1,38 @@
+"""GPU (-m gpu), needs >= 2 MI355X (skipped on a 1-GPU box): the data-parallel paths through libpnvo.so under
+torch.distributed with backend nccl (RCCL over xGMI) — SURVEY.md section 4(iii) / section 8(e).
+  * sharded inference: N-rank gathered result == 1-GPU result, bit for bit
+  * VOTrainStep: 2-rank step (RunningMeanAndVar's three all-reduces, running_mean_and_var.py:27-38, and the ONE flat
+    gradient all-reduce) == the single-GPU step on the concatenated batch
+The same host logic runs under gloo on CPU in tests/test_distributed_cpu.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+need2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least 2 GPUs")
+
+
+def _run(mode):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "mgpu_worker.py"), "--mode", mode],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@need2
+def test_two_gpu_sharded_inference_equals_one_gpu():
+    _run("infer")
+
+
+@need2
+def test_two_gpu_train_step_equals_one_gpu_step_on_the_concatenated_batch():
+    _run("train")

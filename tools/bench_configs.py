@@ -1,0 +1,188 @@
+"""The non-headline configurations of bench.py (`--config dual_bf16`, `--config train`): same timing contract — preheat,
+W warm-up steps, EXACTLY K steps between (barrier + synchronize) brackets, max over ranks, ONE JSON line on rank 0 — on
+    dual_bf16: BASELINE configs[2]  act_left_right_inv_joint, geometric-invariance dual forward, 256 pairs, bf16
+    train    : BASELINE configs[3] per-GPU shape: 128 pairs, forward + backward + Adam (+ one flat-gradient all-reduce), fp32
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from pointnav_vo_amd import model_spec as ms, parallel, synth, vo_cnn  # noqa: E402
+from pointnav_vo_amd.registry import baseline_registry  # noqa: E402
+
+# Algorithmic HBM bytes per pair of ONE model forward (fp32 layer streaming) and of the stem launch of the
+# dual bf16 forward: the 30-channel fp32 observation tensors read once (7 856 640 B) + two bf16 stem outputs (96*171*32*2 B).
+STREAM_BYTES_PER_PAIR = 22493692.0
+STEM_DUAL_BYTES_PER_PAIR = 7856640.0 + 2 * 96 * 171 * 32 * 2
+
+
+def _swapped(obs):
+    return {k: np.concatenate([v[..., v.shape[-1] // 2:], v[..., : v.shape[-1] // 2]], axis=-1) for k, v in obs.items()}
+
+
+def _cpu_baseline_dual(sds, ngroups, budget_s=12.0):
+    """The oracle C port (fp32, OpenMP) running BOTH models on a bounded sample: the second on the swapped pair."""
+    from oracle import oracle
+    cores = oracle.usable_cores()
+    thr = min(cores, 32)
+    oracle.set_threads(thr)
+    obs1 = synth.make_obs_pairs(2, bench.H, bench.W, observation_space=bench.SPACE, dd_bins=bench.BINS, seed=99)
+    oracle.forward(sds[0], obs1, ngroups=ngroups, dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.forward(sds[0], obs1, ngroups=ngroups, dtype=np.float32)
+    t1 = (time.perf_counter() - t0) / 2
+    n = int(max(2, min(32, budget_s / max(2 * t1, 1e-3))))
+    obs = synth.make_obs_pairs(n, bench.H, bench.W, observation_space=bench.SPACE, dd_bins=bench.BINS, seed=100)
+    t0 = time.perf_counter()
+    oracle.forward(sds[0], obs, ngroups=ngroups, dtype=np.float32)
+    oracle.forward(sds[1], _swapped(obs), ngroups=ngroups, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frame-pairs/s (both models)", "cores": thr, "kind": "port", "host_cores": cores,
+            "sample": f"{n} pairs through both models (fp32 oracle C port, OpenMP {thr} threads; the reference has no bf16 CPU path)"}
+
+
+def run_dual_bf16(args, rank, world, dist, dev, sync_all):
+    B = args.batch or 256
+    models, sds = [], []
+    for seed in (0, 1):                               # the two action models of act_left_right_inv_joint
+        m, sd = bench.build_model(dev, seed=seed)
+        models.append(m.set_precision("bfloat16"))
+        sds.append(sd)
+    ma, mb = models
+    obs = bench.make_inputs(B, dev, rank)
+    step = lambda: vo_cnn.dual_forward(ma, mb, obs)
+
+    with torch.no_grad():
+        oa, ob = step()
+        torch.cuda.synchronize(dev)
+        err = None
+        if rank == 0:
+            from oracle import oracle
+            nchk = 2
+            host = {k: v[:nchk].cpu().numpy() for k, v in obs.items()}
+            ra = oracle.forward(sds[0], host, ngroups=ma.cfg.ngroups, dtype=np.float64)
+            rb = oracle.forward(sds[1], _swapped(host), ngroups=mb.cfg.ngroups, dtype=np.float64)
+            ea = np.linalg.norm(oa[:nchk].cpu().numpy().astype(np.float64) - ra, axis=1)
+            eb = np.linalg.norm(ob[:nchk].cpu().numpy().astype(np.float64) - rb, axis=1)
+            err = {"abs_l2_model_a": float(ea.max()), "abs_l2_model_b": float(eb.max()),
+                   "ref_l2": float(max(np.linalg.norm(ra, axis=1).max(), np.linalg.norm(rb, axis=1).max()))}
+        pre = (0.0, 0, None) if args.no_preheat else bench.preheat(step, dev)
+        for _ in range(args.warmup):
+            step()
+        dt, per_step = bench.timed_steps(step, args.steps, sync_all, dev)
+        ma.timing(True)
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        kt = ma.timing_read()
+        ma.timing(False)
+    dt = parallel.max_over_ranks(dt, dev)
+    if rank == 0:
+        value = world * B * args.steps / dt
+        dom = max((k for k in kt if k["name"].startswith("bf16:")), key=lambda k: k["total_ms"])
+        launch_ms = dom["total_ms"] / dom["launches"]
+        is_stem = dom["name"] == "bf16:stem"
+        alg_bytes = B * STEM_DUAL_BYTES_PER_PAIR if is_stem else dom["bytes"] / dom["launches"]
+        ach = alg_bytes / (launch_ms * 1e-3) / 1e9
+        traffic, note = bench.measured_traffic("dual_bf16", dom["name"], B)
+        total_kernel_ms = sum(k["total_ms"] for k in kt)
+        res = {
+            "metric": "RGB-D frame-pair VO inferences/s @341x192 (geometric-invariance dual forward: two action models per pair)",
+            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: act_left_right_inv_joint dual forward (vo_cnn_rgb_d_dd_top_down x 2, second "
+                                   "model on the channel-swapped pair), 341x192, bf16 operands / fp32 accumulation, seeded random "
+                                   "weights", "pairs_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"dp{world} (independent pairs, no collective)"},
+            "ms_per_step_events": per_step, "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
+            "kernel_ms_per_step": total_kernel_ms / args.steps,
+            "pose_abs_err_vs_fp64_oracle": err,
+            "frac_hbm_streaming_model": value * 2 * STREAM_BYTES_PER_PAIR / 1e9 / (bench.PEAK_HBM_GBS * world),
+            "roofline": {"kernel": dom["name"], "bound": "hbm", "achieved": ach, "peak": bench.PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": ach / bench.PEAK_HBM_GBS, "traffic": traffic, "traffic_note": note,
+                         "definition": "algorithmic bytes of the launch (fp32 observation tensors read once + bf16 outputs of "
+                                       "both models) / HIP-event launch duration",
+                         "launch_ms": launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
+            "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches": k["launches"] // args.steps,
+                                "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
+                                "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
+                               for k in kt), key=lambda k: -k["ms_per_step"])[:40],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = _cpu_baseline_dual(sds, ma.cfg.ngroups)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_train(args, rank, world, dist, dev, sync_all):
+    from pointnav_vo_amd.train import VOTrainStep
+    B = args.batch or 128
+    model = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(bench.W, bench.H), hidden_size=512, backbone="resnet18",
+        normalize_visual_inputs=True, output_dim=3, dropout_p=0.2, discretized_depth_channels=bench.BINS)   # reference p
+    sd = synth.make_state_dict(ms.state_dict_spec(model.cfg), seed=0)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model = model.to(dev)
+    ts = VOTrainStep(model)
+    obs = bench.make_inputs(B, dev, rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7 + rank)
+    tgt = (torch.rand((B, 3), device=dev, generator=g) - 0.5) * 0.5
+    losses = []
+
+    def step():
+        _, loss = ts.step(obs, tgt)
+        losses.append(loss)
+
+    pre = (0.0, 0, None) if args.no_preheat else bench.preheat(step, dev)
+    for _ in range(args.warmup):
+        step()
+    dt, per_step = bench.timed_steps(step, args.steps, sync_all, dev)
+    model.timing(True)
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    kt = model.timing_read()
+    model.timing(False)
+    dt = parallel.max_over_ranks(dt, dev)
+    if rank == 0:
+        value = world * B * args.steps / dt
+        flops = 3 * 2.0 * ms.macs_per_pair(model.cfg)
+        agg = {}
+        for k in kt:
+            key = k["name"].split(":")[0]
+            agg[key] = agg.get(key, 0.0) + k["total_ms"] / args.steps
+        dom = max((k for k in kt if k["flops"]), key=lambda k: k["total_ms"])
+        launch_ms = dom["total_ms"] / dom["launches"]
+        ach = dom["flops"] / dom["launches"] / (launch_ms * 1e-3) / 1e12
+        lv = [float(x) for x in losses]
+        res = {
+            "metric": "VO training step (fwd+bwd+Adam) frame-pairs/s @341x192", "value": value, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3] per-GPU shape: VO training step of vo_cnn_rgb_d_dd_top_down, 128 pairs per GPU, "
+                                   "341x192, fp32, dropout 0.2, Adam lr 2.5e-4; N > 1: one flat 15.85 MB gradient all-reduce (RCCL)",
+                       "pairs_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}"},
+            "ms_per_step_events": per_step, "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
+            "loss_first_last": [lv[0], lv[-1]], "tflops_3x_fwd": value * flops / 1e12,
+            "frac_fp32_peak_3x_fwd": value * flops / 1e12 / (bench.PEAK_FP32_TFLOPS * world),
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": bench.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / bench.PEAK_FP32_TFLOPS, "traffic": None, "launch_ms": launch_ms},
+            "ms_by_kernel_class": agg,
+        }
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

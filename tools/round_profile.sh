@@ -1,14 +1,22 @@
-# One-shot evidence run on the GPU box: full GPU tests, bench, rocprofv3 kernel trace + PMC passes (separate runs).
-# Usage: bash tools/round_profile.sh <tag>     (outputs under gpurun_out/<tag>_*)
-tag=${1:-r1}
-python -m pytest tests -m gpu -q 2>&1 | tail -3
-python bench.py --steps 10 --warmup 3 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 600 gpurun_out/${tag}_bench.json
+# One-shot evidence run on the GPU box: benches of the three configurations, rocprofv3 kernel traces and PMC passes
+# (separate runs, kernel-trace only), profiles/traffic.json.  Usage: bash tools/round_profile.sh <tag>
+# Outputs land in gpurun_out/<tag>_* ; copy what should be judged into profiles/.
+tag=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_trace.log 2>&1
-python tools/rocprof_summary.py gpurun_out/${tag}_trace/p_results.db > gpurun_out/${tag}_kernel_trace.md 2>&1
-for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT"; do
-  n=$(echo $set | cut -d" " -f1)
-  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/${tag}_pmc_$n -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_$n.log 2>&1
-  python tools/rocprof_summary.py gpurun_out/${tag}_pmc_$n/p_results.db --pmc 2>&1 | awk '/## counters/{f=1} f' > gpurun_out/${tag}_pmc_$n.md
+O=gpurun_out
+python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 300 $O/${tag}_bench.json; echo
+python bench.py --config dual_bf16 > $O/${tag}_bench_dual_bf16.json 2> $O/${tag}_bench_dual_bf16.err; tail -c 300 $O/${tag}_bench_dual_bf16.json; echo
+python bench.py --config train --steps 10 --warmup 3 > $O/${tag}_bench_train.json 2> $O/${tag}_bench_train.err; tail -c 300 $O/${tag}_bench_train.json; echo
+for cfg in fwd_fp32 dual_bf16; do
+  rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_$cfg -o p -- python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $O/${tag}_trace_$cfg.log 2>&1
+  python tools/rocprof_summary.py $O/${tag}_trace_$cfg/p_results.db > $O/${tag}_kernel_trace_$cfg.md 2>&1
+  for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
+    n=$(echo $set | cut -d" " -f1)
+    rocprofv3 --kernel-trace --pmc $set -d $O/${tag}_pmc_${cfg}_$n -o p -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-preheat > $O/${tag}_pmc_${cfg}_$n.log 2>&1
+    python tools/rocprof_summary.py $O/${tag}_pmc_${cfg}_$n/p_results.db --pmc 2>&1 | awk '/## counters/{f=1} f' > $O/${tag}_pmc_${cfg}_$n.md
+  done
+  python tools/make_traffic.py $cfg 256 $O/${tag}_pmc_${cfg}_FETCH_SIZE/p_results.db $O/${tag}_pmc_${cfg}_WRITE_SIZE/p_results.db $O/${tag}_traffic.json
+  cat $O/${tag}_pmc_${cfg}_*.md > $O/${tag}_pmc_$cfg.md
+  rm -rf $O/${tag}_pmc_${cfg}_* $O/${tag}_trace_$cfg
 done
-head -12 gpurun_out/${tag}_kernel_trace.md
+head -14 $O/${tag}_kernel_trace_fwd_fp32.md
