@@ -8,6 +8,7 @@
 // block outputs); GroupNorm statistics come from the fp32 accumulators and stay fp32 (scale/shift, whitening constants,
 // the compression output, both Linear layers).  Kernels: stem_mx.hip (PIECES = 1), conv_bf16.hip, the fp32 split-K
 // linear kernels of conv_mfma.hip for visual_fc / output_head.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -217,7 +218,13 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     {
       PnvoTimed t(m, s, "bf16:stem", 2.0 * nm * M * stem.cout * stem.cin * 49,
                   4.0 * (double)B * c.height * c.width * stem.cin + 2.0 * nm * M * stem.cout);
-      HIPCHK(m, launch_stem_mx(a, 1, nm, true, s));
+      const char *ex = std::getenv("PNVO_BF16_STEM3");         // experiment: exact three-piece stem in front of the bf16 stages
+      if (ex && ex[0] == '1' && nm == 1) {
+        a.wpk = m->mx_wpk3;
+        HIPCHK(m, launch_stem_mx(a, 3, 1, true, s));
+      } else {
+        HIPCHK(m, launch_stem_mx(a, 1, nm, true, s));
+      }
     }
     PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
     auto st = each([&](int z) { return (const float *)bs[z]->stats; });

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     };
     loadB(wave, b0);
     loadA0(wave, a00);
-    // taps wave, wave+4, ...: six pairs for every wave, plus tap 48 for wave 0
+    // taps wave, wave+4, ... wave+44: six pairs for every wave; tap 48 goes to wave 3 (wave 0 staged the nine extra pixels)
 #pragma unroll 1
     for (int it = 0; it < 6; ++it) {
       const int tap = wave + 8 * it;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       __builtin_amdgcn_sched_barrier(0);
       mfmas(a00, b0);
       __builtin_amdgcn_sched_barrier(0);
-      const int t2 = tap + 8 < 49 ? tap + 8 : tap;         // (waves 1-3: the last prefetch is a harmless repeat)
+      const int t2 = it < 5 ? tap + 8 : (wave == 3 ? 48 : tap);   // (waves 0-2: the last prefetch is a harmless repeat)
       loadA1(tap + 4, a1, ax);
       loadB(t2, b0);
       loadA0(t2, a00);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       mfmas(a01, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (wave == 0) {
+    if (wave == 3) {
       loadA1(48, a1, ax);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(a00, b0);
@@ -446,6 +446,9 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
   if (pieces == 3 && !bf16_out) {
     const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<3, 1, false>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+  } else if (pieces == 3 && bf16_out) {                  // float32-exact stem feeding the bf16 stages (accuracy experiments)
+    const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
+    hipLaunchKernelGGL((stem_mx_kernel<3, 1, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
   } else if (pieces == 1 && bf16_out && ntiles_n % 2 == 0) {
     const size_t ldsb = RED_OFF + 4 * 2 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<1, 2, true>), dim3(gx, (unsigned)(ntiles_n / 2)), dim3(NTHREADS), ldsb, s, p);

