@@ -62,13 +62,17 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
   const int PR = p.PR, PC = p.PC, CK = p.CK;
   const int pitch = CK * 2 + 16;
   const int npix = p.TR * p.TC;
-  unsigned *qtab = reinterpret_cast<unsigned *>(lds + PR * PC * pitch);   // [MT*32]: patch offset | tr << 24 | tc << 16 ... see below
-  // pixel table: for tile pixel q (row-major): low 20 bits = patch byte offset of its top-left tap, bits 20-25 = tile row,
-  // bits 26-31 = tile column (rows / columns < 64)
+  // pixel table, two planes of MT*32 words: [0] patch byte offset of tile pixel q's top-left tap; [1] element offset of its
+  // output pixel inside the sample's output plane ((tr*Wo + tc)*COUTP) with bit 31 set when the pixel does not exist
+  // (beyond the tile's pixel count or outside the output)
+  unsigned *qtab = reinterpret_cast<unsigned *>(lds + PR * PC * pitch);
+  unsigned *otab = qtab + p.MT * 32;
   if ((int)threadIdx.x < p.MT * 32) {
     const int q = min((int)threadIdx.x, npix - 1);
     const int tr = q / p.TC, tc = q - tr * p.TC;
-    qtab[threadIdx.x] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch) | ((unsigned)tr << 20) | ((unsigned)tc << 26);
+    qtab[threadIdx.x] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch);
+    const bool ok = (int)threadIdx.x < npix && r0 + tr < p.Ho && c0 + tc < p.Wo;
+    otab[threadIdx.x] = (unsigned)((tr * p.Wo + tc) * p.COUTP) | (ok ? 0u : 0x80000000u);
   }
 
   const int wn = p.wn;                                                   // wave grid: (4 / wn) x wn
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       const int mt = min(wave_m * MW + i, p.MT - 1);
-      aoff[i] = (qtab[mt * 32 + (lane & 31)] & 0xfffffu) + (unsigned)((lane >> 5) * 16);
+      aoff[i] = qtab[mt * 32 + (lane & 31)] + (unsigned)((lane >> 5) * 16);
     }
     const int kcc = CK >> 4;                                             // k-chunks per staged chunk
     const int nsteps = KS * KS * kcc;
@@ -194,15 +198,18 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
     }
   }
 
-  // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot)
+  // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot).
+  // lane = output channel, registers = 16 pixels of the M-tile (rows 4 q4 + e + 8 ... of the accumulator layout); the
+  // pixel's output offset comes from the table (four 16-byte LDS reads per M-tile), the store is base + 32-bit offset.
   const int rr16 = lane >> 5;
+  const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
 #pragma unroll
   for (int i = 0; i < MW; ++i) {
     const int mt = wave_m * MW + i;
     if (mt >= p.MT) continue;
-    unsigned ent[16];
+    u32x4 ent[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ent[r] = qtab[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * rr16];
+    for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int nt = wave_n * NW + j;
@@ -211,17 +218,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * rr16;
-        const int tr = (ent[r] >> 20) & 63, tc = ent[r] >> 26;
-        const int ho = r0 + tr, wo = c0 + tc;
-        const bool ok = q < npix && ho < p.Ho && wo < p.Wo;
+        const unsigned e = ent[r >> 2][r & 3];
+        const bool ok = (int)e >= 0;
         const float v = ok ? acc[i][j][r] : 0.f;
         if (ok) {
-          const long o = (((long)n * p.Ho + ho) * p.Wo + wo) * p.COUTP + co;
           if (F32OUT)
-            reinterpret_cast<float *>(p.y[z])[o] = v;
+            (reinterpret_cast<float *>(p.y[z]) + ybase + co)[e] = v;
           else
-            reinterpret_cast<__bf16 *>(p.y[z])[o] = (__bf16)v;
+            (reinterpret_cast<__bf16 *>(p.y[z]) + ybase + co)[e] = (__bf16)v;
         }
         s1 += v;
         s2 = __builtin_fmaf(v, v, s2);
@@ -312,7 +316,7 @@ bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *
   if (a.CIN % ck) return false;
   a.CK = ck;
   a.slots = a.tiles_r * a.tiles_c * a.MT;
-  *lds_bytes = (size_t)a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4;
+  *lds_bytes = (size_t)a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
   return true;
 }
 
