@@ -125,6 +125,24 @@ int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstrid
                       const float *consts, int rows_around_center, float *out, int64_t out_fstride,
                       int64_t out_pstride, void *work, void *stream);
 
+/*
+ * Replaces: the observation construction of BaseRLTrainerWithVO._compute_local_delta_states_from_vo
+ * (base_trainer_with_vo.py:172-269) for n (prev, cur) pairs at once — numpy -> tensor copies, pair concatenation,
+ * _discretize_depth_func, the two top-down views — as one pairs kernel + the top-down kernels on the given stream:
+ *   rgb_frames   device uint8   [n][2][H][W][3]  (prev frame, cur frame; NULL for models without rgb)
+ *   depth_frames device float32 [n][2][H][W]
+ *   -> rgb_pairs [n,H,W,6] (0..255 as float), depth_pairs [n,H,W,2], dd_pairs [n,H,W,2*bins] (bins > 0), tdv_pairs [n,H,W,2]
+ *      (NULL: skip; tdv_consts as for pnvo_topdown_view, tdv_work >= pnvo_topdown_workspace_bytes(n,H,W))
+ *   err_flag (device int32, may be NULL) is set when a depth lies outside [0,1] (the reference asserts, :136-137).
+ */
+int pnvo_build_obs_pairs(const uint8_t *rgb_frames, const float *depth_frames, int n, int H, int W, int bins,
+                         const float *tdv_consts, int rows_around_center, void *tdv_work, float *rgb_pairs, float *depth_pairs,
+                         float *dd_pairs, float *tdv_pairs, int32_t *err_flag, void *stream);
+
+/* Host helper of the same boundary: gathers n separately allocated host frames (each bytes_each long) into one (pinned)
+ * staging buffer with `threads` copy threads — the per-frame numpy copies were what bounded the batched boundary call. */
+int pnvo_stage_frames(const void *const *src, int n, size_t bytes_each, void *dst, int threads);
+
 /* ---- VO dataset input pipeline on the device: what StatePairRegressionDataset._process_data
  * does per sample on 20 CPU workers (pointnav_vo/vo/dataset/regression_geo_invariance_iter_dataset.py:205-454), per chunk
  * on the GPU.  Reading the HDF5 file stays with the caller (h5py). ---- */

@@ -350,35 +350,43 @@ size_t topdown_workspace_bytes(int N, int H, int W) {
   return (size_t)N * (sizeof(TopdownWork) + sizeof(int) * (size_t)H * W);
 }
 
+// bbox is kept in a zero-initialised, max-only encoding so that any number of workgroups per frame can contribute with
+// atomicMax and the whole workspace is prepared by ONE memset:  e[0] = max(H - r), e[1] = max(r + 1), e[2] = max(W - c),
+// e[3] = max(c + 1) over the non-zero pixels (0 = none)  ->  min_row = H - e[0], max_row = e[1] - 1, ... (empty: H, -1, W, -1).
+__device__ __forceinline__ void topdown_decode_bbox(const TopdownWork &w, int H, int W, int &r0, int &r1, int &c0, int &c1) {
+  r0 = H - w.bbox[0];
+  r1 = w.bbox[1] - 1;
+  c0 = W - w.bbox[2];
+  c1 = w.bbox[3] - 1;
+}
+
 __global__ __launch_bounds__(256) void topdown_bbox_kernel(const float *depth, long fstride, long pstride, int H, int W,
                                                          TopdownWork *work) {
-  __shared__ int sb[4];
-  const int n = blockIdx.x;
-  if (threadIdx.x == 0) {
-    sb[0] = H;
-    sb[1] = -1;
-    sb[2] = W;
-    sb[3] = -1;
-  }
-  __syncthreads();
-  int r0 = H, r1 = -1, c0 = W, c1 = -1;
+  const int n = blockIdx.y;
+  int e0 = 0, e1 = 0, e2 = 0, e3 = 0;
   const float *d = depth + (long)n * fstride;
-  for (int p = threadIdx.x; p < H * W; p += 256) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < H * W; p += gridDim.x * 256) {
     if (d[(long)p * pstride] > 0.f) {   // depth >= 0, so "row/col sum > 0" == "any element > 0"
       const int r = p / W, c = p - r * W;
-      r0 = min(r0, r);
-      r1 = max(r1, r);
-      c0 = min(c0, c);
-      c1 = max(c1, c);
+      e0 = max(e0, H - r);
+      e1 = max(e1, r + 1);
+      e2 = max(e2, W - c);
+      e3 = max(e3, c + 1);
     }
   }
-  atomicMin(&sb[0], r0);
-  atomicMax(&sb[1], r1);
-  atomicMin(&sb[2], c0);
-  atomicMax(&sb[3], c1);
-  __syncthreads();
-  if (threadIdx.x < 4) work[n].bbox[threadIdx.x] = sb[threadIdx.x];
-  if (threadIdx.x == 4) work[n].maxcnt = 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    e0 = max(e0, __shfl_xor(e0, o));
+    e1 = max(e1, __shfl_xor(e1, o));
+    e2 = max(e2, __shfl_xor(e2, o));
+    e3 = max(e3, __shfl_xor(e3, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (e0) atomicMax(&work[n].bbox[0], e0);
+    if (e1) atomicMax(&work[n].bbox[1], e1);
+    if (e2) atomicMax(&work[n].bbox[2], e2);
+    if (e3) atomicMax(&work[n].bbox[3], e3);
+  }
 }
 
 __device__ __forceinline__ float blur_row(const float *d, long pstride, int W, int r, int c, int c0, int c1) {
@@ -397,7 +405,8 @@ __global__ __launch_bounds__(256) void topdown_project_kernel(const float *depth
                                                             int W, const TopdownConsts tc, int rows_around_center,
                                                             TopdownWork *work, int *cnt) {
   const int n = blockIdx.y;
-  const int r0 = work[n].bbox[0], r1 = work[n].bbox[1], c0 = work[n].bbox[2], c1 = work[n].bbox[3];
+  int r0, r1, c0, c1;
+  topdown_decode_bbox(work[n], H, W, r0, r1, c0, c1);
   if (r1 < r0 || c1 < c0) return;              // all-zero frame (:522-525)
   const int hc = r1 - r0 + 1, wc = c1 - c0 + 1;
   const int half = (hc + 1) / 2;               // int(np.ceil(hc / 2)) (:609-617)
@@ -405,8 +414,9 @@ __global__ __launch_bounds__(256) void topdown_project_kernel(const float *depth
   if (b0 < 0) b0 = 0;
   int b1 = half + rows_around_center;
   if (b1 > hc) b1 = hc;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= (b1 - b0) * wc) return;
+  const int t0_ = blockIdx.x * 256 + threadIdx.x;
+  const bool active = t0_ < (b1 - b0) * wc;
+  const int t = active ? t0_ : 0;              // (tail lanes compute pixel 0 and contribute nothing)
   const int j = b0 + t / wc, i = t % wc;       // crop coordinates
   const int r = r0 + j, c = c0 + i;            // image coordinates
   const float *d = depth + (long)n * fstride;
@@ -426,29 +436,25 @@ __global__ __launch_bounds__(256) void topdown_project_kernel(const float *depth
   const float rf = sub_rn((float)H, ceilf(mul_rn((float)H, zn)));    // :686-688
   const float cf = floorf(mul_rn((float)W, xn));                        // :689
   const long row = (long)rf, col = (long)cf;                               // .long() (:692)
-  if (row >= 0 && row < H && col >= 0 && col < W) atomicAdd(&cnt[((long)n * H + row) * W + col], 1);
+  int now = 0;
+  if (active && row >= 0 && row < H && col >= 0 && col < W) now = atomicAdd(&cnt[((long)n * H + row) * W + col], 1) + 1;
+  // running maximum of the frame's counts (the normalisation divides by it): one atomicMax per wave, and only when the
+  // wave's maximum exceeds a (possibly stale, but monotone) read of the current one
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) now = max(now, __shfl_xor(now, o));
+  if ((threadIdx.x & 63) == 0 && now > __hip_atomic_load(&work[n].maxcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&work[n].maxcnt, now);
 }
 
-__global__ __launch_bounds__(256) void topdown_normalize_kernel(int H, int W, TopdownWork *work, const int *cnt,
+__global__ __launch_bounds__(256) void topdown_normalize_kernel(int H, int W, const TopdownWork *work, const int *cnt,
                                                               float *out, long ofstride, long opstride) {
-  __shared__ int smax;
-  const int n = blockIdx.x;
-  if (threadIdx.x == 0) smax = 0;
-  __syncthreads();
-  const int *c = cnt + (long)n * H * W;
-  int m = 0;
-  for (int p = threadIdx.x; p < H * W; p += 256) m = max(m, c[p]);
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(&smax, m);
-  __syncthreads();
-  const int mx = smax;
-  float *o = out + (long)n * ofstride;
-  for (int p = threadIdx.x; p < H * W; p += 256) {
-    float v = 0.f;
-    if (mx > 0) v = fminf(div_rn((float)c[p], (float)mx), 1.0f);   // :543-554
-    o[(long)p * opstride] = v;
-  }
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int mx = work[n].maxcnt;
+  float v = 0.f;
+  if (mx > 0) v = fminf(div_rn((float)cnt[(long)n * H * W + p], (float)mx), 1.0f);   // :543-554
+  out[(long)n * ofstride + (long)p * opstride] = v;
 }
 
 // The dataset-side twin NormalizedDepth2TopDownViewHabitat (numpy, geometry_utils.py:275-470) does the same projection
@@ -462,7 +468,8 @@ __global__ __launch_bounds__(256) void topdown_project_f64_kernel(const float *d
                                                                 int W, const TopdownConsts64 tc, int rows_around_center,
                                                                 TopdownWork *work, int *cnt) {
   const int n = blockIdx.y;
-  const int r0 = work[n].bbox[0], r1 = work[n].bbox[1], c0 = work[n].bbox[2], c1 = work[n].bbox[3];
+  int r0, r1, c0, c1;
+  topdown_decode_bbox(work[n], H, W, r0, r1, c0, c1);
   if (r1 < r0 || c1 < c0) return;              // all-zero frame (:296-297)
   const int hc = r1 - r0 + 1, wc = c1 - c0 + 1;
   const int half = (hc + 1) / 2;               // int(np.ceil(hc / 2)) (:371-378)
@@ -470,8 +477,9 @@ __global__ __launch_bounds__(256) void topdown_project_f64_kernel(const float *d
   if (b0 < 0) b0 = 0;
   int b1 = half + rows_around_center;
   if (b1 > hc) b1 = hc;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= (b1 - b0) * wc) return;
+  const int t0_ = blockIdx.x * 256 + threadIdx.x;
+  const bool active = t0_ < (b1 - b0) * wc;
+  const int t = active ? t0_ : 0;              // (tail lanes compute pixel 0 and contribute nothing)
   const int j = b0 + t / wc, i = t % wc;
   const int r = r0 + j, c = c0 + i;
   const float *d = depth + (long)n * fstride;
@@ -490,7 +498,14 @@ __global__ __launch_bounds__(256) void topdown_project_f64_kernel(const float *d
   const double rf = (double)H - ceil((double)H * zn);                    // :443-445
   const double cf = floor((double)W * xn);                               // :446
   const long row = (long)rf, col = (long)cf;                             // .astype(np.int) (:448)
-  if (row >= 0 && row < H && col >= 0 && col < W) atomicAdd(&cnt[((long)n * H + row) * W + col], 1);
+  int now = 0;
+  if (active && row >= 0 && row < H && col >= 0 && col < W) now = atomicAdd(&cnt[((long)n * H + row) * W + col], 1) + 1;
+  // running maximum of the frame's counts (the normalisation divides by it): one atomicMax per wave, and only when the
+  // wave's maximum exceeds a (possibly stale, but monotone) read of the current one
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) now = max(now, __shfl_xor(now, o));
+  if ((threadIdx.x & 63) == 0 && now > __hip_atomic_load(&work[n].maxcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&work[n].maxcnt, now);
 }
 
 hipError_t launch_topdown_f64(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
@@ -498,9 +513,10 @@ hipError_t launch_topdown_f64(const float *depth, int N, int H, int W, int64_t i
                               int64_t out_pstride, void *work, hipStream_t s) {
   TopdownWork *tw = reinterpret_cast<TopdownWork *>(work);
   int *cnt = reinterpret_cast<int *>(tw + N);
-  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N * H * W, s);
+  hipError_t e = hipMemsetAsync(work, 0, topdown_workspace_bytes(N, H, W), s);   // counts, bbox encodings, maxima
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(topdown_bbox_kernel, dim3((unsigned)N), dim3(256), 0, s, depth, (long)in_fstride,
+  const int gb = N >= 64 ? 4 : 32;               // workgroups per frame of the bbox scan
+  hipLaunchKernelGGL(topdown_bbox_kernel, dim3((unsigned)gb, (unsigned)N), dim3(256), 0, s, depth, (long)in_fstride,
                      (long)in_pstride, H, W, tw);
   const int band = 2 * rows_around_center < H ? 2 * rows_around_center : H;
   TopdownConsts64 tc;
@@ -508,8 +524,8 @@ hipError_t launch_topdown_f64(const float *depth, int N, int H, int W, int64_t i
   tc.c[7] = 0.0;
   hipLaunchKernelGGL(topdown_project_f64_kernel, dim3((unsigned)((band * W + 255) / 256), (unsigned)N), dim3(256), 0, s,
                      depth, (long)in_fstride, (long)in_pstride, H, W, tc, rows_around_center, tw, cnt);
-  hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)N), dim3(256), 0, s, H, W, tw, cnt, out,
-                     (long)out_fstride, (long)out_pstride);
+  hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N), dim3(256), 0, s, H, W, tw,
+                     cnt, out, (long)out_fstride, (long)out_pstride);
   return hipGetLastError();
 }
 
@@ -605,14 +621,85 @@ hipError_t launch_dataset_pairs(const unsigned char *prev_rgb, const unsigned ch
   return hipGetLastError();
 }
 
+// Boundary: raw simulator frames -> the observation-pair tensors of _compute_local_delta_states_from_vo
+// (base_trainer_with_vo.py:172-229): rgb uint8 [n][2][H][W][3] and depth float32 [n][2][H][W] (prev, cur) ->
+// rgb_pairs [n,H,W,6] (0..255 as float), depth_pairs [n,H,W,2], dd_pairs [n,H,W,2*bins] one-hot (float32 edges i/bins,
+// last bin closed — the arithmetic of discretize_depth_kernel).  One thread per pixel of a pair.
+struct FramePairsArgs {
+  const unsigned char *rgb;
+  const float *depth;
+  float *o_rgb, *o_depth, *o_dd;
+  int *err_flag;
+  long npix;
+  int bins;
+  DepthEdges ed;
+};
+
+__global__ __launch_bounds__(256) void frame_pairs_kernel(const FramePairsArgs a) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (p >= a.npix) return;
+  const long e = (long)m * a.npix + p;
+  const long f0 = ((long)m * 2) * a.npix + p, f1 = f0 + a.npix;           // the pair's prev / cur frame pixels
+  if (a.o_rgb != nullptr) {                                               // 24 B per pair pixel: three 8-byte stores
+    const unsigned char *r0 = a.rgb + f0 * 3, *r1 = a.rgb + f1 * 3;
+    float2 *o = reinterpret_cast<float2 *>(a.o_rgb + e * 6);
+    o[0] = make_float2((float)r0[0], (float)r0[1]);
+    o[1] = make_float2((float)r0[2], (float)r1[0]);
+    o[2] = make_float2((float)r1[1], (float)r1[2]);
+  }
+  const float d[2] = {a.depth[f0], a.depth[f1]};
+  if (a.o_depth != nullptr) *reinterpret_cast<float2 *>(a.o_depth + e * 2) = make_float2(d[0], d[1]);
+  if (a.o_dd != nullptr) {
+    if ((!(d[0] >= 0.f && d[0] <= 1.f) || !(d[1] >= 0.f && d[1] <= 1.f)) && a.err_flag != nullptr) *a.err_flag = 1;
+    float *o = a.o_dd + e * (2 * a.bins);
+    if (a.bins == 10) {                                                   // 80 B per pair pixel: five 16-byte stores
+      float v[20];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const float lo = a.ed.e[k], hi = a.ed.e[k + 1];
+          v[10 * f + k] = ((k == 9) ? (d[f] >= lo && d[f] <= hi) : (d[f] >= lo && d[f] < hi)) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+      for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < a.bins; ++k) {
+          const float lo = a.ed.e[k], hi = a.ed.e[k + 1];
+          o[f * a.bins + k] = ((k == a.bins - 1) ? (d[f] >= lo && d[f] <= hi) : (d[f] >= lo && d[f] < hi)) ? 1.0f : 0.0f;
+        }
+    }
+  }
+}
+
+hipError_t launch_frame_pairs(const unsigned char *rgb, const float *depth, int n, int H, int W, int bins, float *o_rgb,
+                              float *o_depth, float *o_dd, int *err_flag, hipStream_t s) {
+  if (bins < 0 || bins > 64) return hipErrorInvalidValue;
+  FramePairsArgs a;
+  a.rgb = rgb;
+  a.depth = depth;
+  a.o_rgb = rgb ? o_rgb : nullptr;
+  a.o_depth = o_depth;
+  a.o_dd = bins > 0 ? o_dd : nullptr;
+  a.err_flag = err_flag;
+  a.npix = (long)H * W;
+  a.bins = bins;
+  for (int k = 0; k <= bins; ++k) a.ed.e[k] = (k == bins ? 1.0f : (float)((double)k / (double)(bins > 0 ? bins : 1)));
+  hipLaunchKernelGGL(frame_pairs_kernel, dim3((unsigned)((a.npix + 255) / 256), (unsigned)n), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const float *consts, int rows_around_center, float *out, int64_t out_fstride,
                           int64_t out_pstride, void *work, hipStream_t s) {
   TopdownWork *tw = reinterpret_cast<TopdownWork *>(work);
   int *cnt = reinterpret_cast<int *>(tw + N);
-  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N * H * W, s);
+  hipError_t e = hipMemsetAsync(work, 0, topdown_workspace_bytes(N, H, W), s);   // counts, bbox encodings, maxima
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(topdown_bbox_kernel, dim3((unsigned)N), dim3(256), 0, s, depth, (long)in_fstride,
+  const int gb = N >= 64 ? 4 : 32;               // workgroups per frame of the bbox scan
+  hipLaunchKernelGGL(topdown_bbox_kernel, dim3((unsigned)gb, (unsigned)N), dim3(256), 0, s, depth, (long)in_fstride,
                      (long)in_pstride, H, W, tw);
   const int band = 2 * rows_around_center < H ? 2 * rows_around_center : H;
   TopdownConsts tc;
@@ -620,8 +707,8 @@ hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fs
   tc.c[7] = 0.f;
   hipLaunchKernelGGL(topdown_project_kernel, dim3((unsigned)((band * W + 255) / 256), (unsigned)N), dim3(256), 0, s,
                      depth, (long)in_fstride, (long)in_pstride, H, W, tc, rows_around_center, tw, cnt);
-  hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)N), dim3(256), 0, s, H, W, tw, cnt, out,
-                     (long)out_fstride, (long)out_pstride);
+  hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N), dim3(256), 0, s, H, W, tw,
+                     cnt, out, (long)out_fstride, (long)out_pstride);
   return hipGetLastError();
 }
 

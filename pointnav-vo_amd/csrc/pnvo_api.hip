@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pnvo_model.h"
@@ -1252,6 +1253,43 @@ int pnvo_dataset_pairs(const uint8_t *prev_rgb, const uint8_t *cur_rgb, const ui
   if (M == 0) return PNVO_OK;
   HIPCHK(nullptr, launch_dataset_pairs(prev_rgb, cur_rgb, prev_depth, cur_depth, tdv_frames, src, swap, N, M, H, W, bins, edges,
                                        rgb_pairs, depth_pairs, dd_pairs, tdv_pairs, err_flag, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
+int pnvo_stage_frames(const void *const *src, int n, size_t bytes_each, void *dst, int threads) {
+  if (!src || !dst || n < 0) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n > 0 ? n : 1;
+  auto work = [&](int t) {
+    for (int i = t; i < n; i += threads) std::memcpy(static_cast<char *>(dst) + (size_t)i * bytes_each, src[i], bytes_each);
+  };
+  if (threads == 1 || (size_t)n * bytes_each < ((size_t)1 << 21)) {      // small jobs: thread start-up would dominate
+    for (int i = 0; i < n; ++i) std::memcpy(static_cast<char *>(dst) + (size_t)i * bytes_each, src[i], bytes_each);
+    return PNVO_OK;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  return PNVO_OK;
+}
+
+int pnvo_build_obs_pairs(const uint8_t *rgb_frames, const float *depth_frames, int n, int H, int W, int bins,
+                         const float *tdv_consts, int rows_around_center, void *tdv_work, float *rgb_pairs, float *depth_pairs,
+                         float *dd_pairs, float *tdv_pairs, int32_t *err_flag, void *stream) {
+  if (!depth_frames || !depth_pairs || n < 0 || H <= 0 || W <= 0 || bins < 0 || bins > 64)
+    return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if ((bins > 0) != (dd_pairs != nullptr)) return fail(nullptr, PNVO_ERR_ARG, "dd_pairs must be given exactly when bins > 0");
+  if (tdv_pairs && (!tdv_consts || !tdv_work)) return fail(nullptr, PNVO_ERR_ARG, "top-down view requested without constants / workspace");
+  if (n == 0) return PNVO_OK;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(nullptr, launch_frame_pairs(rgb_frames, depth_frames, n, H, W, bins, rgb_pairs, depth_pairs, dd_pairs, err_flag, s));
+  if (tdv_pairs) {
+    const int64_t hw = (int64_t)H * W;
+    for (int k = 0; k < 2; ++k)        // prev frames then cur frames (base_trainer_with_vo.py:239-249), written into channel k
+      HIPCHK(nullptr, launch_topdown(depth_frames + k * hw, n, H, W, 2 * hw, 1, tdv_consts, rows_around_center, tdv_pairs + k, 2 * hw,
+                                     2, tdv_work, s));
+  }
   return PNVO_OK;
 }
 

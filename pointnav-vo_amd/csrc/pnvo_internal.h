@@ -181,6 +181,8 @@ hipError_t launch_dataset_pairs(const unsigned char *prev_rgb, const unsigned ch
                                 const unsigned short *cur_depth, const float *tdv_frames, const int *src, const int *swap,
                                 int N, int M, int H, int W, int bins, const float *edges, float *o_rgb, float *o_depth,
                                 float *o_dd, float *o_tdv, int *err_flag, hipStream_t s);
+hipError_t launch_frame_pairs(const unsigned char *rgb, const float *depth, int n, int H, int W, int bins, float *o_rgb,
+                              float *o_depth, float *o_dd, int *err_flag, hipStream_t s);
 size_t topdown_workspace_bytes(int N, int H, int W);
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const float *consts_host, int rows_around_center, float *out, int64_t out_fstride,

@@ -201,58 +201,130 @@ class BaseRLTrainerWithVO:
             obs_pairs["top_down_view"] = tdv
         return obs_pairs
 
+    def _boundary_buffers(self, n, H, W, bins, want_rgb, want_tdv):
+        """Reusable staging for n pairs: pinned host frames, their device twins, the observation-pair tensors, the
+        top-down workspace and a pinned error flag — allocated once per (capacity, shape)."""
+        st = getattr(self, "_bstage", None)
+        if st is None or st["cap"] < n or st["shape"] != (H, W, bins, want_rgb, want_tdv):
+            same = st is not None and st["shape"] == (H, W, bins, want_rgb, want_tdv)
+            cap = max(n, 2 * st["cap"]) if same else n        # grow geometrically for callers with a varying pair count
+            dev = self.device
+            st = dict(cap=cap, shape=(H, W, bins, want_rgb, want_tdv),
+                      h_rgb=torch.empty((cap, 2, H, W, 3), dtype=torch.uint8).pin_memory() if want_rgb else None,
+                      h_dep=torch.empty((cap, 2, H, W), dtype=torch.float32).pin_memory(),
+                      d_rgb=torch.empty((cap, 2, H, W, 3), dtype=torch.uint8, device=dev) if want_rgb else None,
+                      d_dep=torch.empty((cap, 2, H, W), dtype=torch.float32, device=dev),
+                      rgb=torch.empty((cap, H, W, 6), dtype=torch.float32, device=dev) if want_rgb else None,
+                      depth=torch.empty((cap, H, W, 2), dtype=torch.float32, device=dev),
+                      dd=torch.empty((cap, H, W, 2 * bins), dtype=torch.float32, device=dev) if bins else None,
+                      tdv=torch.empty((cap, H, W, 2), dtype=torch.float32, device=dev) if want_tdv else None,
+                      work=torch.empty(int(_lib.lib.pnvo_topdown_workspace_bytes(cap, H, W)), dtype=torch.uint8, device=dev)
+                      if want_tdv else None,
+                      flag=torch.zeros(1, dtype=torch.int32, device=dev), h_flag=torch.zeros(1, dtype=torch.int32).pin_memory())
+            self._bstage = st
+        return st
+
+    @staticmethod
+    def _frame_ptrs(frames, dtype, shape):
+        """ctypes pointer array over separately allocated numpy frames (made contiguous / cast only when they are not)."""
+        need = 1
+        for d in shape:
+            need *= int(d)
+        keep = [f if (type(f) is np.ndarray and f.dtype == dtype and f.size == need and f.flags.c_contiguous)
+                else np.ascontiguousarray(np.asarray(f, dtype=dtype).reshape(shape)) for f in frames]
+        arr = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        return arr, keep
+
     def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts):
         """Batched sibling of _compute_local_delta_states_from_vo: lists of observation dicts and actions ->
-        float32 array [N,3].  Pairs are grouped per action model (sep_act) and each group is one forward."""
+        float32 array [N,3].  Host side: the 2N raw frames are gathered into pinned staging by pnvo_stage_frames (parallel
+        memcpy), shipped in two async transfers, and turned into the observation-pair tensors (pair concatenation, uint8 ->
+        float, one-hot depth, both top-down views — base_trainer_with_vo.py:172-269) by pnvo_build_obs_pairs; pairs are
+        grouped per action model (sep_act) and each group is one forward; one host synchronisation at the end."""
         assert len(prev_obs_list) == len(cur_obs_list) == len(acts)
         n = len(acts)
         H, W = prev_obs_list[0]["depth"].shape[:2]
-        # host -> device: every frame is copied ONCE into a reusable pinned staging buffer (uint8 rgb, fp32 depth) and
-        # shipped in one async transfer; the (prev | cur) channel concatenation and the uint8 -> float widening happen
-        # on the device (the reference builds FloatTensors on the host and copies 4 tensors per pair, :172-193)
-        st = getattr(self, "_staging", None)
-        if st is None or st[0].shape[0] < n or st[0].shape[2:4] != (H, W):
-            st = (torch.empty((n, 2, H, W, 3), dtype=torch.uint8).pin_memory(),
-                  torch.empty((n, 2, H, W, 1), dtype=torch.float32).pin_memory())
-            self._staging = st
-        prgb, pdep = st[0][:n].numpy(), st[1][:n].numpy()
-        for i, (p, c) in enumerate(zip(prev_obs_list, cur_obs_list)):
-            prgb[i, 0] = p["rgb"]
-            prgb[i, 1] = c["rgb"]
-            pdep[i, 0] = p["depth"]
-            pdep[i, 1] = c["depth"]
-        drgb = st[0][:n].to(self.device, non_blocking=True)
-        ddep = st[1][:n].to(self.device, non_blocking=True)
-        rgb_pair = drgb.permute(0, 2, 3, 1, 4).reshape(n, H, W, 6).to(torch.float32)     # [prev_rgb | cur_rgb]
-        depth_pair = ddep.permute(0, 2, 3, 1, 4).reshape(n, H, W, 2).contiguous()        # [prev_d | cur_d]
-        obs_pairs = self._build_obs_pairs(rgb_pair, depth_pair)
-        if getattr(self, "_dd_flag", None) is not None:
-            assert self._dd_flag.item() == 0, "depth must lie in [0, 1]"
-        out = np.zeros((n, 3), dtype=np.float32)
-        std = np.zeros((n, 3), dtype=np.float32)
         rm = self.config.VO.REGRESS_MODEL
         if rm.mode not in ("det", "rnd"):
             raise NotImplementedError(f"VO.REGRESS_MODEL.mode == {rm.mode!r}")
+        name = rm.name
+        vis = list(rm.visual_type)
+        want_rgb = "rgb" in vis
+        bins = int(rm.discretized_depth_channels) if ("discretize_depth" in name or "dd" in name) else 0
+        want_tdv = "top_down" in name
+        st = self._boundary_buffers(n, H, W, bins, want_rgb, want_tdv)
+        dev = self.device
+        p = lambda t, off=0: C.c_void_p(t[off:].data_ptr()) if t is not None else None
+        gen = self._top_down_view_generator if want_tdv else None
+        out = np.zeros((n, 3), dtype=np.float32)
+        std = np.zeros((n, 3), dtype=np.float32)
         keys = ["all"] * n if rm.regress_type == "unified_act" else [ACT_IDX2NAME[a] for a in acts]
-        with torch.no_grad():
-            for key in sorted(set(keys)):
-                idx = [i for i, k in enumerate(keys) if k == key]
-                sel = torch.as_tensor(idx, device=self.device)
-                sub = obs_pairs if len(idx) == n else {k: v.index_select(0, sel) for k, v in obs_pairs.items()}
-                model = self.vo_model[key]
-                if rm.mode == "det":                      # :285-294
-                    model.eval()
-                    if "act_embed" in rm.name:
-                        a = torch.as_tensor([acts[i] for i in idx], dtype=torch.long, device=self.device)
-                        res = model(sub, a)
+        # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, chunk
+        # c-1 is pre-processed and evaluated on the caller's stream (host staging, transfer and device work overlap).
+        nchunks = 1 if n < 32 else (2 if n < 128 else 4)
+        bounds = [(n * c // nchunks, n * (c + 1) // nchunks) for c in range(nchunks)]
+        main = torch.cuda.current_stream(dev)
+        if nchunks > 1 and getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+        copy = self._copy_stream if nchunks > 1 else main
+        pending = []
+        frames = [o for pc in zip(prev_obs_list, cur_obs_list) for o in pc]
+        with torch.cuda.device(dev), torch.no_grad():
+            st["flag"].zero_()
+            if nchunks > 1:
+                copy.wait_stream(main)
+            for lo, hi in bounds:
+                m = hi - lo
+                threads = min(4, max(1, m // 8))          # measured: 4 copy threads saturate the host side
+                with torch.cuda.stream(copy):
+                    if want_rgb:
+                        ptrs, keep_r = self._frame_ptrs([f["rgb"] for f in frames[2 * lo:2 * hi]], np.uint8, (H, W, 3))
+                        _lib.check(_lib.lib.pnvo_stage_frames(ptrs, 2 * m, H * W * 3, p(st["h_rgb"], lo), threads))
+                        st["d_rgb"][lo:hi].copy_(st["h_rgb"][lo:hi], non_blocking=True)
+                    ptrs, keep_d = self._frame_ptrs([f["depth"] for f in frames[2 * lo:2 * hi]], np.float32, (H, W))
+                    _lib.check(_lib.lib.pnvo_stage_frames(ptrs, 2 * m, H * W * 4, p(st["h_dep"], lo), threads))
+                    st["d_dep"][lo:hi].copy_(st["h_dep"][lo:hi], non_blocking=True)
+                if nchunks > 1:
+                    main.wait_stream(copy)
+                _lib.check(_lib.lib.pnvo_build_obs_pairs(
+                    p(st["d_rgb"], lo), p(st["d_dep"], lo), int(m), int(H), int(W), int(bins), gen._consts if gen else None,
+                    int(gen._rows_around_center) if gen else 0, p(st["work"]), p(st["rgb"], lo), p(st["depth"], lo),
+                    p(st["dd"], lo), p(st["tdv"], lo), p(st["flag"]), _stream(dev)))
+                obs_pairs = {"depth": st["depth"][lo:hi]}
+                if want_rgb:
+                    obs_pairs["rgb"] = st["rgb"][lo:hi]
+                if bins:
+                    obs_pairs["discretized_depth"] = st["dd"][lo:hi]
+                if want_tdv:
+                    obs_pairs["top_down_view"] = st["tdv"][lo:hi]
+                obs_pairs = {k: v for k, v in obs_pairs.items() if k in vis}
+                ckeys = keys[lo:hi]
+                for key in sorted(set(ckeys)):
+                    idx = [i for i, k in enumerate(ckeys) if k == key]
+                    if len(idx) == m:
+                        sub = obs_pairs
                     else:
-                        res = model(sub)
-                    out[idx] = res.cpu().numpy()
-                else:                                     # 'rnd', :295-308: rnd_mode_n train-mode (dropout) forwards
-                    model.train()
-                    samples = np.stack([model(sub).cpu().numpy() for _ in range(int(rm.rnd_mode_n))])
-                    out[idx] = samples.mean(axis=0)
-                    std[idx] = samples.std(axis=0)
+                        sel = torch.as_tensor(idx, device=dev)
+                        sub = {k: v.index_select(0, sel) for k, v in obs_pairs.items()}
+                    gidx = [lo + i for i in idx]
+                    model = self.vo_model[key]
+                    a = torch.as_tensor([acts[i] for i in gidx], dtype=torch.long, device=dev) if "act_embed" in name else None
+                    if rm.mode == "det":                      # :285-294
+                        if model.training:                    # (eval() walks ~75 sub-modules: only when it changes anything)
+                            model.eval()
+                        pending.append((gidx, model(sub, a) if a is not None else model(sub)))
+                    else:                                     # 'rnd', :295-308: rnd_mode_n train-mode (dropout) forwards
+                        model.train()
+                        samples = np.stack([(model(sub, a) if a is not None else model(sub)).cpu().numpy()
+                                            for _ in range(int(rm.rnd_mode_n))])
+                        out[gidx] = samples.mean(axis=0)
+                        std[gidx] = samples.std(axis=0)
+            st["h_flag"].copy_(st["flag"], non_blocking=True)
+            for gidx, res in pending:                     # the first .cpu() is the one synchronisation of the call
+                out[gidx] = res.cpu().numpy()
+        if not pending:
+            torch.cuda.current_stream(dev).synchronize()
+        assert int(st["h_flag"][0]) == 0, "depth must lie in [0, 1]"      # the reference's asserts (:136-137)
         self._last_std = std
         return out
 

@@ -101,9 +101,20 @@ class VisualOdometryCNNBase(nn.Module):
         return self
 
     def _tensors(self):
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
-        return [(name, sd[name]) for name, _ in self._spec]
+        """(name, tensor) in state_dict order.  The owning (module, attribute) pairs are resolved once — walking the module
+        tree costs ~0.1 ms, which a batch-1 boundary call pays on every forward — and read through getattr each time, so a
+        buffer re-assigned by a train-mode forward (RunningMeanAndVar) or a parameter re-pointed by .to() is seen."""
+        slots = getattr(self, "_tensor_slots", None)
+        if slots is None:
+            slots = []
+            for name, _ in self._spec:
+                parts = name.split(".")
+                mod = self
+                for q in parts[:-1]:
+                    mod = getattr(mod, q)
+                slots.append((name, mod, parts[-1]))
+            object.__setattr__(self, "_tensor_slots", slots)
+        return [(name, getattr(mod, leaf)) for name, mod, leaf in slots]
 
     def _ensure_handle(self, device):
         if self._handle is not None and self._handle_dev == device.index:

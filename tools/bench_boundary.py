@@ -32,11 +32,11 @@ for k in t.vo_model:
     t.vo_model[k].load_state_dict({n: torch.from_numpy(np.array(v)) for n, v in sd.items()})
 obs = [synth.make_raw_obs(H, W, seed=3, index=i) for i in range(65)]
 res = {}
-for _ in range(5):
-    t._compute_local_delta_states_from_vo(obs[0], obs[1], 1)
+for i in range(9):                       # warm-up touches all three action models (weight upload, workspaces)
+    t._compute_local_delta_states_from_vo(obs[i], obs[i + 1], 1 + i % 3)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 50
+n = 200
 for i in range(n):
     t._compute_local_delta_states_from_vo(obs[i % 64], obs[i % 64 + 1], 1 + i % 3)
 res["batch1_boundary_ms"] = (time.perf_counter() - t0) / n * 1e3
