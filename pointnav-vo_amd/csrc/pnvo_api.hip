@@ -527,7 +527,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
   int rc = PNVO_OK;
   const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
   const char *sel = std::getenv("PNVO_STEM");
-  if (m->mx_ok && !m->in_train_forward && (!sel || std::strcmp(sel, "mx") == 0)) {
+  if (m->mx_ok && (!m->in_train_forward || m->train_mx) && (!sel || std::strcmp(sel, "mx") == 0)) {
     // bf16 matrix cores, three exact weight pieces: float32 results (stem_mx.hip).  The training step keeps the kernels
     // below, whose operands it rebuilds on the device after every Adam step.
     StemMXArgs a;
@@ -828,7 +828,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     const bool shape_ok = (c.n_rgb == 0 || c.n_rgb == 6) && (c.n_depth == 0 || c.n_depth == 2) && (c.n_dd == 0 || c.n_dd == 20) &&
                           (c.n_tdv == 0 || c.n_tdv == 2);
     if (shape_ok && (st.cout == 32 || st.cout == 64) && st.k == 7) {
-      std::vector<int> slot_ref(32, -1), slot_ref_sw(32, -1), slot_tensor(32, -1);
+      std::vector<int> slot_ref(32, -1), slot_ref_sw(32, -1), slot_tensor(32, -1), slot_new(32, -1);
       const int first_slot[4] = {20, 26, 0, 28};           // rgb, depth, dd, tdv
       for (int x = 0; x < 4; ++x) h->mx_xslot[x] = -1;
       if (c.n_depth) h->mx_xslot[0] = 26, h->mx_xslot[1] = 27;
@@ -842,6 +842,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
             if (h->stem_ch_of_new[k] == (ch + nsrc[tn] / 2) % nsrc[tn]) ncs = k;   // the frame-swapped twin
           }
           slot_ref[first_slot[tn] + ch] = h->stem_ref_of_new[nc];
+          slot_new[first_slot[tn] + ch] = nc;
           slot_ref_sw[first_slot[tn] + ch] = h->stem_ref_of_new[ncs];
           slot_tensor[first_slot[tn] + ch] = tn;
         }
@@ -865,6 +866,8 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
       };
       fold(slot_ref, h->mx_wk);
       fold(slot_ref_sw, h->mx_wk_swapped);
+      h->mx_slot_ref = slot_ref;
+      h->mx_slot_new = slot_new;
       std::vector<unsigned short> pk(stem_mx_packed_u16(3, st.cout / 32));
       pack_stem_mx_weight(h->mx_wk.data(), st.cout, 3, h->mx_xslot, pk.data());
       if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_wpk3), reinterpret_cast<const float *>(pk.data()), pk.size() / 2)) !=

@@ -100,6 +100,8 @@ int stem_mx_slots(int Ho, int Wo);
 size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
+hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
+                                 const int *slot_new, const int *xslot, unsigned short *wpk3, hipStream_t s);
 
 // Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).
 struct ConvBArgs {

@@ -59,9 +59,11 @@ struct pnvo_model_s {
   std::vector<float> mx_wk, mx_wk_swapped;   // host [cout][32 slots][49]: whitening-folded weights, as is / for the
                                              //   (cur, prev) channel-swapped pair (geometric-invariance dual forward)
   int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels
+  std::vector<int> mx_slot_ref, mx_slot_new; // K-slot -> reference channel / position in the stem's tensor-major order (-1: none)
   float *mx_pages = nullptr;                 // device: 64 zeros (out-of-image reads)
   unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx
   bool in_train_forward = false;
+  bool train_mx = false;                     // the attached training step rebuilds the mx stem operands every step
   int precision = 0;                         // pnvo_set_precision: 0 float32 (default), 1 bfloat16 (BASELINE config 3)
   unsigned long long load_gen = 0;           // bumped by pnvo_load_weights (operands derived lazily are rebuilt)
   void *bf = nullptr;                        // Bf16State (pnvo_bf16.hip)             // set by pnvo_train_forward: its stem operands are rebuilt on the device

@@ -41,6 +41,7 @@ struct TrainState {
   std::vector<std::array<float *, 4>> dgrad_wph;   // stride-2 3x3 convs: one sub-kernel per output parity phase (ph*2 + pw)
   float *fc_t = nullptr, *head_t = nullptr;
   int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
+  int *d_mxmaps = nullptr;          // mx stem: [slot_ref 32 | slot_new 32 | xslot 4]
   int *d_ddmaps = nullptr;          // one-hot stem: [dense_ref 12 | dense_new 12 | dd_ref 2*bins | dd_new 2*bins]
   int dd_nd = 0;
   size_t stem_w_off = 0;            // offset of the OIHW stem weight in the flat parameter buffer
@@ -254,6 +255,21 @@ int build_maps(pnvo_handle m, TrainState *t) {
   HIPCHK(m, hipMemcpy(t->d_ref_of_new, ron.data(), m->CPL * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(m, hipMemcpy(t->d_tensor_of_new, ton.data(), m->CPL * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(m, hipMemcpy(t->d_ciperm, perm.data(), 32 * sizeof(int), hipMemcpyHostToDevice));
+  m->train_mx = false;
+  if (m->mx_ok && m->convs[0].cout == 32 && m->mx_slot_ref.size() == 32) {   // stem on the bf16 matrix cores: device-side repack
+    std::vector<int> mp(68, -1);
+    for (int k = 0; k < 32; ++k) {
+      mp[k] = m->mx_slot_ref[k];
+      mp[32 + k] = m->mx_slot_new[k];
+    }
+    for (int x = 0; x < 4; ++x) mp[64 + x] = m->mx_xslot[x];
+    if ((rc = dmalloc(m, (void **)&t->d_mxmaps, mp.size() * sizeof(int))) != PNVO_OK) return rc;
+    HIPCHK(m, hipMemcpy(t->d_mxmaps, mp.data(), mp.size() * sizeof(int), hipMemcpyHostToDevice));
+    auto it = t->toc.find(m->convs[0].name + ".weight");
+    if (it == t->toc.end()) return pnvo_fail(m, PNVO_ERR_WEIGHTS, "stem weight missing from the parameter table");
+    t->stem_w_off = it->second.off;
+    m->train_mx = true;
+  }
   if (m->dd_ok) {                  // the one-hot-aware stem's operands are rebuilt on the device after every step
     const int bins = m->dd_bins;
     std::vector<int> mp(24 + 4 * bins, -1);
@@ -285,8 +301,14 @@ int build_maps(pnvo_handle m, TrainState *t) {
   return PNVO_OK;
 }
 
-// Rebuild the one-hot-aware stem's operands from the flat parameters and the current whitening tables.
+// Rebuild the stem's operands from the flat parameters and the current whitening tables: the three-piece bf16 B operand of
+// stem_mx.hip when the model runs it (32 stem outputs), else the one-hot-aware stem's table / dense weights.
 int refresh_stem_dd(pnvo_handle m, TrainState *t, hipStream_t s) {
+  if (m->train_mx) {
+    HIPCHK(m, launch_stem_mx_repack(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_mxmaps, t->d_mxmaps + 32,
+                                    t->d_mxmaps + 64, m->mx_wpk3, s));
+    return PNVO_OK;
+  }
   if (!m->dd_ok) return PNVO_OK;
   const int bins = m->dd_bins;
   HIPCHK(m, launch_stem_dd_repack(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_ddmaps,
@@ -566,9 +588,11 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->head_t);
   dfree(t->d_ref_of_new);
   dfree(t->d_ddmaps);
+  dfree(t->d_mxmaps);
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
   if (t->embed_err) (void)hipHostFree(t->embed_err);
+  m->train_mx = false;
   delete t;
   m->train = nullptr;
 }

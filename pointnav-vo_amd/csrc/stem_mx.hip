@@ -437,6 +437,60 @@ void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot
           }
 }
 
+// Training: rebuild the three-piece B operand ON THE DEVICE from the current OIHW stem weight (inside the flat parameter
+// buffer) and the current whitening tables sc/sh of the stem's "new" channel order (sc = 1/(div*std), sh = -mean/std) —
+// both change every optimisation step.  Same arithmetic as pnvo_load_weights + pack_stem_mx_weight (double products,
+// rounded to float once, then split exactly).  One thread per bf16 element of the packed array (32 output channels).
+__global__ __launch_bounds__(256) void stem_mx_repack_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
+                                                           const int *slot_ref, const int *slot_new, const int *xslot,
+                                                           unsigned short *out, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = e & 7, ln = (e >> 3) & 63;
+  int r = e >> 9;
+  const int f = r % 7, tap = r / 7;                  // (one N-tile: cout = 32)
+  const int kh = ln >> 5, co = ln & 31;
+  auto wk = [&](int slot) -> float {
+    if (slot == 30) {                                // "inside the image" indicator: sum_c W * (-mean_c / std_c)
+      double ind = 0.0;
+      for (int k = 0; k < 30; ++k)
+        if (slot_ref[k] >= 0) ind += (double)w[((long)co * cin + slot_ref[k]) * 49 + tap] * (double)sh_new[slot_new[k]];
+      return (float)ind;
+    }
+    if (slot > 30 || slot_ref[slot] < 0) return 0.f;
+    return (float)((double)w[((long)co * cin + slot_ref[slot]) * 49 + tap] * (double)sc_new[slot_new[slot]]);
+  };
+  auto piece = [&](float v, int pc) -> unsigned short {
+    const unsigned hs = pack_bf16(v, 0.f) & 0xffffu;
+    if (pc == 0) return (unsigned short)hs;
+    const float r1 = v - bf16_lo(hs);
+    const unsigned ms = pack_bf16(r1, 0.f) & 0xffffu;
+    if (pc == 1) return (unsigned short)ms;
+    return (unsigned short)(pack_bf16(r1 - bf16_lo(ms), 0.f) & 0xffffu);
+  };
+  unsigned short val = 0;
+  if (f < 6) {
+    const int pc = f / 2, q = f % 2;
+    val = piece(wk(16 * q + 8 * kh + j), pc);
+  } else {
+    const int x = j & 3;
+    if (xslot[x] >= 0) {
+      const float v = wk(xslot[x]);
+      if (kh == 0) val = piece(v, 0);
+      else if (j < 4) val = piece(v, 1);
+    }
+  }
+  out[e] = val;
+}
+
+hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
+                                 const int *slot_new, const int *xslot, unsigned short *wpk3, hipStream_t s) {
+  const int total = 49 * 7 * 64 * 8;
+  hipLaunchKernelGGL(stem_mx_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cin, sc_new, sh_new,
+                     slot_ref, slot_new, xslot, wpk3, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s) {
   StemMXArgs p = a;
   p.tiles_x = (a.Wo + TW - 1) / TW;
