@@ -15,6 +15,7 @@
 // fragments stream from L2 (uniform base + lane), A fragments from LDS, both double-buffered one (tap, k-chunk) step
 // ahead.  Input channels beyond CK are processed in chunks with the accumulators kept in registers.
 // blockIdx.z selects one of up to two models (the geometric-invariance dual forward runs both in every launch).
+#include <cstdlib>
 #include <cstring>
 
 #include "pnvo_internal.h"
@@ -271,8 +272,15 @@ bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *
   // output tile: <= 128 pixels; 8 x 16 for the wide stages, whole-width strips for the narrow ones
   int TR, TC;
   if (a.Wo >= 32) {
+    // 16 x 16 tiles (two / four M-tiles per wave: every B fragment feeds more MFMAs, the per-tile overheads halve) where
+    // the layer is narrow enough for the accumulators and the patch still fits; measured on layer 1: 0.155 -> 0.116 ms
     TR = 8;
     TC = 16;
+    if (ntt == 1 && a.Ho % 16 == 0 && !std::getenv("PNVO_BF16_T8")) {   // (layer 2 at 24 x 43 wastes a third of 16-row tiles: slower)
+      const int cs_ = ks == 1 ? 1 : stride;
+      const size_t patch = (size_t)(15 * cs_ + ks) * (15 * cs_ + ks) * (a.CIN * 2 + 16);
+      if (patch <= (size_t)56 * 1024) TR = 16;
+    }
   } else {
     TC = a.Wo;
     TR = 128 / TC;
@@ -292,11 +300,11 @@ bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *
   // wave grid and accumulators per wave
   if (ntt == 1) {
     a.wn = 1;
-    *mw = 1;
+    *mw = TR * TC > 128 ? 2 : 1;
     *nw = 1;
   } else if (ntt == 2) {
     a.wn = 2;
-    *mw = 2;
+    *mw = TR * TC > 128 ? 4 : 2;
     *nw = 1;
   } else if (ntt == 4) {
     a.wn = 4;
