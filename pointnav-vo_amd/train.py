@@ -314,10 +314,12 @@ def compute_loss_weights(actions, targets, multiplier=None, fixed=True):
     return {k: torch.exp(float(multiplier[k]) * torch.abs(nn[:, d] - t[:, 0])) for d, k in enumerate(("dx", "dz", "dyaw"))}
 
 
-def regression_coef(n, data_types=None, loss_weights=None, dz_regress_masks=None, device=None):
+def regression_coef(n, data_types=None, loss_weights=None, dz_regress_masks=None, device=None, allowed_types=None):
     """coef [n,3] such that sum(coef * (gt - pred)^2) is what the reference adds up for one action model
-    (vo_cnn_regression_geo_invariance_engine.py:618-740 calling vo_cnn_engine.py:135-198): for every data type present
-    and every d in (dx, dz, dyaw): mean over that subset of (diff^2 [* dz_regress_mask for dz]) * loss_weights[d]."""
+    (vo_cnn_regression_geo_invariance_engine.py:618-740 calling vo_cnn_engine.py:135-198): for every data type the engine
+    regresses (`tmp_data_types`, :679-684: CUR_REL_TO_PREV always, PREV_REL_TO_CUR only with inverse_data_augment_only /
+    inverse_joint_train) and every d in (dx, dz, dyaw): mean over that subset of (diff^2 [* dz_regress_mask for dz]) *
+    loss_weights[d].  Entries of any other data type carry no regression loss (coef 0)."""
     coef = torch.ones((n, 3), dtype=torch.float32)
     if data_types is None:
         coef /= float(n)
@@ -325,7 +327,10 @@ def regression_coef(n, data_types=None, loss_weights=None, dz_regress_masks=None
         dt = torch.as_tensor(data_types).reshape(-1).cpu()
         for t in torch.unique(dt).tolist():
             sel = dt == t
-            coef[sel] /= float(int(sel.sum()))
+            if allowed_types is not None and t not in allowed_types:
+                coef[sel] = 0.0
+            else:
+                coef[sel] /= float(int(sel.sum()))
     if loss_weights is not None:
         for d, k in enumerate(("dx", "dz", "dyaw")):
             coef[:, d] *= torch.as_tensor(loss_weights[k], dtype=torch.float32).reshape(-1).cpu()
@@ -363,6 +368,7 @@ class GeoInvarianceTrainStep:
         M = actions.numel()
         joint = "inverse_joint_train" in self.invariance_types
         use_types = len(self.invariance_types) > 0
+        allowed = [CUR_REL_TO_PREV] + ([PREV_REL_TO_CUR] if (joint or "inverse_data_augment_only" in self.invariance_types) else [])
         preds = torch.zeros((M, 3), device=dev, dtype=torch.float32)
         idx_of, grads, total = {}, {}, torch.zeros(1, device=dev)
         with torch.cuda.device(dev), torch.no_grad():
@@ -378,7 +384,8 @@ class GeoInvarianceTrainStep:
                 coef = regression_coef(
                     idx.numel(), data_types[idx] if use_types else None,
                     None if loss_weights is None else {k: torch.as_tensor(v).reshape(-1)[idx] for k, v in loss_weights.items()},
-                    None if dz_regress_masks is None else torch.as_tensor(dz_regress_masks).reshape(-1)[idx], device=dev)
+                    None if dz_regress_masks is None else torch.as_tensor(dz_regress_masks).reshape(-1)[idx], device=dev,
+                    allowed_types=allowed if use_types else None)
                 g = torch.empty_like(out)
                 tgt = targets.index_select(0, di).contiguous()
                 _lib.check(_lib.lib.pnvo_mse_loss_coef(_ptr(out), _ptr(tgt), _ptr(coef), int(out.numel()), _ptr(st._loss),
@@ -406,6 +413,13 @@ class GeoInvarianceTrainStep:
                         grads[act] += full.index_select(0, di)
             for act, di in idx_of.items():
                 self.steps[act].backward(grads[act])
-            for act in idx_of:
-                self.steps[act].optimizer_step()
+            for act, st in self.steps.items():
+                if act in idx_of:
+                    st.optimizer_step()
+                elif st.step_count > 0:
+                    # the reference zero_grad()s and step()s EVERY action model each iteration (:855-901); a model without
+                    # entries in this batch has all-zero gradients once it has had a backward, so Adam still decays and
+                    # applies its moments (torch 1.x zero_grad keeps zero tensors, environment.yml)
+                    st.grad.zero_()
+                    st.optimizer_step()
         return total, preds
