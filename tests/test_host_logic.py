@@ -78,3 +78,26 @@ def test_synth_is_deterministic_and_shard_consistent():
         np.testing.assert_array_equal(a[k][1:], b[k])
     assert a["discretized_depth"].sum() == 3 * 40 * 48 * 2
     assert a["rgb"].min() >= 0 and a["rgb"].max() <= 255 and a["rgb"].dtype == np.float32
+
+
+def test_policy_exposes_what_the_reference_trainers_read():
+    """ppo_trainer.py:618 / ddppo_trainer.py:279 read policy.net.num_recurrent_layers (and net.output_size) to allocate the
+    recurrent state; ddppo_trainer.py:150 calls policy.net.visual_encoder.load_state_dict(...)."""
+    from types import SimpleNamespace
+    from pointnav_vo_amd import policy as pol
+    space = SimpleNamespace(spaces={"depth": SimpleNamespace(shape=(192, 341, 1)), "pointgoal_with_gps_compass": SimpleNamespace(shape=(2,))})
+    p = baseline_registry.get_policy("resnet_rnn_policy")(observation_space=space, action_space=SimpleNamespace(n=4), hidden_size=512,
+                                                          num_recurrent_layers=2, rnn_type="LSTM", resnet_baseplanes=32,
+                                                          backbone="resnet18", normalize_visual_inputs=False)
+    assert p.net.num_recurrent_layers == 4 and p.num_recurrent_layers == 4          # LSTM: h and c per layer
+    assert p.net.output_size == 512 and p.net.is_blind is False
+    enc_sd = p.net.visual_encoder.state_dict()
+    p.net.visual_encoder.load_state_dict(enc_sd)                                     # a Module with the reference's keys
+    assert any(k.startswith("backbone.") for k in enc_sd)
+
+
+def test_set_precision_is_validated_on_the_host():
+    m = baseline_registry.get_vo_model("vo_cnn")(observation_space=["rgb", "depth"], **KW)
+    assert m.set_precision("bfloat16") is m and m._precision == "bfloat16"
+    with pytest.raises(ValueError):
+        m.set_precision("float16")
