@@ -11,6 +11,11 @@ from pointnav_vo_amd import vo_cnn  # noqa: F401
 from pointnav_vo_amd.train import VOTrainStep
 
 pytestmark = pytest.mark.gpu
+# Gradient tolerance (relative L2 per parameter tensor, vs the fp64 checker).  Measured (tools/grad_error_table.py, MI355X):
+# the HIP step's worst tensor is 2.5e-6 (median 1.0-1.6e-6); the SAME checker run in float32 on the CPU deviates from its
+# float64 self by 3.1e-6 median / 4.1e-6 worst on the 96x64 fixture — the HIP kernels (fp32 FMA chains, fixed-order fp64
+# reductions of the partial sums) are as accurate as a float32 framework.  GRAD_TOL leaves ~10x for other inputs.
+GRAD_TOL = 3e-5
 
 
 def build(rec, dropout_p=0.0):
@@ -50,7 +55,7 @@ def test_train_step_matches_reference(fname):
         gr = chk["grads"][name].reshape(-1).numpy()
         err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
         gn = float(rec[f"g1norm/{name}"])
-        if err > 2e-3 or abs(np.linalg.norm(g) - gn) > 5e-3 * max(gn, 1e-9):
+        if err > GRAD_TOL or abs(np.linalg.norm(g) - gn) > 5e-3 * max(gn, 1e-9):
             bad.append((name, err, np.linalg.norm(g), gn))
     assert not bad, bad
     # Adam: first step moves every parameter by lr * sign(g) (|m|/sqrt(v) = 1); compare with the checker where |g| is
@@ -115,7 +120,7 @@ def test_dropout_step_matches_checker_given_the_same_masks():
         g = ts.grad[off:off + n].cpu().double().numpy()
         gr = chk["grads"][name].reshape(-1).numpy()
         err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
-        if err > 2e-3:
+        if err > GRAD_TOL:
             bad.append((name, err))
     assert not bad, bad
     # a second forward draws a different mask; a fresh trainer with the same seed repeats the first one bit for bit
@@ -182,7 +187,7 @@ def test_joint_inverse_train_step_matches_reference_engine(fname):
             gr = chk["grads"][a][name].reshape(-1).numpy()
             err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
             gn = float(rec[f"gnorm{a}/{name}"])
-            if err > 2e-3 or abs(np.linalg.norm(g) - gn) > 5e-3 * max(gn, 1e-9):
+            if err > GRAD_TOL or abs(np.linalg.norm(g) - gn) > 5e-3 * max(gn, 1e-9):
                 bad.append((name, err, np.linalg.norm(g), gn))
         assert not bad, (a, bad)
         assert not torch.equal(before[a], st.flat)
@@ -243,7 +248,7 @@ def test_act_embed_train_step_matches_reference(dropout_p):
         g = ts.grad[off:off + n].cpu().double().numpy()
         gr = chk["grads"][name].reshape(-1).numpy()
         err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
-        if err > 2e-3:
+        if err > GRAD_TOL:
             bad.append((name, err, np.linalg.norm(g), np.linalg.norm(gr)))
         if dropout_p == 0:
             gn = float(rec[f"g1norm/{name}"])
@@ -281,7 +286,7 @@ def test_bottleneck_train_step_matches_reference():
         gr = chk["grads"][name].reshape(-1).numpy()
         err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-12)
         gn = float(rec[f"g1norm/{name}"])
-        if err > 5e-3 or abs(np.linalg.norm(g) - gn) > 1e-2 * max(gn, 1e-9):
+        if err > GRAD_TOL or abs(np.linalg.norm(g) - gn) > 1e-2 * max(gn, 1e-9):
             bad.append((name, err, np.linalg.norm(g), gn))
     assert not bad, bad[:8]
     ts.optimizer_step()
