@@ -943,6 +943,9 @@ int pnvo_forward_dual(pnvo_handle ha, pnvo_handle hb, const float *rgb, const fl
     return fail(ha, PNVO_ERR_STATE, "pnvo_forward_dual runs the bfloat16 path: call pnvo_set_precision(h, 1) on both models");
   if (std::memcmp(&ha->cfg, &hb->cfg, sizeof(pnvo_config)) != 0 || ha->device != hb->device)
     return fail(ha, PNVO_ERR_ARG, "the two models of a dual forward must share architecture and device");
+  if (ha->cfg.act_embed)
+    return fail(ha, PNVO_ERR_ARG, "pnvo_forward_dual covers the separate-action models (act_left_right_inv_joint); act-embed "
+                                  "models take their actions through pnvo_forward");
   const pnvo_config &c = ha->cfg;
   if ((c.n_rgb > 0) != (rgb != nullptr) || (c.n_depth > 0) != (depth != nullptr) || (c.n_dd > 0) != (dd != nullptr) ||
       (c.n_tdv > 0) != (tdv != nullptr))

@@ -79,6 +79,14 @@ inline float host_bf16_to_float(unsigned short h) {
 }
 }  // namespace
 
+struct TapOffsets {
+  unsigned v[49];
+  constexpr TapOffsets() : v() {
+    for (int t = 0; t < 49; ++t) v[t] = (unsigned)((t / 7) * ROW + ((t % 7) & 1) * PAR + ((t % 7) >> 1) * PITCH);
+  }
+};
+__constant__ const TapOffsets TAPOFF{};
+
 template <int PIECES, int NT, bool BF16OUT>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_mx_kernel(const StemMXArgs p) {
   constexpr bool EXTRA = PIECES == 3;
@@ -218,12 +226,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int f = 0; f < NFT; ++f)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[f * NT + nt] = wt[(f * ntg + nt) * 64 + lane];
+        for (int nt = 0; nt < NT; ++nt) {
+          const int q = (f * ntg + nt) * 64;                  // fragment offset (16-byte units), uniform
+          const u32x4 *base = wt + (q & ~255);                //  split so that the remainder fits the load's immediate (< 4 KiB)
+          b[f * NT + nt] = base[(q & 255) + lane];
+        }
     };
-    auto tapoff = [&](int tap) {
-      const int kh = tap / 7, kw = tap - 7 * kh;
-      return (unsigned)(kh * ROW + (kw & 1) * PAR + (kw >> 1) * PITCH);
-    };
+    auto tapoff = [&](int tap) { return TAPOFF.v[tap]; };    // (kh*ROW + (kw&1)*PAR + (kw>>1)*PITCH from a constant table: one
+                                                             //  scalar load instead of a divide-by-7 sequence per use)
     auto loadA0 = [&](int tap, u32x4 *a) {                 // K-slots 0..15 of the four M-tiles
       const unsigned toff = tapoff(tap);
 #pragma unroll
