@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
   for (int ck0 = 0; ck0 < p.CIN; ck0 += CK) {
     if (ck0 > 0) __syncthreads();                                        // the previous chunk's patch is no longer read
     {
-      f32x4 sc0, sc1, sh0, sh1;
-      if (MODE == 1) {
+      f32x4 sc0, sc1, sh0, sh1, rc0, rc1, rh0, rh1;
+      if (MODE >= 1) {
         const float *ps = p.in_scale[z] + (long)n * p.CIN + ck0 + 8 * cg;
         const float *pt = p.in_shift[z] + (long)n * p.CIN + ck0 + 8 * cg;
         sc0 = *reinterpret_cast<const f32x4 *>(ps);
@@ -107,11 +107,28 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         sh0 = *reinterpret_cast<const f32x4 *>(pt);
         sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
       }
+      const bool r_affine = MODE == 2 && p.in_scale2[z] != nullptr;       // the skip branch is a raw conv output (downsample)
+      if (MODE == 2) {
+        rc0 = rc1 = f32x4{1.f, 1.f, 1.f, 1.f};
+        rh0 = rh1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r_affine) {
+          const float *ps = p.in_scale2[z] + (long)n * p.CIN + ck0 + 8 * cg;
+          const float *pt = p.in_shift2[z] + (long)n * p.CIN + ck0 + 8 * cg;
+          rc0 = *reinterpret_cast<const f32x4 *>(ps);
+          rc1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+          rh0 = *reinterpret_cast<const f32x4 *>(pt);
+          rh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+        }
+      }
       int pr = pl / PC, pc = pl - pr * PC;
-      const unsigned short *xb = x + ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
+      const long xoff = ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
+      const unsigned short *xb = x + xoff;
+      const unsigned short *xb2 = MODE == 2 ? p.x2[z] + xoff : nullptr;
+      unsigned short *xo = (MODE == 2 && p.xout[z] != nullptr) ? p.xout[z] + xoff : nullptr;
       for (int pix = pl; pix < nppix; pix += 4 * PS) {
-        u32x4 v[4];
-        unsigned off[4], inmask = 0;
+        u32x4 v[4], v2[4];
+        unsigned off[4], inmask = 0, ownmask = 0;
+        long eoff[4];
         bool ok[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -119,8 +136,16 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
           ok[k] = pix + k * PS < nppix;
           const bool in = ok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
           off[k] = (unsigned)((pr * PC + pc) * pitch + 16 * cg);
+          eoff[k] = ((long)hi * p.W + wi) * p.CIN;
           v[k] = u32x4{0u, 0u, 0u, 0u};
-          if (in) v[k] = *reinterpret_cast<const u32x4 *>(xb + ((long)hi * p.W + wi) * p.CIN);
+          if (in) v[k] = *reinterpret_cast<const u32x4 *>(xb + eoff[k]);
+          if (MODE == 2) {
+            v2[k] = u32x4{0u, 0u, 0u, 0u};
+            if (in) v2[k] = *reinterpret_cast<const u32x4 *>(xb2 + eoff[k]);
+            // every input pixel is materialised by exactly one tile: the one whose output region it falls into
+            const int qr = hi / STRIDE - r0, qc = wi / STRIDE - c0;
+            ownmask |= (unsigned)(in && qr >= 0 && qr < p.TR && qc >= 0 && qc < p.TC) << k;
+          }
           inmask |= (unsigned)in << k;                                   // outside the image: zero AFTER the transform
           pr += dr;
           pc += dc;
@@ -133,21 +158,31 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         for (int k = 0; k < 4; ++k) {
           if (!ok[k]) continue;
           u32x4 o = v[k];
-          if (MODE == 1) {
+          if (MODE >= 1) {
             if (!((inmask >> k) & 1u)) {
               o = u32x4{0u, 0u, 0u, 0u};
             } else {
-              o[0] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][0]), sc0[0], sh0[0]), 0.f),
-                           fmaxf(__builtin_fmaf(hi_f(v[k][0]), sc0[1], sh0[1]), 0.f));
-              o[1] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][1]), sc0[2], sh0[2]), 0.f),
-                           fmaxf(__builtin_fmaf(hi_f(v[k][1]), sc0[3], sh0[3]), 0.f));
-              o[2] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][2]), sc1[0], sh1[0]), 0.f),
-                           fmaxf(__builtin_fmaf(hi_f(v[k][2]), sc1[1], sh1[1]), 0.f));
-              o[3] = pack2(fmaxf(__builtin_fmaf(lo_f(v[k][3]), sc1[2], sh1[2]), 0.f),
-                           fmaxf(__builtin_fmaf(hi_f(v[k][3]), sc1[3], sh1[3]), 0.f));
+              float f[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f32x4 &sc = e < 2 ? sc0 : sc1, &sh = e < 2 ? sh0 : sh1;
+                f[2 * e] = __builtin_fmaf(lo_f(v[k][e]), sc[(2 * e) & 3], sh[(2 * e) & 3]);
+                f[2 * e + 1] = __builtin_fmaf(hi_f(v[k][e]), sc[(2 * e + 1) & 3], sh[(2 * e + 1) & 3]);
+              }
+              if (MODE == 2) {                                           // BasicBlock tail: + skip branch, then the ReLU
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const f32x4 &sc = e < 2 ? rc0 : rc1, &sh = e < 2 ? rh0 : rh1;
+                  f[2 * e] += __builtin_fmaf(lo_f(v2[k][e]), sc[(2 * e) & 3], sh[(2 * e) & 3]);
+                  f[2 * e + 1] += __builtin_fmaf(hi_f(v2[k][e]), sc[(2 * e + 1) & 3], sh[(2 * e + 1) & 3]);
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = pack2(fmaxf(f[2 * e], 0.f), fmaxf(f[2 * e + 1], 0.f));
             }
           }
           *reinterpret_cast<u32x4 *>(lds + off[k]) = o;
+          if (MODE == 2 && xo != nullptr && ((ownmask >> k) & 1u)) *reinterpret_cast<u32x4 *>(xo + eoff[k]) = o;
         }
       }
     }
@@ -258,6 +293,11 @@ hipError_t launch_ks(const ConvBArgs &a, int mode, bool f32out, int mw, int nw, 
   PNVO_CB(0, false, 3, 1) PNVO_CB(1, false, 3, 1) PNVO_CB(0, false, 3, 2) PNVO_CB(1, false, 3, 2) PNVO_CB(0, true, 3, 2)
   PNVO_CB(0, true, 3, 1)
   PNVO_CB(0, true, 1, 1) PNVO_CB(0, true, 2, 1) PNVO_CB(0, true, 4, 1) PNVO_CB(0, true, 4, 2)
+  if (KS == 3) {                                   // fused BasicBlock tail (MODE 2): conv1 of a block / the compression conv
+    PNVO_CB(2, false, 1, 1) PNVO_CB(2, false, 2, 1) PNVO_CB(2, false, 4, 1) PNVO_CB(2, false, 4, 2)
+    PNVO_CB(2, false, 3, 1) PNVO_CB(2, false, 3, 2)
+    PNVO_CB(2, true, 1, 1) PNVO_CB(2, true, 2, 1) PNVO_CB(2, true, 3, 1) PNVO_CB(2, true, 3, 2) PNVO_CB(2, true, 4, 1) PNVO_CB(2, true, 4, 2)
+  }
 #undef PNVO_CB
   return hipErrorInvalidValue;
 }

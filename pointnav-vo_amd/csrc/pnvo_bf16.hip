@@ -245,8 +245,15 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     HIPCHK(m, launch_gn_relu_maxpool_bf16(x.v, sc.v, sh.v, B, m->Hs, m->Ws, 32, o.v, nm, s));
   }
 
-  // one conv of the residual stages + its GroupNorm finalisation
-  auto conv = [&](size_t li, auto xin, auto yout, int ss_sel /*0 A, 1 B, 2 D, 3 C*/, int in_sel /*-1 none, 0 A*/, bool f32out) -> int {
+  // one conv of the residual stages + its GroupNorm finalisation.  mode 0: plain input; 1: relu(GN(x)) of the producer
+  // (ssA); 2: the fused BasicBlock tail relu(GN2(rawB) + skip) — computed while staging and written to `xout`
+  struct Skip {
+    bool on = false, affine = false;     // affine: the skip branch is the raw downsample conv (GN applied in the fetch)
+    int buf = 0;                         // else: the block input bufY[buf]
+  };
+  const bool fuse = std::getenv("PNVO_BF16_NOFUSE") == nullptr;
+  auto conv = [&](size_t li, int mode, auto xin, auto yout, int ss_sel /*0 A, 1 B, 2 D, 3 C*/, bool f32out, const Skip &sk,
+                  int out_buf) -> int {
     const Layer &l = m->convs[li];
     ConvBArgs a = bs[0]->layers[li].plan;
     a.B = B;
@@ -256,15 +263,19 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       a.wpk[z] = bs[k]->layers[li].wpk;
       a.y[z] = yout(k);
       a.stats[z] = bs[k]->stats;
-      a.in_scale[z] = in_sel == 0 ? bs[k]->ssA[0] : nullptr;
-      a.in_shift[z] = in_sel == 0 ? bs[k]->ssA[1] : nullptr;
+      a.in_scale[z] = mode == 1 ? bs[k]->ssA[0] : mode == 2 ? bs[k]->ssB[0] : nullptr;
+      a.in_shift[z] = mode == 1 ? bs[k]->ssA[1] : mode == 2 ? bs[k]->ssB[1] : nullptr;
+      a.x2[z] = mode == 2 ? (sk.affine ? bs[k]->rawD : bs[k]->bufY[sk.buf]) : nullptr;
+      a.in_scale2[z] = mode == 2 && sk.affine ? bs[k]->ssD[0] : nullptr;
+      a.in_shift2[z] = mode == 2 && sk.affine ? bs[k]->ssD[1] : nullptr;
+      a.xout[z] = mode == 2 && out_buf >= 0 ? bs[k]->bufY[out_buf] : nullptr;
     }
     const double macs = (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw;
     {
       PnvoTimed t(m, s, "bf16:conv:" + l.name, 2.0 * nm * macs,
-                  2.0 * nm * ((double)B * l.hin * l.win * l.cin + (double)B * l.hout * l.wout * l.cout));
-      HIPCHK(m, launch_conv_bf16(a, l.k, l.stride, in_sel == 0 ? 1 : 0, f32out, bs[0]->layers[li].mw, bs[0]->layers[li].nw,
-                                 bs[0]->layers[li].lds, nm, s));
+                  2.0 * nm * ((double)B * l.hin * l.win * l.cin * (mode == 2 ? 3 : 1) + (double)B * l.hout * l.wout * l.cout));
+      HIPCHK(m, launch_conv_bf16(a, l.k, l.stride, mode, f32out, bs[0]->layers[li].mw, bs[0]->layers[li].nw, bs[0]->layers[li].lds,
+                                 nm, s));
     }
     PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
     auto ssof = [&](int z) { return ss_sel == 0 ? bs[z]->ssA : ss_sel == 1 ? bs[z]->ssB : ss_sel == 2 ? bs[z]->ssD : bs[z]->ssC; };
@@ -278,26 +289,48 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     return PNVO_OK;
   };
 
-  // (a8) residual stages (BasicBlock: conv3x3(s) -> GN -> ReLU -> conv3x3 -> GN; + identity / conv1x1(s)+GN; ReLU)
+  // (a8) residual stages (BasicBlock: conv3x3(s) -> GN -> ReLU -> conv3x3 -> GN; + identity / conv1x1(s)+GN; ReLU).
+  // The tail of block k (GN2 + skip + ReLU) is not a pass of its own: conv1 of block k+1 (and the compression conv after
+  // the last block) computes it while staging its input patch and writes the block output for the later readers (the
+  // next skip branch / downsample conv).  PNVO_BF16_NOFUSE=1 keeps the separate residual kernel (A/B measurements).
   size_t li = 1;
+  Skip pend;                                       // tail of the previous block, still to be applied
+  const Skip none;
   for (int stage = 1; stage <= 4; ++stage)
     for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
       const size_t l1 = li++, l2 = li++;
       const bool ds = li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos;
       const Layer &c2 = m->convs[l2];
-      auto xcur = [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; };
-      if ((rc = conv(l1, xcur, [&](int z) { return (void *)bs[z]->rawA; }, 0, -1, false)) != PNVO_OK) return rc;
-      if ((rc = conv(l2, [&](int z) { return (const unsigned short *)bs[z]->rawA; }, [&](int z) { return (void *)bs[z]->rawB; }, 1,
-                     0, false)) != PNVO_OK)
+      if (pend.on) {                               // input = relu(GN2(rawB) + skip) of the previous block -> bufY[cur ^ 1]
+        if ((rc = conv(l1, 2, [&](int z) { return (const unsigned short *)bs[z]->rawB; }, [&](int z) { return (void *)bs[z]->rawA; }, 0,
+                       false, pend, cur ^ 1)) != PNVO_OK)
+          return rc;
+        cur ^= 1;
+      } else if ((rc = conv(l1, 0, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; },
+                            [&](int z) { return (void *)bs[z]->rawA; }, 0, false, none, -1)) != PNVO_OK) {
+        return rc;
+      }
+      if ((rc = conv(l2, 1, [&](int z) { return (const unsigned short *)bs[z]->rawA; }, [&](int z) { return (void *)bs[z]->rawB; }, 1,
+                     false, none, -1)) != PNVO_OK)
         return rc;
       const long P = (long)c2.hout * c2.wout;
+      if (ds) {
+        const size_t ld = li++;
+        if ((rc = conv(ld, 0, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; }, [&](int z) { return (void *)bs[z]->rawD; },
+                       2, false, none, -1)) != PNVO_OK)
+          return rc;
+      }
+      if (fuse) {
+        pend.on = true;
+        pend.affine = ds;
+        pend.buf = cur;
+        continue;
+      }
       auto a_ = each([&](int z) { return (const unsigned short *)bs[z]->rawB; });
       auto sa = each([&](int z) { return (const float *)bs[z]->ssB[0]; });
       auto ta = each([&](int z) { return (const float *)bs[z]->ssB[1]; });
       auto y_ = each([&](int z) { return bs[z]->bufY[cur ^ 1]; });
       if (ds) {
-        const size_t ld = li++;
-        if ((rc = conv(ld, xcur, [&](int z) { return (void *)bs[z]->rawD; }, 2, -1, false)) != PNVO_OK) return rc;
         auto b_ = each([&](int z) { return (const unsigned short *)bs[z]->rawD; });
         auto sb = each([&](int z) { return (const float *)bs[z]->ssD[0]; });
         auto tb = each([&](int z) { return (const float *)bs[z]->ssD[1]; });
@@ -311,9 +344,14 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       cur ^= 1;
     }
   // (a10) compression conv + GroupNorm(1, C): fp32 output for the Linear layers
-  if ((rc = conv(li, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; }, [&](int z) { return (void *)bs[z]->comp_raw; }, 3,
-                 -1, true)) != PNVO_OK)
+  if (pend.on) {
+    if ((rc = conv(li, 2, [&](int z) { return (const unsigned short *)bs[z]->rawB; }, [&](int z) { return (void *)bs[z]->comp_raw; }, 3,
+                   true, pend, -1)) != PNVO_OK)
+      return rc;
+  } else if ((rc = conv(li, 0, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; },
+                        [&](int z) { return (void *)bs[z]->comp_raw; }, 3, true, none, -1)) != PNVO_OK) {
     return rc;
+  }
   // (a11) Flatten + Linear + ReLU + output head: the fp32 split-K linear kernels on each model
   for (int z = 0; z < nm; ++z) {
     pnvo_handle h = hs[z];

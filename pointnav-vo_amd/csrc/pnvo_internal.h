@@ -109,6 +109,11 @@ struct ConvBArgs {
   const unsigned short *wpk[2];      // pack_conv_bf16_weight()
   void *y[2];                        // [B,Ho,Wo,COUTP] raw output, bf16 (or float for the compression conv)
   const float *in_scale[2], *in_shift[2];   // [B,CIN] MODE 1: relu(x*scale+shift) applied while staging
+  // MODE 2 (fused BasicBlock tail, resnet.py:47-55): the conv's input is relu(x*scale+shift + r), r = x2 (final activations)
+  // or x2*scale2+shift2 (downsample branch); computed while staging and written to xout by the tile that owns the pixel
+  const unsigned short *x2[2];
+  const float *in_scale2[2], *in_shift2[2];
+  unsigned short *xout[2];
   float *stats[2];                   // [B,slots,COUTP,2] GroupNorm partial sums
   int B, H, W, CIN, Ho, Wo, COUTP;
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_bf16_plan

@@ -147,3 +147,17 @@ def test_dual_forward_at_baseline_batch_256():
     assert oa.shape == (256, 3) and torch.isfinite(oa).all() and torch.isfinite(ob).all()
     for k in (0, 1, 2, 129, 255):
         assert torch.equal(oa[k], ra[k % 3]) and torch.equal(ob[k], rb[k % 3]), k
+
+
+def test_fused_block_tail_equals_the_separate_residual_pass(monkeypatch):
+    """conv1 of the next block computes relu(GN2(conv2) + skip) while staging (conv_bf16.hip MODE 2) and writes the block
+    output; PNVO_BF16_NOFUSE=1 keeps the separate residual kernel.  Same float32 expression, same bf16 rounding: the
+    network outputs must be identical bit for bit (identity and downsample skips, strided and compression consumers)."""
+    rec = load_golden("model_default_341x192_b2.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    with torch.no_grad():
+        fused = model(tobs).clone()
+        monkeypatch.setenv("PNVO_BF16_NOFUSE", "1")
+        plain = model(tobs).clone()
+        monkeypatch.delenv("PNVO_BF16_NOFUSE")
+    assert torch.equal(fused, plain), (fused, plain)
