@@ -669,7 +669,7 @@ int pnvo_ensure_workspace(pnvo_handle m, int B) { return ensure_workspace(m, B);
 // ==================================================================================================================
 extern "C" {
 
-const char *pnvo_version(void) { return "pnvo 0.1 (gfx950, fp32 MFMA)"; }
+const char *pnvo_version(void) { return "pnvo 0.2 (gfx950: fp32 + bf16 MFMA)"; }
 
 const char *pnvo_last_error(pnvo_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
