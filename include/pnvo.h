@@ -199,7 +199,8 @@ int pnvo_train_backward(pnvo_handle h, const float *grad_out, void *stream);
 
 /* Per-channel moments of the assembled network input (reference channel order, rgb/255), the statistics behind
  * RunningMeanAndVar's train-mode update: out[c] = mean_{n,pixel} (x_c - center_c)^power, power in {1,2}; center may be
- * NULL (0).  out: device [C]. */
+ * NULL (0).  out: device [C].  power 3: both moments about `center` in ONE pass over the observation tensors —
+ * out[c] = mean (x_c - center_c), out[C + c] = mean (x_c - center_c)^2, out: device [2C]. */
 int pnvo_input_moments(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
                        const float *center, int power, float *out, void *stream);
 

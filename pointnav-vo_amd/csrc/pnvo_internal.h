@@ -250,6 +250,12 @@ hipError_t launch_geo_inverse_loss(const float *deltas, const int *actions, int 
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps,
                        int step, hipStream_t s);
 hipError_t launch_gather(const float *src, const int *map, long n, float *dst, hipStream_t s);
+struct GatherSeg {
+  const int *map;
+  float *dst;
+  long start;
+};
+hipError_t launch_gather_all(const float *src, const GatherSeg *segs, int nseg, long total, hipStream_t s);
 hipError_t launch_whiten_table(const float *mean, const float *var, const int *ref_of_new, const int *tensor_of_new, int CPL,
                                float *sc, float *sh, hipStream_t s);
 struct MomentsArgs {

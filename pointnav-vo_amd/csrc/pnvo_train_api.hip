@@ -41,6 +41,9 @@ struct TrainState {
   std::vector<std::array<float *, 4>> dgrad_wph;   // stride-2 3x3 convs: one sub-kernel per output parity phase (ph*2 + pw)
   float *fc_t = nullptr, *head_t = nullptr;
   int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
+  GatherSeg *d_segs = nullptr;      // all re-pack maps as one segment table (pnvo_train_refresh)
+  long seg_total = 0;
+  int nseg = 0;
   int *d_mxmaps = nullptr;          // mx stem: [slot_ref 32 | slot_new 32 | xslot 4]
   int *d_ddmaps = nullptr;          // one-hot stem: [dense_ref 12 | dense_new 12 | dd_ref 2*bins | dd_new 2*bins]
   int dd_nd = 0;
@@ -589,6 +592,7 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->d_ref_of_new);
   dfree(t->d_ddmaps);
   dfree(t->d_mxmaps);
+  dfree(t->d_segs);
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
   if (t->embed_err) (void)hipHostFree(t->embed_err);
@@ -633,7 +637,20 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   HIPCHK(m, hipSetDevice(m->device));
   TrainState *t = TS(m);
-  for (const PackMap &pm : t->maps) HIPCHK(m, launch_gather(t->params, pm.map, pm.n, pm.dst, (hipStream_t)stream));
+  if (!t->d_segs) {                 // segment table of all re-pack maps (built once; the maps never change after attach)
+    std::vector<GatherSeg> segs;
+    long start = 0;
+    for (const PackMap &pm : t->maps) {
+      segs.push_back(GatherSeg{pm.map, pm.dst, start});
+      start += pm.n;
+    }
+    t->seg_total = start;
+    t->nseg = (int)segs.size();
+    int rc0 = dmalloc(m, (void **)&t->d_segs, segs.size() * sizeof(GatherSeg));
+    if (rc0 != PNVO_OK) return rc0;
+    HIPCHK(m, hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice));
+  }
+  HIPCHK(m, launch_gather_all(t->params, t->d_segs, t->nseg, t->seg_total, (hipStream_t)stream));
   if (m->cfg.act_embed) {      // eval-mode bias rows bias[a][o] = b1[o] + W1[o][flat:] . emb[a]  (pnvo_load_weights does this on the host)
     const pnvo_config &c = m->cfg;
     const int rows = c.n_acts + 1, flat = m->comp_c * m->fh * m->fw;
@@ -990,7 +1007,7 @@ int pnvo_train_dropout_mask(pnvo_handle m, int layer, float *out, void *stream) 
 int pnvo_input_moments(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
                        const float *center, int power, float *out, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
-  if (!out || (power != 1 && power != 2)) return pnvo_fail(m, PNVO_ERR_ARG, "bad argument");
+  if (!out || power < 1 || power > 3) return pnvo_fail(m, PNVO_ERR_ARG, "bad argument");
   HIPCHK(m, hipSetDevice(m->device));
   TrainState *t = TS(m);
   int rc = ensure_train_ws(m, t, B);

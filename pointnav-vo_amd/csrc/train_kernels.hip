@@ -947,32 +947,42 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_idx_kernel(const float *x
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *dpool, const unsigned char *idx, int B, int H,
                                                         int W, int C, int Ho, int Wo, float *dact) {
-  // gather form (deterministic): input pixel (hi, wi) collects dPool of every window that elected it
+  // gather form (deterministic): input pixel (hi, wi) collects dPool of every window that elected it; four channels per
+  // thread (16-byte gradient loads / stores, 4-byte index loads)
   const long g = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)B * H * W * C;
+  const int Q = C >> 2;
+  const long total = (long)B * H * W * Q;
   if (g >= total) return;
-  const int c = (int)(g % C);
-  long r = g / C;
+  const int c = 4 * (int)(g % Q);
+  long r = g / Q;
   const int wi = (int)(r % W);
   r /= W;
   const int hi = (int)(r % H);
   const int n = (int)(r / H);
-  float acc = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int t = hi + 1 - kh;          // 2*ho = hi + 1 - kh
     if (t < 0 || (t & 1)) continue;
     const int ho = t >> 1;
     if (ho >= Ho) continue;
+#pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int u = wi + 1 - kw;
       if (u < 0 || (u & 1)) continue;
       const int wo = u >> 1;
       if (wo >= Wo) continue;
       const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
-      if (idx[o] == kh * 3 + kw) acc += dpool[o];
+      const unsigned ix = *reinterpret_cast<const unsigned *>(idx + o);
+      const float4 dp = *reinterpret_cast<const float4 *>(dpool + o);
+      const unsigned k = (unsigned)(kh * 3 + kw);
+      if ((ix & 0xffu) == k) acc[0] += dp.x;
+      if (((ix >> 8) & 0xffu) == k) acc[1] += dp.y;
+      if (((ix >> 16) & 0xffu) == k) acc[2] += dp.z;
+      if ((ix >> 24) == k) acc[3] += dp.w;
     }
   }
-  dact[g] = acc;
+  reinterpret_cast<float4 *>(dact)[g] = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 hipError_t launch_maxpool_train(const float *x, const float *scale, const float *shift, int B, int H, int W, int C,
@@ -987,7 +997,7 @@ hipError_t launch_maxpool_train(const float *x, const float *scale, const float 
 hipError_t launch_maxpool_bwd(const float *dpool, const unsigned char *idx, int B, int H, int W, int C, float *dact,
                               hipStream_t s) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long total = (long)B * H * W * C;
+  const long total = (long)B * H * W * (C / 4);          // C is a multiple of 32
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpool, idx, B, H, W, C, Ho,
                      Wo, dact);
   return hipGetLastError();
@@ -1160,6 +1170,27 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *src, const int
   dst[e] = k > 0 ? src[k - 1] : 0.f;
 }
 
+// All re-pack maps of a model in ONE launch (they were ~50 launches of a few microseconds each after every Adam step):
+// element e of the concatenation belongs to the segment with the largest start <= e.
+__global__ __launch_bounds__(256) void gather_all_kernel(const float *src, const GatherSeg *segs, int nseg, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].start <= e) lo = mid; else hi = mid - 1;
+  }
+  const GatherSeg sg = segs[lo];
+  const long i = e - sg.start;
+  const int k = sg.map[i];
+  sg.dst[i] = k > 0 ? src[k - 1] : 0.f;
+}
+
+hipError_t launch_gather_all(const float *src, const GatherSeg *segs, int nseg, long total, hipStream_t s) {
+  hipLaunchKernelGGL(gather_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, segs, nseg, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather(const float *src, const int *map, long n, float *dst, hipStream_t s) {
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, map, n, dst);
   return hipGetLastError();
@@ -1213,7 +1244,7 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const MomentsArgs 
     if (a.tensor[c] == t && a.ch[c] == 2 * piece + 1) c1 = c;
   }
   const float ctr0 = (a.center && c0 >= 0) ? a.center[c0] : 0.f, ctr1 = (a.center && c1 >= 0) ? a.center[c1] : 0.f;
-  double s0 = 0.0, s1 = 0.0;
+  double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;           // pw 3: first AND second moment about `center` in one pass
   if (gid < stride) {
     const long total = a.npix * np;
     for (long e = gid; e < total; e += stride) {
@@ -1221,10 +1252,16 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const MomentsArgs 
       const float d0 = v[0] / div - ctr0, d1 = v[1] / div - ctr1;
       s0 += a.pw == 2 ? (double)d0 * (double)d0 : (double)d0;
       s1 += a.pw == 2 ? (double)d1 * (double)d1 : (double)d1;
+      if (a.pw == 3) {
+        q0 += (double)d0 * (double)d0;
+        q1 += (double)d1 * (double)d1;
+      }
     }
   }
-  red[0][threadIdx.x] = s0;
-  red[1][threadIdx.x] = s1;
+  for (int pass = 0; pass < (a.pw == 3 ? 2 : 1); ++pass) {
+  if (pass) __syncthreads();
+  red[0][threadIdx.x] = pass ? q0 : s0;
+  red[1][threadIdx.x] = pass ? q1 : s1;
   __syncthreads();
   // thread j < nch sums, in a fixed order, the lanes that own channel j's piece
   if ((int)threadIdx.x < nch) {
@@ -1235,11 +1272,12 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const MomentsArgs 
     int c = -1;
     for (int cc = 0; cc < C; ++cc)
       if (a.tensor[cc] == t && a.ch[cc] == (int)threadIdx.x) c = cc;
-    if (c >= 0) part[(long)c * gridDim.x + blockIdx.x] = s;
+    if (c >= 0) part[((long)pass * C + c) * gridDim.x + blockIdx.x] = s;
+  }
   }
 }
 
-__global__ void moments_final_kernel(const double *part, int nblk, long npix, int C, float *out) {
+__global__ void moments_final_kernel(const double *part, int nblk, long npix, int C, float *out) {   // C = rows to reduce
   const int c = threadIdx.x;
   if (c >= C) return;
   double s = 0.0;
@@ -1250,7 +1288,8 @@ __global__ void moments_final_kernel(const double *part, int nblk, long npix, in
 hipError_t launch_moments(const MomentsArgs &a, int C, double *part, float *out, hipStream_t s) {
   const int nblk = 512;
   hipLaunchKernelGGL(moments_partial_kernel, dim3(nblk, 4), dim3(256), 0, s, a, C, part);
-  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(64), 0, s, part, nblk, a.npix, C, out);
+  const int rows = a.pw == 3 ? 2 * C : C;               // pw 3: out[0..C) first moments, out[C..2C) second moments
+  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(128), 0, s, part, nblk, a.npix, rows, out);
   return hipGetLastError();
 }
 

@@ -79,8 +79,7 @@ class VOTrainStep:
         enc = model.visual_encoder
         self.rmv = getattr(enc, "running_mean_and_var", None) if model.cfg.normalize else None
         Cc = model.cfg.in_channels
-        self._m1 = torch.empty(Cc, device=self.dev)
-        self._m2 = torch.empty(Cc, device=self.dev)
+        self._m12 = torch.empty(2 * Cc, device=self.dev)
         self._loss = torch.zeros(1, device=self.dev)
         self._psig = self._param_sig()
 
@@ -182,20 +181,25 @@ class VOTrainStep:
         _lib.check(_lib.lib.pnvo_input_moments(h, *ptrs, int(B), _ptr(center), int(power), _ptr(out), stream), h)
 
     def _update_running_stats(self, ptrs, B, stream):
-        """RunningMeanAndVar.forward, training branch (running_mean_and_var.py:23-60): batch statistics from
-        _input_moments, the three all-reduces of :27-38 when torch.distributed is initialised, Chan's merge :44-60."""
+        """RunningMeanAndVar.forward, training branch (running_mean_and_var.py:23-60): batch statistics from ONE pass over
+        the observation tensors (_input_moments power 3: first and second moment about the current running mean c), the
+        three all-reduces of :27-38 when torch.distributed is initialised, Chan's merge :44-60.  The reference's second
+        pass — the variance about the GLOBAL batch mean mu — follows algebraically from the one-pass moments of this
+        rank: mean((x - mu)^2) = E[(x-c)^2] - 2 (mu - c) E[x-c] + (mu - c)^2."""
         rmv = self.rmv
         distributed = dist.is_available() and dist.is_initialized()
-        self._input_moments(ptrs, B, None, 1, self._m1, stream)
-        new_mean = (self._m1 * B).view(1, -1, 1, 1)                 # = adaptive_avg_pool2d(x, 1).sum(0)
+        C_ = self._m12.numel() // 2
+        center = rmv._mean.reshape(-1).to(torch.float32).contiguous()
+        self._input_moments(ptrs, B, center, 3, self._m12, stream)
+        e1, e2 = self._m12[:C_].double(), self._m12[C_:].double()
+        new_mean = ((center.double() + e1) * B).to(torch.float32).view(1, -1, 1, 1)   # = adaptive_avg_pool2d(x, 1).sum(0)
         new_count = torch.full_like(rmv._count, B)
         if distributed:
             dist.all_reduce(new_mean)
             dist.all_reduce(new_count)
         new_mean = new_mean / new_count
-        ctr = new_mean.reshape(-1).contiguous()
-        self._input_moments(ptrs, B, ctr, 2, self._m2, stream)
-        new_var = (self._m2 * B).view(1, -1, 1, 1)
+        delta = new_mean.reshape(-1).double() - center.double()
+        new_var = ((e2 - 2.0 * delta * e1 + delta * delta) * B).to(torch.float32).view(1, -1, 1, 1)
         if distributed:
             dist.all_reduce(new_var)
         new_var = new_var / new_count

@@ -90,8 +90,7 @@ class _HostStatsStep:
         self.rmv._mean = torch.zeros(1, C, 1, 1)
         self.rmv._var = torch.zeros(1, C, 1, 1)
         self.rmv._count = torch.zeros(())
-        self._m1 = torch.empty(C)
-        self._m2 = torch.empty(C)
+        self._m12 = torch.empty(2 * C)
         self._x = _assembled(obs)
         return self
 
@@ -99,7 +98,9 @@ class _HostStatsStep:
     def _moments(self, ptrs, B, center, power, out, stream):
         x = self._x
         c = torch.zeros(x.shape[1]) if center is None else center
-        out.copy_(((x - c.view(1, -1, 1, 1)) ** power).mean(dim=(0, 2, 3)))
+        d = x - c.view(1, -1, 1, 1)
+        assert power == 3                          # one pass: first and second moment about `center`
+        out.copy_(torch.cat([d.mean(dim=(0, 2, 3)), (d * d).mean(dim=(0, 2, 3))]))
 
 
 def _assembled(obs):
