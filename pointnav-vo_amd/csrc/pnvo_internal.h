@@ -215,6 +215,9 @@ struct WgradArgs {
   long pix_per_chunk;
   // LDS-staged path (wgrad3_lds_kernel: 3x3 stride-1 convs with 32-channel multiples), chosen by wgrad_plan
   int lds3, TH, TW, tiles_x, tiles_y, tiles_per_chunk;
+  // twelve-wave path (wgrad3_mw_kernel, lds3 = 4 / 5): units per workgroup = cs ci-tiles x os co-tiles x rs row groups (= 4),
+  // workgroups = pair groups x wg_chunks, LDS buffers
+  int cs, os, rs, wg_chunks, nbuf;
   long grad_pitch;          // row pitch of the OIHW gradient tensor (0: cin_out * KH * KW)
 };
 void wgrad_plan(WgradArgs &a);
@@ -264,8 +267,10 @@ struct MomentsArgs {
   int tensor[64], ch[64];   // reference channel c -> (observation tensor, channel inside it)
   const float *center;      // [C] or nullptr
   long npix;
-  int pw;                   // 1: mean of (x - center), 2: mean of (x - center)^2
+  int pw;                   // 1: mean of (x - center), 2: mean of (x - center)^2, 3: both (out[0..C), out[C..2C))
+  int nblk[4];              // filled by launch_moments: blocks of each tensor (proportional to its channel count)
 };
+constexpr int MOMENTS_BLOCKS = 2048;   // partial slots per row: `part` holds 2 * C * MOMENTS_BLOCKS doubles
 hipError_t launch_moments(const MomentsArgs &a, int C, double *part, float *out, hipStream_t s);
 
 }  // namespace pnvo

@@ -457,7 +457,7 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
     if ((rc = dmalloc(m, (void **)&t->hdrop, hf * 4)) != PNVO_OK) return rc;
     if ((rc = dmalloc(m, (void **)&t->dmask, (zf > hf ? zf : hf) * 4)) != PNVO_OK) return rc;
   }
-  if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)64 * 512 * 8)) != PNVO_OK) return rc;
+  if ((rc = dmalloc(m, (void **)&t->mom_part, (size_t)128 * MOMENTS_BLOCKS * 8)) != PNVO_OK) return rc;
   if (c.act_embed) {
     const int rows = std::max(B, c.n_acts + 1);
     if ((rc = dmalloc(m, (void **)&t->egath, (size_t)rows * 32 * 4)) != PNVO_OK) return rc;

@@ -294,6 +294,192 @@ __global__ __launch_bounds__(576) void wgrad3_lds_kernel(const WgradArgs p) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Twelve-wave version of the kernel above (the default for the 3x3 convs): three waves per SIMD instead of 3/2/2/2.
+// A workgroup owns FOUR units of (ci-tile, co-tile, row group of the tile) — cs x os x rs = 4, chosen by wgrad_plan from
+// the layer's tile counts — and wave (kh, u) runs the three taps (kh, 0..2) of unit u: one dY fragment feeds three MFMAs,
+// and with lane half h on pixel s + h*TW/2 the input fragments slide along the row (stride 1: one new ds_read_b32 per
+// three MFMAs).  The patch / slab of tile t+1 is written to the second LDS buffer while tile t is multiplied (one
+// barrier per tile; single buffer + two barriers when 2 buffers exceed 160 KB).  Row groups are summed inside the
+// workgroup; partials: unit = pair * chunks + chunk, summed by wgrad_reduce_kernel in the same fixed order as before.
+template <int MODE, int S>
+__global__ __launch_bounds__(768) void wgrad3_mw_kernel(const WgradArgs p) {
+  constexpr int PP = 36;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int TH = p.TH, TW = p.TW, PH = (TH - 1) * S + 3, PWR = (TW - 1) * S + 3;
+  const int CS = p.cs, OS = p.os, RS = p.rs;
+  const int npx = PH * PWR, npd = TH * TW;
+  const int xplane = npx * PP, dplane = npd * PP;
+  const int bufsz = CS * xplane + OS * dplane;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int kh = wave % 3, u = wave / 3;
+  const int ci_sub = u % CS, co_sub = (u / CS) % OS, row_sub = u / (CS * OS);
+  const int pg = blockIdx.x / p.wg_chunks, chunk = blockIdx.x - pg * p.wg_chunks;
+  const int cigs = p.ci_tiles / CS;
+  const int cig = pg % cigs, cog = pg / cigs;
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  const int g = tid & 7;                   // 768 % 8 == 0: a thread keeps its 16-byte channel slot
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  // staging items (16 bytes): X patch planes first, then dY slab planes; per item: LDS float offset | row | col | plane
+  constexpr int NX = 5, ND = 2;            // wgrad_plan keeps the item counts within these
+  int xl[NX], xrc[NX], dl[ND], drc[ND];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int q = (tid + k * 768) >> 3;
+    const int plane = q / npx, pix = q - plane * npx;
+    const int pr = pix / PWR, pc = pix - pr * PWR;
+    xl[k] = plane < CS ? plane * xplane + pix * PP + 4 * g : -1;
+    xrc[k] = pr | (pc << 8) | (plane << 16);
+  }
+#pragma unroll
+  for (int k = 0; k < ND; ++k) {
+    const int q = (tid + k * 768) >> 3;
+    const int plane = q / npd, pix = q - plane * npd;
+    const int qy = pix / TW, qx = pix - qy * TW;
+    dl[k] = plane < OS ? CS * xplane + plane * dplane + pix * PP + 4 * g : -1;
+    drc[k] = qy | (qx << 8) | (plane << 16);
+  }
+  f32x4 vx[NX], vd[ND];
+  f32x4 scp[2], shp[2];                    // MODE 1: scale / shift of this thread's four channels in each ci plane
+  unsigned inmask = 0;                     // MODE 1: in-image flags of the patch items (zero padding AFTER the transform)
+  auto gload = [&](int t) {
+    int q = t;
+    const int tx = q % p.tiles_x;
+    q /= p.tiles_x;
+    const int ty = q % p.tiles_y;
+    const int n = q / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;      // output-tile origin; the input patch starts at (y0 * S - 1, x0 * S - 1)
+    const float *xb = p.x + ((long)n * p.H * p.W) * p.CIN + cig * CS * 32 + 4 * g;
+    inmask = 0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int pr = xrc[k] & 255, pc = (xrc[k] >> 8) & 255, plane = xrc[k] >> 16;
+      const int yy = y0 * S - 1 + pr, xx = x0 * S - 1 + pc;
+      const bool in = xl[k] >= 0 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      vx[k] = in ? *reinterpret_cast<const f32x4 *>(xb + ((long)yy * p.W + xx) * p.CIN + plane * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+      inmask |= (in ? 1u : 0u) << k;
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const long so = (long)n * p.CIN + (cig * CS + (pl < CS ? pl : 0)) * 32 + 4 * g;
+        scp[pl] = *reinterpret_cast<const f32x4 *>(p.in_scale + so);
+        shp[pl] = *reinterpret_cast<const f32x4 *>(p.in_shift + so);
+      }
+    }
+    const float *db = p.dy + ((long)n * p.Ho * p.Wo) * p.DYC + cog * OS * 32 + 4 * g;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int qy = drc[k] & 255, qx = (drc[k] >> 8) & 255, plane = drc[k] >> 16;
+      const int oy = y0 + qy, ox = x0 + qx;
+      const bool in = dl[k] >= 0 && oy < p.Ho && ox < p.Wo;          // pixels outside the image contribute nothing
+      vd[k] = in ? *reinterpret_cast<const f32x4 *>(db + ((long)oy * p.Wo + ox) * p.DYC + plane * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](float *buf) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+      if (xl[k] >= 0) {
+        f32x4 v = vx[k];
+        if (MODE == 1) {
+          const bool pl1 = (xrc[k] >> 16) != 0, in = (inmask >> k) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = in ? fmaxf(__builtin_fmaf(v[e], pl1 ? scp[1][e] : scp[0][e], pl1 ? shp[1][e] : shp[0][e]), 0.f) : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(buf + xl[k]) = v;
+      }
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      if (dl[k] >= 0) *reinterpret_cast<f32x4 *>(buf + dl[k]) = vd[k];
+  };
+
+  int t0 = chunk * p.tiles_per_chunk, t1 = t0 + p.tiles_per_chunk;
+  if (t1 > ntiles) t1 = ntiles;
+  const int half_w = TW >> 1;
+  const int rpw = (TH + RS - 1) / RS;
+  const int r0 = row_sub * rpw, r1 = min(TH, r0 + rpw);
+  const int xo = ci_sub * xplane + (kh * PWR + h * half_w * S) * PP + i;
+  const int dofs = CS * xplane + co_sub * dplane + h * half_w * PP + i;
+  const bool two = p.nbuf == 2;
+  int cur = 0;
+  if (t0 < t1) {
+    gload(t0);
+    lstore(lds);
+  }
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const float *buf = lds + cur * bufsz;
+    if (t + 1 < t1) gload(t + 1);
+    for (int qy = r0; qy < r1; ++qy) {
+      const float *xr = buf + xo + qy * S * PWR * PP, *dr = buf + dofs + qy * TW * PP;
+      if (S == 1) {
+        float a0 = xr[0], a1 = xr[PP];
+        for (int sx = 0; sx < half_w; ++sx) {
+          const float a2 = xr[(sx + 2) * PP], b = dr[sx * PP];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc[2], 0, 0, 0);
+          a0 = a1;
+          a1 = a2;
+        }
+      } else {
+        float a0 = xr[0];
+        for (int sx = 0; sx < half_w; ++sx) {
+          const float a1 = xr[(2 * sx + 1) * PP], a2 = xr[(2 * sx + 2) * PP], b = dr[sx * PP];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc[2], 0, 0, 0);
+          a0 = a2;
+        }
+      }
+    }
+    if (t + 1 < t1) {
+      if (!two) __syncthreads();           // single buffer: every wave is done reading it
+      lstore(lds + (two ? (cur ^ 1) * bufsz : 0));
+      if (two) cur ^= 1;
+    }
+    __syncthreads();
+  }
+  // row groups of one (ci, co) pair are summed here, in a fixed order, through the (now idle) staging buffers
+  if (RS > 1) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      if (kw > 0) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[(wave * 16 + r) * 64 + lane] = acc[kw][r];
+      __syncthreads();
+      if (row_sub == 0)
+        for (int k = 1; k < RS; ++k) {
+          const int w2 = wave + 3 * CS * OS * k;          // same kh / ci / co, row group k
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[kw][r] += lds[(w2 * 16 + r) * 64 + lane];
+        }
+    }
+    if (row_sub != 0) return;
+  }
+  // C/D layout: col j (= co) = lane&31, row i (= ci) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int pair = (cog * OS + co_sub) * p.ci_tiles + cig * CS + ci_sub;
+  const long unit = (long)pair * p.chunks + chunk;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    float *dst = p.partial + ((unit * 9 + kh * 3 + kw) * 32) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[(long)row * 32 + i] = acc[kw][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // LDS-staged weight gradient of the 7x7 stride-2 stem (mode 2: input gathered from the observation tensors and whitened):
 //   dW[kh][kw][c][co] = sum_pix X[2*pix + (kh,kw) - 3][c] * dY[pix][co],   49 taps x (32 x 32) = 49 MFMA accumulators.
 // One persistent workgroup per CU, 7 waves = the 7 kernel rows; wave kh keeps the 7 accumulators of its row (independent
@@ -461,9 +647,61 @@ static hipError_t launch_wgrad_t(const WgradArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// tile + unit plan of wgrad3_mw_kernel; false: shape outside it (the nine-wave kernel or the generic one takes over)
+static bool wgrad_plan_mw(WgradArgs &a) {
+  const int S = a.stride;
+  const int cit = a.CIN / 32, cot = a.COUT / 32;
+  if (cit % 2 == 0 && cot % 2 == 0) {
+    a.cs = 2; a.os = 2; a.rs = 1;
+  } else if (cit == 1 && cot % 2 == 0) {
+    a.cs = 1; a.os = 2; a.rs = 2;
+  } else if (cit % 2 == 0 && cot == 1) {
+    a.cs = 2; a.os = 1; a.rs = 2;
+  } else if (cit == 1 && cot == 1) {
+    a.cs = 1; a.os = 1; a.rs = 4;
+  } else {
+    return false;
+  }
+  const int tw_max = S == 1 ? 24 : 12;
+  a.tiles_x = (a.Wo + tw_max - 1) / tw_max;
+  a.TW = ((a.Wo + a.tiles_x - 1) / a.tiles_x + 1) / 2 * 2;
+  const size_t lds_max = 160 * 1024;
+  auto bytes = [&](int th) {
+    return (size_t)(a.cs * ((th - 1) * S + 3) * ((a.TW - 1) * S + 3) + a.os * th * a.TW) * 36 * 4;
+  };
+  auto items_ok = [&](int th) {
+    return (long)a.cs * ((th - 1) * S + 3) * ((a.TW - 1) * S + 3) * 8 <= 5 * 768 && (long)a.os * th * a.TW * 8 <= 2 * 768;
+  };
+  int th = a.Ho < 8 ? a.Ho : 8;
+  while (th > 1 && (!items_ok(th) || 2 * bytes(th) > lds_max)) --th;
+  if (!items_ok(th) || bytes(th) > lds_max) return false;
+  a.tiles_y = (a.Ho + th - 1) / th;
+  a.TH = (a.Ho + a.tiles_y - 1) / a.tiles_y;
+  a.nbuf = 2 * bytes(a.TH) <= lds_max ? 2 : 1;
+  a.TG = 9;
+  a.groups = 1;
+  a.ci_tiles = cit;
+  a.pairs = cit * cot;
+  const int pgs = (cit / a.cs) * (cot / a.os);
+  const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+  long chunks = 256 / pgs;                              // one 12-wave workgroup per CU
+  if (chunks < 1) chunks = 1;
+  if (chunks > ntiles) chunks = ntiles;
+  a.tiles_per_chunk = (int)((ntiles + chunks - 1) / chunks);
+  a.wg_chunks = (int)((ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk);
+  a.chunks = a.wg_chunks;                               // row groups are summed inside the workgroup
+  a.pix_per_chunk = 0;
+  a.lds3 = S == 1 ? 4 : 5;
+  return true;
+}
+
 void wgrad_plan(WgradArgs &a) {
   a.lds3 = 0;
   static const bool no_lds = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "generic") == 0;
+  static const bool nine = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "lds9") == 0;
+  if (!no_lds && !nine && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.CIN % 32 == 0 && a.COUT % 32 == 0 &&
+      a.DYC % 4 == 0 && ((a.stride == 1 && a.H == a.Ho && a.W == a.Wo) || a.stride == 2) && wgrad_plan_mw(a))
+    return;
   if (!no_lds && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.CIN % 32 == 0 &&
       a.COUT % 32 == 0 && a.DYC % 4 == 0 && a.H == a.Ho && a.W == a.Wo) {
     a.lds3 = 1;
@@ -552,6 +790,25 @@ hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(49 * 32)), dim3(256), 0, s, a, a.TG, grad, ci_perm, cin_out);
+    return hipGetLastError();
+  }
+  if (a.lds3 == 4 || a.lds3 == 5) {
+    const int S = a.lds3 == 5 ? 2 : 1;
+    size_t lds = (size_t)(a.cs * ((a.TH - 1) * S + 3) * ((a.TW - 1) * S + 3) + a.os * a.TH * a.TW) * 36 * 4 * a.nbuf;
+    if (a.rs > 1 && lds < 12 * 16 * 64 * 4) lds = 12 * 16 * 64 * 4;      // the row-group sum at the end goes through LDS
+    dim3 grid((unsigned)((a.ci_tiles / a.cs) * (a.COUT / 32 / a.os) * a.wg_chunks));
+    if (S == 2 && a.mode == 1)
+      hipLaunchKernelGGL((wgrad3_mw_kernel<1, 2>), grid, dim3(768), lds, s, a);
+    else if (S == 2)
+      hipLaunchKernelGGL((wgrad3_mw_kernel<0, 2>), grid, dim3(768), lds, s, a);
+    else if (a.mode == 1)
+      hipLaunchKernelGGL((wgrad3_mw_kernel<1, 1>), grid, dim3(768), lds, s, a);
+    else
+      hipLaunchKernelGGL((wgrad3_mw_kernel<0, 1>), grid, dim3(768), lds, s, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.pairs * 9 * 32)), dim3(256), 0, s, a, a.TG, grad, ci_perm,
+                       cin_out);
     return hipGetLastError();
   }
   if (a.lds3) {
@@ -1230,13 +1487,13 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const MomentsArgs 
   const int t = blockIdx.y;
   const float *base = a.src[t];
   const int nch = a.nch[t];
-  if (base == nullptr || nch <= 0) return;
+  if (base == nullptr || nch <= 0 || (int)blockIdx.x >= a.nblk[t]) return;   // blocks per tensor ~ its channel count
   const int np = nch >> 1;                                 // 2-channel pieces per pixel (nch is even: 6, 2, 20, 2)
-  const long T = (long)gridDim.x * 256;
+  const long T = (long)a.nblk[t] * 256;
   const long stride = T - T % np;                          // a multiple of np: the piece of a thread never changes
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const int piece = (int)(gid % np);
-  const float div = t == 0 ? 255.0f : 1.0f;
+  const bool rgb = t == 0;
   // reference channels of this thread's two tensor channels
   int c0 = -1, c1 = -1;
   for (int c = 0; c < C; ++c) {
@@ -1247,49 +1504,73 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const MomentsArgs 
   double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;           // pw 3: first AND second moment about `center` in one pass
   if (gid < stride) {
     const long total = a.npix * np;
-    for (long e = gid; e < total; e += stride) {
-      const f32x2 v = *reinterpret_cast<const f32x2 *>(base + 2 * e);
-      const float d0 = v[0] / div - ctr0, d1 = v[1] / div - ctr1;
-      s0 += a.pw == 2 ? (double)d0 * (double)d0 : (double)d0;
-      s1 += a.pw == 2 ? (double)d1 * (double)d1 : (double)d1;
-      if (a.pw == 3) {
-        q0 += (double)d0 * (double)d0;
-        q1 += (double)d1 * (double)d1;
+    constexpr int U = 4;                                   // independent loads in flight per thread
+    for (long e = gid; e < total; e += U * stride) {
+      f32x2 v[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+        v[k] = e + k * stride < total ? *reinterpret_cast<const f32x2 *>(base + 2 * (e + k * stride)) : f32x2{0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        if (e + k * stride >= total) break;
+        const float d0 = (rgb ? v[k][0] / 255.0f : v[k][0]) - ctr0, d1 = (rgb ? v[k][1] / 255.0f : v[k][1]) - ctr1;
+        const double e0 = (double)d0, e1 = (double)d1;
+        if (a.pw == 2) {
+          s0 += e0 * e0;
+          s1 += e1 * e1;
+        } else {
+          s0 += e0;
+          s1 += e1;
+        }
+        if (a.pw == 3) {
+          q0 += e0 * e0;
+          q1 += e1 * e1;
+        }
       }
     }
   }
   for (int pass = 0; pass < (a.pw == 3 ? 2 : 1); ++pass) {
-  if (pass) __syncthreads();
-  red[0][threadIdx.x] = pass ? q0 : s0;
-  red[1][threadIdx.x] = pass ? q1 : s1;
-  __syncthreads();
-  // thread j < nch sums, in a fixed order, the lanes that own channel j's piece
-  if ((int)threadIdx.x < nch) {
-    const int q = threadIdx.x >> 1, e = threadIdx.x & 1;
-    const int first = (int)(((long)q - (long)blockIdx.x * 256 % np + np) % np);   // first tid of this block with piece q
-    double s = 0.0;
-    for (int k = first; k < 256; k += np) s += red[e][k];
-    int c = -1;
-    for (int cc = 0; cc < C; ++cc)
-      if (a.tensor[cc] == t && a.ch[cc] == (int)threadIdx.x) c = cc;
-    if (c >= 0) part[((long)pass * C + c) * gridDim.x + blockIdx.x] = s;
-  }
+    if (pass) __syncthreads();
+    red[0][threadIdx.x] = pass ? q0 : s0;
+    red[1][threadIdx.x] = pass ? q1 : s1;
+    __syncthreads();
+    // thread j < nch sums, in a fixed order, the lanes that own channel j's piece
+    if ((int)threadIdx.x < nch) {
+      const int q = threadIdx.x >> 1, e = threadIdx.x & 1;
+      const int first = (int)(((long)q - (long)blockIdx.x * 256 % np + np) % np);   // first tid of this block with piece q
+      double s = 0.0;
+      for (int k = first; k < 256; k += np) s += red[e][k];
+      int c = -1;
+      for (int cc = 0; cc < C; ++cc)
+        if (a.tensor[cc] == t && a.ch[cc] == (int)threadIdx.x) c = cc;
+      if (c >= 0) part[((long)pass * C + c) * gridDim.x + blockIdx.x] = s;
+    }
   }
 }
 
-__global__ void moments_final_kernel(const double *part, int nblk, long npix, int C, float *out) {   // C = rows to reduce
-  const int c = threadIdx.x;
-  if (c >= C) return;
+// one wave per output row (channel, or channel + C for the second moments): fixed-order fp64 sum of its tensor's blocks
+__global__ __launch_bounds__(64) void moments_final_kernel(const MomentsArgs a, const double *part, int nbx, int C, float *out) {
+  const int row = blockIdx.x, c = row % C;
+  const int nb = a.nblk[a.tensor[c]];
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += part[(long)c * nblk + k];
-  out[c] = (float)(s / (double)npix);
+  for (int k = threadIdx.x; k < nb; k += 64) s += part[(long)row * nbx + k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) out[row] = (float)(s / (double)a.npix);
 }
 
-hipError_t launch_moments(const MomentsArgs &a, int C, double *part, float *out, hipStream_t s) {
-  const int nblk = 512;
-  hipLaunchKernelGGL(moments_partial_kernel, dim3(nblk, 4), dim3(256), 0, s, a, C, part);
+hipError_t launch_moments(const MomentsArgs &a0, int C, double *part, float *out, hipStream_t s) {
+  MomentsArgs a = a0;
+  int maxch = 1;
+  for (int t = 0; t < 4; ++t)
+    if (a.src[t] != nullptr && a.nch[t] > maxch) maxch = a.nch[t];
+  for (int t = 0; t < 4; ++t) {
+    a.nblk[t] = a.src[t] != nullptr && a.nch[t] > 0 ? (MOMENTS_BLOCKS * a.nch[t] + maxch - 1) / maxch : 0;
+    if (a.nblk[t] > MOMENTS_BLOCKS) a.nblk[t] = MOMENTS_BLOCKS;
+  }
+  hipLaunchKernelGGL(moments_partial_kernel, dim3(MOMENTS_BLOCKS, 4), dim3(256), 0, s, a, C, part);
   const int rows = a.pw == 3 ? 2 * C : C;               // pw 3: out[0..C) first moments, out[C..2C) second moments
-  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(128), 0, s, part, nblk, a.npix, rows, out);
+  hipLaunchKernelGGL(moments_final_kernel, dim3(rows), dim3(64), 0, s, a, part, MOMENTS_BLOCKS, C, out);
   return hipGetLastError();
 }
 

@@ -181,6 +181,10 @@ def run_train(args, rank, world, dist, dev, sync_all):
             "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": bench.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / bench.PEAK_FP32_TFLOPS, "traffic": None, "launch_ms": launch_ms},
             "ms_by_kernel_class": agg,
+            "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches": k["launches"] // args.steps,
+                                "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
+                                "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
+                               for k in kt), key=lambda k: -k["ms_per_step"])[:70],
         }
         print(json.dumps(res))
     if dist is not None:
