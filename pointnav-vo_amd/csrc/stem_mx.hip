@@ -247,22 +247,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (EXTRA) ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + toff + m * 4 * ROW);
       }
     };
-    // Software pipeline: the next tap's B fragments (L2) and first A chunk (LDS) are fetched during this tap's MFMAs,
-    // this tap's second A chunk / remainders at its start (first needed 12 / 24 MFMAs later); two register sets used
-    // alternately (no copies); sched_barriers keep the fetches ahead of the MFMAs (the scheduler would sink them).
-    u32x4 b0[NFT * NT], b1[NFT * NT], a00[4], a01[4], a1[4], ax[4];
-    auto mfmas = [&](const u32x4 *aq0, const u32x4 *b) {
+    // Software pipeline.  B fragments come from L2 (~1 us under load): fetched TWO taps ahead into three register sets in
+    // rotation.  A chunks come from LDS: chunk 1 / the remainders of a tap at its start (first needed 12 / 24 MFMAs
+    // later), chunk 0 of the NEXT tap as soon as this tap's chunk-0 MFMAs have issued (16 MFMAs before its first use) —
+    // one register set each.  sched_barriers keep the fetches where they are (the scheduler would sink them).
+    // Taps of this wave: wave, wave+4, ... wave+44; tap 48 goes to wave 3 (wave 0 staged the nine extra pixels).
+    u32x4 b0[NFT * NT], b1[NFT * NT], b2[NFT * NT], a0[4], a1[4], ax[4];
+    auto mfmas_q = [&](int q, const u32x4 *aq, const u32x4 *b) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int pc = 0; pc < PIECES; ++pc)
 #pragma unroll
-        for (int pc = 0; pc < PIECES; ++pc)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q == 0 ? aq0[m] : a1[m]),
-                                                                   __builtin_bit_cast(bf16x8, b[(pc * 2 + q) * NT + nt]),
-                                                                   acc[m][nt], 0, 0, 0);
+          for (int m = 0; m < 4; ++m)
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m]),
+                                                                 __builtin_bit_cast(bf16x8, b[(pc * 2 + q) * NT + nt]),
+                                                                 acc[m][nt], 0, 0, 0);
+    };
+    auto mfmas_x = [&](const u32x4 *b) {
       if (EXTRA) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -273,30 +275,34 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                                  acc[m][nt], 0, 0, 0);
       }
     };
-    loadB(wave, b0);
-    loadA0(wave, a00);
-    // taps wave, wave+4, ... wave+44: six pairs for every wave; tap 48 goes to wave 3 (wave 0 staged the nine extra pixels)
+    auto tapof = [&](int i) { return i < 12 ? wave + 4 * i : (wave == 3 ? 48 : wave + 44); };   // (past the end: harmless repeats)
+    auto step = [&](int i, const u32x4 *bcur, u32x4 *bnext2) {
+      loadA1(tapof(i), a1, ax);
+      loadB(tapof(i + 2), bnext2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas_q(0, a0, bcur);
+      __builtin_amdgcn_sched_barrier(0);
+      loadA0(tapof(i + 1), a0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas_q(1, a1, bcur);
+      mfmas_x(bcur);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    loadB(tapof(0), b0);
+    loadB(tapof(1), b1);
+    loadA0(tapof(0), a0);
 #pragma unroll 1
-    for (int it = 0; it < 6; ++it) {
-      const int tap = wave + 8 * it;
-      loadA1(tap, a1, ax);
-      loadB(tap + 4, b1);
-      loadA0(tap + 4, a01);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(a00, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      const int t2 = it < 5 ? tap + 8 : (wave == 3 ? 48 : tap);   // (waves 0-2: the last prefetch is a harmless repeat)
-      loadA1(tap + 4, a1, ax);
-      loadB(t2, b0);
-      loadA0(t2, a00);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(a01, b1);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 12; i += 3) {
+      step(i, b0, b2);
+      step(i + 1, b1, b0);
+      step(i + 2, b2, b1);
     }
     if (wave == 3) {
       loadA1(48, a1, ax);
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(a00, b0);
+      mfmas_q(0, a0, b0);
+      mfmas_q(1, a1, b0);
+      mfmas_x(b0);
     }
   }
 
