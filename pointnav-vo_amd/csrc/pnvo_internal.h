@@ -220,6 +220,20 @@ struct WgradArgs {
   int cs, os, rs, wg_chunks, nbuf;
   long grad_pitch;          // row pitch of the OIHW gradient tensor (0: cin_out * KH * KW)
 };
+// Weight gradient of the 7x7 stem on the bf16 matrix cores (wgrad_stem_mx.hip): exact three-piece bf16 on both operands.
+struct WgradStemMXArgs {
+  const float *src[4];        // rgb, depth, discretised depth, top-down view observation tensors (nullptr if absent)
+  const float *dy;            // [B,Ho,Wo,32] gradient of the stem's raw output
+  const float *zero_page;     // >= 16 B of zeros (source of the DMA pieces outside the image)
+  float *partial;             // [nwg][49][48][32] (set by the launcher)
+  int B, H, W, Ho, Wo;
+  int tiles_x, tiles_y, tiles_per_wg, nwg;   // filled by wgrad_stem_mx_plan
+  unsigned long long *prof;   // PNVO_WSM_PROF: phase cycle counters of one workgroup, or nullptr
+};
+void wgrad_stem_mx_plan(WgradStemMXArgs &a);
+size_t wgrad_stem_mx_scratch_floats(const WgradStemMXArgs &a);
+hipError_t launch_wgrad_stem_mx(const WgradStemMXArgs &a, float *scratch, const float *sc_new, const float *sh_new, const int *slot_ref,
+                                const int *slot_new, int cin, float *grad, hipStream_t s);
 void wgrad_plan(WgradArgs &a);
 size_t wgrad_partial_floats(const WgradArgs &a);
 hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int cin_out, hipStream_t s);

@@ -408,6 +408,15 @@ int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
     WgradArgs h = wgrad_args(m->head, B, c.hidden, 8);
     wgmax = std::max(wgmax, wgrad_partial_floats(h));
   }
+  if (m->train_mx) {                 // stem weight gradient on the bf16 matrix cores
+    WgradStemMXArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.B = B;
+    a.Ho = m->Hs;
+    a.Wo = m->Ws;
+    wgrad_stem_mx_plan(a);
+    wgmax = std::max(wgmax, wgrad_stem_mx_scratch_floats(a));
+  }
   t->wg_partial_floats = wgmax;
   if ((rc = dmalloc(m, (void **)&t->wg_partial, wgmax * 4)) != PNVO_OK) return rc;
   // block outputs: y[0] = pooled stem output, y[k] = output of residual block k (plan order)
@@ -945,6 +954,27 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     const Layer &l = m->convs[0];
     HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
     if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
+    static const bool stem_fp32 = std::getenv("PNVO_WGRAD_STEM") && std::strcmp(std::getenv("PNVO_WGRAD_STEM"), "fp32") == 0;
+    if (m->train_mx && l.coutp == 32 && !stem_fp32) {
+      WgradStemMXArgs a;
+      std::memset(&a, 0, sizeof(a));
+      for (int k = 0; k < 4; ++k) a.src[k] = t->src[k];
+      a.dy = t->dStem;
+      a.zero_page = m->zero_page;
+      a.B = B;
+      a.H = c.height;
+      a.W = c.width;
+      a.Ho = m->Hs;
+      a.Wo = m->Ws;
+      wgrad_stem_mx_plan(a);
+      if (wgrad_stem_mx_scratch_floats(a) > t->wg_partial_floats) return pnvo_fail(m, PNVO_ERR_STATE, "wgrad scratch too small");
+      int rc2 = PNVO_OK;
+      float *g = gradp(m, t, l.name + ".weight", &rc2);
+      if (!g) return rc2;
+      PnvoTimed tm(m, s, "wgrad:" + l.name + ".weight", 2.0 * (double)B * m->Hs * m->Ws * l.cout * l.cin * 49, 0.0);
+      HIPCHK(m, launch_wgrad_stem_mx(a, t->wg_partial, m->stem_sc, m->stem_sh, t->d_mxmaps, t->d_mxmaps + 32, l.cin, g, s));
+      return PNVO_OK;
+    }
     WgradArgs a = wgrad_args(l, B, 32, l.coutp, 2);
     a.dy = t->dStem;
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
