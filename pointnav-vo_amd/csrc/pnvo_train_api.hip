@@ -954,7 +954,8 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
     const Layer &l = m->convs[0];
     HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
     if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
-    static const bool stem_fp32 = std::getenv("PNVO_WGRAD_STEM") && std::strcmp(std::getenv("PNVO_WGRAD_STEM"), "fp32") == 0;
+    const char *wsel = std::getenv("PNVO_WGRAD_STEM");      // "fp32": the float32-MFMA kernel (read per call: tests compare the two)
+    const bool stem_fp32 = wsel && std::strcmp(wsel, "fp32") == 0;
     if (m->train_mx && l.coutp == 32 && !stem_fp32) {
       WgradStemMXArgs a;
       std::memset(&a, 0, sizeof(a));

@@ -44,3 +44,16 @@ KNOBS = [{}, {"PNVO_CONV_WSPLIT": "1"}, {"PNVO_CONV_WSPLIT": "0"}, {"PNVO_CONV_T
 def test_knob_keeps_parity(env):
     r = subprocess.run([sys.executable, "-c", CHECK], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+TRAIN_KNOBS = [{"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"}]
+
+
+@pytest.mark.parametrize("env", TRAIN_KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_training_knob_keeps_gradient_parity(env):
+    """The alternative weight-gradient kernels pass the same golden gradient check as the defaults."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_train.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "test_train_step_matches_reference"], env={**os.environ, **env}, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
