@@ -166,7 +166,15 @@ def run_train(args, rank, world, dist, dev, sync_all):
             agg[key] = agg.get(key, 0.0) + k["total_ms"] / args.steps
         dom = max((k for k in kt if k["flops"]), key=lambda k: k["total_ms"])
         launch_ms = dom["total_ms"] / dom["launches"]
-        ach = dom["flops"] / dom["launches"] / (launch_ms * 1e-3) / 1e12
+        alg = dom["flops"] / dom["launches"] / (launch_ms * 1e-3) / 1e12
+        stem_mx = dom["name"].endswith("conv1.0.weight") and os.environ.get("PNVO_WGRAD_STEM") != "fp32"
+        if stem_mx:
+            # the stem's weight gradient runs on the bf16 matrix cores (wgrad_stem_mx.hip): EXECUTED work = tiles (6 x 13 outputs)
+            # x 49 taps x 3 K-chunks x 18 v_mfma_f32_16x16x32_bf16 (3 M-tiles x 2 N-tiles x 3 dY pieces) of 16384 FLOP
+            tiles = B * ((bench.H // 2 + 5) // 6) * ((bench.W // 2 + 1 + 12) // 13)
+            ach, peak, pipe = tiles * 49 * 3 * 18 * 16384 / (launch_ms * 1e-3) / 1e12, bench.PEAK_BF16_TFLOPS, "bf16 MFMA (exact three-piece operands)"
+        else:
+            ach, peak, pipe = alg, bench.PEAK_FP32_TFLOPS, "fp32 MFMA"
         lv = [float(x) for x in losses]
         res = {
             "metric": "VO training step (fwd+bwd+Adam) frame-pairs/s @341x192", "value": value, "unit": "frame-pairs/s",
@@ -178,8 +186,9 @@ def run_train(args, rank, world, dist, dev, sync_all):
             "ms_per_step_events": per_step, "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
             "loss_first_last": [lv[0], lv[-1]], "tflops_3x_fwd": value * flops / 1e12,
             "frac_fp32_peak_3x_fwd": value * flops / 1e12 / (bench.PEAK_FP32_TFLOPS * world),
-            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": bench.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / bench.PEAK_FP32_TFLOPS, "traffic": None, "launch_ms": launch_ms},
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "pipe": pipe, "definition": "EXECUTED matrix-core FLOPs per launch / HIP-event launch duration / peak of that pipe",
+                         "algorithmic_tflops": alg, "traffic": None, "launch_ms": launch_ms},
             "ms_by_kernel_class": agg,
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches": k["launches"] // args.steps,
                                 "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,

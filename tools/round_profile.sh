@@ -19,4 +19,9 @@ for cfg in fwd_fp32 dual_bf16; do
   cat $O/${tag}_pmc_${cfg}_*.md > $O/${tag}_pmc_$cfg.md
   rm -rf $O/${tag}_pmc_${cfg}_* $O/${tag}_trace_$cfg
 done
+# training step: kernel trace only (its kernels are MFMA / HBM bound by construction; counters are taken for the forward)
+rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_train -o p -- python bench.py --config train --steps 10 --warmup 3 > $O/${tag}_trace_train.log 2>&1
+python tools/rocprof_summary.py $O/${tag}_trace_train/p_results.db > $O/${tag}_kernel_trace_train.md 2>&1
+rm -rf $O/${tag}_trace_train
+PNVO_WSM_PROF=1 python bench.py --config train --steps 10 --warmup 3 2>&1 >/dev/null | grep "pnvo\]" > $O/${tag}_wgrad_stem_phases.txt
 head -14 $O/${tag}_kernel_trace_fwd_fp32.md
