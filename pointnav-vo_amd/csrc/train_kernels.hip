@@ -650,7 +650,7 @@ static hipError_t launch_wgrad_t(const WgradArgs &a, hipStream_t s) {
 // tile + unit plan of wgrad3_mw_kernel; false: shape outside it (the nine-wave kernel or the generic one takes over)
 static bool wgrad_plan_mw(WgradArgs &a) {
   const int S = a.stride;
-  const int cit = a.CIN / 32, cot = a.COUT / 32;
+  const int cit = a.CIN / 32, cot = (a.COUT + 31) / 32;    // (a padded last co-tile reads dY's zero pad channels)
   if (cit % 2 == 0 && cot % 2 == 0) {
     a.cs = 2; a.os = 2; a.rs = 1;
   } else if (cit == 1 && cot % 2 == 0) {
@@ -699,7 +699,7 @@ void wgrad_plan(WgradArgs &a) {
   a.lds3 = 0;
   static const bool no_lds = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "generic") == 0;
   static const bool nine = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "lds9") == 0;
-  if (!no_lds && !nine && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.CIN % 32 == 0 && a.COUT % 32 == 0 &&
+  if (!no_lds && !nine && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.CIN % 32 == 0 && a.DYC >= (a.COUT + 31) / 32 * 32 &&
       a.DYC % 4 == 0 && ((a.stride == 1 && a.H == a.Ho && a.W == a.Wo) || a.stride == 2) && wgrad_plan_mw(a))
     return;
   if (!no_lds && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.CIN % 32 == 0 &&
@@ -796,7 +796,7 @@ hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int
     const int S = a.lds3 == 5 ? 2 : 1;
     size_t lds = (size_t)(a.cs * ((a.TH - 1) * S + 3) * ((a.TW - 1) * S + 3) + a.os * a.TH * a.TW) * 36 * 4 * a.nbuf;
     if (a.rs > 1 && lds < 12 * 16 * 64 * 4) lds = 12 * 16 * 64 * 4;      // the row-group sum at the end goes through LDS
-    dim3 grid((unsigned)((a.ci_tiles / a.cs) * (a.COUT / 32 / a.os) * a.wg_chunks));
+    dim3 grid((unsigned)((a.ci_tiles / a.cs) * ((a.COUT + 31) / 32 / a.os) * a.wg_chunks));
     if (S == 2 && a.mode == 1)
       hipLaunchKernelGGL((wgrad3_mw_kernel<1, 2>), grid, dim3(768), lds, s, a);
     else if (S == 2)
@@ -1265,16 +1265,18 @@ hipError_t launch_maxpool_bwd(const float *dpool, const unsigned char *idx, int 
 
 // ------------------------------------------------------------------------------------------------------------------
 // out[c] = sum_r x[r][c]  (bias gradients), fixed order, fp64
+// one wave per column: lane l sums rows l, l + 64, ... in fp64, fixed xor tree (bias gradients of the Linear layers)
 __global__ __launch_bounds__(256) void colsum_kernel(const float *x, int rows, int cols, int ld, float *out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= cols) return;
   double a = 0.0;
-  for (int r = 0; r < rows; ++r) a += (double)x[(long)r * ld + c];
-  out[c] = (float)a;
+  for (int r = lane; r < rows; r += 64) a += (double)x[(long)r * ld + c];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[c] = (float)a;
 }
-
 hipError_t launch_colsum(const float *x, int rows, int cols, int ld, float *out, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, x, rows, cols, ld, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, x, rows, cols, ld, out);
   return hipGetLastError();
 }
 
