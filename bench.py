@@ -146,8 +146,12 @@ def timed_steps(step, steps, sync_all, dev):
         ev[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
-    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
-    return dt, {"p50": per[len(per) // 2], "min": per[0], "max": per[-1]}
+    raw = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    per = sorted(raw)
+    out = {"p50": per[len(per) // 2], "min": per[0], "max": per[-1]}
+    if per[-1] > 1.5 * per[len(per) // 2]:                 # an outlier step: say which one (a one-off stall shows, it is not hidden)
+        out["slowest_step"] = raw.index(per[-1])
+    return dt, out
 
 
 def stem_executed(kt_entry, B, per_launch_ms):

@@ -204,6 +204,12 @@ int pnvo_train_backward(pnvo_handle h, const float *grad_out, void *stream);
 int pnvo_input_moments(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
                        const float *center, int power, float *out, void *stream);
 
+/* RunningMeanAndVar.forward, training branch, for ONE process (running_mean_and_var.py:41-60; the multi-process branch
+ * :27-38 needs its all-reduces between the steps and stays on the host): m12 = pnvo_input_moments(power 3, center = the
+ * current running mean) of a batch of B pairs; mean / var [C] and count [1] are the module's float32 buffers, updated in place
+ * (batch mean, variance about it, Chan's merge).  All pointers are device pointers; asynchronous on `stream`. */
+int pnvo_rmv_merge(const float *m12, int C, int B, float *mean, float *var, float *count, void *stream);
+
 /* loss = sum_d mean_i (target - pred)^2 (vo_cnn_engine.py:146-194, unit weights) into *loss (device scalar, may be
  * NULL) and dLoss/dPred into grad [B,D] (may be NULL). */
 int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, void *stream);

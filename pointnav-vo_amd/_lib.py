@@ -65,6 +65,7 @@ _SIGNATURES = {
     "pnvo_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_input_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p]),
+    "pnvo_rmv_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_train_set_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pnvo_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_mse_loss_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

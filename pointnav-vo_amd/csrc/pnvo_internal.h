@@ -247,6 +247,7 @@ hipError_t launch_maxpool_train(const float *x, const float *scale, const float 
                                 float *out, unsigned char *idx, hipStream_t s);
 hipError_t launch_maxpool_bwd(const float *dpool, const unsigned char *idx, int B, int H, int W, int C, float *dact,
                               hipStream_t s);
+hipError_t launch_rmv_merge(const float *m12, int C, int B, float *mean, float *var, float *count, hipStream_t s);
 hipError_t launch_colsum(const float *x, int rows, int cols, int ld, float *out, hipStream_t s);
 hipError_t launch_padcopy(const float *src, int rows, int cols, int ldd, float *dst, hipStream_t s);
 // y = [relu(x*scale[n,c]+shift[n,c]) or x] * keep/(1-p); keep = hash(seed, step, layer, element) >= p.  x viewed as

@@ -1067,6 +1067,11 @@ int pnvo_input_moments(pnvo_handle m, const float *rgb, const float *depth, cons
   return PNVO_OK;
 }
 
+int pnvo_rmv_merge(const float *m12, int C, int B, float *mean, float *var, float *count, void *stream) {
+  if (!m12 || !mean || !var || !count || C < 1 || C > 1024 || B < 1) return PNVO_ERR_ARG;
+  return launch_rmv_merge(m12, C, B, mean, var, count, (hipStream_t)stream) == hipSuccess ? PNVO_OK : PNVO_ERR_HIP;
+}
+
 int pnvo_mse_loss(const float *pred, const float *target, int B, int D, float *loss, float *grad, void *stream) {
   if (!pred || !target || B <= 0 || D <= 0) return pnvo_fail(nullptr, PNVO_ERR_ARG, "bad argument");
   HIPCHK(nullptr, launch_mse_loss(pred, target, B, D, loss, grad, (hipStream_t)stream));

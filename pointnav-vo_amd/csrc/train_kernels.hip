@@ -1564,6 +1564,31 @@ __global__ __launch_bounds__(64) void moments_final_kernel(const MomentsArgs a, 
   if (threadIdx.x == 0) out[row] = (float)(s / (double)a.npix);
 }
 
+// RunningMeanAndVar's train-mode update in one launch (single process; running_mean_and_var.py:41-60): batch mean and the
+// variance about it from the one-pass moments e1 = E[x - c], e2 = E[(x - c)^2] about the old running mean c, then Chan's merge.
+__global__ void rmv_merge_kernel(const float *m12, int C, float nb, float *mean, float *var, float *count) {
+  const int c = threadIdx.x;
+  const float cnt = *count;
+  __syncthreads();                                        // (everybody has read the old count)
+  if (c < C) {
+    const double ctr = (double)mean[c], e1 = (double)m12[c], e2 = (double)m12[C + c];
+    const float new_mean = (float)(ctr + e1);
+    const double delta = (double)new_mean - ctr;
+    const float new_var = (float)(e2 - 2.0 * delta * e1 + delta * delta);
+    const float m_a = var[c] * cnt, m_b = new_var * nb;
+    const float dm = new_mean - mean[c];
+    const float M2 = m_a + m_b + dm * dm * cnt * nb / (cnt + nb);
+    var[c] = M2 / (cnt + nb);
+    mean[c] = (cnt * mean[c] + nb * new_mean) / (cnt + nb);
+  }
+  if (c == 0) *count = cnt + nb;
+}
+
+hipError_t launch_rmv_merge(const float *m12, int C, int B, float *mean, float *var, float *count, hipStream_t s) {
+  hipLaunchKernelGGL(rmv_merge_kernel, dim3(1), dim3(((C + 63) / 64) * 64), 0, s, m12, C, (float)B, mean, var, count);
+  return hipGetLastError();
+}
+
 hipError_t launch_moments(const MomentsArgs &a0, int C, double *part, float *out, hipStream_t s) {
   MomentsArgs a = a0;
   int maxch = 1;
