@@ -125,13 +125,20 @@ def preheat(step, dev, cap_s=2.0, tol=0.02):
     while True:
         t0 = time.perf_counter()
         step()
-        torch.cuda.synchronize(dev)
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize(dev)
         hist.append(time.perf_counter() - t0)
         el = time.perf_counter() - t_start
-        if len(hist) >= 3 and max(hist[-3:]) <= (1.0 + tol) * min(hist[-3:]):
-            return el, len(hist), True
-        if el >= cap_s:
-            return el, len(hist), False
+        ok = len(hist) >= 3 and max(hist[-3:]) <= (1.0 + tol) * min(hist[-3:])
+        stop = ok or el >= cap_s
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # every rank leaves after the same number of steps (a step may contain collectives): stop when ALL ranks want to
+            flag = torch.tensor([0.0 if stop else 1.0, 0.0 if ok else 1.0], device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            stop, ok = flag[0].item() == 0.0, flag[1].item() == 0.0
+        if stop:
+            return el, len(hist), ok
 
 
 def timed_steps(step, steps, sync_all, dev):
@@ -309,6 +316,14 @@ def dry_run(args, rank, world, dist):
             dist.barrier()
 
     B = args.batch or 256
+    # the pre-heat loop with a stub whose step times settle at a rank-dependent moment: all ranks must leave it together
+    calls = [0]
+
+    def stub():
+        calls[0] += 1
+        time.sleep(0.004 if calls[0] <= 2 + 2 * rank else 0.001)
+
+    pre = preheat(stub, cpu, cap_s=1.0, tol=0.5)
     for _ in range(args.warmup):
         time.sleep(0.001)
     sync_all()
@@ -325,8 +340,9 @@ def dry_run(args, rank, world, dist):
         print(json.dumps({"metric": "dry-run (no GPU work)", "value": world * B * args.steps / dt, "unit": "frame-pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
-                          "data": "none", "config": {"workload": "dry run of the N-rank control flow", "backend": args.backend,
-                                                     "shard_counts": counts}}))
+                          "data": "none", "preheat_steps": pre[1],
+                          "config": {"workload": "dry run of the N-rank control flow", "backend": args.backend,
+                                     "shard_counts": counts}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -550,7 +550,6 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.Ho = m->Hs;
     a.Wo = m->Ws;
     a.slots = stem_mx_slots(m->Hs, m->Ws);
-    if (const char *e = std::getenv("PNVO_STEM_MXDBG")) a.dbg = std::atoi(e);
     if (const char *e = std::getenv("PNVO_STEM_DBG"))
       if (std::atoi(e) == 9) {
         if (!m->mx_prof) {

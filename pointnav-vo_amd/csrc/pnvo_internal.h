@@ -94,7 +94,6 @@ struct StemMXArgs {
   int y_cstride, stats_cstride;
   int B, H, W, Ho, Wo, slots, tiles_x, tiles_y;
   unsigned long long *prof;   // [4 waves][8] phase cycle sums (PNVO_STEM_DBG=9) or nullptr
-  int dbg;                    // timing experiments (wrong results): PNVO_STEM_MXDBG bit 0 no global loads, 1 no LDS writes, 2 no K loop
 };
 int stem_mx_slots(int Ho, int Wo);
 size_t stem_mx_packed_u16(int pieces, int ntiles);

@@ -181,3 +181,6 @@ def test_bench_multi_rank_control_flow_runs_under_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["config"]["shard_counts"] == [256, 256]
     assert rec["ms_per_step"] >= 2.0                                  # the slower rank (2 ms per stub step) sets the time
+    # the pre-heat loop is left by all ranks together (its steps may contain collectives): rank 1's stub settles two steps
+    # later than rank 0's, and the run did not hang
+    assert rec["preheat_steps"] >= 6
