@@ -240,6 +240,9 @@ hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int
 hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
                          const float *rstd, const float *gamma, int B, long P, int C, int Creal, int G, int mask,
                          float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s);
+hipError_t launch_gn_bwd_pool(const float *x, const float *dpool, const unsigned char *idx, int Hs, int Ws, int Hp, int Wp,
+                              const float *scale, const float *shift, const float *mu, const float *rstd, const float *gamma, int B, int C,
+                              int G, float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s);
 hipError_t launch_relu_mask(const float *dy, const float *y, const float *add, long n, float *g, hipStream_t s);
 hipError_t launch_add(const float *a, const float *b, long n, float *o, hipStream_t s);
 hipError_t launch_maxpool_train(const float *x, const float *scale, const float *shift, int B, int H, int W, int C,

@@ -952,8 +952,21 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
   // ---- stem: maxpool <- dY, GroupNorm + ReLU, weight gradient (no input gradient)
   {
     const Layer &l = m->convs[0];
-    HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
-    if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
+    static const bool unfused = std::getenv("PNVO_POOL_BWD") && std::strcmp(std::getenv("PNVO_POOL_BWD"), "separate") == 0;
+    if (!unfused && l.coutp == l.cout && l.cout % 4 == 0 && l.cout <= 256 && 256 % (l.cout / 4) == 0) {
+      // max-pool backward folded into the stem's GroupNorm backward: the un-pooled gradient is never materialised
+      const ConvSave &cs0 = t->cs[0];
+      float *dg = gradp(m, t, l.gn + ".weight", &rc);
+      if (!dg) return rc;
+      float *db = gradp(m, t, l.gn + ".bias", &rc);
+      if (!db) return rc;
+      PnvoTimed tm(m, s, "gn_bwd", 0.0, 0.0);
+      HIPCHK(m, launch_gn_bwd_pool(cs0.raw, dY, t->pool_idx, m->Hs, m->Ws, m->Hp, m->Wp, cs0.ss[0], cs0.ss[1], cs0.mu, cs0.rstd, l.gamma,
+                                   B, l.cout, l.groups, t->gn_part, t->gn_coef, dg, db, t->dStem, s));
+    } else {
+      HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
+      if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
+    }
     const char *wsel = std::getenv("PNVO_WGRAD_STEM");      // "fp32": the float32-MFMA kernel (read per call: tests compare the two)
     const bool stem_fp32 = wsel && std::strcmp(wsel, "fp32") == 0;
     if (m->train_mx && l.coutp == 32 && !stem_fp32) {

@@ -985,6 +985,145 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, const
   *reinterpret_cast<f32x4 *>(dx + e) = out;
 }
 
+// ---- the stem's GroupNorm backward with the max-pool backward folded in: dOut of the stem's GN+ReLU is the gather of the
+// pooled gradient (pixel (hi, wi) collects dPool of every 3x3 stride-2 window that elected it), computed on the fly in both
+// passes instead of materialising the 4 x larger tensor (one write + two reads of 270 MB at 128 pairs saved).
+struct PoolGrad {
+  const float *dpool;          // [B, Hp, Wp, C] gradient of the pooled activations
+  const unsigned char *idx;    // [B, Hp, Wp, C] elected tap (kh * 3 + kw) of each window
+  int H, W, Hp, Wp;            // H x W: the stem's output, Hp x Wp: pooled
+};
+__device__ __forceinline__ f32x4 pool_grad4(const PoolGrad &q, int n, int hi, int wi, int C, int c) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int t = hi + 1 - kh;          // 2*ho = hi + 1 - kh
+    if (t < 0 || (t & 1)) continue;
+    const int ho = t >> 1;
+    if (ho >= q.Hp) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int u = wi + 1 - kw;
+      if (u < 0 || (u & 1)) continue;
+      const int wo = u >> 1;
+      if (wo >= q.Wp) continue;
+      const long o = (((long)n * q.Hp + ho) * q.Wp + wo) * C + c;
+      const unsigned ix = *reinterpret_cast<const unsigned *>(q.idx + o);
+      const f32x4 dp = *reinterpret_cast<const f32x4 *>(q.dpool + o);
+      const unsigned k = (unsigned)(kh * 3 + kw);
+      if ((ix & 0xffu) == k) acc[0] += dp[0];
+      if (((ix >> 8) & 0xffu) == k) acc[1] += dp[1];
+      if (((ix >> 16) & 0xffu) == k) acc[2] += dp[2];
+      if ((ix >> 24) == k) acc[3] += dp[3];
+    }
+  }
+  return acc;
+}
+
+// reduce pass, four channels per thread: block = (sample, pixel chunk); thread = (channel quad t % (C/4), pixel lane t / (C/4))
+__global__ __launch_bounds__(256) void gn_bwd_reduce_pool_kernel(const float *x, const PoolGrad q, const float *scale, const float *shift,
+                                                               const float *mu, const float *rstd, int C, int G, long P, int chunks,
+                                                               float *part) {
+  __shared__ float red[256 * 8];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long ppc = (P + chunks - 1) / chunks;
+  const long p0 = (long)chunk * ppc;
+  long p1 = p0 + ppc;
+  if (p1 > P) p1 = P;
+  const int Q = C >> 2, cq = threadIdx.x % Q, pl = threadIdx.x / Q, pstep = 256 / Q, c = 4 * cq;
+  const int cpg = C / G;
+  f32x4 m_, r_;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m_[e] = mu[n * G + (c + e) / cpg];
+    r_[e] = rstd[n * G + (c + e) / cpg];
+  }
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + c), sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + c);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long p = p0 + pl; p < p1; p += pstep) {
+    const int hi = (int)(p / q.W), wi = (int)(p - (long)hi * q.W);
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + ((long)n * P + p) * C + c);
+    const f32x4 gv = pool_grad4(q, n, hi, wi, C, c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = __builtin_fmaf(xv[e], sc[e], sh[e]) > 0.f ? gv[e] : 0.f;
+      s1[e] += g;
+      s2[e] = __builtin_fmaf(g, (xv[e] - m_[e]) * r_[e], s2[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[threadIdx.x * 8 + 2 * e] = s1[e];
+    red[threadIdx.x * 8 + 2 * e + 1] = s2[e];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {                              // thread = channel: sums its quad's pixel lanes in a fixed order
+    const int qd = threadIdx.x >> 2, e = threadIdx.x & 3;
+    float a1 = 0.f, a2 = 0.f;
+    for (int k = 0; k < pstep; ++k) {
+      a1 += red[(k * Q + qd) * 8 + 2 * e];
+      a2 += red[(k * Q + qd) * 8 + 2 * e + 1];
+    }
+    float *dst = part + (((long)n * chunks + chunk) * C + threadIdx.x) * 2;
+    dst[0] = a1;
+    dst[1] = a2;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_pool_kernel(const float *x, const PoolGrad q, const float *scale, const float *shift,
+                                                              const float *mu, const float *rstd, const float *gamma, const float *coef,
+                                                              int C, int G, long P, long total4, float *dx) {
+  const long e4 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e4 >= total4) return;
+  const long e = e4 * 4;
+  const int c0 = (int)(e % C);
+  const long pix = e / C;
+  const int n = (int)(pix / P);
+  const long p = pix - (long)n * P;
+  const int hi = (int)(p / q.W), wi = (int)(p - (long)hi * q.W);
+  const int cpg = C / G;
+  const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + e), gv = pool_grad4(q, n, hi, wi, C, c0);
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + c0), sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + c0);
+  f32x4 out;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = c0 + t, g = c / cpg;
+    const float gd = __builtin_fmaf(xv[t], sc[t], sh[t]) > 0.f ? gv[t] : 0.f;
+    const float r_ = rstd[n * G + g];
+    const float xh = (xv[t] - mu[n * G + g]) * r_;
+    out[t] = r_ * (gamma[c] * gd - coef[((long)n * G + g) * 2] - xh * coef[((long)n * G + g) * 2 + 1]);
+  }
+  *reinterpret_cast<f32x4 *>(dx + e) = out;
+}
+
+// GroupNorm (+ ReLU mask) backward of the stem with dOut = max-pool backward of dpool (C % 4 == 0, C <= 256, no pad channels)
+hipError_t launch_gn_bwd_pool(const float *x, const float *dpool, const unsigned char *idx, int Hs, int Ws, int Hp, int Wp,
+                              const float *scale, const float *shift, const float *mu, const float *rstd, const float *gamma, int B, int C,
+                              int G, float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s) {
+  const long P = (long)Hs * Ws;
+  int chunks = (int)(P / 256);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  PoolGrad q;
+  q.dpool = dpool;
+  q.idx = idx;
+  q.H = Hs;
+  q.W = Ws;
+  q.Hp = Hp;
+  q.Wp = Wp;
+  hipLaunchKernelGGL(gn_bwd_reduce_pool_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, q, scale, shift, mu, rstd, C, G, P,
+                     chunks, part);
+  float *nc = part + (size_t)B * chunks * C * 2;
+  hipLaunchKernelGGL(gn_bwd_sum_chunks_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, s, part, B, C, chunks, nc);
+  const int nb_coef = (B * G + 255) / 256;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)(nb_coef + (C + 3) / 4)), dim3(256), 0, s, nc, B, C, C, G, P, gamma, coef,
+                     dgamma, dbeta, nb_coef);
+  const long total4 = (long)B * P * C / 4;
+  hipLaunchKernelGGL(gn_bwd_apply_pool_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, q, scale, shift, mu, rstd,
+                     gamma, coef, C, G, P, total4, dx);
+  return hipGetLastError();
+}
+
 hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
                          const float *rstd, const float *gamma, int B, long P, int C, int Creal, int G, int mask,
                          float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s) {
