@@ -1,8 +1,11 @@
 """Worker of tests/test_gpu_multi.py: one process per GPU (torch.distributed.run), backend nccl (= RCCL).
-    --mode infer : rank r runs its contiguous shard of the pairs through libpnvo.so; the gathered result must equal the
-                   single-GPU result of the whole batch BIT FOR BIT (rank 0 computes both)
+    --mode infer : rank r runs its contiguous shard of the pairs through libpnvo.so; the gathered result must equal, BIT FOR
+                   BIT, the same shards evaluated one after the other on one GPU, and the whole batch at once to 1e-5
+                   (kernel / tile choices depend on the batch size of a launch)
     --mode train : data-parallel VOTrainStep (RunningMeanAndVar all-reduces + one flat-gradient all-reduce, Adam) on the
                    rank's half of the batch must equal the single-GPU step on the concatenated batch (rank 0 checks)
+    --shared-gpu : both ranks use cuda:0 and the collectives go through gloo — the 2-rank logic on the real kernels of a
+                   1-GPU box (everything but RCCL itself)
 Exit code 0 = all assertions held."""
 import argparse
 import os
@@ -34,11 +37,17 @@ def build(dev, dropout_p=0.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", required=True, choices=["infer", "train"])
+    ap.add_argument("--shared-gpu", action="store_true")
     a = ap.parse_args()
     rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    if a.shared_gpu:
+        lr = 0
     torch.cuda.set_device(lr)
     dev = torch.device("cuda", lr)
-    dist.init_process_group("nccl", device_id=dev)
+    if a.shared_gpu:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     total = 7 if a.mode == "infer" else 6
     lo, hi = parallel.shard_bounds(total, rank, world)
     shard = {k: torch.from_numpy(v).to(dev) for k, v in
@@ -50,8 +59,14 @@ def main():
         with torch.no_grad():
             mine = model(shard)
             gathered = parallel.gather_results(mine, total)
-            single = model(full)
+            # kernel and tile choices depend on the batch size of a launch (measured on one GPU: 7 pairs at once vs 4 + 3
+            # differ by 9e-7), so the bit-exact reference evaluates the same shards one after the other on this GPU; the
+            # whole batch at once must agree to 1e-5
+            single = torch.cat([model({k: v[a:b] for k, v in full.items()})
+                                for a, b in (parallel.shard_bounds(total, r, world) for r in range(world))])
+            whole = model(full)
         assert torch.equal(gathered, single), (rank, (gathered - single).abs().max())
+        assert (gathered - whole).abs().max() <= 1e-5 * max(1.0, float(whole.abs().max())), (rank, (gathered - whole).abs().max())
     else:
         tgt_full = torch.from_numpy(np.random.default_rng(4).normal(size=(total, 3)).astype(np.float32) * 0.2).to(dev)
         m_dp, m_one = build(dev), build(dev)

@@ -1,9 +1,10 @@
 """GPU (-m gpu), needs >= 2 MI355X (skipped on a 1-GPU box): the data-parallel paths through libpnvo.so under
 torch.distributed with backend nccl (RCCL over xGMI) — SURVEY.md section 4(iii) / section 8(e).
-  * sharded inference: N-rank gathered result == 1-GPU result, bit for bit
+  * sharded inference: N-rank gathered result == the same shards on one GPU, bit for bit (and the whole batch to 1e-5)
   * VOTrainStep: 2-rank step (RunningMeanAndVar's three all-reduces, running_mean_and_var.py:27-38, and the ONE flat
     gradient all-reduce) == the single-GPU step on the concatenated batch
-The same host logic runs under gloo on CPU in tests/test_distributed_cpu.py."""
+The same host logic runs under gloo on CPU in tests/test_distributed_cpu.py, and — on any GPU box — as two ranks that share
+cuda:0 with gloo collectives (the `shared_gpu` tests below: everything but RCCL itself)."""
 import os
 import socket
 import subprocess
@@ -17,15 +18,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 need2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least 2 GPUs")
 
 
-def _run(mode):
+def _run(mode, *extra):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "mgpu_worker.py"), "--mode", mode],
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "mgpu_worker.py"), "--mode", mode, *extra],
                        capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_two_ranks_sharing_one_gpu_sharded_inference():
+    """The 2-rank sharding / gather logic on the real kernels of a 1-GPU box (collectives over gloo)."""
+    _run("infer", "--shared-gpu")
+
+
+def test_two_ranks_sharing_one_gpu_train_step_equals_the_step_on_the_concatenated_batch():
+    """Data-parallel VOTrainStep (statistics + gradient all-reduces over gloo, both ranks on cuda:0) against the single
+    process step on the concatenated batch."""
+    _run("train", "--shared-gpu")
 
 
 @need2
