@@ -197,12 +197,15 @@ def main():
                     help="process-group backend of the N>1 launch (nccl = RCCL; gloo only exercises the host logic)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: run the N-rank control flow (barriers, max-over-ranks, JSON) with a stub step")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="testing aid for 1-GPU boxes: every rank uses cuda:0 (with --backend gloo), so the N > 1 code path runs "
+                         "on the real kernels; the value it prints is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-preheat", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: one process per GPU over RCCL

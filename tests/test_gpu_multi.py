@@ -48,3 +48,23 @@ def test_two_gpu_sharded_inference_equals_one_gpu():
 @need2
 def test_two_gpu_train_step_equals_one_gpu_step_on_the_concatenated_batch():
     _run("train")
+
+
+@pytest.mark.parametrize("config", ["fwd_fp32", "train"])
+def test_bench_two_ranks_sharing_one_gpu(config):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run), both ranks on cuda:0 over gloo: the real timed
+    path of the N > 1 launch — collective pre-heat exit, barrier brackets, max over ranks, ONE JSON line from rank 0."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--backend", "gloo", "--shared-gpu", "--no-cpu-baseline", "--config", config,
+                        "--batch", "16"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["global_batch"] == 32 and rec["value"] > 0
+
