@@ -1,0 +1,410 @@
+// conv_x3.hip — float32 convs of the residual stages on the bf16 matrix cores, gfx950 only.
+//
+// The 3x3 convs after the stem (resnet.py:29-55,189-212; 16 of them = 41.6 % of the MACs) are bound
+// by the fp32 matrix pipe (157 TFLOP/s; the fp32 kernels of conv3_lds.hip / conv_mfma.hip run at 100-119).  The bf16 pipe is 16
+// times faster, and a float32 number is EXACTLY the sum of three bf16 numbers (hi + mid + lo: 3 x 8 significand bits), so
+//   a * w = (a0 + a1 + a2)(w0 + w1 + w2) ~ a0 w0 + a0 w1 + a1 w0 + a0 w2 + a2 w0 + a1 w1
+// with every kept product exact in the float32 accumulator and the three dropped ones (a1 w2, a2 w1, a2 w2) below 2^-23 of
+// a * w — the size of one float32 rounding.  Six bf16 MFMAs replace sixteen fp32-MFMA issue slots of the same K: 2.7 x the
+// fp32 rate at equal pipe utilisation, float32-grade results (measured against the fp64 reference in tests/test_gpu_parity.py,
+// same tolerances as the fp32 kernels).  The stem (stem_mx.hip) uses the exact special case (inputs exact in bf16).
+//
+// Structure = conv_bf16.hip (implicit GEMM on v_mfma_f32_32x32x16_bf16, input patch of the workgroup's output tile staged in
+// LDS, producer's GroupNorm + ReLU applied once per element while staging, zero padding after it, pixel table for ragged
+// tiles, raw float32 output + per-slot GroupNorm partial sums) with float32 activations in HBM: the stager splits every
+// element into its three pieces (three LDS planes), the weights are split at load (three B fragments per step).
+#include <cstdlib>
+#include <cstring>
+
+#include "pnvo_internal.h"
+
+namespace pnvo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const bf16x2 r = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+}  // namespace
+
+template <int KS, int STRIDE, int MODE, int MW, int NW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3_kernel(const ConvX3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
+  constexpr int CS = KS == 1 ? 1 : STRIDE;         // patch pixels per output pixel
+  constexpr int PAD = KS / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32x4 *wpk = reinterpret_cast<const u32x4 *>(p.wpk);
+
+  const int ntiles = p.B * p.tiles_r * p.tiles_c;
+  const int chunk = (ntiles + 7) >> 3;
+  int bid = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);     // consecutive tiles of an XCD are neighbours
+  if (bid >= ntiles) return;
+  const int tci = bid % p.tiles_c;
+  bid /= p.tiles_c;
+  const int tri = bid % p.tiles_r;
+  const int n = bid / p.tiles_r;
+  const int r0 = tri * p.TR, c0 = tci * p.TC;
+  const int hi0 = r0 * STRIDE - PAD, wi0 = c0 * STRIDE - PAD;
+  const int PR = p.PR, PC = p.PC, CK = p.CK;
+  const int pitch = CK * 2 + 16;                   // bytes per patch pixel in one piece plane (odd number of 16-byte units)
+  const int plane = PR * PC * pitch;               // bytes of one piece plane
+  const int npix = p.TR * p.TC;
+  // pixel table behind the three planes: [0] patch byte offset of tile pixel q's top-left tap; [1] element offset of its output
+  // pixel inside the sample's output plane, bit 31 set when the pixel does not exist
+  unsigned *qtab = reinterpret_cast<unsigned *>(lds + 3 * plane);
+  unsigned *otab = qtab + p.MT * 32;
+  if ((int)threadIdx.x < p.MT * 32) {
+    const int q = min((int)threadIdx.x, npix - 1);
+    const int tr = q / p.TC, tc = q - tr * p.TC;
+    qtab[threadIdx.x] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch);
+    const bool ok = (int)threadIdx.x < npix && r0 + tr < p.Ho && c0 + tc < p.Wo;
+    otab[threadIdx.x] = (unsigned)((tr * p.Wo + tc) * p.COUTP) | (ok ? 0u : 0x80000000u);
+  }
+
+  const int wn = p.wn;                                                   // wave grid: (4 / wn) x wn
+  const int wave_m = wave / wn;
+  const int wave_n = (wave & (wn - 1)) + (int)blockIdx.y * wn;            // blockIdx.y = group of wn * NW N-tiles
+  const int ntt = p.COUTP >> 5, kct = p.CIN >> 4;                        // N-tiles, 16-channel k-chunks of the layer
+
+  f32x16 acc[MW][NW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging role: thread -> (pixel lane, 8-channel group); G groups per pixel, 256 / G pixels per step
+  const int G = CK >> 3;
+  const int cg = threadIdx.x & (G - 1), pl = threadIdx.x / G, PS = 256 / G;
+  const int dr = PS / PC, dc = PS - dr * PC;
+  const int nppix = PR * PC;
+
+  for (int ck0 = 0; ck0 < p.CIN; ck0 += CK) {
+    if (ck0 > 0) __syncthreads();                                        // the previous chunk's patch is no longer read
+    {
+      f32x4 sc0, sc1, sh0, sh1;
+      if (MODE == 1) {
+        const float *ps = p.in_scale + (long)n * p.CIN + ck0 + 8 * cg;
+        const float *pt = p.in_shift + (long)n * p.CIN + ck0 + 8 * cg;
+        sc0 = *reinterpret_cast<const f32x4 *>(ps);
+        sc1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+        sh0 = *reinterpret_cast<const f32x4 *>(pt);
+        sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+      }
+      int pr = pl / PC, pc = pl - pr * PC;
+      const float *xb = p.x + ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
+      for (int pix = pl; pix < nppix; pix += 2 * PS) {
+        f32x4 v[2][2];
+        unsigned off[2];
+        bool ok[2], in[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int hi = hi0 + pr * PSTEP, wi = wi0 + pc * PSTEP;
+          ok[k] = pix + k * PS < nppix;
+          in[k] = ok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+          off[k] = (unsigned)((pr * PC + pc) * pitch + 16 * cg);
+          v[k][0] = v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (in[k]) {
+            const float *src = xb + ((long)hi * p.W + wi) * p.CIN;
+            v[k][0] = *reinterpret_cast<const f32x4 *>(src);
+            v[k][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+          }
+          pr += dr;
+          pc += dc;
+          if (pc >= PC) {
+            pc -= PC;
+            pr += 1;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (!ok[k]) continue;
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = v[k][e >> 2][e & 3];
+            if (MODE == 1) {                                             // the producer's GroupNorm + ReLU; zero padding AFTER it
+              const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
+              t = in[k] ? fmaxf(__builtin_fmaf(t, sc[e & 3], sh[e & 3]), 0.f) : 0.f;
+            }
+            f[e] = t;
+          }
+          u32x4 o0, o1, o2;                                              // the three bf16 pieces of the eight channels
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = f[2 * e], b = f[2 * e + 1];
+            const unsigned h = pack2(a, b);
+            const float ra = a - lo_f(h), rb = b - hi_f(h);
+            const unsigned m = pack2(ra, rb);
+            o0[e] = h;
+            o1[e] = m;
+            o2[e] = pack2(ra - lo_f(m), rb - hi_f(m));
+          }
+          *reinterpret_cast<u32x4 *>(lds + off[k]) = o0;
+          *reinterpret_cast<u32x4 *>(lds + plane + off[k]) = o1;
+          *reinterpret_cast<u32x4 *>(lds + 2 * plane + off[k]) = o2;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- compute: steps s = (tap, 16-channel chunk).  B fragments (three weight pieces per N-tile) stream from L2 one
+    // step ahead (two register sets); A fragments (three planes per M-tile) come from LDS at the start of the step.
+    unsigned aoff[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = min(wave_m * MW + i, p.MT - 1);
+      aoff[i] = qtab[mt * 32 + (lane & 31)] + (unsigned)((lane >> 5) * 16);
+    }
+    const int kcc = CK >> 4;                                             // k-chunks per staged chunk
+    const int nsteps = KS * KS * kcc;
+    const int kc_base = ck0 >> 4;
+    auto loadA = [&](int s, u32x4 (*a)[MW]) {
+      const int tap = s / kcc, kc = s - tap * kcc;
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const unsigned toff = (unsigned)((kh * PC + kw) * pitch + kc * 32);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int i = 0; i < MW; ++i) a[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + toff);
+    };
+    auto loadB = [&](int s, u32x4 (*b)[NW]) {
+      const int tap = s / kcc, kc = s - tap * kcc;
+      const u32x4 *wb = wpk + ((long)(tap * kct + kc_base + kc) * ntt) * 3 * 64;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int nt = min(wave_n * NW + j, ntt - 1);                    // (N-tiles past the layer's repeat the last one)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) b[pc][j] = wb[(nt * 3 + pc) * 64 + lane];
+      }
+    };
+    auto mfmas = [&](const u32x4 (*a)[MW], const u32x4 (*b)[NW]) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+          // smallest terms first: a1 w1, a2 w0, a0 w2, a1 w0, a0 w1, a0 w0
+          constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[TA[t]][i]),
+                                                                __builtin_bit_cast(bf16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
+        }
+    };
+    u32x4 a[3][MW], b0[3][NW], b1[3][NW];
+    loadB(0, b0);
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 2) {                                // nsteps is even for every supported shape
+      loadA(s, a);
+      loadB(s + 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      loadA(s + 1, a);
+      loadB(s + 2 < nsteps ? s + 2 : s, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot).
+  const int rr16 = lane >> 5;
+  const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int mt = wave_m * MW + i;
+    if (mt >= p.MT) continue;
+    u32x4 ent[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int nt = wave_n * NW + j;
+      if (nt >= ntt) continue;
+      const int co = nt * 32 + (lane & 31);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned e = ent[r >> 2][r & 3];
+        const bool ok = (int)e >= 0;
+        const float v = ok ? acc[i][j][r] : 0.f;
+        if (ok) (p.y + ybase + co)[e] = v;
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32 && p.stats != nullptr) {
+        const int slot = (tri * p.tiles_c + tci) * p.MT + mt;
+        float *dst = p.stats + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int KS, int STRIDE>
+hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, size_t ldsb, hipStream_t s) {
+#define PNVO_X3(MODE_, MW_, NW_)                                                                      \
+  if (mode == MODE_ && mw == MW_ && nw == NW_) {                                                      \
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_>), grid, dim3(256), ldsb, s, a);   \
+    return hipGetLastError();                                                                         \
+  }
+  PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 4, 1) PNVO_X3(1, 4, 1)
+  PNVO_X3(0, 3, 1) PNVO_X3(1, 3, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)
+  PNVO_X3(0, 4, 2) PNVO_X3(1, 4, 2)
+#undef PNVO_X3
+  return hipErrorInvalidValue;
+}
+}  // namespace
+
+// Fills the plan fields of `a` from its shape fields; false: the layer is outside what the kernel covers.
+bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes) {
+  if (a.CIN % 32 || a.COUTP % 32 || a.COUTP > 1024 || a.CIN > 1024) return false;
+  if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 2))) return false;
+  const int ntt = a.COUTP / 32;
+  // Operand bandwidth decides the wave tile: per wave and cycle the MFMAs want 16/NW bytes of A (LDS, 128 B/clk per CU) and
+  // 16/MW bytes of B (L1, 64 B/clk per CU) at full rate, eight waves per CU.  (MW, NW) = (3, 2) keeps both under their limits
+  // (64 and 43 B/clk); (2, 2) sits on the L1 limit, (2, 1) on both.  A layer with one N-tile cannot reuse A at all (16 B per
+  // cycle and wave from LDS alone): such layers stay on the fp32 kernels.
+  if (ntt < 2) return false;
+  int TR, TC;
+  if (a.Wo >= 32) {
+    TR = 8;
+    TC = 16;
+  } else {
+    TC = a.Wo;
+    const int target = ntt == 4 ? 192 : (ntt >= 8 ? 96 : 128);     // pixels per tile: six / three / four M-tiles
+    TR = target / TC;
+    if (TR < 1) TR = 1;
+    if (TR > a.Ho) TR = a.Ho;
+  }
+  a.TR = TR;
+  a.TC = TC;
+  a.tiles_r = (a.Ho + TR - 1) / TR;
+  a.tiles_c = (a.Wo + TC - 1) / TC;
+  a.MT = (TR * TC + 31) / 32;
+  const int cs = ks == 1 ? 1 : stride;
+  a.PR = (TR - 1) * cs + ks;
+  a.PC = (TC - 1) * cs + ks;
+  // wave grid (4 / wn) x wn and accumulators per wave (accumulators + one A set + two B sets within 256 registers)
+  if (ntt == 2) {
+    a.wn = 2;
+    *mw = 2;
+    *nw = 1;
+  } else if (ntt == 4) {
+    a.wn = 2;
+    *mw = a.MT > 4 ? 3 : 2;
+    *nw = 2;
+  } else {
+    a.wn = 4;
+    *mw = a.MT > 2 ? 3 : 2;
+    *nw = 2;
+  }
+  if ((4 / a.wn) * *mw < a.MT) return false;
+  // channel chunk: the largest multiple-of-32 divisor of CIN (power-of-two steps) whose three planes fit 72 KB
+  int ck = a.CIN;
+  while (ck > 32 && (size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)72 * 1024) ck /= 2;
+  if ((size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
+  if (a.CIN % ck) return false;
+  a.CK = ck;
+  a.slots = a.tiles_r * a.tiles_c * a.MT;
+  *lds_bytes = (size_t)3 * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
+  return true;
+}
+
+hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s) {
+  const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
+  const int ntt = a.COUTP / 32, per_wg = a.wn * nw;   // N-tiles one workgroup covers
+  dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((ntt + per_wg - 1) / per_wg), 1u);
+  if (ks == 3 && stride == 1) return launch_ks<3, 1>(a, mode, mw, nw, grid, lds_bytes, s);
+  if (ks == 3 && stride == 2) return launch_ks<3, 2>(a, mode, mw, nw, grid, lds_bytes, s);
+  if (ks == 1 && stride == 2) return launch_ks<1, 2>(a, mode, mw, nw, grid, lds_bytes, s);
+  return hipErrorInvalidValue;
+}
+
+// B operand: out[tap][k-chunk (cin/16)][N-tile (coutp/32)][piece 3][lane = kh*32 + n][8 bf16]
+//            = piece of W[N-tile*32 + n][16 kc + 8 kh + j][tap]   (hi + mid + lo == the float32 weight exactly)
+void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh_, int kw_, unsigned short *out) {
+  const int T = kh_ * kw_, kct = cinp / 16, ntt = coutp / 32;
+  auto bf = [](float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  };
+  auto tof = [](unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  for (int tap = 0; tap < T; ++tap)
+    for (int kc = 0; kc < kct; ++kc)
+      for (int nt = 0; nt < ntt; ++nt)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
+            float v = 0.f;
+            if (co < cout && ci < cin) v = oihw[((size_t)co * cin + ci) * T + tap];
+            const unsigned short h = bf(v);
+            const float r1 = v - tof(h);
+            const unsigned short m = bf(r1);
+            const unsigned short l = bf(r1 - tof(m));
+            const size_t base = ((((size_t)tap * kct + kc) * ntt + nt) * 3) * 64 * 8 + (size_t)ln * 8 + j;
+            out[base] = h;
+            out[base + 64 * 8] = m;
+            out[base + 2 * 64 * 8] = l;
+          }
+}
+
+// The same packing on the device from an OIHW float32 weight (the training step's flat parameter buffer: after an optimiser
+// step the eval forward must see the new weights without a host round trip).  One thread per packed element triple.
+__global__ __launch_bounds__(256) void conv_x3_repack_kernel(const float *w, int cout, int cin, int cinp, int coutp, int T,
+                                                           unsigned short *out, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e & 7), ln = (int)((e >> 3) & 63);
+  long r = e >> 9;
+  const int ntt = coutp / 32, kct = cinp / 16;
+  const int nt = (int)(r % ntt);
+  r /= ntt;
+  const int kc = (int)(r % kct), tap = (int)(r / kct);
+  const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
+  const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * T + tap] : 0.f;
+  const unsigned h = pack2(v, 0.f) & 0xffffu;
+  const float r1 = v - lo_f(h);
+  const unsigned m = pack2(r1, 0.f) & 0xffffu;
+  const unsigned l = pack2(r1 - lo_f(m), 0.f) & 0xffffu;
+  const long base = ((((long)tap * kct + kc) * ntt + nt) * 3) * 512 + (long)ln * 8 + j;
+  out[base] = (unsigned short)h;
+  out[base + 512] = (unsigned short)m;
+  out[base + 1024] = (unsigned short)l;
+}
+
+hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out,
+                                 hipStream_t s) {
+  const long total = (long)kh * kw * (cinp / 16) * (coutp / 32) * 512;
+  hipLaunchKernelGGL(conv_x3_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cout, cin, cinp, coutp,
+                     kh * kw, out, total);
+  return hipGetLastError();
+}
+
+}  // namespace pnvo

@@ -291,6 +291,20 @@ size_t stats_floats(const Layer &l, int B) {
   choose_tile(M, l.coutp, &MT, &NT);
   int slots = conv_slots((int)P, MT), s2 = 0;
   if (layer_on_lds(l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
+  if (l.k == 3 && l.stride == 1) {                               // conv_x3: slots = tiles x M-tiles
+    ConvX3Args xa;
+    std::memset(&xa, 0, sizeof(xa));
+    xa.B = B;
+    xa.H = l.hin;
+    xa.W = l.win;
+    xa.CIN = l.cinp;
+    xa.Ho = l.hout;
+    xa.Wo = l.wout;
+    xa.COUTP = l.coutp;
+    int mw, nw;
+    size_t ldsb;
+    if (conv_x3_plan(xa, 3, 1, &mw, &nw, &ldsb) && xa.slots > slots) slots = xa.slots;
+  }
   return (size_t)B * (size_t)slots * l.coutp * 2;
 }
 
@@ -463,6 +477,54 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   const double macs = (double)M * l.cout * l.cin * l.k * l.kw;
   const double bytes = 4.0 * ((double)B * l.hin * l.win * l.cin + (double)M * l.cout + (double)l.cout * l.cin * l.k * l.kw);
   const char *sel = std::getenv("PNVO_CONV");
+  // 3x3 stride-1 convs with GroupNorm: float32 results from the bf16 matrix cores (three-piece operands, conv_x3.hip);
+  // PNVO_CONV=fp32 keeps the fp32-MFMA kernels.  Not in the training forward (its saved activations feed the backward kernels
+  // that were validated against the fp32 forward), not with a fused stem source, bias or output ReLU.
+  if (ss && src == nullptr && bias == nullptr && !relu_out && l.k == 3 && l.kw == 3 && l.stride == 1 && l.pad == 1 &&
+      y_cstride == l.coutp && !l.host_w.empty() && !m->in_train_forward && !(sel && std::strcmp(sel, "x3") != 0)) {
+    ConvX3Args xa;
+    std::memset(&xa, 0, sizeof(xa));
+    xa.B = B;
+    xa.H = l.hin;
+    xa.W = l.win;
+    xa.CIN = l.cinp;
+    xa.Ho = l.hout;
+    xa.Wo = l.wout;
+    xa.COUTP = l.coutp;
+    int mw = 0, nw = 0;
+    size_t ldsb = 0;
+    if (conv_x3_plan(xa, 3, 1, &mw, &nw, &ldsb)) {              // (the statistics buffer is sized for it: stats_floats)
+      Layer &lm = const_cast<Layer &>(l);
+      if (!lm.wpk_x3 || lm.x3_gen != m->weights_gen) {           // (re)build the three-piece operand of this layer
+        const size_t nel = (size_t)9 * l.cinp * l.coutp * 3;
+        if (!lm.wpk_x3) HIPCHK(m, hipMalloc((void **)&lm.wpk_x3, nel * 2));
+        const float *dev_w = m->train ? pnvo_train_weight_ptr(m, l.name + ".weight") : nullptr;
+        if (dev_w != nullptr) {          // training attached: the current weight lives in the flat parameter buffer
+          HIPCHK(m, launch_conv_x3_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, 3, 3, lm.wpk_x3, s));
+        } else {
+          std::vector<unsigned short> pk(nel);
+          pack_conv_x3_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, 3, 3, pk.data());
+          HIPCHK(m, hipMemcpyAsync(lm.wpk_x3, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
+          HIPCHK(m, hipStreamSynchronize(s));
+        }
+        lm.x3_gen = m->weights_gen;
+      }
+      xa.x = x;
+      xa.wpk = lm.wpk_x3;
+      xa.y = y;
+      xa.in_scale = in_scale;
+      xa.in_shift = in_shift;
+      xa.stats = m->stats;
+      {
+        Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
+        HIPCHK(m, launch_conv_x3(xa, 3, 1, in_scale ? 1 : 0, mw, nw, ldsb, s));
+      }
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
+                                   xa.slots, mu_out, rstd_out));
+      return PNVO_OK;
+    }
+  }
   const bool lds3 = conv3_lds_supported(a) && !(sel && std::strcmp(sel, "generic") == 0);
   if (lds3) {                    // 3x3 stride-1 residual-stage conv: input patch staged in LDS
     int nt = (l.coutp / 32) % 2 == 0 ? 2 : 1;
@@ -923,6 +985,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
   }
   h->loaded = true;
   h->load_gen += 1;
+  h->weights_gen += 1;
   return PNVO_OK;
 }
 
@@ -1307,6 +1370,7 @@ int pnvo_destroy(pnvo_handle m) {
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   for (Layer &l : m->convs) {
     free_dev(l.wpk);
+    free_dev(reinterpret_cast<float *&>(l.wpk_x3));
     free_dev(l.gamma);
     free_dev(l.beta);
   }

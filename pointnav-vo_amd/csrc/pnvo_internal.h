@@ -102,6 +102,22 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                  const int *slot_new, const int *xslot, unsigned short *wpk3, hipStream_t s);
 
+// float32 convs on the bf16 matrix cores by three-piece operand splitting (conv_x3.hip)
+struct ConvX3Args {
+  const float *x;                    // [B,H,W,CIN] float32 NHWC
+  const unsigned short *wpk;         // pack_conv_x3_weight()
+  float *y;                          // [B,Ho,Wo,COUTP] raw output
+  const float *in_scale, *in_shift;  // [B,CIN] MODE 1: relu(x*scale+shift) applied while staging
+  float *stats;                      // [B,slots,COUTP,2] GroupNorm partial sums or nullptr
+  int B, H, W, CIN, Ho, Wo, COUTP;
+  int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_x3_plan
+};
+bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
+hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
+hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out,
+                                 hipStream_t s);
+void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);
+
 // Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).
 struct ConvBArgs {
   const unsigned short *x[2];        // [B,H,W,CIN] bf16 NHWC

@@ -18,6 +18,9 @@ struct Layer {
   int hin = 0, win = 0, hout = 0, wout = 0, groups = 1;
   float *wpk = nullptr, *gamma = nullptr, *beta = nullptr;   // device
   std::vector<float> host_w;  // OIHW copy of the loaded weight (source of the bf16 packing, pnvo_bf16.hip)
+  // float32-on-bf16-pipe path (conv_x3.hip): three-piece packed weights, built on first use after a (re)load
+  unsigned short *wpk_x3 = nullptr;
+  unsigned long long x3_gen = 0;
 };
 
 struct TimingRec {
@@ -66,6 +69,7 @@ struct pnvo_model_s {
   bool train_mx = false;                     // the attached training step rebuilds the mx stem operands every step
   int precision = 0;                         // pnvo_set_precision: 0 float32 (default), 1 bfloat16 (BASELINE config 3)
   unsigned long long load_gen = 0;           // bumped by pnvo_load_weights (operands derived lazily are rebuilt)
+  unsigned long long weights_gen = 0;        // bumped by pnvo_load_weights AND by every pnvo_train_refresh (conv_x3 operands)
   void *bf = nullptr;                        // Bf16State (pnvo_bf16.hip)             // set by pnvo_train_forward: its stem operands are rebuilt on the device
 
   int cap = 0;                       // batch the workspace is sized for
@@ -118,6 +122,7 @@ void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, 
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
                   hipStream_t s);
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
+const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name);   // pnvo_train_api.hip: device pointer or nullptr
 void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip
 int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *depth, const float *dd, const float *tdv,
                       const int64_t *actions, int B, float *const *outs, hipStream_t s);

@@ -642,10 +642,19 @@ int pnvo_train_attach(pnvo_handle m, float *params, float *grads, size_t n_float
   return pnvo_train_refresh(m, nullptr);
 }
 
+// device pointer of a parameter inside the caller's flat buffer (nullptr: not attached / unknown name)
+extern "C++" const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name) {
+  if (!m || !m->train) return nullptr;
+  TrainState *t = TS(m);
+  auto it = t->toc.find(name);
+  return it == t->toc.end() ? nullptr : t->params + it->second.off;
+}
+
 int pnvo_train_refresh(pnvo_handle m, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   HIPCHK(m, hipSetDevice(m->device));
   TrainState *t = TS(m);
+  m->weights_gen += 1;               // operands derived lazily from the weights (conv_x3) are rebuilt at their next use
   if (!t->d_segs) {                 // segment table of all re-pack maps (built once; the maps never change after attach)
     std::vector<GatherSeg> segs;
     long start = 0;

@@ -35,9 +35,12 @@ print("WORST", worst)
 assert worst < 1e-4, worst
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
-KNOBS = [{}, {"PNVO_CONV_WSPLIT": "1"}, {"PNVO_CONV_WSPLIT": "0"}, {"PNVO_CONV_TILE": "12"}, {"PNVO_CONV_TILE": "22"},
-         {"PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {"PNVO_CONV3": "tile"}, {"PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"},
-         {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}]
+# default = float32 convs on the bf16 matrix cores (conv_x3.hip); PNVO_CONV=fp32 selects the fp32-MFMA kernels, whose own knobs
+# only matter then
+_FP32 = {"PNVO_CONV": "fp32"}
+KNOBS = [{}, _FP32, {**_FP32, "PNVO_CONV_WSPLIT": "1"}, {**_FP32, "PNVO_CONV_WSPLIT": "0"}, {**_FP32, "PNVO_CONV_TILE": "12"},
+         {**_FP32, "PNVO_CONV_TILE": "22"}, {**_FP32, "PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {**_FP32, "PNVO_CONV3": "tile"},
+         {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
