@@ -319,7 +319,9 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   }
   if ((4 / a.wn) * *mw < a.MT) return false;
   // channel chunk: the largest multiple-of-32 divisor of CIN (power-of-two steps) whose three planes fit 72 KB
-  int ck = a.CIN;
+  // (a power of two: the stager's thread -> (pixel, 8-channel group) split uses masks; 32 always divides CIN)
+  int ck = 32;
+  while (ck < 256 && a.CIN % (2 * ck) == 0) ck *= 2;
   while (ck > 32 && (size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)72 * 1024) ck /= 2;
   if ((size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
   if (a.CIN % ck) return false;
@@ -377,8 +379,10 @@ void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int cou
 
 // The same packing on the device from an OIHW float32 weight (the training step's flat parameter buffer: after an optimiser
 // step the eval forward must see the new weights without a host round trip).  One thread per packed element triple.
+// transposed = 1: the operand of the backward-data conv of the layer whose OIHW weight is `w` [cin][cout][T] as seen from
+// here (output channels = the layer's inputs, input channels = its outputs, taps flipped).
 __global__ __launch_bounds__(256) void conv_x3_repack_kernel(const float *w, int cout, int cin, int cinp, int coutp, int T,
-                                                           unsigned short *out, long total) {
+                                                           int transposed, unsigned short *out, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int j = (int)(e & 7), ln = (int)((e >> 3) & 63);
@@ -388,7 +392,8 @@ __global__ __launch_bounds__(256) void conv_x3_repack_kernel(const float *w, int
   r /= ntt;
   const int kc = (int)(r % kct), tap = (int)(r / kct);
   const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
-  const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * T + tap] : 0.f;
+  const float v = (co < cout && ci < cin) ? (transposed ? w[((long)ci * cout + co) * T + (T - 1 - tap)] : w[((long)co * cin + ci) * T + tap])
+                                          : 0.f;
   const unsigned h = pack2(v, 0.f) & 0xffffu;
   const float r1 = v - lo_f(h);
   const unsigned m = pack2(r1, 0.f) & 0xffffu;
@@ -399,11 +404,11 @@ __global__ __launch_bounds__(256) void conv_x3_repack_kernel(const float *w, int
   out[base + 1024] = (unsigned short)l;
 }
 
-hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out,
-                                 hipStream_t s) {
+hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,
+                                 unsigned short *out, hipStream_t s) {
   const long total = (long)kh * kw * (cinp / 16) * (coutp / 32) * 512;
   hipLaunchKernelGGL(conv_x3_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cout, cin, cinp, coutp,
-                     kh * kw, out, total);
+                     kh * kw, transposed, out, total);
   return hipGetLastError();
 }
 

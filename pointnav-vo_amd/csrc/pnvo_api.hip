@@ -478,10 +478,10 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   const double bytes = 4.0 * ((double)B * l.hin * l.win * l.cin + (double)M * l.cout + (double)l.cout * l.cin * l.k * l.kw);
   const char *sel = std::getenv("PNVO_CONV");
   // 3x3 stride-1 convs with GroupNorm: float32 results from the bf16 matrix cores (three-piece operands, conv_x3.hip);
-  // PNVO_CONV=fp32 keeps the fp32-MFMA kernels.  Not in the training forward (its saved activations feed the backward kernels
-  // that were validated against the fp32 forward), not with a fused stem source, bias or output ReLU.
+  // PNVO_CONV=fp32 keeps the fp32-MFMA kernels.  Also in the training forward (the three-piece operand is rebuilt on the
+  // device after every optimiser step); not with a fused stem source, bias or output ReLU.
   if (ss && src == nullptr && bias == nullptr && !relu_out && l.k == 3 && l.kw == 3 && l.stride == 1 && l.pad == 1 &&
-      y_cstride == l.coutp && !l.host_w.empty() && !m->in_train_forward && !(sel && std::strcmp(sel, "x3") != 0)) {
+      y_cstride == l.coutp && !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0)) {
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.B = B;
@@ -500,7 +500,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         if (!lm.wpk_x3) HIPCHK(m, hipMalloc((void **)&lm.wpk_x3, nel * 2));
         const float *dev_w = m->train ? pnvo_train_weight_ptr(m, l.name + ".weight") : nullptr;
         if (dev_w != nullptr) {          // training attached: the current weight lives in the flat parameter buffer
-          HIPCHK(m, launch_conv_x3_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, 3, 3, lm.wpk_x3, s));
+          HIPCHK(m, launch_conv_x3_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, 3, 3, 0, lm.wpk_x3, s));
         } else {
           std::vector<unsigned short> pk(nel);
           pack_conv_x3_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, 3, 3, pk.data());

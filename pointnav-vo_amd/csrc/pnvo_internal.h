@@ -114,8 +114,8 @@ struct ConvX3Args {
 };
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
-hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out,
-                                 hipStream_t s);
+hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,
+                                 unsigned short *out, hipStream_t s);
 void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);
 
 // Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).

@@ -39,6 +39,8 @@ struct TrainState {
   std::vector<PackMap> maps;
   std::vector<float *> dgrad_w;     // per conv of m->convs (nullptr for the stem: no input gradient)
   std::vector<std::array<float *, 4>> dgrad_wph;   // stride-2 3x3 convs: one sub-kernel per output parity phase (ph*2 + pw)
+  std::vector<unsigned short *> dgrad_x3;          // 3x3 stride-1 convs: three-piece operand of the backward-data conv (conv_x3.hip)
+  std::vector<unsigned long long> dgrad_x3_gen;    //   ... built from the flat parameters when m->weights_gen moved
   float *fc_t = nullptr, *head_t = nullptr;
   int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
   GatherSeg *d_segs = nullptr;      // all re-pack maps as one segment table (pnvo_train_refresh)
@@ -133,6 +135,8 @@ int build_maps(pnvo_handle m, TrainState *t) {
   const pnvo_config &c = m->cfg;
   t->dgrad_w.assign(m->convs.size(), nullptr);
   t->dgrad_wph.assign(m->convs.size(), std::array<float *, 4>{nullptr, nullptr, nullptr, nullptr});
+  t->dgrad_x3.assign(m->convs.size(), nullptr);
+  t->dgrad_x3_gen.assign(m->convs.size(), 0);
   for (size_t li = 0; li < m->convs.size(); ++li) {
     Layer &l = m->convs[li];
     const TocEnt *w = need(m, t, l.name + ".weight", &rc);
@@ -528,6 +532,39 @@ int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw,
       }
     return PNVO_OK;
   }
+  // 3x3 stride-1: float32 results from the bf16 matrix cores (three-piece operands), as in the forward (PNVO_CONV=fp32: off)
+  static const char *csel = std::getenv("PNVO_CONV");
+  if (l.k == 3 && l.kw == 3 && l.stride == 1 && l.pad == 1 && !accum && l.cin % 32 == 0 && !(csel && std::strcmp(csel, "x3") != 0)) {
+    ConvX3Args xa;
+    std::memset(&xa, 0, sizeof(xa));
+    xa.B = B;
+    xa.H = l.hout;
+    xa.W = l.wout;
+    xa.CIN = l.coutp;
+    xa.Ho = l.hin;
+    xa.Wo = l.win;
+    xa.COUTP = l.cin;
+    int mw = 0, nw = 0;
+    size_t ldsb = 0;
+    auto it = t->toc.find(l.name + ".weight");
+    if (it != t->toc.end() && conv_x3_plan(xa, 3, 1, &mw, &nw, &ldsb)) {
+      if (!t->dgrad_x3[li] || t->dgrad_x3_gen[li] != m->weights_gen) {
+        const size_t nel = (size_t)9 * l.coutp * l.cin * 3;
+        if (!t->dgrad_x3[li]) {
+          int rc = dmalloc(m, (void **)&t->dgrad_x3[li], nel * 2);
+          if (rc != PNVO_OK) return rc;
+        }
+        HIPCHK(m, launch_conv_x3_repack(t->params + it->second.off, l.cin, l.cout, l.coutp, l.cin, 3, 3, 1, t->dgrad_x3[li], s));
+        t->dgrad_x3_gen[li] = m->weights_gen;
+      }
+      xa.x = draw;
+      xa.wpk = t->dgrad_x3[li];
+      xa.y = dx;
+      PnvoTimed tm(m, s, "dgrad:" + l.name, 2.0 * (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw, 0.0);
+      HIPCHK(m, launch_conv_x3(xa, 3, 1, 0, mw, nw, ldsb, s));
+      return PNVO_OK;
+    }
+  }
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = draw;
@@ -601,6 +638,7 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->d_ref_of_new);
   dfree(t->d_ddmaps);
   dfree(t->d_mxmaps);
+  for (unsigned short *&q : t->dgrad_x3) dfree(q);
   dfree(t->d_segs);
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
