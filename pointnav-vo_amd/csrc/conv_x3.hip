@@ -13,6 +13,7 @@
 // LDS, producer's GroupNorm + ReLU applied once per element while staging, zero padding after it, pixel table for ragged
 // tiles, raw float32 output + per-slot GroupNorm partial sums) with float32 activations in HBM: the stager splits every
 // element into its three pieces (three LDS planes), the weights are split at load (three B fragments per step).
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -44,7 +45,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int PAD = KS / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const u32x4 *wpk = reinterpret_cast<const u32x4 *>(p.wpk);
 
   const int ntiles = p.B * p.tiles_r * p.tiles_c;
   const int chunk = (ntiles + 7) >> 3;
@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int dr = PS / PC, dc = PS - dr * PC;
   const int nppix = PR * PC;
 
+  unsigned long long c_stage = 0, c_mm = 0, t_0 = __builtin_readcyclecounter(), r_0 = wall_clock64();
   for (int ck0 = 0; ck0 < p.CIN; ck0 += CK) {
+    unsigned long long t_a = __builtin_readcyclecounter();
     if (ck0 > 0) __syncthreads();                                        // the previous chunk's patch is no longer read
     {
       f32x4 sc0, sc1, sh0, sh1;
@@ -159,6 +161,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     __syncthreads();
+    unsigned long long t_b = __builtin_readcyclecounter();
+    c_stage += t_b - t_a;
 
     // ---- compute: steps s = (tap, 16-channel chunk).  B fragments (three weight pieces per N-tile) stream from L2 one
     // step ahead (two register sets); A fragments (three planes per M-tile) come from LDS at the start of the step.
@@ -170,31 +174,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int kcc = CK >> 4;                                             // k-chunks per staged chunk
     const int nsteps = KS * KS * kcc;
-    const int kc_base = ck0 >> 4;
-    auto loadA = [&](int s, u32x4 (*a)[MW]) {
-      const int tap = s / kcc, kc = s - tap * kcc;
-      const int kh = tap / KS, kw = tap - kh * KS;
-      const unsigned toff = (unsigned)((kh * PC + kw) * pitch + kc * 32);
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-        for (int i = 0; i < MW; ++i) a[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + toff);
-    };
-    auto loadB = [&](int s, u32x4 (*b)[NW]) {
-      const int tap = s / kcc, kc = s - tap * kcc;
-      const u32x4 *wb = wpk + ((long)(tap * kct + kc_base + kc) * ntt) * 3 * 64;
-#pragma unroll
-      for (int j = 0; j < NW; ++j) {
-        const int nt = min(wave_n * NW + j, ntt - 1);                    // (N-tiles past the layer's repeat the last one)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) b[pc][j] = wb[(nt * 3 + pc) * 64 + lane];
+    // The step being fetched (one ahead of the one being multiplied), kept as running offsets: a division per step costs the
+    // wave ~50 scalar instructions between two MFMA groups, and with one wave per SIMD (6 x 11 maps) nobody fills that gap.
+    const unsigned kstep = (unsigned)ntt * 3072u;                        // bytes of one k-chunk of B (all N-tiles, three pieces)
+    const char *wb_n = reinterpret_cast<const char *>(p.wpk) + (long)(ck0 >> 4) * kstep;
+    unsigned toff_n = 0;                                                 // patch byte offset of the step's (tap, k-chunk)
+    int kc_n = 0, kw_n = 0;
+    auto advance = [&]() {
+      ++kc_n;
+      toff_n += 32;
+      wb_n += kstep;
+      if (kc_n == kcc) {
+        kc_n = 0;
+        toff_n += (unsigned)(pitch - kcc * 32);
+        wb_n += (long)(kct - kcc) * kstep;
+        if (++kw_n == KS) {
+          kw_n = 0;
+          toff_n += (unsigned)((PC - KS) * pitch);
+        }
       }
     };
-    auto mfmas = [&](const u32x4 (*a)[MW], const u32x4 (*b)[NW]) {
+    unsigned voff[NW];                                                   // lane's byte offset inside a k-chunk of B
+#pragma unroll
+    for (int j = 0; j < NW; ++j) voff[j] = (unsigned)min(wave_n * NW + j, ntt - 1) * 3072u + (unsigned)lane * 16u;   // (N-tiles past the layer's repeat the last one)
+    // A fragments of M-tile i (three planes) / B fragments (three weight pieces per N-tile) of the step being fetched
+    auto loadA = [&](int i, u32x4 (*a)[MW]) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) a[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + toff_n);
+    };
+    auto loadB = [&](u32x4 (*b)[NW]) {
 #pragma unroll
       for (int j = 0; j < NW; ++j)
 #pragma unroll
-        for (int i = 0; i < MW; ++i) {
+        for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wb_n + (size_t)voff[j] + pc * 1024);
+    };
+    // One step: M-tile by M-tile; as soon as an M-tile's MFMAs are issued its A registers take the NEXT step's fragments, so
+    // the LDS latency hides behind the other M-tiles' MFMAs
+    auto step = [&](u32x4 (*a)[MW], const u32x4 (*b)[NW]) {
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
           // smallest terms first: a1 w1, a2 w0, a0 w2, a1 w0, a0 w1, a0 w0
           constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
@@ -202,23 +222,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[TA[t]][i]),
                                                                 __builtin_bit_cast(bf16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(i, a);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     u32x4 a[3][MW], b0[3][NW], b1[3][NW];
-    loadB(0, b0);
+    loadB(b0);
+#pragma unroll
+    for (int i = 0; i < MW; ++i) loadA(i, a);
+    advance();                                                           // -> step 1
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += 2) {                                // nsteps is even for every supported shape
-      loadA(s, a);
-      loadB(s + 1, b1);
+      const bool more = s + 2 < nsteps;                                  // (the last iteration re-fetches step s + 1: unused)
+      loadB(b1);
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(a, b0);
+      step(a, b0);                                                       // multiplies step s, fetches A of step s + 1
+      if (more) advance();
+      loadB(b0);
       __builtin_amdgcn_sched_barrier(0);
-      loadA(s + 1, a);
-      loadB(s + 2 < nsteps ? s + 2 : s, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(a, b1);
-      __builtin_amdgcn_sched_barrier(0);
+      step(a, b1);                                                       // multiplies step s + 1, fetches A of step s + 2
+      if (more) advance();
     }
+    c_mm += __builtin_readcyclecounter() - t_b;
   }
+  unsigned long long t_e = __builtin_readcyclecounter();
 
   // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot).
   const int rr16 = lane >> 5;
@@ -255,6 +283,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+  if (p.prof && lane == 0 && blockIdx.x == 13 && blockIdx.y == 0) {
+    const unsigned long long t_f = __builtin_readcyclecounter();
+    unsigned long long *d = p.prof + wave * 8;
+    d[0] = c_stage;
+    d[1] = c_mm;
+    d[2] = t_f - t_e;
+    d[3] = t_f - t_0;
+    d[4] = wall_clock64() - r_0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -266,9 +303,7 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_>), grid, dim3(256), ldsb, s, a);   \
     return hipGetLastError();                                                                         \
   }
-  PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 4, 1) PNVO_X3(1, 4, 1)
-  PNVO_X3(0, 3, 1) PNVO_X3(1, 3, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)
-  PNVO_X3(0, 4, 2) PNVO_X3(1, 4, 2)
+  PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
 #undef PNVO_X3
   return hipErrorInvalidValue;
 }
@@ -338,7 +373,28 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   return true;
 }
 
-hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s) {
+hipError_t launch_conv_x3(const ConvX3Args &a0, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s) {
+  ConvX3Args a = a0;
+  static unsigned long long *prof = nullptr;             // PNVO_X3_PROF=1: phase cycles of workgroup 13, printed per launch (syncs)
+  static const bool want = std::getenv("PNVO_X3_PROF") != nullptr;
+  if (want && !prof) {
+    (void)hipMalloc((void **)&prof, 512);
+    (void)hipMemset(prof, 0, 512);
+  }
+  a.prof = prof;
+  struct Dump {
+    const ConvX3Args &a; int mw, nw; hipStream_t s; unsigned long long *prof;
+    ~Dump() {
+      static int calls = 0;
+      if (!prof || ++calls > 40) return;
+      unsigned long long h[64];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h, prof, 512, hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[pnvo] conv_x3 B %d %dx%d cin %d cout %d tile %dx%d MT %d CK %d (%d,%d) wn %d: wave0 stage %llu mfma %llu epi %llu total %llu "
+                           "(100MHz ticks %llu) | wave3 stage %llu mfma %llu epi %llu total %llu\n", a.B, a.Ho, a.Wo, a.CIN, a.COUTP, a.TR, a.TC,
+                   a.MT, a.CK, mw, nw, a.wn, h[0], h[1], h[2], h[3], h[4], h[24], h[25], h[26], h[27]);
+    }
+  } dump{a, mw, nw, s, prof};
   const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
   const int ntt = a.COUTP / 32, per_wg = a.wn * nw;   // N-tiles one workgroup covers
   dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((ntt + per_wg - 1) / per_wg), 1u);
