@@ -303,7 +303,7 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_>), grid, dim3(256), ldsb, s, a);   \
     return hipGetLastError();                                                                         \
   }
-  PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
+  PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
 #undef PNVO_X3
   return hipErrorInvalidValue;
 }
@@ -320,7 +320,16 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   // cycle and wave from LDS alone): such layers stay on the fp32 kernels.
   if (ntt < 2) return false;
   int TR, TC;
-  if (a.Wo >= 32) {
+  if (stride == 2 && ks == 3) {
+    // the patch of a stride-2 conv is four times its output tile: the tile is what 76 KB of three-piece patch allow at 32-channel
+    // chunks (PR x PC <= 324 pixels of 240 B): 4 x 16 outputs on the wide maps, else whole rows
+    TC = a.Wo >= 32 ? 16 : a.Wo;
+    const int pc = 2 * TC + 1;
+    TR = (324 / pc - 1) / 2;
+    if (TR < 1) return false;
+    if (TR > a.Ho) TR = a.Ho;
+    while (TR > 1 && TR * TC > (ntt == 2 ? 64 : (ntt == 4 ? 128 : 96))) --TR;    // M-tiles the wave grid below covers
+  } else if (a.Wo >= 32) {
     TR = 8;
     TC = 16;
   } else {
@@ -341,7 +350,7 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   // wave grid (4 / wn) x wn and accumulators per wave (accumulators + one A set + two B sets within 256 registers)
   if (ntt == 2) {
     a.wn = 2;
-    *mw = 2;
+    *mw = a.MT > 2 ? 2 : 1;
     *nw = 1;
   } else if (ntt == 4) {
     a.wn = 2;

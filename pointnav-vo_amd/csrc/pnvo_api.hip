@@ -291,7 +291,7 @@ size_t stats_floats(const Layer &l, int B) {
   choose_tile(M, l.coutp, &MT, &NT);
   int slots = conv_slots((int)P, MT), s2 = 0;
   if (layer_on_lds(l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
-  if (l.k == 3 && l.stride == 1) {                               // conv_x3: slots = tiles x M-tiles
+  if (l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || l.stride == 2)) {   // conv_x3: slots = tiles x M-tiles
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.B = B;
@@ -303,7 +303,7 @@ size_t stats_floats(const Layer &l, int B) {
     xa.COUTP = l.coutp;
     int mw, nw;
     size_t ldsb;
-    if (conv_x3_plan(xa, 3, 1, &mw, &nw, &ldsb) && xa.slots > slots) slots = xa.slots;
+    if (conv_x3_plan(xa, 3, l.stride, &mw, &nw, &ldsb) && xa.slots > slots) slots = xa.slots;
   }
   return (size_t)B * (size_t)slots * l.coutp * 2;
 }
@@ -480,7 +480,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   // 3x3 stride-1 convs with GroupNorm: float32 results from the bf16 matrix cores (three-piece operands, conv_x3.hip);
   // PNVO_CONV=fp32 keeps the fp32-MFMA kernels.  Also in the training forward (the three-piece operand is rebuilt on the
   // device after every optimiser step); not with a fused stem source, bias or output ReLU.
-  if (ss && src == nullptr && bias == nullptr && !relu_out && l.k == 3 && l.kw == 3 && l.stride == 1 && l.pad == 1 &&
+  if (ss && src == nullptr && bias == nullptr && !relu_out && l.k == 3 && l.kw == 3 && (l.stride == 1 || (l.stride == 2 && !std::getenv("PNVO_X3_S2_OFF"))) && l.pad == 1 &&
       y_cstride == l.coutp && !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0)) {
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
@@ -493,7 +493,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     xa.COUTP = l.coutp;
     int mw = 0, nw = 0;
     size_t ldsb = 0;
-    if (conv_x3_plan(xa, 3, 1, &mw, &nw, &ldsb)) {              // (the statistics buffer is sized for it: stats_floats)
+    if (conv_x3_plan(xa, 3, l.stride, &mw, &nw, &ldsb)) {       // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
       if (!lm.wpk_x3 || lm.x3_gen != m->weights_gen) {           // (re)build the three-piece operand of this layer
         const size_t nel = (size_t)9 * l.cinp * l.coutp * 3;
@@ -517,7 +517,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       xa.stats = m->stats;
       {
         Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
-        HIPCHK(m, launch_conv_x3(xa, 3, 1, in_scale ? 1 : 0, mw, nw, ldsb, s));
+        HIPCHK(m, launch_conv_x3(xa, 3, l.stride, in_scale ? 1 : 0, mw, nw, ldsb, s));
       }
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
