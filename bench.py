@@ -145,11 +145,13 @@ def timed_steps(step, steps, sync_all, dev):
     """EXACTLY `steps` calls between two (barrier + synchronize) brackets -> wall seconds; one event per step boundary on
     the launch stream gives the per-step distribution without serialising anything."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    # one untimed step bracketed by events first: on a cold box the first event-recorded step of a process sometimes takes
+    # untimed steps bracketed by events first: on a cold box the first event-recorded step of a process sometimes takes
     # ~50 ms of host time (seen as `slowest_step: 0` before this line existed) — first-use costs belong to the warm-up
-    ev[0].record()
-    step()
-    ev[1].record()
+    # (and on the first process of a fresh box a training step ~10 steps into the run stalls 30-40 ms once: three of them here)
+    for i in range(min(3, steps)):
+        ev[i].record()
+        step()
+        ev[i + 1].record()
     sync_all()
     t0 = time.perf_counter()
     ev[0].record()
