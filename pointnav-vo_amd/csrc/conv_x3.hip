@@ -318,7 +318,6 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   // 16/MW bytes of B (L1, 64 B/clk per CU) at full rate, eight waves per CU.  (MW, NW) = (3, 2) keeps both under their limits
   // (64 and 43 B/clk); (2, 2) sits on the L1 limit, (2, 1) on both.  A layer with one N-tile cannot reuse A at all (16 B per
   // cycle and wave from LDS alone): such layers stay on the fp32 kernels.
-  if (ntt < 2) return false;
   int TR, TC;
   if (stride == 2 && ks == 3) {
     // the patch of a stride-2 conv is four times its output tile: the tile is what 76 KB of three-piece patch allow at 32-channel
@@ -329,6 +328,14 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
     if (TR < 1) return false;
     if (TR > a.Ho) TR = a.Ho;
     while (TR > 1 && TR * TC > (ntt == 2 ? 64 : (ntt == 4 ? 128 : 96))) --TR;    // M-tiles the wave grid below covers
+  } else if (ntt == 1) {
+    // one N-tile (32 output channels): all four waves along M, two M-tiles each -> 16 x 16 outputs (18 x 18 patch = 76 KB)
+    if (stride != 1 || ks != 3 || a.CIN != 32) return false;
+    TC = a.Wo >= 16 ? 16 : a.Wo;
+    TR = 256 / TC;
+    while (TR > 1 && (TR + 2) * (TC + 2) > 324) --TR;
+    if (TR > a.Ho) TR = a.Ho;
+    if (TR * TC <= 96) return false;                               // (small maps: not worth it)
   } else if (a.Wo >= 32) {
     TR = 8;
     TC = 16;
@@ -348,7 +355,11 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   a.PR = (TR - 1) * cs + ks;
   a.PC = (TC - 1) * cs + ks;
   // wave grid (4 / wn) x wn and accumulators per wave (accumulators + one A set + two B sets within 256 registers)
-  if (ntt == 2) {
+  if (ntt == 1) {
+    a.wn = 1;
+    *mw = 2;
+    *nw = 1;
+  } else if (ntt == 2) {
     a.wn = 2;
     *mw = a.MT > 2 ? 2 : 1;
     *nw = 1;
