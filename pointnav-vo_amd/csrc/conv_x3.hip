@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned long long t_a = __builtin_readcyclecounter();
     if (ck0 > 0) __syncthreads();                                        // the previous chunk's patch is no longer read
     {
-      f32x4 sc0, sc1, sh0, sh1;
-      if (MODE == 1) {
+      f32x4 sc0, sc1, sh0, sh1, rs0, rs1, rt0, rt1;
+      const bool res_ss = MODE == 2 && p.res_scale != nullptr;
+      if (MODE >= 1) {
         const float *ps = p.in_scale + (long)n * p.CIN + ck0 + 8 * cg;
         const float *pt = p.in_shift + (long)n * p.CIN + ck0 + 8 * cg;
         sc0 = *reinterpret_cast<const f32x4 *>(ps);
@@ -105,23 +106,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sh0 = *reinterpret_cast<const f32x4 *>(pt);
         sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
       }
+      if (res_ss) {
+        const float *ps = p.res_scale + (long)n * p.CIN + ck0 + 8 * cg;
+        const float *pt = p.res_shift + (long)n * p.CIN + ck0 + 8 * cg;
+        rs0 = *reinterpret_cast<const f32x4 *>(ps);
+        rs1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+        rt0 = *reinterpret_cast<const f32x4 *>(pt);
+        rt1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+      }
       int pr = pl / PC, pc = pl - pr * PC;
-      const float *xb = p.x + ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
-      for (int pix = pl; pix < nppix; pix += 2 * PS) {
-        f32x4 v[2][2];
+      const long img = ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
+      const float *xb = p.x + img;
+      // two pixels per thread and round; the loads of the next round are in flight while this one is split and stored
+      struct Round {
+        f32x4 v[2][2], w[2][2];
         unsigned off[2];
-        bool ok[2], in[2];
+        int gofs[2];
+        bool ok[2], in[2], own[2];
+      };
+      auto fetch = [&](int pix, Round &r) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int hi = hi0 + pr * PSTEP, wi = wi0 + pc * PSTEP;
-          ok[k] = pix + k * PS < nppix;
-          in[k] = ok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-          off[k] = (unsigned)((pr * PC + pc) * pitch + 16 * cg);
-          v[k][0] = v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (in[k]) {
+          r.ok[k] = pix + k * PS < nppix;
+          r.in[k] = r.ok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+          r.off[k] = (unsigned)((pr * PC + pc) * pitch + 16 * cg);
+          r.v[k][0] = r.v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (MODE == 2) {
+            // the tile owns the input pixels under its own outputs (stride 2: the 2 x 2 block of each): every pixel once
+            r.own[k] = r.in[k] && blockIdx.y == 0 && pr >= PAD && pr < PAD + p.TR * CS && pc >= PAD && pc < PAD + p.TC * CS;
+            r.gofs[k] = (hi * p.W + wi) * p.CIN;
+          }
+          if (r.in[k]) {
             const float *src = xb + ((long)hi * p.W + wi) * p.CIN;
-            v[k][0] = *reinterpret_cast<const f32x4 *>(src);
-            v[k][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+            r.v[k][0] = *reinterpret_cast<const f32x4 *>(src);
+            r.v[k][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+            if (MODE == 2) {
+              const float *rsrc = p.res + img + ((long)hi * p.W + wi) * p.CIN;
+              r.w[k][0] = *reinterpret_cast<const f32x4 *>(rsrc);
+              r.w[k][1] = *reinterpret_cast<const f32x4 *>(rsrc + 4);
+            }
           }
           pr += dr;
           pc += dc;
@@ -130,18 +154,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pr += 1;
           }
         }
+      };
+      auto split_store = [&](const Round &r) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          if (!ok[k]) continue;
+          if (!r.ok[k]) continue;
           float f[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float t = v[k][e >> 2][e & 3];
+            float t = r.v[k][e >> 2][e & 3];
             if (MODE == 1) {                                             // the producer's GroupNorm + ReLU; zero padding AFTER it
               const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
-              t = in[k] ? fmaxf(__builtin_fmaf(t, sc[e & 3], sh[e & 3]), 0.f) : 0.f;
+              t = r.in[k] ? fmaxf(__builtin_fmaf(t, sc[e & 3], sh[e & 3]), 0.f) : 0.f;
+            }
+            if (MODE == 2) {                                             // block tail: the same operations as residual_kernel
+              const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
+              float u = r.w[k][e >> 2][e & 3];
+              if (res_ss) u = __builtin_fmaf(u, (e < 4 ? rs0 : rs1)[e & 3], (e < 4 ? rt0 : rt1)[e & 3]);
+              t = r.in[k] ? fmaxf(__builtin_fmaf(t, sc[e & 3], sh[e & 3]) + u, 0.f) : 0.f;
             }
             f[e] = t;
+          }
+          if (MODE == 2 && r.own[k]) {
+            float *dst = p.xout + img + r.gofs[k];
+            *reinterpret_cast<f32x4 *>(dst) = f32x4{f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{f[4], f[5], f[6], f[7]};
           }
           u32x4 o0, o1, o2;                                              // the three bf16 pieces of the eight channels
 #pragma unroll
@@ -154,9 +191,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             o1[e] = m;
             o2[e] = pack2(ra - lo_f(m), rb - hi_f(m));
           }
-          *reinterpret_cast<u32x4 *>(lds + off[k]) = o0;
-          *reinterpret_cast<u32x4 *>(lds + plane + off[k]) = o1;
-          *reinterpret_cast<u32x4 *>(lds + 2 * plane + off[k]) = o2;
+          *reinterpret_cast<u32x4 *>(lds + r.off[k]) = o0;
+          *reinterpret_cast<u32x4 *>(lds + plane + r.off[k]) = o1;
+          *reinterpret_cast<u32x4 *>(lds + 2 * plane + r.off[k]) = o2;
+        }
+      };
+      constexpr bool PIPE = !(MODE == 2 && MW * NW >= 6);              // (the block-tail stager of the 96-accumulator tile would spill)
+      if (PIPE) {
+        Round cur, nxt;
+        fetch(pl, cur);
+        for (int pix = pl; pix < nppix; pix += 2 * PS) {
+          const bool more = pix + 2 * PS < nppix;
+          if (more) fetch(pix + 2 * PS, nxt);
+          split_store(cur);
+          if (more) cur = nxt;
+        }
+      } else {
+        for (int pix = pl; pix < nppix; pix += 2 * PS) {
+          Round cur;
+          fetch(pix, cur);
+          split_store(cur);
         }
       }
     }
@@ -258,20 +312,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32x4 ent[4];
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
+    unsigned flags = 0;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) flags |= ent[g4][0] | ent[g4][1] | ent[g4][2] | ent[g4][3];
+    const bool whole = !__any((int)(flags >> 31));                       // wave-uniform
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int nt = wave_n * NW + j;
       if (nt >= ntt) continue;
       const int co = nt * 32 + (lane & 31);
       float s1 = 0.f, s2 = 0.f;
+      if (whole) {                                                       // every pixel of the M-tile exists: plain stores
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned e = ent[r >> 2][r & 3];
-        const bool ok = (int)e >= 0;
-        const float v = ok ? acc[i][j][r] : 0.f;
-        if (ok) (p.y + ybase + co)[e] = v;
-        s1 += v;
-        s2 = __builtin_fmaf(v, v, s2);
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          (p.y + ybase + co)[ent[r >> 2][r & 3]] = v;
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned e = ent[r >> 2][r & 3];
+          const bool ok = (int)e >= 0;
+          const float v = ok ? acc[i][j][r] : 0.f;
+          if (ok) (p.y + ybase + co)[e] = v;
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
+        }
       }
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
@@ -304,6 +372,7 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
     return hipGetLastError();                                                                         \
   }
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
+  PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2)
 #undef PNVO_X3
   return hipErrorInvalidValue;
 }

@@ -427,10 +427,43 @@ void pnvo_drop_graphs(pnvo_handle m) {
   m->seen.clear();
 }
 
+namespace {
+// 3x3 (stride 1 or 2, pad 1) GroupNorm-ed convs run on conv_x3.hip unless PNVO_CONV selects another kernel family
+bool x3_layer(const Layer &l) {
+  const char *sel = std::getenv("PNVO_CONV");
+  return l.k == 3 && l.kw == 3 && (l.stride == 1 || (l.stride == 2 && !std::getenv("PNVO_X3_S2_OFF"))) && l.pad == 1 &&
+         !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0);
+}
+bool x3_args(const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
+  std::memset(&xa, 0, sizeof(xa));
+  xa.B = B;
+  xa.H = l.hin;
+  xa.W = l.win;
+  xa.CIN = l.cinp;
+  xa.Ho = l.hout;
+  xa.Wo = l.wout;
+  xa.COUTP = l.coutp;
+  return conv_x3_plan(xa, 3, l.stride, mw, nw, ldsb);
+}
+}  // namespace
+
+bool pnvo_conv_on_x3(const Layer &l, int B) {
+  if (!x3_layer(l) || l.groups <= 0) return false;
+  ConvX3Args xa;
+  int mw, nw;
+  size_t ldsb;
+  return x3_args(l, B, xa, &mw, &nw, &ldsb);
+}
+
+bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B) {
+  if (m->tap_dst != nullptr || std::getenv("PNVO_TAIL") != nullptr) return false;   // taps want the block outputs of the plain schedule; PNVO_TAIL=separate: the pass of its own
+  return pnvo_conv_on_x3(l, B);
+}
+
 // One conv + (optionally) the GroupNorm statistics finalisation that follows it.
 int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
                   float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
-                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out) {
+                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail) {
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
   if (src != nullptr) {          // fused stem: gather A from the observation tensors
@@ -480,8 +513,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   // 3x3 stride-1 convs with GroupNorm: float32 results from the bf16 matrix cores (three-piece operands, conv_x3.hip);
   // PNVO_CONV=fp32 keeps the fp32-MFMA kernels.  Also in the training forward (the three-piece operand is rebuilt on the
   // device after every optimiser step); not with a fused stem source, bias or output ReLU.
-  if (ss && src == nullptr && bias == nullptr && !relu_out && l.k == 3 && l.kw == 3 && (l.stride == 1 || (l.stride == 2 && !std::getenv("PNVO_X3_S2_OFF"))) && l.pad == 1 &&
-      y_cstride == l.coutp && !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0)) {
+  if (ss && src == nullptr && bias == nullptr && !relu_out && y_cstride == l.coutp && x3_layer(l)) {
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.B = B;
@@ -515,9 +547,16 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       xa.in_scale = in_scale;
       xa.in_shift = in_shift;
       xa.stats = m->stats;
+      if (tail != nullptr) {
+        if (in_scale == nullptr) return fail(m, PNVO_ERR_STATE, "block tail without the conv's GroupNorm scale/shift");
+        xa.res = tail->res;
+        xa.res_scale = tail->res_scale;
+        xa.res_shift = tail->res_shift;
+        xa.xout = tail->out;
+      }
       {
-        Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
-        HIPCHK(m, launch_conv_x3(xa, 3, l.stride, in_scale ? 1 : 0, mw, nw, ldsb, s));
+        Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes + (tail ? 8.0 * B * l.hin * l.win * l.cin : 0.0));
+        HIPCHK(m, launch_conv_x3(xa, 3, l.stride, tail ? 2 : (in_scale ? 1 : 0), mw, nw, ldsb, s));
       }
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
@@ -525,6 +564,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       return PNVO_OK;
     }
   }
+  if (tail != nullptr) return fail(m, PNVO_ERR_STATE, "block tail handed to a conv that cannot take it (" + l.name + ")");
   const bool lds3 = conv3_lds_supported(a) && !(sel && std::strcmp(sel, "generic") == 0);
   if (lds3) {                    // 3x3 stride-1 residual-stage conv: input patch staged in LDS
     int nt = (l.coutp / 32) % 2 == 0 ? 2 : 1;
@@ -1163,6 +1203,8 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   if ((rc = maybe_tap(m, "maxpool", cur, (size_t)B * m->Hp * m->Wp * stem.coutp, s)) != PNVO_OK) return rc;
 
   // (a8) residual stages
+  BlockTail tail{};
+  bool have_tail = false;
   for (int stage = 1; stage <= 4; ++stage) {
     for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
       if (m->bottleneck) {                           // conv1x1 -> GN -> ReLU -> conv3x3(s) -> GN -> ReLU -> conv1x1 -> GN
@@ -1197,10 +1239,17 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       const Layer &c1 = m->convs[li++];
       const Layer &c2 = m->convs[li++];
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
-      if ((rc = run_conv(m, c1, B, cur, nullptr, nullptr, m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s)) != PNVO_OK)
+      if (have_tail) {           // the previous block's tail rides on this conv's stager, which also writes the block output
+        if ((rc = pnvo_run_conv(m, c1, B, m->rawB, m->ssB[0], m->ssB[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr,
+                                nullptr, nullptr, &tail)) != PNVO_OK)
+          return rc;
+        std::swap(cur, nxt);
+        have_tail = false;
+      } else if ((rc = run_conv(m, c1, B, cur, nullptr, nullptr, m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s)) != PNVO_OK) {
         return rc;
+      }
       const long P = (long)c2.hout * c2.wout;
-      if (!layer_on_lds(c2, nullptr) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20)) {
+      if (!layer_on_lds(c2, nullptr) && !pnvo_conv_on_x3(c2, B) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20)) {
         // small deep stage on the generic kernel: its per-tap GroupNorm+ReLU prologue costs more than one streaming
         // pass over the (L2-sized) tensor, so normalise once and run the conv on final activations
         {
@@ -1217,11 +1266,20 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
         const Layer &cd = m->convs[li++];
         if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK)
           return rc;
+      }
+      const bool last = stage == 4 && bi + 1 == m->nblocks[3];
+      if (!last && pnvo_conv_takes_tail(m, m->convs[li], B)) {   // relu(GN2(conv2) + skip): computed by the next block's first conv
+        tail.res = ds ? m->rawD : cur;
+        tail.res_scale = ds ? m->ssD[0] : nullptr;
+        tail.res_shift = ds ? m->ssD[1] : nullptr;
+        tail.out = nxt;
+        have_tail = true;
+        continue;
+      }
+      {
         Timed t(m, s, "residual", 0.0, 12.0 * B * P * c2.coutp);
-        HIPCHK(m, launch_residual(m->rawB, m->ssB[0], m->ssB[1], m->rawD, m->ssD[0], m->ssD[1], B, P, c2.coutp, nxt, s));
-      } else {
-        Timed t(m, s, "residual", 0.0, 12.0 * B * P * c2.coutp);
-        HIPCHK(m, launch_residual(m->rawB, m->ssB[0], m->ssB[1], cur, nullptr, nullptr, B, P, c2.coutp, nxt, s));
+        HIPCHK(m, launch_residual(m->rawB, m->ssB[0], m->ssB[1], ds ? m->rawD : cur, ds ? m->ssD[0] : nullptr, ds ? m->ssD[1] : nullptr, B,
+                                  P, c2.coutp, nxt, s));
       }
       std::swap(cur, nxt);
       const std::string tn = "layer" + std::to_string(stage) + "." + std::to_string(bi);

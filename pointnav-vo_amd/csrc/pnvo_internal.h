@@ -108,6 +108,10 @@ struct ConvX3Args {
   const unsigned short *wpk;         // pack_conv_x3_weight()
   float *y;                          // [B,Ho,Wo,COUTP] raw output
   const float *in_scale, *in_shift;  // [B,CIN] MODE 1: relu(x*scale+shift) applied while staging
+  // MODE 2 (fused BasicBlock tail, resnet.py:47-55): the conv's input is relu(x*scale+shift + r), r = res (final activations)
+  // or res*res_scale+res_shift (downsample branch); computed while staging and written to xout by the tile that owns the pixel
+  const float *res, *res_scale, *res_shift;
+  float *xout;
   float *stats;                      // [B,slots,COUTP,2] GroupNorm partial sums or nullptr
   int B, H, W, CIN, Ho, Wo, COUTP;
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_x3_plan

@@ -114,10 +114,20 @@ struct pnvo_model_s {
 };
 
 
+// The tail of the previous BasicBlock (resnet.py:47-55) handed to the next block's first conv instead of a pass of its own:
+// that conv's input is relu(x*in_scale+in_shift + r), r = res or res*res_scale+res_shift, and it also writes it to `out`
+// (the block output: the next skip branch / downsample conv read it).
+struct BlockTail {
+  const float *res, *res_scale, *res_shift;
+  float *out;
+};
+
 // helpers implemented in pnvo_api.hip
 int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
                   float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
-                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out);
+                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail = nullptr);
+bool pnvo_conv_on_x3(const Layer &l, int B);                        // would pnvo_run_conv(l) use conv_x3.hip?
+bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B);   // would pnvo_run_conv(l) accept a BlockTail (conv_x3 path)?
 void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out);
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
                   hipStream_t s);

@@ -756,6 +756,9 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
   // residual blocks: a chain of K convs (BasicBlock K = 2, resnet.py:29-55; Bottleneck K = 3, :58-117) + the skip branch
   const int K = m->bottleneck ? 3 : 2;
   int yk = 0;
+  BlockTail tail{};
+  const ConvSave *tail_x = nullptr;
+  bool have_tail = false;
   for (int stage = 1; stage <= 4; ++stage)
     for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
       const float *xin = t->y[yk];
@@ -767,9 +770,15 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
         const Layer &ck = m->convs[ik[k]];
         ConvSave &sk = t->cs[ik[k]];
         const ConvSave *sp = k ? &t->cs[ik[k - 1]] : nullptr;
-        if ((rc = pnvo_run_conv(m, ck, B, k ? sp->raw : xin, k ? sp->ss[0] : nullptr, k ? sp->ss[1] : nullptr, sk.raw, ck.coutp,
-                                sk.ss, nullptr, nullptr, 0, s, nullptr, sk.mu, sk.rstd)) != PNVO_OK)
-          return rc;
+        if (k == 0 && have_tail) {       // the previous block's tail rides on this conv's stager, which writes xin (= tail.out)
+          rc = pnvo_run_conv(m, ck, B, tail_x->raw, tail_x->ss[0], tail_x->ss[1], sk.raw, ck.coutp, sk.ss, nullptr, nullptr, 0, s, nullptr,
+                             sk.mu, sk.rstd, &tail);
+          have_tail = false;
+        } else {
+          rc = pnvo_run_conv(m, ck, B, k ? sp->raw : xin, k ? sp->ss[0] : nullptr, k ? sp->ss[1] : nullptr, sk.raw, ck.coutp, sk.ss, nullptr,
+                             nullptr, 0, s, nullptr, sk.mu, sk.rstd);
+        }
+        if (rc != PNVO_OK) return rc;
       }
       const Layer &cl = m->convs[ik[K - 1]];
       ConvSave &sl = t->cs[ik[K - 1]];
@@ -781,9 +790,16 @@ int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, cons
         if ((rc = pnvo_run_conv(m, cd, B, xin, nullptr, nullptr, sd.raw, cd.coutp, sd.ss, nullptr, nullptr, 0, s, nullptr,
                                 sd.mu, sd.rstd)) != PNVO_OK)
           return rc;
-        HIPCHK(m, launch_residual(sl.raw, sl.ss[0], sl.ss[1], sd.raw, sd.ss[0], sd.ss[1], B, P, cl.coutp, yout, s));
+        tail = BlockTail{sd.raw, sd.ss[0], sd.ss[1], yout};
       } else {
-        HIPCHK(m, launch_residual(sl.raw, sl.ss[0], sl.ss[1], xin, nullptr, nullptr, B, P, cl.coutp, yout, s));
+        tail = BlockTail{xin, nullptr, nullptr, yout};
+      }
+      const bool last = stage == 4 && bi + 1 == m->nblocks[3];
+      if (!last && pnvo_conv_takes_tail(m, m->convs[li], B)) {   // the next block's first conv computes and writes yout
+        tail_x = &sl;
+        have_tail = true;
+      } else {
+        HIPCHK(m, launch_residual(sl.raw, sl.ss[0], sl.ss[1], tail.res, tail.res_scale, tail.res_shift, B, P, cl.coutp, yout, s));
       }
       ++yk;
     }
