@@ -302,9 +302,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   unsigned long long t_e = __builtin_readcyclecounter();
 
-  // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot).
+  // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).
   const int rr16 = lane >> 5;
   const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
+  float t1[NW], t2[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < MW; ++i) {
     const int mt = wave_m * MW + i;
@@ -341,11 +344,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           s2 = __builtin_fmaf(v, v, s2);
         }
       }
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32 && p.stats != nullptr) {
-        const int slot = (tri * p.tiles_c + tci) * p.MT + mt;
-        float *dst = p.stats + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
+      t1[j] += s1 + __shfl_xor(s1, 32);                                  // M-tiles of this wave, in order
+      t2[j] += s2 + __shfl_xor(s2, 32);
+    }
+  }
+  if (p.stats != nullptr) {                                              // one slot per tile: the waves along M meet in LDS
+    const int rows = 4 / wn;
+    float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
+    if (rows > 1) {
+      __syncthreads();                                                   // the patch is no longer read
+      if (lane < 32)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
+      __syncthreads();
+    }
+    if (wave_m == 0 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int nt = wave_n * NW + j;
+        if (nt >= ntt) continue;
+        float s1 = t1[j], s2 = t2[j];
+        for (int w = 1; w < rows; ++w) {                                 // fixed order: bit-reproducible
+          const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
+          s1 += o[0];
+          s2 += o[1];
+        }
+        float *dst = p.stats + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -457,7 +481,7 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   if ((size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
   if (a.CIN % ck) return false;
   a.CK = ck;
-  a.slots = a.tiles_r * a.tiles_c * a.MT;
+  a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
   *lds_bytes = (size_t)3 * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
   return true;
 }

@@ -291,7 +291,7 @@ size_t stats_floats(const Layer &l, int B) {
   choose_tile(M, l.coutp, &MT, &NT);
   int slots = conv_slots((int)P, MT), s2 = 0;
   if (layer_on_lds(l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
-  if (l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || l.stride == 2)) {   // conv_x3: slots = tiles x M-tiles
+  if (l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || l.stride == 2)) {   // conv_x3: slots = tiles
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.B = B;

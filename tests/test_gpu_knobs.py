@@ -40,13 +40,26 @@ assert worst < 1e-4, worst
 _FP32 = {"PNVO_CONV": "fp32"}
 KNOBS = [{}, _FP32, {**_FP32, "PNVO_CONV_WSPLIT": "1"}, {**_FP32, "PNVO_CONV_WSPLIT": "0"}, {**_FP32, "PNVO_CONV_TILE": "12"},
          {**_FP32, "PNVO_CONV_TILE": "22"}, {**_FP32, "PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {**_FP32, "PNVO_CONV3": "tile"},
-         {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}]
+         {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}, {"PNVO_TAIL": "separate"},
+         {"PNVO_X3_S2_OFF": "1"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
 def test_knob_keeps_parity(env):
     r = subprocess.run([sys.executable, "-c", CHECK], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_fused_block_tail_is_bit_identical_to_the_separate_pass():
+    """relu(GN2(conv2) + skip) computed in the next conv's stager (default) uses the same float operations as
+    residual_kernel (PNVO_TAIL=separate): the network output must not change by a single bit."""
+    outs = []
+    for env in ({}, {"PNVO_TAIL": "separate"}):
+        r = subprocess.run([sys.executable, "-c", CHECK + "\nprint('BITS', out.tobytes().hex())\n"], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("BITS")][-1])
+    assert outs[0] == outs[1]
 
 
 TRAIN_KNOBS = [{"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"}]
