@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           r.in[k] = r.ok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
           r.off[k] = (unsigned)((pr * PC + pc) * pitch + 16 * cg);
           r.v[k][0] = r.v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (MODE == 2) {
+          if (MODE >= 2) {
             // the tile owns the input pixels under its own outputs (stride 2: the 2 x 2 block of each): every pixel once
             r.own[k] = r.in[k] && blockIdx.y == 0 && pr >= PAD && pr < PAD + p.TR * CS && pc >= PAD && pc < PAD + p.TC * CS;
             r.gofs[k] = (hi * p.W + wi) * p.CIN;
@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
               t = r.in[k] ? fmaxf(__builtin_fmaf(t, sc[e & 3], sh[e & 3]), 0.f) : 0.f;
             }
+            if (MODE == 3) {                                             // pooled stem keys (stem_mx.hip POOL): decode, |scale|, shift, ReLU
+              const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
+              int key = __builtin_bit_cast(int, t);
+              key = key >= 0 ? key : key ^ 0x7fffffff;
+              t = r.in[k] ? fmaxf(__builtin_fmaf(__builtin_bit_cast(float, key), __builtin_fabsf(sc[e & 3]), sh[e & 3]), 0.f) : 0.f;
+            }
             if (MODE == 2) {                                             // block tail: the same operations as residual_kernel
               const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
               float u = r.w[k][e >> 2][e & 3];
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             f[e] = t;
           }
-          if (MODE == 2 && r.own[k]) {
+          if (MODE >= 2 && r.own[k]) {
             float *dst = p.xout + img + r.gofs[k];
             *reinterpret_cast<f32x4 *>(dst) = f32x4{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{f[4], f[5], f[6], f[7]};
@@ -396,7 +402,7 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
     return hipGetLastError();                                                                         \
   }
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
-  PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2)
+  PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2) PNVO_X3(3, 1, 1) PNVO_X3(3, 2, 1) PNVO_X3(3, 2, 2) PNVO_X3(3, 3, 2)
 #undef PNVO_X3
   return hipErrorInvalidValue;
 }

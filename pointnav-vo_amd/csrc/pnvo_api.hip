@@ -556,7 +556,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       }
       {
         Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes + (tail ? 8.0 * B * l.hin * l.win * l.cin : 0.0));
-        HIPCHK(m, launch_conv_x3(xa, 3, l.stride, tail ? 2 : (in_scale ? 1 : 0), mw, nw, ldsb, s));
+        HIPCHK(m, launch_conv_x3(xa, 3, l.stride, tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0), mw, nw, ldsb, s));
       }
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
@@ -622,14 +622,20 @@ inline int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const 
 
 // The fused stem: input assembly + /255 + whitening gathered in the operand fetch (LDS-staged kernel when the channel
 // count allows, else MODE 2 of the generic kernel), raw output + GroupNorm scale/shift (+ optional mean/rstd).
+bool pnvo_stem_on_mx(pnvo_handle m) {
+  const char *sel = std::getenv("PNVO_STEM");
+  return m->mx_ok && (!m->in_train_forward || m->train_mx) && (!sel || std::strcmp(sel, "mx") == 0);
+}
+
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
-                  hipStream_t s) {
+                  hipStream_t s, int *pool_keys) {
   const pnvo_config &c = m->cfg;
   const Layer &stem = m->convs[0];
   int rc = PNVO_OK;
   const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
   const char *sel = std::getenv("PNVO_STEM");
-  if (m->mx_ok && (!m->in_train_forward || m->train_mx) && (!sel || std::strcmp(sel, "mx") == 0)) {
+  if (pool_keys != nullptr && !pnvo_stem_on_mx(m)) return fail(m, PNVO_ERR_STATE, "pooled stem output asked of a stem kernel without it");
+  if (pnvo_stem_on_mx(m)) {
     // bf16 matrix cores, three exact weight pieces: float32 results (stem_mx.hip).  The training step keeps the kernels
     // below, whose operands it rebuilds on the device after every Adam step.
     StemMXArgs a;
@@ -652,6 +658,10 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.Ho = m->Hs;
     a.Wo = m->Ws;
     a.slots = stem_mx_slots(m->Hs, m->Ws);
+    a.pool = pool_keys;
+    a.pool_gamma = stem.gamma;
+    a.Hp = m->Hp;
+    a.Wp = m->Wp;
     if (const char *e = std::getenv("PNVO_STEM_DBG"))
       if (std::atoi(e) == 9) {
         if (!m->mx_prof) {
@@ -1189,14 +1199,24 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   }
   size_t li = 0;
   const Layer &stem = m->convs[li++];
+  // (a7) GN + ReLU + maxpool.  Default: no pass at all — the stem writes pooled order-preserving keys (stem_mx.hip POOL), the
+  // first block's first conv decodes / normalises them while staging and writes the pooled activations the skip branch needs
+  // (conv_x3 MODE 3).  PNVO_POOL=separate, taps, Bottleneck models and the other stem kernels keep the pass.
+  float *cur = m->bufY[0], *nxt = m->bufY[1];
+  const bool pool_fused = !m->bottleneck && pnvo_stem_on_mx(m) && std::getenv("PNVO_POOL") == nullptr && m->convs.size() > 1 &&
+                          stem.coutp == stem.cout && pnvo_conv_takes_tail(m, m->convs[1], B);
   {
     const float *src[4] = {rgb, depth, dd, tdv};
-    if ((rc = pnvo_run_stem(m, B, src, m->stem_raw, m->ssA, nullptr, nullptr, s)) != PNVO_OK) return rc;
+    if (pool_fused) {
+      Timed t(m, s, "pool_init", 0.0, 4.0 * B * m->Hp * m->Wp * stem.coutp);
+      HIPCHK(m, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nxt), STEM_POOL_INIT, (size_t)B * m->Hp * m->Wp * stem.coutp, s));
+    }
+    if ((rc = pnvo_run_stem(m, B, src, m->stem_raw, m->ssA, nullptr, nullptr, s, pool_fused ? reinterpret_cast<int *>(nxt) : nullptr)) !=
+        PNVO_OK)
+      return rc;
   }
   if ((rc = maybe_tap(m, "stem_conv", m->stem_raw, (size_t)B * m->Hs * m->Ws * stem.coutp, s)) != PNVO_OK) return rc;
-  // (a7) GN + ReLU + maxpool
-  float *cur = m->bufY[0], *nxt = m->bufY[1];
-  {
+  if (!pool_fused) {
     Timed t(m, s, "gn_relu_maxpool", 0.0, 4.0 * B * ((double)m->Hs * m->Ws + (double)m->Hp * m->Wp) * stem.coutp);
     HIPCHK(m, launch_gn_relu_maxpool(m->stem_raw, m->ssA[0], m->ssA[1], B, m->Hs, m->Ws, stem.coutp, cur, s));
   }
@@ -1204,7 +1224,7 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
 
   // (a8) residual stages
   BlockTail tail{};
-  bool have_tail = false;
+  bool have_tail = false, have_keys = pool_fused;
   for (int stage = 1; stage <= 4; ++stage) {
     for (int bi = 0; bi < m->nblocks[stage - 1]; ++bi) {
       if (m->bottleneck) {                           // conv1x1 -> GN -> ReLU -> conv3x3(s) -> GN -> ReLU -> conv1x1 -> GN
@@ -1239,7 +1259,13 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       const Layer &c1 = m->convs[li++];
       const Layer &c2 = m->convs[li++];
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
-      if (have_tail) {           // the previous block's tail rides on this conv's stager, which also writes the block output
+      if (have_keys) {           // pooled stem keys in `nxt`: decoded + normalised by this conv's stager, activations -> `cur`
+        BlockTail keys{nullptr, nullptr, nullptr, cur};
+        if ((rc = pnvo_run_conv(m, c1, B, nxt, m->ssA[0], m->ssA[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
+                                nullptr, &keys)) != PNVO_OK)
+          return rc;
+        have_keys = false;
+      } else if (have_tail) {    // the previous block's tail rides on this conv's stager, which also writes the block output
         if ((rc = pnvo_run_conv(m, c1, B, m->rawB, m->ssB[0], m->ssB[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr,
                                 nullptr, nullptr, &tail)) != PNVO_OK)
           return rc;

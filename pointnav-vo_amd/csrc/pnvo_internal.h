@@ -94,7 +94,13 @@ struct StemMXArgs {
   int y_cstride, stats_cstride;
   int B, H, W, Ho, Wo, slots, tiles_x, tiles_y;
   unsigned long long *prof;   // [4 waves][8] phase cycle sums (PNVO_STEM_DBG=9) or nullptr
+  // pooled output (float32 results only): [B,Hp,Wp,y_cstride] order-preserving integer keys of max over the 3x3/2 window of
+  // sgn(pool_gamma[c]) * x, pre-set to STEM_POOL_INIT; y is not written.  nullptr: the raw output goes to y
+  int *pool;
+  const float *pool_gamma;    // GroupNorm weight of the stem [cout] (its sign decides max or min)
+  int Hp, Wp;
 };
+constexpr int STEM_POOL_INIT = (int)0x807fffffu;   // key of -inf
 int stem_mx_slots(int Ho, int Wo);
 size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);

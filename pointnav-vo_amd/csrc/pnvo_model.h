@@ -117,6 +117,8 @@ struct pnvo_model_s {
 // The tail of the previous BasicBlock (resnet.py:47-55) handed to the next block's first conv instead of a pass of its own:
 // that conv's input is relu(x*in_scale+in_shift + r), r = res or res*res_scale+res_shift, and it also writes it to `out`
 // (the block output: the next skip branch / downsample conv read it).
+// res == nullptr: the conv's input x holds the pooled stem keys of stem_mx.hip (POOL); the conv decodes them, applies
+// |in_scale|, in_shift and ReLU, and writes the pooled activations to `out`.
 struct BlockTail {
   const float *res, *res_scale, *res_shift;
   float *out;
@@ -130,7 +132,8 @@ bool pnvo_conv_on_x3(const Layer &l, int B);                        // would pnv
 bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B);   // would pnvo_run_conv(l) accept a BlockTail (conv_x3 path)?
 void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out);
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
-                  hipStream_t s);
+                  hipStream_t s, int *pool_keys = nullptr);
+bool pnvo_stem_on_mx(pnvo_handle m);
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
 const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name);   // pnvo_train_api.hip: device pointer or nullptr
 void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip

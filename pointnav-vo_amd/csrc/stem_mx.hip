@@ -87,7 +87,7 @@ struct TapOffsets {
 };
 __constant__ const TapOffsets TAPOFF{};
 
-template <int PIECES, int NT, bool BF16OUT>
+template <int PIECES, int NT, bool BF16OUT, bool POOL = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_mx_kernel(const StemMXArgs p) {
   constexpr bool EXTRA = PIECES == 3;
   constexpr int NFT = PIECES * 2 + (EXTRA ? 1 : 0);        // B fragments per (tap, N-tile)
@@ -336,7 +336,51 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int co = p.y_coff[g] + (lane & 31);
     const long rowpix = ((long)n * p.Ho + ho0 + 2 * wave) * p.Wo + wo0 + 4 * rr16;   // pixel of register 0
     float s1 = 0.f, s2 = 0.f;
-    if (full) {
+    if (POOL) {
+      // MaxPool2d(3, 2, 1) of the stem (resnet.py:168) without a pass of its own.  relu(x*scale+shift) is monotone in x, rising
+      // when the GroupNorm weight is >= 0 and falling otherwise, so the window maximum of the activation is the activation of
+      // the window maximum of sgn(gamma)*x: the tile pools sgn*x through LDS and writes ORDER-PRESERVING INTEGER KEYS of the
+      // maxima — plain stores for windows inside the tile, integer atomic max (exact, order-free) for windows that straddle
+      // tiles; the consumer (conv_x3 MODE 3) decodes, applies |scale|, shift and ReLU: the same bits as pooling afterwards.
+      // The raw stem output is never written.  GroupNorm partial sums come from the full-resolution values as always.
+      const float sgn = p.pool_gamma[co] < 0.f ? -1.f : 1.f;
+      __syncthreads();                                    // every wave has its `tot`: the exchange area is free
+      float *pb = reinterpret_cast<float *>(lds);        // [8 rows][16 cols][32 channels]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16;
+        const int row = 2 * wave + (i >> 4), col = i & 15;
+        const bool ok = ho0 + row < p.Ho && wo0 + col < p.Wo;
+        const float v = ok ? tot[r] : 0.f;
+        pb[(row * 16 + col) * 32 + (lane & 31)] = ok ? sgn * tot[r] : -__builtin_inff();
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+      __syncthreads();
+      const int ch = threadIdx.x & 31;
+#pragma unroll 1
+      for (int pp = threadIdx.x >> 5; pp < 45; pp += 8) {  // 5 x 9 pooled pixels touch the 8 x 16 tile
+        const int pi = pp / 9, pj = pp - 9 * pi;
+        const int I = (ho0 >> 1) + pi, J = (wo0 >> 1) + pj;
+        if (I >= p.Hp || J >= p.Wp) continue;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+          for (int dc = -1; dc <= 1; ++dc) {
+            const int lr = 2 * pi + dr, lc = 2 * pj + dc;
+            if (lr >= 0 && lr < 8 && lc >= 0 && lc < 16) mx = fmaxf(mx, pb[(lr * 16 + lc) * 32 + ch]);
+          }
+        int key = __builtin_bit_cast(int, mx);
+        key = key >= 0 ? key : key ^ 0x7fffffff;
+        int *dst = p.pool + (((long)n * p.Hp + I) * p.Wp + J) * p.y_cstride + p.y_coff[g] + ch;
+        const bool inside = (pi >= 1 || ho0 == 0) && pi <= 3 && (pj >= 1 || wo0 == 0) && pj <= 7;
+        if (inside)
+          *dst = key;
+        else
+          atomicMax(dst, key);
+      }
+    } else if (full) {
       if (BF16OUT) {
         __bf16 *y0 = reinterpret_cast<__bf16 *>(p.y[g]) + rowpix * p.y_cstride + co;
 #pragma unroll
@@ -513,7 +557,10 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
   p.tiles_y = (a.Ho + TH - 1) / TH;
   const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
   const unsigned gx = (unsigned)(((ntiles + 7) / 8) * 8);
-  if (pieces == 3 && !bf16_out) {
+  if (pieces == 3 && !bf16_out && a.pool != nullptr) {   // pooled keys instead of the raw output (inference)
+    const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
+    hipLaunchKernelGGL((stem_mx_kernel<3, 1, false, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+  } else if (pieces == 3 && !bf16_out) {
     const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<3, 1, false>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
   } else if (pieces == 3 && bf16_out) {                  // float32-exact stem feeding the bf16 stages (accuracy experiments)

@@ -15,7 +15,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 from conftest import golden_case, load_golden
 from pointnav_vo_amd.registry import baseline_registry
 from pointnav_vo_amd import vo_cnn
-worst = 0.0
+worst, bits = 0.0, []
 for fname in ("model_default_341x192_b2.npz", "model_default_45x37_b3.npz", "model_wider_64x48_b2.npz"):
     rec = load_golden(fname)
     cfg, sd, obs, _ = golden_case(rec)
@@ -31,6 +31,7 @@ for fname in ("model_default_341x192_b2.npz", "model_default_45x37_b3.npz", "mod
     ref = rec["out64"]
     err = np.linalg.norm(out - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
     worst = max(worst, float(err.max()))
+    bits.append(out.tobytes().hex())
 print("WORST", worst)
 assert worst < 1e-4, worst
 """ % (ROOT, os.path.join(ROOT, "tests"))
@@ -41,7 +42,7 @@ _FP32 = {"PNVO_CONV": "fp32"}
 KNOBS = [{}, _FP32, {**_FP32, "PNVO_CONV_WSPLIT": "1"}, {**_FP32, "PNVO_CONV_WSPLIT": "0"}, {**_FP32, "PNVO_CONV_TILE": "12"},
          {**_FP32, "PNVO_CONV_TILE": "22"}, {**_FP32, "PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {**_FP32, "PNVO_CONV3": "tile"},
          {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}, {"PNVO_TAIL": "separate"},
-         {"PNVO_X3_S2_OFF": "1"}]
+         {"PNVO_POOL": "separate"}, {"PNVO_X3_S2_OFF": "1"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
@@ -50,12 +51,15 @@ def test_knob_keeps_parity(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-def test_fused_block_tail_is_bit_identical_to_the_separate_pass():
-    """relu(GN2(conv2) + skip) computed in the next conv's stager (default) uses the same float operations as
-    residual_kernel (PNVO_TAIL=separate): the network output must not change by a single bit."""
+@pytest.mark.parametrize("knob", ["PNVO_TAIL", "PNVO_POOL"])
+def test_fused_passes_are_bit_identical_to_the_separate_ones(knob):
+    """relu(GN2(conv2) + skip) computed in the next conv's stager (default; PNVO_TAIL=separate: residual_kernel) and the
+    max-pool taken on order-preserving keys of sgn(gamma) * x in the stem's epilogue, normalised by the first conv's stager
+    (default; PNVO_POOL=separate: gn_relu_maxpool_kernel) use the same float operations as the passes they replace: the
+    network output must not change by a single bit."""
     outs = []
-    for env in ({}, {"PNVO_TAIL": "separate"}):
-        r = subprocess.run([sys.executable, "-c", CHECK + "\nprint('BITS', out.tobytes().hex())\n"], env={**os.environ, **env},
+    for env in ({}, {knob: "separate"}):
+        r = subprocess.run([sys.executable, "-c", CHECK + "\nprint('BITS', ''.join(bits))\n"], env={**os.environ, **env},
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("BITS")][-1])
