@@ -345,40 +345,55 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       // The raw stem output is never written.  GroupNorm partial sums come from the full-resolution values as always.
       const float sgn = p.pool_gamma[co] < 0.f ? -1.f : 1.f;
       __syncthreads();                                    // every wave has its `tot`: the exchange area is free
-      float *pb = reinterpret_cast<float *>(lds);        // [8 rows][16 cols][32 channels]
+      float *pb = reinterpret_cast<float *>(lds);        // [8 rows][16 cols][33: 32 channels + 1 pad]
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16;
         const int row = 2 * wave + (i >> 4), col = i & 15;
         const bool ok = ho0 + row < p.Ho && wo0 + col < p.Wo;
         const float v = ok ? tot[r] : 0.f;
-        pb[(row * 16 + col) * 32 + (lane & 31)] = ok ? sgn * tot[r] : -__builtin_inff();
+        pb[(row * 16 + col) * 33 + (lane & 31)] = ok ? sgn * tot[r] : -__builtin_inff();
         s1 += v;
         s2 = __builtin_fmaf(v, v, s2);
       }
       __syncthreads();
-      const int ch = threadIdx.x & 31;
-#pragma unroll 1
-      for (int pp = threadIdx.x >> 5; pp < 45; pp += 8) {  // 5 x 9 pooled pixels touch the 8 x 16 tile
-        const int pi = pp / 9, pj = pp - 9 * pi;
-        const int I = (ho0 >> 1) + pi, J = (wo0 >> 1) + pj;
-        if (I >= p.Hp || J >= p.Wp) continue;
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-          for (int dc = -1; dc <= 1; ++dc) {
-            const int lr = 2 * pi + dr, lc = 2 * pj + dc;
-            if (lr >= 0 && lr < 8 && lc >= 0 && lc < 16) mx = fmaxf(mx, pb[(lr * 16 + lc) * 32 + ch]);
-          }
+      // 5 x 9 pooled pixels touch the 8 x 16 tile.  Thread = (pooled column pj 0..7, channel): the three-column maxima of the
+      // eight tile rows first, then the five pooled rows from them; the ninth column (tile column 15 only) afterwards.
+      const int ch = threadIdx.x & 31, pj = threadIdx.x >> 5;
+      const int Ib = ho0 >> 1, Jb = wo0 >> 1;
+      int *const pool0 = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[g] + ch;
+      auto emit = [&](int I, int J, float mx, bool inside) {
+        if (I >= p.Hp || J >= p.Wp) return;
         int key = __builtin_bit_cast(int, mx);
         key = key >= 0 ? key : key ^ 0x7fffffff;
-        int *dst = p.pool + (((long)n * p.Hp + I) * p.Wp + J) * p.y_cstride + p.y_coff[g] + ch;
-        const bool inside = (pi >= 1 || ho0 == 0) && pi <= 3 && (pj >= 1 || wo0 == 0) && pj <= 7;
+        int *dst = pool0 + (I * p.Wp + J) * p.y_cstride;
         if (inside)
           *dst = key;
         else
           atomicMax(dst, key);
+      };
+      {
+        const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;   // (pj = 0: column -1 belongs to the left tile)
+        float cm[8];
+#pragma unroll
+        for (int lr = 0; lr < 8; ++lr)
+          cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
+        const bool colin = pj >= 1 || wo0 == 0;           // the window's columns are all this tile's (or padding)
+        emit(Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
+        emit(Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
+        emit(Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
+        emit(Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
+        emit(Ib + 4, Jb + pj, cm[7], false);
+      }
+      if (threadIdx.x < 160) {                            // ninth pooled column: tile column 15, always shared with the right tile
+        const int pi = threadIdx.x >> 5;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr) {
+          const int lr = 2 * pi + dr;
+          if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
+        }
+        emit(Ib + pi, Jb + 8, mx, false);
       }
     } else if (full) {
       if (BF16OUT) {
