@@ -294,10 +294,10 @@ def main():
             "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
             "kernel_ms_per_step": total_kernel_ms / args.steps,
             "pose_rel_err_vs_fp64_oracle": rel,
-            "arithmetic": ("float32 activations, weights, accumulators and results; the stem and the 3x3 stride-1 convs of stages "
-                           "2-4 multiply on the bf16 matrix cores with every float32 operand split into three bf16 pieces (hi + mid + "
-                           "lo == the float32 value): products exact (stem: inputs exact in bf16) or within 2^-23 (six of the nine "
-                           "cross terms), float32 accumulation; PNVO_CONV=fp32 / PNVO_STEM=dense select the fp32-MFMA kernels"
+            "arithmetic": ("float32 activations, weights, accumulators and results; the stem and the sixteen 3x3 convs of the "
+                           "residual stages multiply on the bf16 matrix cores with every float32 operand split into three bf16 pieces "
+                           "(hi + mid + lo == the float32 value): products exact (stem: inputs exact in bf16) or within 2^-23 (six of "
+                           "the nine cross terms), float32 accumulation; PNVO_CONV=fp32 / PNVO_STEM=dense select the fp32-MFMA kernels"
                            if os.environ.get("PNVO_CONV", "x3") == "x3" else "float32 (fp32 MFMA convs); stem: see PNVO_STEM"),
             "model_tflops": value * flops_pair / 1e12,
             "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),

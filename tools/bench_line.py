@@ -1,3 +1,4 @@
+"""Headline fields and the slowest kernels of a bench.py JSON line: python tools/bench_line.py <file with the line>."""
 import json,sys
 r=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 print("value",r["value"],"ms",r["ms_per_step"],"p50",r.get("ms_per_step_p50"),"frac",r["roofline"]["frac"],"traffic",r["roofline"].get("traffic"))

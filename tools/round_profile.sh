@@ -17,6 +17,7 @@ for cfg in fwd_fp32 dual_bf16; do
   done
   python tools/make_traffic.py $cfg 256 $O/${tag}_pmc_${cfg}_FETCH_SIZE/p_results.db $O/${tag}_pmc_${cfg}_WRITE_SIZE/p_results.db $O/${tag}_traffic.json
   cat $O/${tag}_pmc_${cfg}_*.md > $O/${tag}_pmc_$cfg.md
+  python tools/mfma_util.py $O/${tag}_kernel_trace_$cfg.md $O/${tag}_pmc_$cfg.md > $O/${tag}_mfma_util_$cfg.md
   rm -rf $O/${tag}_pmc_${cfg}_* $O/${tag}_trace_$cfg
 done
 # training step: kernel trace only (its kernels are MFMA / HBM bound by construction; counters are taken for the forward)
@@ -24,4 +25,6 @@ rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_train -o p -- python bench.p
 python tools/rocprof_summary.py $O/${tag}_trace_train/p_results.db > $O/${tag}_kernel_trace_train.md 2>&1
 rm -rf $O/${tag}_trace_train
 PNVO_WSM_PROF=1 python bench.py --config train --steps 10 --warmup 3 2>&1 >/dev/null | grep "pnvo\]" > $O/${tag}_wgrad_stem_phases.txt
+PNVO_X3_PROF=1 python bench.py --steps 1 --warmup 0 --no-preheat --no-cpu-baseline 2>&1 >/dev/null | grep "pnvo\] conv_x3" | sort -u -t: -k1,1 > $O/${tag}_conv_x3_phases.txt
+PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-preheat --no-cpu-baseline 2>&1 >/dev/null | grep "pnvo\] stem_mx" > $O/${tag}_stem_phases.txt
 head -14 $O/${tag}_kernel_trace_fwd_fp32.md
