@@ -203,7 +203,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       };
       constexpr bool PIPE = !(MODE == 2 && MW * NW >= 6);              // (the block-tail stager of the 96-accumulator tile would spill)
-      if (PIPE) {
+      if (MW * NW <= 2) {
+        // few accumulators: registers for three rounds in flight — the whole patch of the 32- / 64-channel stages is ONE memory
+        // latency instead of three (their staging phase is as long as their MFMA phase)
+        for (int pix = pl; pix < nppix; pix += 6 * PS) {
+          Round r0, r1, r2;
+          fetch(pix, r0);
+          fetch(pix + 2 * PS, r1);
+          fetch(pix + 4 * PS, r2);
+          split_store(r0);
+          split_store(r1);
+          split_store(r2);
+        }
+      } else if (PIPE) {
         Round cur, nxt;
         fetch(pl, cur);
         for (int pix = pl; pix < nppix; pix += 2 * PS) {
