@@ -499,6 +499,15 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   if ((size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
   if (a.CIN % ck) return false;
   a.CK = ck;
+  // Few workgroups (small batches: the reference's navigation loop calls with ONE pair): a workgroup walks its whole K loop alone
+  // (≈ 60-110 us on the deep stages) while the fp32 kernels split small problems over the chip — they keep those launches
+  // (measured: batch 1 0.41 ms against 0.72 with conv_x3 everywhere; break-even per layer at ~200 workgroups).  PNVO_CONV=x3 forces.
+  {
+    const char *sel = std::getenv("PNVO_CONV");
+    const bool force = sel != nullptr && std::strcmp(sel, "x3") == 0;
+    const long wgs = (long)a.B * a.tiles_r * a.tiles_c * ((ntt + a.wn * *nw - 1) / (a.wn * *nw));
+    if (wgs < 192 && !force) return false;
+  }
   a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
   *lds_bytes = (size_t)3 * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
   return true;

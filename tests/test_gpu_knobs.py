@@ -36,13 +36,15 @@ print("WORST", worst)
 assert worst < 1e-4, worst
 """ % (ROOT, os.path.join(ROOT, "tests"))
 
-# default = float32 convs on the bf16 matrix cores (conv_x3.hip); PNVO_CONV=fp32 selects the fp32-MFMA kernels, whose own knobs
-# only matter then
+# default = float32 convs on the bf16 matrix cores (conv_x3.hip) for every launch of >= 192 workgroups — none of the golden sizes,
+# so PNVO_CONV=x3 (forced) is what covers those kernels here; PNVO_CONV=fp32 selects the fp32-MFMA kernels, whose own knobs only
+# matter then
 _FP32 = {"PNVO_CONV": "fp32"}
-KNOBS = [{}, _FP32, {**_FP32, "PNVO_CONV_WSPLIT": "1"}, {**_FP32, "PNVO_CONV_WSPLIT": "0"}, {**_FP32, "PNVO_CONV_TILE": "12"},
+KNOBS = [{}, {"PNVO_CONV": "x3"}, _FP32, {**_FP32, "PNVO_CONV_WSPLIT": "1"}, {**_FP32, "PNVO_CONV_WSPLIT": "0"}, {**_FP32, "PNVO_CONV_TILE": "12"},
          {**_FP32, "PNVO_CONV_TILE": "22"}, {**_FP32, "PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {**_FP32, "PNVO_CONV3": "tile"},
-         {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"}, {"PNVO_TAIL": "separate"},
-         {"PNVO_POOL": "separate"}, {"PNVO_X3_S2_OFF": "1"}]
+         {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"},
+         {"PNVO_CONV": "x3", "PNVO_TAIL": "separate"}, {"PNVO_CONV": "x3", "PNVO_POOL": "separate"},
+         {"PNVO_CONV": "x3", "PNVO_X3_S2_OFF": "1"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
@@ -58,7 +60,7 @@ def test_fused_passes_are_bit_identical_to_the_separate_ones(knob):
     (default; PNVO_POOL=separate: gn_relu_maxpool_kernel) use the same float operations as the passes they replace: the
     network output must not change by a single bit."""
     outs = []
-    for env in ({}, {knob: "separate"}):
+    for env in ({"PNVO_CONV": "x3"}, {"PNVO_CONV": "x3", knob: "separate"}):
         r = subprocess.run([sys.executable, "-c", CHECK + "\nprint('BITS', ''.join(bits))\n"], env={**os.environ, **env},
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -66,7 +68,16 @@ def test_fused_passes_are_bit_identical_to_the_separate_ones(knob):
     assert outs[0] == outs[1]
 
 
-TRAIN_KNOBS = [{"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"}]
+def test_parity_and_training_suites_with_conv_x3_forced():
+    """The golden sizes launch fewer than 192 workgroups per conv, where the default keeps the fp32-MFMA kernels: run the
+    forward parity suite (every intermediate activation) and the training suite again with conv_x3 forced."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_train.py"), "-m", "gpu", "-x", "-q"],
+                       env={**os.environ, "PNVO_CONV": "x3"}, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+TRAIN_KNOBS = [{"PNVO_CONV": "x3"}, {"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"}]
 
 
 @pytest.mark.parametrize("env", TRAIN_KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
