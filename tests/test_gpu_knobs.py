@@ -77,6 +77,44 @@ def test_parity_and_training_suites_with_conv_x3_forced():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+SIZES = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from pointnav_vo_amd import model_spec as ms, synth
+from pointnav_vo_amd.registry import baseline_registry
+from pointnav_vo_amd import vo_cnn
+space = ["rgb", "depth", "discretized_depth", "top_down_view"]
+for (w, h, b) in ((97, 55, 3), (120, 67, 2), (200, 113, 3), (64, 33, 5), (341, 192, 12)):
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(observation_space=space, observation_size=(w, h), hidden_size=512,
+        backbone="resnet18", normalize_visual_inputs=True, output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=w)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    obs = synth.make_obs_pairs(b, h, w, observation_space=space, dd_bins=10, seed=h)
+    with torch.no_grad():
+        out = m({k: torch.from_numpy(np.asarray(v)).to("cuda:0") for k, v in obs.items()}).cpu().numpy()
+    print("OUT", w, h, " ".join(repr(float(x)) for x in out.reshape(-1)))
+""" % ROOT
+
+
+def test_conv_x3_agrees_with_the_fp32_kernels_at_odd_sizes():
+    """Ragged tiles, odd maps under the stride-2 convs, tile ownership of the fused block tails and of the pooled stem keys:
+    conv_x3 forced against the fp32-MFMA kernels on sizes no golden covers (and 12 pairs at 341x192, where the default mixes
+    both families).  Float32-grade agreement: 2e-5 of the pose norm (measured <= 3e-6)."""
+    res = {}
+    for name, env in (("x3", {"PNVO_CONV": "x3"}), ("fp32", {"PNVO_CONV": "fp32"}), ("auto", {})):
+        r = subprocess.run([sys.executable, "-c", SIZES], env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[name] = [[float(x) for x in ln.split()[3:]] for ln in r.stdout.splitlines() if ln.startswith("OUT")]
+        assert len(res[name]) == 5
+    import numpy as np
+    for other in ("x3", "auto"):
+        for a, b in zip(res[other], res["fp32"]):
+            a, b = np.array(a).reshape(-1, 3), np.array(b).reshape(-1, 3)
+            err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-2)
+            assert err.max() < 2e-5, (other, err.max())
+
+
 TRAIN_KNOBS = [{"PNVO_CONV": "x3"}, {"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"}]
 
 
