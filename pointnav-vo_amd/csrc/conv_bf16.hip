@@ -197,19 +197,34 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
     }
     const int kcc = CK >> 4;                                             // k-chunks per staged chunk
     const int nsteps = KS * KS * kcc;
-    const int kc_base = ck0 >> 4;
-    auto loadAB = [&](int s, u32x4 *a, u32x4 *b) {
-      const int tap = s / kcc, kc = s - tap * kcc;
-      const int kh = tap / KS, kw = tap - kh * KS;
-      const unsigned toff = (unsigned)((kh * PC + kw) * pitch + kc * 32);
-#pragma unroll
-      for (int i = 0; i < MW; ++i) a[i] = *reinterpret_cast<const u32x4 *>(lds + aoff[i] + toff);
-      const u32x4 *wb = wpk + ((long)(tap * kct + kc_base + kc) * ntt + wave_n * NW) * 64;
-#pragma unroll
-      for (int j = 0; j < NW; ++j) {
-        const int jj = min(wave_n * NW + j, ntt - 1) - wave_n * NW;      // (N-tiles past the layer's repeat the last one)
-        b[j] = wb[jj * 64 + lane];
+    // The step being fetched, kept as running offsets (a division per step costs ~50 scalar instructions between two small
+    // MFMA groups — these kernels are bound by their instruction count, not by the matrix pipe).
+    const unsigned kstep = (unsigned)ntt * 1024u;                        // bytes of one k-chunk of B (all N-tiles)
+    const char *wb_n = reinterpret_cast<const char *>(wpk) + (long)(ck0 >> 4) * kstep;
+    unsigned toff_n = 0;                                                 // patch byte offset of the step's (tap, k-chunk)
+    int kc_n = 0, kw_n = 0;
+    auto advance = [&]() {
+      ++kc_n;
+      toff_n += 32;
+      wb_n += kstep;
+      if (kc_n == kcc) {
+        kc_n = 0;
+        toff_n += (unsigned)(pitch - kcc * 32);
+        wb_n += (long)(kct - kcc) * kstep;
+        if (++kw_n == KS) {
+          kw_n = 0;
+          toff_n += (unsigned)((PC - KS) * pitch);
+        }
       }
+    };
+    unsigned voff[NW];                                                   // lane's byte offset inside a k-chunk of B
+#pragma unroll
+    for (int j = 0; j < NW; ++j) voff[j] = (unsigned)min(wave_n * NW + j, ntt - 1) * 1024u + (unsigned)lane * 16u;   // (N-tiles past the layer's repeat the last one)
+    auto loadAB = [&](u32x4 *a, u32x4 *b) {
+#pragma unroll
+      for (int i = 0; i < MW; ++i) a[i] = *reinterpret_cast<const u32x4 *>(lds + aoff[i] + toff_n);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) b[j] = *reinterpret_cast<const u32x4 *>(wb_n + (size_t)voff[j]);
     };
     auto mfmas = [&](const u32x4 *a, const u32x4 *b) {
 #pragma unroll
@@ -220,17 +235,21 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
                                                               acc[i][j], 0, 0, 0);
     };
     u32x4 a0[MW], b0[NW], a1[MW], b1[NW];
-    loadAB(0, a0, b0);
+    loadAB(a0, b0);
+    advance();                                                           // -> step 1
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += 2) {                                // nsteps is even for every supported shape
-      loadAB(s + 1, a1, b1);
+      const bool more = s + 2 < nsteps;                                  // (the last iteration re-fetches step s + 1: unused)
+      loadAB(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      loadAB(s + 2 < nsteps ? s + 2 : s, a0, b0);
+      if (more) advance();
+      loadAB(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
+      if (more) advance();
     }
   }
 
@@ -239,6 +258,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
   // pixel's output offset comes from the table (four 16-byte LDS reads per M-tile), the store is base + 32-bit offset.
   const int rr16 = lane >> 5;
   const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
+  float t1[NW], t2[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < MW; ++i) {
     const int mt = wave_m * MW + i;
@@ -266,11 +288,32 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         s1 += v;
         s2 = __builtin_fmaf(v, v, s2);
       }
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32 && p.stats[z] != nullptr) {
-        const int slot = (tri * p.tiles_c + tci) * p.MT + mt;
-        float *dst = p.stats[z] + (((long)n * p.slots + slot) * p.COUTP + co) * 2;
+      t1[j] += s1 + __shfl_xor(s1, 32);                                  // M-tiles of this wave, in order
+      t2[j] += s2 + __shfl_xor(s2, 32);
+    }
+  }
+  if (p.stats[z] != nullptr) {                                           // one slot per tile: the waves along M meet in LDS
+    const int rows = 4 / wn;
+    float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
+    if (rows > 1) {
+      __syncthreads();                                                   // the patch is no longer read
+      if (lane < 32)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
+      __syncthreads();
+    }
+    if (wave_m == 0 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int nt = wave_n * NW + j;
+        if (nt >= ntt) continue;
+        float s1 = t1[j], s2 = t2[j];
+        for (int w = 1; w < rows; ++w) {                                 // fixed order: bit-reproducible
+          const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
+          s1 += o[0];
+          s2 += o[1];
+        }
+        float *dst = p.stats[z] + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -363,7 +406,7 @@ bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *
   if ((size_t)a.PR * a.PC * (ck * 2 + 16) > (size_t)60 * 1024) return false;
   if (a.CIN % ck) return false;
   a.CK = ck;
-  a.slots = a.tiles_r * a.tiles_c * a.MT;
+  a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
   *lds_bytes = (size_t)a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
   return true;
 }
