@@ -75,6 +75,27 @@ def test_gradients_are_additive_over_pairs_at_full_resolution():
     assert not bad, bad
 
 
+def test_fused_pool_and_block_tails_are_bit_identical_at_full_size():
+    """128 pairs at 341x192 (every 3x3 conv on conv_x3, the max-pool in the stem's epilogue, seven block tails in the next
+    conv's stager) against the same forward with the separate gn_relu_maxpool / residual passes: not one bit differs, and
+    two runs of the default path agree bit for bit (the pooled keys are merged with integer atomic max: order-free)."""
+    obs = bench.make_inputs(128, torch.device(DEV), 5)
+    model, _ = default_model()
+    model.eval()
+    outs = []
+    with torch.no_grad():
+        for env in ({}, {}, {"PNVO_TAIL": "separate", "PNVO_POOL": "separate"}):
+            os.environ.update(env)
+            try:
+                outs.append(model(obs).clone())
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_both_stem_weight_gradient_kernels_agree_at_full_resolution():
     """The stem's weight gradient on the bf16 matrix cores (exact three-piece operands, wgrad_stem_mx.hip) against the
     float32-MFMA kernel (PNVO_WGRAD_STEM=fp32) on 16 pairs at 341x192, whitening on: the products are exact in both, only the
