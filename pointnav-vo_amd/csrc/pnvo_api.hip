@@ -291,7 +291,7 @@ size_t stats_floats(const Layer &l, int B) {
   choose_tile(M, l.coutp, &MT, &NT);
   int slots = conv_slots((int)P, MT), s2 = 0;
   if (layer_on_lds(l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
-  if (l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || l.stride == 2)) {   // conv_x3: slots = tiles
+  if ((l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || l.stride == 2)) || (l.k == 1 && l.stride == 2)) {   // conv_x3: slots = tiles
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.B = B;
@@ -303,7 +303,7 @@ size_t stats_floats(const Layer &l, int B) {
     xa.COUTP = l.coutp;
     int mw, nw;
     size_t ldsb;
-    if (conv_x3_plan(xa, 3, l.stride, &mw, &nw, &ldsb) && xa.slots > slots) slots = xa.slots;
+    if (conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb) && xa.slots > slots) slots = xa.slots;
   }
   return (size_t)B * (size_t)slots * l.coutp * 2;
 }
@@ -431,8 +431,10 @@ namespace {
 // 3x3 (stride 1 or 2, pad 1) GroupNorm-ed convs run on conv_x3.hip unless PNVO_CONV selects another kernel family
 bool x3_layer(const Layer &l) {
   const char *sel = std::getenv("PNVO_CONV");
-  return l.k == 3 && l.kw == 3 && (l.stride == 1 || (l.stride == 2 && !std::getenv("PNVO_X3_S2_OFF"))) && l.pad == 1 &&
-         !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0);
+  const bool s2 = l.stride == 2 && !std::getenv("PNVO_X3_S2_OFF");
+  const bool k3 = l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || s2);
+  const bool k1 = l.k == 1 && l.kw == 1 && l.pad == 0 && s2;      // the 1x1 stride-2 downsample convs (resnet.py:192-195)
+  return (k3 || k1) && !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0);
 }
 bool x3_args(const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
   std::memset(&xa, 0, sizeof(xa));
@@ -443,7 +445,7 @@ bool x3_args(const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ld
   xa.Ho = l.hout;
   xa.Wo = l.wout;
   xa.COUTP = l.coutp;
-  return conv_x3_plan(xa, 3, l.stride, mw, nw, ldsb);
+  return conv_x3_plan(xa, l.k, l.stride, mw, nw, ldsb);
 }
 }  // namespace
 
@@ -525,17 +527,17 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     xa.COUTP = l.coutp;
     int mw = 0, nw = 0;
     size_t ldsb = 0;
-    if (conv_x3_plan(xa, 3, l.stride, &mw, &nw, &ldsb)) {       // (the statistics buffer is sized for it: stats_floats)
+    if (conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
       if (!lm.wpk_x3 || lm.x3_gen != m->weights_gen) {           // (re)build the three-piece operand of this layer
-        const size_t nel = (size_t)9 * l.cinp * l.coutp * 3;
+        const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 3;
         if (!lm.wpk_x3) HIPCHK(m, hipMalloc((void **)&lm.wpk_x3, nel * 2));
         const float *dev_w = m->train ? pnvo_train_weight_ptr(m, l.name + ".weight") : nullptr;
         if (dev_w != nullptr) {          // training attached: the current weight lives in the flat parameter buffer
-          HIPCHK(m, launch_conv_x3_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, 3, 3, 0, lm.wpk_x3, s));
+          HIPCHK(m, launch_conv_x3_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, 0, lm.wpk_x3, s));
         } else {
           std::vector<unsigned short> pk(nel);
-          pack_conv_x3_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, 3, 3, pk.data());
+          pack_conv_x3_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pk.data());
           HIPCHK(m, hipMemcpyAsync(lm.wpk_x3, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
           HIPCHK(m, hipStreamSynchronize(s));
         }
@@ -556,7 +558,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       }
       {
         Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes + (tail ? 8.0 * B * l.hin * l.win * l.cin : 0.0));
-        HIPCHK(m, launch_conv_x3(xa, 3, l.stride, tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0), mw, nw, ldsb, s));
+        HIPCHK(m, launch_conv_x3(xa, l.k, l.stride, tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0), mw, nw, ldsb, s));
       }
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
