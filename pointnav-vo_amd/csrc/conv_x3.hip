@@ -13,6 +13,16 @@
 // LDS, producer's GroupNorm + ReLU applied once per element while staging, zero padding after it, pixel table for ragged
 // tiles, raw float32 output + per-slot GroupNorm partial sums) with float32 activations in HBM: the stager splits every
 // element into its three pieces (three LDS planes), the weights are split at load (three B fragments per step).
+//
+// Input modes of the stager (template MODE):
+//   0  final activations
+//   1  relu(x * scale + shift): the producer's GroupNorm + ReLU
+//   2  the previous BasicBlock's tail (resnet.py:47-55): relu(x * scale + shift + r), r = res or res * res_scale + res_shift
+//      (downsample branch); the tile that owns an input pixel also writes the result to xout (the block output the next skip
+//      branch / downsample conv reads).  Same float operations as residual_kernel: bit-identical to the separate pass.
+//   3  pooled stem keys (stem_mx.hip POOL): decode, * |scale| + shift, ReLU; pooled activations written to xout.
+// Also covers the 1x1 stride-2 downsample convs (KS = 1: the stager reads only the pixels the conv uses).
+// conv_x3_plan() takes a layer only when its launch has >= 192 workgroups (PNVO_CONV=x3 forces it).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
