@@ -96,6 +96,21 @@ def test_fused_pool_and_block_tails_are_bit_identical_at_full_size():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_large_batch_equals_its_small_batches_at_full_resolution():
+    """The kernel family of a conv depends on the launch size (conv_x3 from 192 workgroups on, fused pool / block tails with
+    it): 96 pairs in one call against the same pairs four at a time (fp32-MFMA kernels, separate passes).  Float32-grade
+    agreement per pair: 2e-5 of the pose norm (measured 3e-6)."""
+    obs = bench.make_inputs(96, torch.device(DEV), 6)
+    model, _ = default_model()
+    model.eval()
+    with torch.no_grad():
+        big = model(obs).double().cpu().numpy()
+        small = np.concatenate([model({k: v[i:i + 4].contiguous() for k, v in obs.items()}).double().cpu().numpy()
+                                for i in range(0, 96, 4)])
+    err = np.linalg.norm(big - small, axis=1) / np.maximum(np.linalg.norm(small, axis=1), 1e-2)
+    assert 0 < err.max() < 2e-5, err.max()          # (0 would mean both ran the same kernels)
+
+
 def test_both_stem_weight_gradient_kernels_agree_at_full_resolution():
     """The stem's weight gradient on the bf16 matrix cores (exact three-piece operands, wgrad_stem_mx.hip) against the
     float32-MFMA kernel (PNVO_WGRAD_STEM=fp32) on 16 pairs at 341x192, whitening on: the products are exact in both, only the
