@@ -101,3 +101,20 @@ def test_set_precision_is_validated_on_the_host():
     assert m.set_precision("bfloat16") is m and m._precision == "bfloat16"
     with pytest.raises(ValueError):
         m.set_precision("float16")
+
+
+def test_mfma_utilisation_table_regenerates_from_the_committed_profiles():
+    """tools/mfma_util.py on the newest committed counter / trace summaries of profiles/ (the evidence DESIGN.md quotes)."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traces = sorted(glob.glob(os.path.join(root, "profiles", "r2*_kernel_trace_fwd_fp32.md")))
+    assert traces
+    tag = os.path.basename(traces[-1]).split("_")[0]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_util.py"), traces[-1],
+                        os.path.join(root, "profiles", f"{tag}_pmc_fwd_fp32.md")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    stem = [ln for ln in r.stdout.splitlines() if ln.startswith("| stem_mx_kernel")]
+    assert stem and 0.3 < float(stem[0].split("|")[5]) < 1.0, r.stdout[:600]
