@@ -10,7 +10,9 @@
  * hipStream_t).  Every function returns 0 (PNVO_OK) or a negative error code and never throws; the message of
  * the last error on a handle is available from pnvo_last_error().  All tensor arguments of the compute entry
  * points are DEVICE pointers owned by the caller, NHWC, float32 unless stated; calls are asynchronous on the
- * given stream and perform no host synchronisation.  A handle is not thread-safe: one handle per
+ * given stream and never wait for the whole forward (the one partial wait — for the stem kernel, so that inputs
+ * outside the fused stems' contract are handled inside the call — is described at pnvo_check_inputs and can be
+ * switched off).  A handle is not thread-safe: one handle per
  * (process, stream), one process per GPU (the reference's own model: launch.py:11-12).
  */
 #ifndef PNVO_H_
@@ -82,6 +84,28 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
  */
 int pnvo_forward(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv,
                  const int64_t *actions, int B, float *out, void *stream);
+
+/*
+ * Per-handle options: kernel-family selection and behaviour switches.  The reference has no counterpart (torch dispatches its
+ * kernels itself); these exist so that tests and benchmarks can A/B the kernel families and so that integrations configure
+ * a handle in code, not through the process environment.  The PNVO_<KEY> environment variables of earlier rounds are only
+ * the DEFAULTS, read once in pnvo_create; no entry point reads the environment afterwards.
+ *   key               values (first = default)             meaning
+ *   "stem"            auto | mx | dd | dense                 stem kernel: bf16 matrix cores with exact 3-piece weights | one-hot
+ *                                                            table gather | all-fp32 MFMA (takes ANY float input)
+ *   "conv"            auto | x3 | fp32 | generic             3x3 / strided convs: 3-piece bf16-pipe kernel for launches of >= 192
+ *                                                            workgroups (auto) or always (x3) | fp32-MFMA LDS kernels | generic
+ *   "x3_s2"           on | off                               stride-2 convs on the 3-piece kernel
+ *   "tail", "pool"    fused | separate                       BasicBlock tails / the max-pool folded into neighbouring kernels
+ *   "input_fallback"  on | off                               see pnvo_check_inputs
+ *   "graph"           0 | 1                                  replay the forward from a captured hipGraph
+ *   "wgrad_stem"      mx | fp32        "pool_bwd" fused | separate        "dgrad" phase | masked        (training step)
+ *   "bf16_fuse"       on | off         "bf16_stem3" 0 | 1    "conv3_nt" 0 | 1   "stem_dbg" <int>            (experiments)
+ * Unknown keys / values return PNVO_ERR_ARG with the accepted spellings in pnvo_last_error.
+ */
+int pnvo_set_option(pnvo_handle h, const char *key, const char *value);
+/* Current value of an option as text ("dense (fallback)" for "stem" once the input fallback engaged). */
+int pnvo_get_option(pnvo_handle h, const char *key, char *buf, size_t cap);
 
 /*
  * Arithmetic of pnvo_forward for this handle: 0 = float32 (default: exact-float32 products on the matrix cores), 1 = bfloat16
@@ -309,11 +333,17 @@ typedef struct {
 int pnvo_forward_features(pnvo_handle h, const float *rgb, const float *depth, const float *dd, const float *tdv,
                           const int64_t *actions, int B, float *hidden_out, void *stream);
 
-/* The discretised-depth observation must be one-hot per frame — what _discretize_depth_func produces and asserts
- * (pointnav_vo/rl/common/base_trainer_with_vo.py:163); the fused stem exploits it.  A forward that meets a depth pixel
- * that is not exactly one 1 and zeros raises a host-visible flag: pnvo_check_inputs returns PNVO_ERR_INPUT once that
- * has been observed (definitive after the caller synchronised the stream), and so does every later pnvo_forward.
- * Callers that feed soft depth codes select the dense stem with the environment variable PNVO_STEM=dense. */
+/* The fused stems exploit the reference's own observation contract: rgb holds integers 0..255 (uint8 frames cast to float,
+ * base_trainer_with_vo.py:196-207) and the discretised depth is one-hot per frame (what _discretize_depth_func produces and
+ * asserts, :163).  The reference MODEL, however, accepts any float tensor (vo_cnn.py:110-176), so a drop-in must too:
+ *   option input_fallback = on (default): a forward whose stem met a value outside the contract is RE-RUN inside the same
+ *     pnvo_forward / pnvo_forward_features / pnvo_train_forward call on the dense fp32 stem — the caller gets the correct
+ *     result from that call — and the handle stays on the dense stem from then on (pnvo_last_error holds a one-line note,
+ *     pnvo_get_option(h, "stem") reports "dense (fallback)"; pnvo_set_option(h, "stem", ...) lifts it).  Cost for contract
+ *     inputs: the call waits for the stem kernel (the first of ~55 launches) before it returns; the rest stays queued.
+ *   option input_fallback = off, or a forward issued while the stream is being captured into a hipGraph: no wait; the stem
+ *     raises a host-visible flag instead and pnvo_check_inputs (definitive after the caller synchronised the stream) as well
+ *     as every later forward on the handle return PNVO_ERR_INPUT until the weights are re-loaded. */
 int pnvo_check_inputs(pnvo_handle h);
 
 int pnvo_timing_mode(pnvo_handle h, int mode);

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "pnvo_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_void_p]),
     "pnvo_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "pnvo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "pnvo_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "pnvo_forward_dual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_build_obs_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,

@@ -511,10 +511,9 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   a.CK = ck;
   // Few workgroups (small batches: the reference's navigation loop calls with ONE pair): a workgroup walks its whole K loop alone
   // (≈ 60-110 us on the deep stages) while the fp32 kernels split small problems over the chip — they keep those launches
-  // (measured: batch 1 0.41 ms against 0.72 with conv_x3 everywhere; break-even per layer at ~200 workgroups).  PNVO_CONV=x3 forces.
+  // (measured: batch 1 0.41 ms against 0.72 with conv_x3 everywhere; break-even per layer at ~200 workgroups).  Option conv=x3 (a.force) takes them anyway.
   {
-    const char *sel = std::getenv("PNVO_CONV");
-    const bool force = sel != nullptr && std::strcmp(sel, "x3") == 0;
+    const bool force = a.force != 0;
     const long wgs = (long)a.B * a.tiles_r * a.tiles_c * ((ntt + a.wn * *nw - 1) / (a.wn * *nw));
     if (wgs < 192 && !force) return false;
   }

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,10 +29,14 @@ int pnvo_fail(pnvo_handle h, int code, const std::string &msg) {
 // rewrites them in place, so device addresses cached elsewhere (the training step's re-pack maps, captured graphs)
 // stay valid across train -> eval -> train switches.
 static std::map<const void *, size_t> g_upload_floats;
+static std::mutex g_upload_mutex;      // handles of different host threads (one per device) load and destroy concurrently
 
 void pnvo_free_dev(float *&p) {
   if (p) {
-    g_upload_floats.erase(p);
+    {
+      std::lock_guard<std::mutex> lk(g_upload_mutex);
+      g_upload_floats.erase(p);
+    }
     (void)hipFree(p);
   }
   p = nullptr;
@@ -186,10 +192,16 @@ const float *find_tensor(pnvo_handle h, const Toc &t, const std::string &name, s
 }
 
 int upload(pnvo_handle h, float *&dst, const float *src, size_t n) {
-  auto it = dst ? g_upload_floats.find(dst) : g_upload_floats.end();
-  if (it == g_upload_floats.end() || it->second != n) {
+  bool same = false;
+  if (dst) {
+    std::lock_guard<std::mutex> lk(g_upload_mutex);
+    auto it = g_upload_floats.find(dst);
+    same = it != g_upload_floats.end() && it->second == n;
+  }
+  if (!same) {
     free_dev(dst);
     HIPCHK(h, hipMalloc((void **)&dst, n * sizeof(float)));
+    std::lock_guard<std::mutex> lk(g_upload_mutex);
     g_upload_floats[dst] = n;
   }
   HIPCHK(h, hipMemcpy(dst, src, n * sizeof(float), hipMemcpyHostToDevice));
@@ -264,7 +276,7 @@ void free_workspace(pnvo_model_s *m) {
 }
 
 // Would this (GroupNorm-ed, bias-free) conv layer run on the LDS-staged 3x3 kernel?  *slots: its statistics slots.
-bool layer_on_lds(const Layer &l, int *slots) {
+bool layer_on_lds(pnvo_handle m, const Layer &l, int *slots) {
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
   a.KH = l.k;
@@ -279,18 +291,17 @@ bool layer_on_lds(const Layer &l, int *slots) {
   a.Ho = l.hout;
   a.Wo = l.wout;
   a.y_cstride = l.coutp;
-  const char *sel = std::getenv("PNVO_CONV");
-  if (!conv3_lds_supported(a) || (sel && std::strcmp(sel, "generic") == 0)) return false;
+  if (!conv3_lds_supported(a) || m->opt.conv == 3) return false;
   if (slots) *slots = conv3_lds_slots(a);
   return true;
 }
 
-size_t stats_floats(const Layer &l, int B) {
+size_t stats_floats(pnvo_handle m, const Layer &l, int B) {
   const long P = (long)l.hout * l.wout, M = (long)B * P;
   int MT, NT;
   choose_tile(M, l.coutp, &MT, &NT);
   int slots = conv_slots((int)P, MT), s2 = 0;
-  if (layer_on_lds(l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
+  if (layer_on_lds(m, l, &s2) && s2 > slots) slots = s2;            // conv3_lds: slots = tiles x waves
   if ((l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || l.stride == 2)) || (l.k == 1 && l.stride == 2)) {   // conv_x3: slots = tiles
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
@@ -301,6 +312,7 @@ size_t stats_floats(const Layer &l, int B) {
     xa.Ho = l.hout;
     xa.Wo = l.wout;
     xa.COUTP = l.coutp;
+    xa.force = 1;                       // (sized for the forced plan: options may change between forwards)
     int mw, nw;
     size_t ldsb;
     if (conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb) && xa.slots > slots) slots = xa.slots;
@@ -326,7 +338,7 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   }
   for (const Layer &l : m->convs) {
     if (l.coutp > maxc) maxc = l.coutp;
-    const size_t s = stats_floats(l, B);
+    const size_t s = stats_floats(m, l, B);
     if (s > st) st = s;
   }
   auto alloc = [&](float *&p, size_t n) -> hipError_t { return hipMalloc((void **)&p, n * sizeof(float)); };
@@ -428,16 +440,16 @@ void pnvo_drop_graphs(pnvo_handle m) {
 }
 
 namespace {
-// 3x3 (stride 1 or 2, pad 1) GroupNorm-ed convs run on conv_x3.hip unless PNVO_CONV selects another kernel family
-bool x3_layer(const Layer &l) {
-  const char *sel = std::getenv("PNVO_CONV");
-  const bool s2 = l.stride == 2 && !std::getenv("PNVO_X3_S2_OFF");
+// 3x3 (stride 1 or 2, pad 1) GroupNorm-ed convs run on conv_x3.hip unless option `conv` selects another kernel family
+bool x3_layer(pnvo_handle m, const Layer &l) {
+  const bool s2 = l.stride == 2 && m->opt.x3_s2;
   const bool k3 = l.k == 3 && l.kw == 3 && l.pad == 1 && (l.stride == 1 || s2);
   const bool k1 = l.k == 1 && l.kw == 1 && l.pad == 0 && s2;      // the 1x1 stride-2 downsample convs (resnet.py:192-195)
-  return (k3 || k1) && !l.host_w.empty() && !(sel && std::strcmp(sel, "x3") != 0);
+  return (k3 || k1) && !l.host_w.empty() && m->opt.conv <= 1;
 }
-bool x3_args(const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
+bool x3_args(pnvo_handle m, const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
   std::memset(&xa, 0, sizeof(xa));
+  xa.force = m->opt.conv == 1;
   xa.B = B;
   xa.H = l.hin;
   xa.W = l.win;
@@ -449,17 +461,17 @@ bool x3_args(const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ld
 }
 }  // namespace
 
-bool pnvo_conv_on_x3(const Layer &l, int B) {
-  if (!x3_layer(l) || l.groups <= 0) return false;
+bool pnvo_conv_on_x3(pnvo_handle m, const Layer &l, int B) {
+  if (!x3_layer(m, l) || l.groups <= 0) return false;
   ConvX3Args xa;
   int mw, nw;
   size_t ldsb;
-  return x3_args(l, B, xa, &mw, &nw, &ldsb);
+  return x3_args(m, l, B, xa, &mw, &nw, &ldsb);
 }
 
 bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B) {
-  if (m->tap_dst != nullptr || std::getenv("PNVO_TAIL") != nullptr) return false;   // taps want the block outputs of the plain schedule; PNVO_TAIL=separate: the pass of its own
-  return pnvo_conv_on_x3(l, B);
+  if (m->tap_dst != nullptr || !m->opt.tail) return false;   // taps want the block outputs of the plain schedule; option tail=separate: the pass of its own
+  return pnvo_conv_on_x3(m, l, B);
 }
 
 // One conv + (optionally) the GroupNorm statistics finalisation that follows it.
@@ -511,13 +523,13 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   a.slots = conv_slots((int)P, a.MT);
   const double macs = (double)M * l.cout * l.cin * l.k * l.kw;
   const double bytes = 4.0 * ((double)B * l.hin * l.win * l.cin + (double)M * l.cout + (double)l.cout * l.cin * l.k * l.kw);
-  const char *sel = std::getenv("PNVO_CONV");
   // 3x3 stride-1 convs with GroupNorm: float32 results from the bf16 matrix cores (three-piece operands, conv_x3.hip);
-  // PNVO_CONV=fp32 keeps the fp32-MFMA kernels.  Also in the training forward (the three-piece operand is rebuilt on the
+  // option conv=fp32 keeps the fp32-MFMA kernels.  Also in the training forward (the three-piece operand is rebuilt on the
   // device after every optimiser step); not with a fused stem source, bias or output ReLU.
-  if (ss && src == nullptr && bias == nullptr && !relu_out && y_cstride == l.coutp && x3_layer(l)) {
+  if (ss && src == nullptr && bias == nullptr && !relu_out && y_cstride == l.coutp && x3_layer(m, l)) {
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
+    xa.force = m->opt.conv == 1;
     xa.B = B;
     xa.H = l.hin;
     xa.W = l.win;
@@ -567,10 +579,10 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     }
   }
   if (tail != nullptr) return fail(m, PNVO_ERR_STATE, "block tail handed to a conv that cannot take it (" + l.name + ")");
-  const bool lds3 = conv3_lds_supported(a) && !(sel && std::strcmp(sel, "generic") == 0);
+  const bool lds3 = conv3_lds_supported(a) && m->opt.conv != 3;
   if (lds3) {                    // 3x3 stride-1 residual-stage conv: input patch staged in LDS
     int nt = (l.coutp / 32) % 2 == 0 ? 2 : 1;
-    if (const char *e = std::getenv("PNVO_CONV3_NT")) nt = std::atoi(e) == 1 ? 1 : nt;
+    if (m->opt.conv3_nt == 1) nt = 1;
     a.slots = conv3_lds_slots(a);
     {
       Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
@@ -625,8 +637,19 @@ inline int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const 
 // The fused stem: input assembly + /255 + whitening gathered in the operand fetch (LDS-staged kernel when the channel
 // count allows, else MODE 2 of the generic kernel), raw output + GroupNorm scale/shift (+ optional mean/rstd).
 bool pnvo_stem_on_mx(pnvo_handle m) {
-  const char *sel = std::getenv("PNVO_STEM");
-  return m->mx_ok && (!m->in_train_forward || m->train_mx) && (!sel || std::strcmp(sel, "mx") == 0);
+  return m->mx_ok && !m->dense_sticky && (!m->in_train_forward || m->train_mx) && m->opt.stem <= 1;
+}
+
+// An event behind a contract-checking stem launch (see pnvo_input_fallback); nothing while a stream capture is under way
+// (an event recorded into a graph cannot be waited for: such forwards keep the deferred check of pnvo_check_inputs).
+int pnvo_mark_stem(pnvo_handle m, hipStream_t s) {
+  if (!m->opt.input_fallback || m->dense_sticky || !m->dd_flag) return PNVO_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return PNVO_OK;
+  if (!m->stem_ev) HIPCHK(m, hipEventCreateWithFlags(&m->stem_ev, hipEventDisableTiming));
+  HIPCHK(m, hipEventRecord(m->stem_ev, s));
+  m->stem_ev_pending = true;
+  return PNVO_OK;
 }
 
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
@@ -635,7 +658,6 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
   const Layer &stem = m->convs[0];
   int rc = PNVO_OK;
   const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
-  const char *sel = std::getenv("PNVO_STEM");
   if (pool_keys != nullptr && !pnvo_stem_on_mx(m)) return fail(m, PNVO_ERR_STATE, "pooled stem output asked of a stem kernel without it");
   if (pnvo_stem_on_mx(m)) {
     // bf16 matrix cores, three exact weight pieces: float32 results (stem_mx.hip).  The training step keeps the kernels
@@ -664,26 +686,26 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.pool_gamma = stem.gamma;
     a.Hp = m->Hp;
     a.Wp = m->Wp;
-    if (const char *e = std::getenv("PNVO_STEM_DBG"))
-      if (std::atoi(e) == 9) {
-        if (!m->mx_prof) {
-          HIPCHK(m, hipMalloc((void **)&m->mx_prof, 256));
-          HIPCHK(m, hipMemset(m->mx_prof, 0, 256));
-        }
-        a.prof = m->mx_prof;
+    if (m->opt.stem_dbg == 9) {
+      if (!m->mx_prof) {
+        HIPCHK(m, hipMalloc((void **)&m->mx_prof, 256));
+        HIPCHK(m, hipMemset(m->mx_prof, 0, 256));
       }
+      a.prof = m->mx_prof;
+    }
     const double M = (double)B * m->Hs * m->Ws;
     {
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
               4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
       HIPCHK(m, launch_stem_mx(a, 3, ntn, false, s));
     }
+    if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
                                    stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
     }
-  } else if (m->dd_ok && !(sel && std::strcmp(sel, "dense") == 0)) {
+  } else if (m->dd_ok && m->opt.stem != 3 && !m->dense_sticky) {
     // one-hot-aware stem (in training its operands are rebuilt on the device every step: refresh_stem_dd)
     const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
     StemDDArgs a;
@@ -712,7 +734,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.Wo = m->Ws;
     a.bins = m->dd_bins;
     a.slots = stem_dd_slots(m->Hs, m->Ws);
-    if (const char *e = std::getenv("PNVO_STEM_DBG")) a.dbg = std::atoi(e);
+    a.dbg = m->opt.stem_dbg;
     if (a.dbg == 9) {
       if (!m->dd_prof) {
         HIPCHK(m, hipMalloc((void **)&m->dd_prof, 64));
@@ -726,6 +748,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
               4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
       HIPCHK(m, launch_stem_dd(a, s));
     }
+    if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
@@ -757,7 +780,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.Wo = m->Ws;
     a.CPL = m->CPL;
     a.slots = stem_tiles_x(m->Ws) * stem_tiles_y(m->Hs);
-    if (const char *e = std::getenv("PNVO_STEM_DBG")) std::sscanf(e, "%d,%d", &a.dbg, &a.lds_pad);
+    a.dbg = m->opt.stem_dbg;
+    a.lds_pad = m->opt.stem_dbg_pad;
     const double M = (double)B * m->Hs * m->Ws;
     {
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
@@ -778,6 +802,101 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
 }
 
 int pnvo_ensure_workspace(pnvo_handle m, int B) { return ensure_workspace(m, B); }
+
+namespace {
+// option table: key -> (member, accepted spellings).  The PNVO_* environment variables of earlier rounds are the DEFAULTS of
+// these options, read once per handle in pnvo_create; nothing on the forward path reads the environment.
+struct OptChoice {
+  const char *word;
+  int value;
+};
+struct OptDef {
+  const char *key, *env;
+  int PnvoOptions::*field;
+  bool numeric;                 // value = atoi(word) instead of a choice
+  OptChoice choices[5];
+};
+const OptDef kOptions[] = {
+    {"stem", "PNVO_STEM", &PnvoOptions::stem, false, {{"auto", 0}, {"mx", 1}, {"dd", 2}, {"dense", 3}, {nullptr, 0}}},
+    {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
+    {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
+    {"pool", "PNVO_POOL", &PnvoOptions::pool, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
+    {"conv3_nt", "PNVO_CONV3_NT", &PnvoOptions::conv3_nt, true, {{nullptr, 0}}},
+    {"graph", "PNVO_GRAPH", &PnvoOptions::graph, true, {{nullptr, 0}}},
+    {"stem_dbg", nullptr, &PnvoOptions::stem_dbg, true, {{nullptr, 0}}},
+    {"stem_dbg_pad", nullptr, &PnvoOptions::stem_dbg_pad, true, {{nullptr, 0}}},
+    {"wgrad_stem", "PNVO_WGRAD_STEM", &PnvoOptions::wgrad_stem, false, {{"mx", 0}, {"fp32", 1}, {nullptr, 0}}},
+    {"pool_bwd", "PNVO_POOL_BWD", &PnvoOptions::pool_bwd, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
+    {"dgrad", "PNVO_DGRAD", &PnvoOptions::dgrad, false, {{"phase", 1}, {"masked", 0}, {nullptr, 0}}},
+    {"bf16_fuse", nullptr, &PnvoOptions::bf16_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"bf16_stem3", "PNVO_BF16_STEM3", &PnvoOptions::bf16_stem3, true, {{nullptr, 0}}},
+    {"input_fallback", "PNVO_INPUT_FALLBACK", &PnvoOptions::input_fallback, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"small_tail", "PNVO_SMALL_TAIL", &PnvoOptions::small_tail, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+};
+
+const OptDef *find_option(const char *key) {
+  for (const OptDef &d : kOptions)
+    if (std::strcmp(d.key, key) == 0) return &d;
+  return nullptr;
+}
+
+bool parse_option(const OptDef &d, const char *word, int *out) {
+  if (d.numeric) {
+    char *end = nullptr;
+    const long v = std::strtol(word, &end, 10);
+    if (end == word || *end != 0) return false;
+    *out = (int)v;
+    return true;
+  }
+  for (const OptChoice *c = d.choices; c->word != nullptr; ++c)
+    if (std::strcmp(c->word, word) == 0) {
+      *out = c->value;
+      return true;
+    }
+  return false;
+}
+
+void env_defaults(pnvo_model_s *m) {
+  for (const OptDef &d : kOptions) {
+    const char *e = d.env ? std::getenv(d.env) : nullptr;
+    int v;
+    if (e && parse_option(d, e, &v)) m->opt.*(d.field) = v;
+  }
+  // spellings of earlier rounds that do not fit the table
+  if (std::getenv("PNVO_X3_S2_OFF")) m->opt.x3_s2 = 0;
+  if (std::getenv("PNVO_BF16_NOFUSE")) m->opt.bf16_fuse = 0;
+  if (const char *e = std::getenv("PNVO_STEM_DBG")) std::sscanf(e, "%d,%d", &m->opt.stem_dbg, &m->opt.stem_dbg_pad);
+}
+}  // namespace
+
+
+// The stems that exploit the observation contract (uint8-valued rgb, one-hot depth: stem_mx.hip, stem_dd.hip) raise a
+// host-mapped flag when a value breaks it.  pnvo_run_stem records an event behind such a stem; once the rest of the forward
+// is enqueued the caller waits for THAT event (the stem is the first kernel of ~55: it has normally finished by then, and the
+// GPU keeps the rest of the queue), and a raised flag re-runs the forward on the dense fp32 stem — which takes any float
+// input, as the reference model does (vo_cnn.py:110-176) — and keeps the handle on it.
+int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun) {
+  *rerun = false;
+  if (!m->stem_ev_pending) return PNVO_OK;
+  m->stem_ev_pending = false;
+  HIPCHK(m, hipEventSynchronize(m->stem_ev));
+  if (!m->dd_flag || *(volatile int *)m->dd_flag == 0) return PNVO_OK;
+  *(volatile int *)m->dd_flag = 0;
+  m->dense_sticky = true;
+  m->fallback_count += 1;
+  pnvo_drop_graphs(m);
+  m->err = "note: observation values outside the fused stems' contract (fractional rgb or depth codes that are not one-hot) — "
+           "the forward was re-run on the dense fp32 stem and this handle stays on it";
+  *rerun = true;
+  return PNVO_OK;
+}
+
+namespace {
+int forward_dispatch(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                     const int64_t *actions, int B, float *out, hipStream_t s);
+}
+
 
 // ==================================================================================================================
 extern "C" {
@@ -803,10 +922,13 @@ int pnvo_create(const pnvo_config *cfg, int device, pnvo_handle *out) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return fail(nullptr, PNVO_ERR_ARG, std::string("libpnvo is built for gfx950 only, device is ") + prop.gcnArchName);
   pnvo_model_s *m = new pnvo_model_s();
+  static std::atomic<unsigned long long> next_uid{1};
+  m->uid = next_uid.fetch_add(1);
   m->cfg = *cfg;
   m->device = device;
   if (m->cfg.flat_size <= 0) m->cfg.flat_size = 2048;
   if (m->cfg.n_acts <= 0) m->cfg.n_acts = 4;
+  env_defaults(m);                 // the ONLY place the PNVO_* environment is read for this handle
   build_plan(m);
   *out = m;
   return PNVO_OK;
@@ -1038,6 +1160,41 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
   h->loaded = true;
   h->load_gen += 1;
   h->weights_gen += 1;
+  h->weights_gen_at_load = h->weights_gen;
+  return PNVO_OK;
+}
+
+int pnvo_set_option(pnvo_handle h, const char *key, const char *value) {
+  if (!h || !key || !value) return fail(h, PNVO_ERR_ARG, "null argument");
+  const OptDef *d = find_option(key);
+  if (!d) return fail(h, PNVO_ERR_ARG, std::string("unknown option '") + key + "'");
+  int v;
+  if (!parse_option(*d, value, &v)) {
+    std::string msg = std::string("option '") + key + "' does not take '" + value + "' (";
+    if (d->numeric) msg += "an integer";
+    for (const OptChoice *c = d->choices; !d->numeric && c->word != nullptr; ++c) msg += std::string(c == d->choices ? "" : " | ") + c->word;
+    return fail(h, PNVO_ERR_ARG, msg + ")");
+  }
+  if (h->opt.*(d->field) == v) return PNVO_OK;
+  h->opt.*(d->field) = v;
+  pnvo_drop_graphs(h);                       // captured launches encode the kernel selection
+  if (d->field == &PnvoOptions::stem) h->dense_sticky = false;   // an explicit choice lifts the fallback
+  return PNVO_OK;
+}
+
+int pnvo_get_option(pnvo_handle h, const char *key, char *buf, size_t cap) {
+  if (!h || !key || !buf || cap == 0) return fail(h, PNVO_ERR_ARG, "null argument");
+  const OptDef *d = find_option(key);
+  if (!d) return fail(h, PNVO_ERR_ARG, std::string("unknown option '") + key + "'");
+  const int v = h->opt.*(d->field);
+  std::string word = std::to_string(v);
+  for (const OptChoice *c = d->choices; !d->numeric && c->word != nullptr; ++c)
+    if (c->value == v) {
+      word = c->word;
+      break;
+    }
+  if (d->field == &PnvoOptions::stem && h->dense_sticky) word = "dense (fallback)";
+  std::snprintf(buf, cap, "%s", word.c_str());
   return PNVO_OK;
 }
 
@@ -1077,7 +1234,8 @@ int pnvo_check_inputs(pnvo_handle m) {
     return fail(m, PNVO_ERR_INPUT,
                 "an earlier forward met observation values outside the reference's contract — a discretised-depth pixel "
                 "that is not one-hot (base_trainer_with_vo.py:163) or an rgb value that is not an integer 0..255 — so its "
-                "outputs are invalid.  Feed contract inputs, or set PNVO_STEM=dense for soft depth codes / fractional rgb");
+                "outputs are invalid (this handle runs with input_fallback=off, or the forward was stream-captured).  Feed "
+                "contract inputs, keep option input_fallback on, or select the dense stem: pnvo_set_option(h, \"stem\", \"dense\")");
   return PNVO_OK;
 }
 
@@ -1107,30 +1265,35 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
   int rc = ensure_workspace(m, B);
   if (rc != PNVO_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = forward_dispatch(m, rgb, depth, dd, tdv, actions, B, out, s)) != PNVO_OK) return rc;
+  bool rerun = false;
+  if ((rc = pnvo_input_fallback(m, s, &rerun)) != PNVO_OK) return rc;
+  return rerun ? forward_dispatch(m, rgb, depth, dd, tdv, actions, B, out, s) : PNVO_OK;
+}
 
-  if (m->graph_mode < 0) {
-    // Opt-in (PNVO_GRAPH=1).  Measured on ROCm 7.2 / MI355X: replaying the ~60-node graph is no faster than the plain
+namespace {
+int forward_dispatch(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
+                     const int64_t *actions, int B, float *out, hipStream_t s) {
+  const pnvo_config &c = m->cfg;
+  int rc = PNVO_OK;
+  {
+    // Opt-in (option graph=1).  Measured on ROCm 7.2 / MI355X: replaying the ~60-node graph is no faster than the plain
     // asynchronous launches — 6.32 vs 6.22 ms at B = 256 (the GPU is never starved) and 0.77 vs 0.80 ms at B = 1 (the
     // dependent-kernel latency of the chain, not the host launches, is what a batch-1 call pays).
-    const char *e = std::getenv("PNVO_GRAPH");
-    m->graph_mode = (e && std::atoi(e) == 1) ? 1 : 0;
+    m->graph_mode = m->opt.graph;
   }
-  const bool plain = !m->graph_mode || m->timing || m->tap_dst != nullptr || m->train != nullptr ||
-                     std::getenv("PNVO_STEM_DBG") != nullptr;
+  const bool plain = !m->graph_mode || m->timing || m->tap_dst != nullptr || m->train != nullptr || m->opt.stem_dbg != 0;
   if (plain) return forward_body(m, rgb, depth, dd, tdv, actions, B, out, s);
 
   // ---- graph replay: key = everything the captured kernel arguments depend on
-  const char *e1 = std::getenv("PNVO_STEM"), *e2 = std::getenv("PNVO_CONV"), *e3 = std::getenv("PNVO_CONV3_NT");
-  const void *key[8] = {rgb, depth, dd, tdv, actions, nullptr,
-                        (const void *)(uintptr_t)((e1 ? e1[0] : 0) | ((e2 ? e2[0] : 0) << 8) | ((e3 ? e3[0] : 0) << 16)),
-                        nullptr};
+  const void *key[8] = {rgb, depth, dd, tdv, actions, nullptr, nullptr, nullptr};   // (pnvo_set_option drops the captured graphs)
   const size_t out_bytes = (size_t)B * c.out_dim * sizeof(float);
   for (auto &g : m->graphs)
     if (g.B == B && std::memcmp(g.key, key, sizeof(key)) == 0) {
       g.stamp = ++m->graph_clock;
       HIPCHK(m, hipGraphLaunch(g.exec, s));
       HIPCHK(m, hipMemcpyAsync(out, m->out_ws, out_bytes, hipMemcpyDeviceToDevice, s));
-      return PNVO_OK;
+      return pnvo_mark_stem(m, s);
     }
   bool again = false;                              // capture only call shapes that come back
   for (auto &g : m->seen) again = again || (g.B == B && std::memcmp(g.key, key, sizeof(key)) == 0);
@@ -1168,16 +1331,17 @@ int pnvo_forward(pnvo_handle m, const float *rgb, const float *depth, const floa
   m->graphs.push_back(g);
   HIPCHK(m, hipGraphLaunch(g.exec, s));
   HIPCHK(m, hipMemcpyAsync(out, m->out_ws, out_bytes, hipMemcpyDeviceToDevice, s));
-  return PNVO_OK;
+  return pnvo_mark_stem(m, s);
 }
+}  // namespace
 
 namespace {
 int forward_body(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
                  const int64_t *actions, int B, float *out, hipStream_t s) {
   const pnvo_config &c = m->cfg;
   int rc = PNVO_OK;
-  // (a4+a5+a6) input assembly + /255 + whitening are fused into the stem conv's operand fetch (MODE 2 of
-  // conv_mfma_kernel): the [B,H,W,30] tensor of the reference (vo_cnn.py:174-176) is never materialised.
+  // (a4+a5+a6) input assembly + /255 + whitening are fused into the stem kernel's operand fetch (pnvo_run_stem): the
+  // [B,H,W,30] tensor of the reference (vo_cnn.py:174-176) is never materialised.
   if (m->tap_dst != nullptr && m->tap_name == "input") {   // introspection only: materialise it for the tap
     AssembleArgs a;
     a.src[0] = rgb;
@@ -1205,7 +1369,7 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   // first block's first conv decodes / normalises them while staging and writes the pooled activations the skip branch needs
   // (conv_x3 MODE 3).  PNVO_POOL=separate, taps, Bottleneck models and the other stem kernels keep the pass.
   float *cur = m->bufY[0], *nxt = m->bufY[1];
-  const bool pool_fused = !m->bottleneck && pnvo_stem_on_mx(m) && std::getenv("PNVO_POOL") == nullptr && m->convs.size() > 1 &&
+  const bool pool_fused = !m->bottleneck && pnvo_stem_on_mx(m) && m->opt.pool && m->convs.size() > 1 &&
                           stem.coutp == stem.cout && pnvo_conv_takes_tail(m, m->convs[1], B);
   {
     const float *src[4] = {rgb, depth, dd, tdv};
@@ -1277,7 +1441,7 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
         return rc;
       }
       const long P = (long)c2.hout * c2.wout;
-      if (!layer_on_lds(c2, nullptr) && !pnvo_conv_on_x3(c2, B) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20)) {
+      if (!layer_on_lds(m, c2, nullptr) && !pnvo_conv_on_x3(m, c2, B) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20)) {
         // small deep stage on the generic kernel: its per-tap GroupNorm+ReLU prologue costs more than one streaming
         // pass over the (L2-sized) tensor, so normalise once and run the conv on final activations
         {
@@ -1354,6 +1518,9 @@ int pnvo_forward_features(pnvo_handle m, const float *rgb, const float *depth, c
   if (rc != PNVO_OK) return rc;
   m->features_only = true;
   rc = forward_body(m, rgb, depth, dd, tdv, actions, B, hidden_out, (hipStream_t)stream);
+  bool rerun = false;
+  if (rc == PNVO_OK) rc = pnvo_input_fallback(m, (hipStream_t)stream, &rerun);
+  if (rc == PNVO_OK && rerun) rc = forward_body(m, rgb, depth, dd, tdv, actions, B, hidden_out, (hipStream_t)stream);
   m->features_only = false;
   return rc;
 }
@@ -1454,6 +1621,7 @@ int pnvo_destroy(pnvo_handle m) {
   pnvo_bf16_free(m);
   free_workspace(m);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+  if (m->stem_ev) (void)hipEventDestroy(m->stem_ev);
   for (Layer &l : m->convs) {
     free_dev(l.wpk);
     free_dev(reinterpret_cast<float *&>(l.wpk_x3));

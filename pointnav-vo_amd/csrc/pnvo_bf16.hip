@@ -32,7 +32,7 @@ struct Bf16State {
   unsigned short *stem_wpk = nullptr;        // PIECES = 1 packing, one N-tile group (this model on (prev, cur))
   std::vector<unsigned short> stem_host, stem_host_sw;   // host copies: as is / for the swapped pair
   unsigned short *dual_stem = nullptr;       // [tap][fragment][2 models][lane]: this model + a partner's swapped packing
-  const void *dual_partner = nullptr;
+  unsigned long long dual_partner = 0;       // process-unique id of the partner handle (an address can be re-used)
   unsigned long long dual_partner_gen = 0, dual_self_gen = 0;
   int cap = 0;
   unsigned short *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr}, *rawA = nullptr, *rawB = nullptr, *rawD = nullptr;
@@ -67,6 +67,12 @@ void free_ws(Bf16State *b) {
 
 int prepare(pnvo_handle m) {
   Bf16State *b = static_cast<Bf16State *>(m->bf);
+  // The bf16 operands are packed from the host copies pnvo_load_weights took.  Parameters that moved on the device since
+  // then (pnvo_adam_step + pnvo_train_refresh bump weights_gen) would silently evaluate as the pre-training weights.
+  if (m->weights_gen != m->weights_gen_at_load)
+    return pnvo_fail(m, PNVO_ERR_STATE, "the bfloat16 operands are built from the weights given to pnvo_load_weights, and the parameters "
+                                        "have been updated on the device since (pnvo_train_refresh): call pnvo_load_weights with the "
+                                        "current parameters before a bfloat16 forward");
   if (b && b->gen == m->load_gen) return PNVO_OK;
   const pnvo_config &c = m->cfg;
   if (m->bottleneck || c.baseplanes != 32 || !m->mx_ok || m->convs[0].cout != 32)
@@ -142,7 +148,7 @@ int ensure_ws(pnvo_handle m, int B) {
 // the stem's B operand for a dual launch: [tap][fragment][model 0 | model 1 on the swapped pair][lane]
 int dual_stem(pnvo_handle m0, pnvo_handle m1) {
   Bf16State *b0 = static_cast<Bf16State *>(m0->bf), *b1 = static_cast<Bf16State *>(m1->bf);
-  if (b0->dual_stem && b0->dual_partner == m1 && b0->dual_partner_gen == m1->load_gen && b0->dual_self_gen == m0->load_gen)
+  if (b0->dual_stem && b0->dual_partner == m1->uid && b0->dual_partner_gen == m1->load_gen && b0->dual_self_gen == m0->load_gen)
     return PNVO_OK;
   const size_t n1 = stem_mx_packed_u16(1, 1);            // 49 taps x 2 fragments x 512 u16
   std::vector<unsigned short> pk(2 * n1);
@@ -152,7 +158,7 @@ int dual_stem(pnvo_handle m0, pnvo_handle m1) {
   }
   if (!b0->dual_stem) HIPCHK(m0, hipMalloc((void **)&b0->dual_stem, pk.size() * 2));
   HIPCHK(m0, hipMemcpy(b0->dual_stem, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
-  b0->dual_partner = m1;
+  b0->dual_partner = m1->uid;
   b0->dual_partner_gen = m1->load_gen;
   b0->dual_self_gen = m0->load_gen;
   return PNVO_OK;
@@ -218,8 +224,7 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     {
       PnvoTimed t(m, s, "bf16:stem", 2.0 * nm * M * stem.cout * stem.cin * 49,
                   4.0 * (double)B * c.height * c.width * stem.cin + 2.0 * nm * M * stem.cout);
-      const char *ex = std::getenv("PNVO_BF16_STEM3");         // experiment: exact three-piece stem in front of the bf16 stages
-      if (ex && ex[0] == '1' && nm == 1) {
+      if (m->opt.bf16_stem3 == 1 && nm == 1) {                 // experiment: exact three-piece stem in front of the bf16 stages
         a.wpk = m->mx_wpk3;
         HIPCHK(m, launch_stem_mx(a, 3, 1, true, s));
       } else {
@@ -251,7 +256,7 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     bool on = false, affine = false;     // affine: the skip branch is the raw downsample conv (GN applied in the fetch)
     int buf = 0;                         // else: the block input bufY[buf]
   };
-  const bool fuse = std::getenv("PNVO_BF16_NOFUSE") == nullptr;
+  const bool fuse = m->opt.bf16_fuse != 0;
   auto conv = [&](size_t li, int mode, auto xin, auto yout, int ss_sel /*0 A, 1 B, 2 D, 3 C*/, bool f32out, const Skip &sk,
                   int out_buf) -> int {
     const Layer &l = m->convs[li];

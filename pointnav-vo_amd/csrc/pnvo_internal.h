@@ -122,6 +122,7 @@ struct ConvX3Args {
   int B, H, W, CIN, Ho, Wo, COUTP;
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_x3_plan
   unsigned long long *prof;          // PNVO_X3_PROF=1: phase cycles of one workgroup (nullptr otherwise)
+  int force;                         // conv_x3_plan: take the layer at any launch size (option conv=x3)
 };
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);

@@ -23,6 +23,25 @@ struct Layer {
   unsigned long long x3_gen = 0;
 };
 
+// Per-handle options (pnvo_set_option; defaults from the PNVO_* environment, read ONCE in pnvo_create).
+struct PnvoOptions {
+  int stem = 0;        // 0 auto (bf16-matrix-core stem when the model's modalities fit it, else one-hot-aware, else dense), 1 mx, 2 dd, 3 dense
+  int conv = 0;        // 0 auto (conv_x3 for launches of >= 192 workgroups, fp32-MFMA kernels below), 1 x3 at any size, 2 fp32, 3 generic
+  int x3_s2 = 1;       // stride-2 convs on conv_x3
+  int tail = 1;        // BasicBlock tails fused into the next conv's stager (0: residual_kernel)
+  int pool = 1;        // max-pool fused into the stem's epilogue (0: gn_relu_maxpool_kernel)
+  int conv3_nt = 0;    // 1: one N-tile per item in conv3_lds
+  int graph = 0;       // forward replayed from a captured hipGraph
+  int stem_dbg = 0, stem_dbg_pad = 0;   // developer instrumentation of the stem kernels
+  int wgrad_stem = 0;  // 0 bf16 matrix cores, 1 fp32
+  int pool_bwd = 1;    // max-pool backward fused into the stem's GroupNorm backward
+  int dgrad = 1;       // stride-2 backward-data as four parity-phase convs (0: masked taps)
+  int bf16_fuse = 1;   // bf16 path: block tails fused
+  int bf16_stem3 = 0;  // bf16 path: exact three-piece stem (experiment)
+  int input_fallback = 1;   // contract-breaking input (fractional rgb, soft depth codes): re-run on the dense stem and stay on it
+  int small_tail = 1;  // small batches: stages 3-4 + compression + Linear layers in one persistent kernel
+};
+
 struct TimingRec {
   hipEvent_t a, b;
   int entry;
@@ -67,8 +86,15 @@ struct pnvo_model_s {
   unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx
   bool in_train_forward = false;
   bool train_mx = false;                     // the attached training step rebuilds the mx stem operands every step
+  PnvoOptions opt;
+  bool dense_sticky = false;                 // an input outside the mx/dd stems' contract was met: this handle stays on the dense stem
+  int fallback_count = 0;                    // forwards re-run on the dense stem
+  hipEvent_t stem_ev = nullptr;              // recorded behind a contract-checking stem launch (pnvo_mark_stem)
+  bool stem_ev_pending = false;
   int precision = 0;                         // pnvo_set_precision: 0 float32 (default), 1 bfloat16 (BASELINE config 3)
   unsigned long long load_gen = 0;           // bumped by pnvo_load_weights (operands derived lazily are rebuilt)
+  unsigned long long weights_gen_at_load = 0;  // weights_gen as pnvo_load_weights left it
+  unsigned long long uid = 0;                // process-unique handle id (cache keys that must not alias a re-used address)
   unsigned long long weights_gen = 0;        // bumped by pnvo_load_weights AND by every pnvo_train_refresh (conv_x3 operands)
   void *bf = nullptr;                        // Bf16State (pnvo_bf16.hip)             // set by pnvo_train_forward: its stem operands are rebuilt on the device
 
@@ -128,12 +154,14 @@ struct BlockTail {
 int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
                   float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
                   hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail = nullptr);
-bool pnvo_conv_on_x3(const Layer &l, int B);                        // would pnvo_run_conv(l) use conv_x3.hip?
+bool pnvo_conv_on_x3(pnvo_handle m, const Layer &l, int B);                        // would pnvo_run_conv(l) use conv_x3.hip?
 bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B);   // would pnvo_run_conv(l) accept a BlockTail (conv_x3 path)?
 void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out);
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
                   hipStream_t s, int *pool_keys = nullptr);
 bool pnvo_stem_on_mx(pnvo_handle m);
+int pnvo_mark_stem(pnvo_handle m, hipStream_t s);
+int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun);   // after the forward is enqueued: wait for the stem, re-run on the dense stem?
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
 const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name);   // pnvo_train_api.hip: device pointer or nullptr
 void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip

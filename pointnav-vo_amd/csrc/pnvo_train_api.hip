@@ -494,8 +494,7 @@ float *gradp(pnvo_handle m, TrainState *t, const std::string &name, int *rc) {
 // backward-data of conv `l`: dX[B, hin, win, cin] (+)= conv(dRaw[B, hout, wout, coutp], flipped/transposed weights)
 int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw, float *dx, bool accum, hipStream_t s) {
   const Layer &l = m->convs[li];
-  static const bool no_phase = std::getenv("PNVO_DGRAD") && std::strcmp(std::getenv("PNVO_DGRAD"), "masked") == 0;
-  if (t->dgrad_wph[li][0] != nullptr && !no_phase) {   // stride-2 3x3: four dense parity-phase convs instead of 9 taps, 3/4 masked
+  if (t->dgrad_wph[li][0] != nullptr && m->opt.dgrad) {   // stride-2 3x3: four dense parity-phase convs instead of 9 taps, 3/4 masked
     PnvoTimed tm(m, s, "dgrad:" + l.name, 2.0 * (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw, 0.0);
     for (int ph = 0; ph < 2; ++ph)
       for (int pw = 0; pw < 2; ++pw) {
@@ -533,10 +532,10 @@ int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw,
     return PNVO_OK;
   }
   // 3x3 stride-1: float32 results from the bf16 matrix cores (three-piece operands), as in the forward (PNVO_CONV=fp32: off)
-  static const char *csel = std::getenv("PNVO_CONV");
-  if (l.k == 3 && l.kw == 3 && l.stride == 1 && l.pad == 1 && !accum && l.cin % 32 == 0 && !(csel && std::strcmp(csel, "x3") != 0)) {
+  if (l.k == 3 && l.kw == 3 && l.stride == 1 && l.pad == 1 && !accum && l.cin % 32 == 0 && m->opt.conv <= 1) {
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
+    xa.force = m->opt.conv == 1;
     xa.B = B;
     xa.H = l.hout;
     xa.W = l.wout;
@@ -719,8 +718,20 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
   return refresh_stem_dd(m, t, (hipStream_t)stream);
 }
 
+static int train_forward_body(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
+                              const float *run_mean, const float *run_var, float *out, void *stream);
+
 int pnvo_train_forward(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
                        const float *run_mean, const float *run_var, float *out, void *stream) {
+  int rc = train_forward_body(m, rgb, depth, dd, tdv, B, run_mean, run_var, out, stream);
+  if (rc != PNVO_OK) return rc;
+  bool rerun = false;                  // an input outside the fused stems' contract: once more on the dense stem (pnvo_api.hip)
+  if ((rc = pnvo_input_fallback(m, (hipStream_t)stream, &rerun)) != PNVO_OK) return rc;
+  return rerun ? train_forward_body(m, rgb, depth, dd, tdv, B, run_mean, run_var, out, stream) : PNVO_OK;
+}
+
+static int train_forward_body(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv, int B,
+                              const float *run_mean, const float *run_var, float *out, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   if (B <= 0 || !out) return pnvo_fail(m, PNVO_ERR_ARG, "bad batch / null output");
   const pnvo_config &c = m->cfg;
@@ -1015,8 +1026,7 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
   // ---- stem: maxpool <- dY, GroupNorm + ReLU, weight gradient (no input gradient)
   {
     const Layer &l = m->convs[0];
-    static const bool unfused = std::getenv("PNVO_POOL_BWD") && std::strcmp(std::getenv("PNVO_POOL_BWD"), "separate") == 0;
-    if (!unfused && l.coutp == l.cout && l.cout % 4 == 0 && l.cout <= 256 && 256 % (l.cout / 4) == 0) {
+    if (m->opt.pool_bwd && l.coutp == l.cout && l.cout % 4 == 0 && l.cout <= 256 && 256 % (l.cout / 4) == 0) {
       // max-pool backward folded into the stem's GroupNorm backward: the un-pooled gradient is never materialised
       const ConvSave &cs0 = t->cs[0];
       float *dg = gradp(m, t, l.gn + ".weight", &rc);
@@ -1030,8 +1040,8 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
       HIPCHK(m, launch_maxpool_bwd(dY, t->pool_idx, B, m->Hs, m->Ws, l.coutp, t->dStem, s));
       if ((rc = run_gn_bwd(m, t, 0, B, t->dStem, 1, t->dStem, s)) != PNVO_OK) return rc;
     }
-    const char *wsel = std::getenv("PNVO_WGRAD_STEM");      // "fp32": the float32-MFMA kernel (read per call: tests compare the two)
-    const bool stem_fp32 = wsel && std::strcmp(wsel, "fp32") == 0;
+    // option wgrad_stem=fp32: the float32-MFMA kernel; also once an input outside the exact-operand contract was met
+    const bool stem_fp32 = m->opt.wgrad_stem == 1 || m->dense_sticky;
     if (m->train_mx && l.coutp == 32 && !stem_fp32) {
       WgradStemMXArgs a;
       std::memset(&a, 0, sizeof(a));

@@ -190,19 +190,28 @@ class VOTrainStep:
         distributed = dist.is_available() and dist.is_initialized()
         C_ = self._m12.numel() // 2
         center = rmv._mean.reshape(-1).to(torch.float32).contiguous()
-        self._input_moments(ptrs, B, center, 3, self._m12, stream)
+        if B > 0:
+            self._input_moments(ptrs, B, center, 3, self._m12, stream)
+        else:                      # a rank without entries for this action model (participate_absent): contributes zeros
+            self._m12.zero_()
         if not distributed and self._fused_rmv_ok():
             # one process: batch mean, variance about it and Chan's merge in ONE launch on the module's own buffers
             # (the ~30 tiny torch kernels below cost 0.12 ms of a 9.6 ms step)
             _lib.check(_lib.lib.pnvo_rmv_merge(_ptr(self._m12), C_, int(B), _ptr(rmv._mean), _ptr(rmv._var), _ptr(rmv._count), stream))
+            # the buffers changed IN PLACE (same data_ptr, same _version): operands the eval path derives from its host copy
+            # of the whitening statistics (bf16 stem, 64-output mx stems) must be rebuilt at the next eval / dual forward
+            self.model._loaded_sig = None
             return
         e1, e2 = self._m12[:C_].double(), self._m12[C_:].double()
-        new_mean = ((center.double() + e1) * B).to(torch.float32).view(1, -1, 1, 1)   # = adaptive_avg_pool2d(x, 1).sum(0)
-        new_count = torch.full_like(rmv._count, B)
+        # the reference's first two all-reduces (batch sum of the per-sample means, sample count: running_mean_and_var.py:
+        # 27-33) travel as ONE buffer of C + 1 floats; the variance needs the global mean and stays a second round (:34-38)
+        mc = torch.empty(C_ + 1, device=self._m12.device, dtype=torch.float32)
+        mc[:C_] = ((center.double() + e1) * B).to(torch.float32)        # = adaptive_avg_pool2d(x, 1).sum(0)
+        mc[C_] = float(B)
         if distributed:
-            dist.all_reduce(new_mean)
-            dist.all_reduce(new_count)
-        new_mean = new_mean / new_count
+            dist.all_reduce(mc)
+        new_count = mc[C_].reshape_as(rmv._count).to(rmv._count.dtype)
+        new_mean = (mc[:C_] / mc[C_]).view(1, -1, 1, 1)
         delta = new_mean.reshape(-1).double() - center.double()
         new_var = ((e2 - 2.0 * delta * e1 + delta * delta) * B).to(torch.float32).view(1, -1, 1, 1)
         if distributed:
@@ -286,6 +295,19 @@ class VOTrainStep:
         with torch.cuda.device(self.dev), torch.no_grad():
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
             _lib.check(_lib.lib.pnvo_train_backward(h, _ptr(grad_out), stream), h)
+
+    def participate_absent(self):
+        """Data-parallel training, a rank whose batch holds NO entry of this action model while another rank's does: issue
+        the same collectives a forward_train would (RunningMeanAndVar's two rounds, with zero contributions — every rank
+        ends with the same running statistics, as in the reference where all ranks merge the all-reduced moments) and leave
+        an all-zero gradient for optimizer_step's all-reduce.  Without it the ranks' collective sequences diverge: a hang,
+        or buffers of different models reduced into one another."""
+        with torch.cuda.device(self.dev), torch.no_grad():
+            stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            if self.rmv is not None:
+                self._update_running_stats(None, 0, stream)
+                self.model._loaded_sig = None
+            self.grad.zero_()
 
     def optimizer_step(self):
         """All-reduce (mean) of the flat gradient buffer across ranks, Adam, re-pack of the kernel operands."""
@@ -385,11 +407,24 @@ class GeoInvarianceTrainStep:
         allowed = [CUR_REL_TO_PREV] + ([PREV_REL_TO_CUR] if (joint or "inverse_data_augment_only" in self.invariance_types) else [])
         preds = torch.zeros((M, 3), device=dev, dtype=torch.float32)
         idx_of, grads, total = {}, {}, torch.zeros(1, device=dev)
+        # Data parallel: which action models have entries on ANY rank this iteration.  Every rank must walk the same
+        # sequence of collectives (forward_train: RunningMeanAndVar rounds; optimizer_step: the gradient all-reduce), so
+        # the set of models that run is decided globally, not from this rank's batch.
+        order = list(self.steps.keys())
+        here = torch.tensor([1.0 if (act == -1 and M > 0) or bool((actions == act).any()) else 0.0 for act in order])
+        anywhere = here.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            anywhere = anywhere.to(dev) if dist.get_backend() == "nccl" else anywhere
+            dist.all_reduce(anywhere, op=dist.ReduceOp.MAX)
+            anywhere = anywhere.cpu()
+        present_anywhere = {act: bool(anywhere[i] > 0) for i, act in enumerate(order)}
         with torch.cuda.device(dev), torch.no_grad():
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             for act, st in self.steps.items():
                 idx = torch.arange(M) if act == -1 else torch.nonzero(actions == act, as_tuple=True)[0]
                 if idx.numel() == 0:
+                    if present_anywhere[act]:
+                        st.participate_absent()          # same collectives as the ranks that hold entries of this action
                     continue
                 di = idx.to(dev)
                 sub = {k: v.index_select(0, di).contiguous() for k, v in batch.items()}
@@ -428,7 +463,7 @@ class GeoInvarianceTrainStep:
             for act, di in idx_of.items():
                 self.steps[act].backward(grads[act])
             for act, st in self.steps.items():
-                if act in idx_of:
+                if act in idx_of or present_anywhere[act]:       # (absent here, present elsewhere: zero gradient, same all-reduce)
                     st.optimizer_step()
                 elif st.step_count > 0:
                     # the reference zero_grad()s and step()s EVERY action model each iteration (:855-901); a model without

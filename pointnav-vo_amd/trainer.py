@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .checkpoint import load_vo_checkpoint
 from .common_vars import ACT_IDX2NAME, ACT_NAME2IDX
 from .registry import baseline_registry
 from . import vo_cnn  # noqa: F401  (registers the models)
@@ -143,8 +144,15 @@ class BaseRLTrainerWithVO:
                 discretized_depth_channels=self.config.VO.REGRESS_MODEL.discretized_depth_channels)
             self.vo_model[k].to(self.device)
         if rm.pretrained:
+            # :83-99.  The reference's files hold a config object and RNG states next to the weights; they are read with an
+            # allow-list unpickler that keeps tensors only (checkpoint.py).  left / right usually name the same
+            # model_states file (configs/rl/ddppo_pointnav.yaml:124-128): read each file once.
+            files = {}
             for k in model_names:
-                ckpt = torch.load(rm.pretrained_ckpt[k], map_location="cpu")
+                path = rm.pretrained_ckpt[k]
+                if path not in files:
+                    files[path] = load_vo_checkpoint(path)
+                ckpt = files[path]
                 if "model_state" in ckpt:
                     self.vo_model[k].load_state_dict(ckpt["model_state"])
                 elif "model_states" in ckpt:

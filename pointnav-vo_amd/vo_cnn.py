@@ -88,6 +88,7 @@ class VisualOdometryCNNBase(nn.Module):
         self._handle_dev = None
         self._loaded_sig = None
         self._precision = "float32"
+        self._options = {}
 
     # ------------------------------------------------------------------ libpnvo plumbing
     def set_precision(self, precision):
@@ -99,6 +100,29 @@ class VisualOdometryCNNBase(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.lib.pnvo_set_precision(self._handle, int(precision == "bfloat16")), self._handle)
         return self
+
+    def set_option(self, key, value):
+        """Per-model kernel-selection / behaviour option (include/pnvo.h pnvo_set_option: "stem", "conv", "tail", "pool",
+        "input_fallback", ...).  Remembered and re-applied when the handle is (re)created; the PNVO_* environment only
+        provides the defaults, read once at handle creation."""
+        self._options[str(key)] = str(value)
+        if self._handle is not None:
+            _lib.check(_lib.lib.pnvo_set_option(self._handle, str(key).encode(), str(value).encode()), self._handle)
+        return self
+
+    def get_option(self, key):
+        dev = next(self.parameters()).device
+        self._ensure_handle(dev)
+        buf = C.create_string_buffer(64)
+        _lib.check(_lib.lib.pnvo_get_option(self._handle, str(key).encode(), buf, 64), self._handle)
+        return buf.value.decode()
+
+    def last_note(self):
+        """Text of pnvo_last_error for this model's handle (also carries the one-line note of the dense-stem fallback)."""
+        if self._handle is None:
+            return ""
+        msg = _lib.lib.pnvo_last_error(self._handle)
+        return msg.decode() if msg else ""
 
     def _tensors(self):
         """(name, tensor) in state_dict order.  The owning (module, attribute) pairs are resolved once — walking the module
@@ -130,6 +154,8 @@ class VisualOdometryCNNBase(nn.Module):
         _lib.check(_lib.lib.pnvo_create(C.byref(cc), int(device.index or 0), C.byref(h)))
         self._handle, self._handle_dev, self._loaded_sig = h, device.index, None
         _lib.check(_lib.lib.pnvo_set_precision(h, int(self._precision == "bfloat16")), h)
+        for k, v in self._options.items():
+            _lib.check(_lib.lib.pnvo_set_option(h, k.encode(), v.encode()), h)
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
@@ -231,9 +257,10 @@ class VisualOdometryCNNBase(nn.Module):
         return out, buf
 
     def check_inputs(self):
-        """Raise PnvoError if an earlier forward met discretised depth that was not one-hot (the reference asserts
-        this where it builds the observation, base_trainer_with_vo.py:163).  Synchronise first for a definitive
-        answer; forward() performs the same check on entry."""
+        """Raise PnvoError if an earlier forward of a handle with input_fallback=off met observation values outside the fused
+        stems' contract (fractional rgb, discretised depth that is not one-hot: base_trainer_with_vo.py:163 asserts the
+        latter where it builds the observation).  With the default input_fallback=on such a forward is re-run on the dense
+        stem inside the call and nothing is raised.  Synchronise first for a definitive answer."""
         if self._handle is not None:
             _lib.check(_lib.lib.pnvo_check_inputs(self._handle), self._handle)
 

@@ -4,6 +4,9 @@
                    (kernel / tile choices depend on the batch size of a launch)
     --mode train : data-parallel VOTrainStep (RunningMeanAndVar all-reduces + one flat-gradient all-reduce, Adam) on the
                    rank's half of the batch must equal the single-GPU step on the concatenated batch (rank 0 checks)
+    --mode geo   : GeoInvarianceTrainStep over {left, right} action models when rank 0's batch holds only `left` entries and
+                   rank 1's only `right` ones: both ranks must issue the same collectives (no hang), end with identical
+                   parameters / running statistics for BOTH models, and the step counts must agree
     --shared-gpu : both ranks use cuda:0 and the collectives go through gloo — the 2-rank logic on the real kernels of a
                    1-GPU box (everything but RCCL itself)
 Exit code 0 = all assertions held."""
@@ -36,7 +39,7 @@ def build(dev, dropout_p=0.0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", required=True, choices=["infer", "train"])
+    ap.add_argument("--mode", required=True, choices=["infer", "train", "geo"])
     ap.add_argument("--shared-gpu", action="store_true")
     a = ap.parse_args()
     rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
@@ -48,6 +51,8 @@ def main():
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("nccl", device_id=dev)
+    if a.mode == "geo":
+        return geo(rank, world, dev)
     total = 7 if a.mode == "infer" else 6
     lo, hi = parallel.shard_bounds(total, rank, world)
     shard = {k: torch.from_numpy(v).to(dev) for k, v in
@@ -91,6 +96,30 @@ def main():
         # Adam's first step is lr * sign(g): compare where the sign is not within rounding noise of zero
         sel = g_one.abs() > 1e-6 * g_one.abs().max()
         assert (ts_dp.flat[sel] - ts_one.flat[sel]).abs().max() < 2e-6
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def geo(rank, world, dev):
+    from pointnav_vo_amd.train import GeoInvarianceTrainStep, TURN_LEFT, TURN_RIGHT, CUR_REL_TO_PREV
+    steps = {TURN_LEFT: VOTrainStep(build(dev)), TURN_RIGHT: VOTrainStep(build(dev))}
+    eng = GeoInvarianceTrainStep(steps, invariance_types=())
+    n = 3
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in
+             synth.make_obs_pairs(n, H, W, observation_space=SPACE, dd_bins=BINS, seed=30 + rank).items()}
+    tgt = torch.from_numpy(np.random.default_rng(5 + rank).normal(size=(n, 3)).astype(np.float32) * 0.2)
+    mine = TURN_LEFT if rank == 0 else TURN_RIGHT
+    for it in range(2):                                   # second iteration: every model has stepped once on every rank
+        total, preds = eng.step(batch, [mine] * n, [CUR_REL_TO_PREV] * n, tgt)
+        assert torch.isfinite(total).all() and torch.isfinite(preds).all()
+    for act, st in steps.items():
+        assert st.step_count == 2, (rank, act, st.step_count)
+        rmv = st.model.visual_encoder.running_mean_and_var
+        for t in (st.flat, rmv._mean.reshape(-1), rmv._var.reshape(-1), rmv._count.reshape(-1)):
+            parts = [torch.empty_like(t.cpu()) for _ in range(world)]
+            dist.all_gather(parts, t.cpu().contiguous())
+            assert torch.equal(parts[0], parts[1]), (rank, act)
+        assert float(rmv._count) == 2 * n                 # the entries of ONE rank per iteration, seen by both
     dist.barrier()
     dist.destroy_process_group()
 

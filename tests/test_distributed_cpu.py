@@ -162,6 +162,43 @@ def test_two_rank_running_stats_and_gradient_mean_equal_single_process():
     assert g0 == g1 == 1.5
 
 
+def _absent_worker(rank, world, port, q):
+    """Rank 0 holds all 4 entries of an action model, rank 1 none: rank 1 walks participate_absent()'s collective sequence
+    (zero contributions) while rank 0 runs its ordinary update; both must finish (no hang) with the SAME statistics."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    obs = synth.make_obs_pairs(4, H, W, observation_space=SPACE, seed=9)
+    st = _HostStatsStep(obs, 8)
+    for _ in range(2):
+        st._update_running_stats(None, 4 if rank == 0 else 0, None)
+    q.put((rank, st.rmv._mean.numpy(), st.rmv._var.numpy(), float(st.rmv._count)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_without_entries_joins_the_running_stats_collectives():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_absent_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (m, v, c)) for r, m, v, c in (q.get(), q.get()))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    obs = synth.make_obs_pairs(4, H, W, observation_space=SPACE, seed=9)
+    st = _HostStatsStep(obs, 8)
+    for _ in range(2):
+        st._update_running_stats(None, 4, None)
+    for r in (0, 1):                                     # both ranks == the single process that saw the 4 entries
+        np.testing.assert_allclose(got[r][0], st.rmv._mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[r][1], st.rmv._var.numpy(), rtol=1e-5, atol=1e-7)
+        assert got[r][2] == 8.0
+
+
 def test_bench_multi_rank_control_flow_runs_under_gloo():
     """`bench.py --backend gloo --dry-run`: rendezvous, barrier brackets, MAX over ranks, result gather and the rank-0
     JSON line of the N > 1 launch, executed as the driver launches it (torch.distributed.run, 2 ranks)."""

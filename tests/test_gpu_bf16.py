@@ -149,15 +149,15 @@ def test_dual_forward_at_baseline_batch_256():
         assert torch.equal(oa[k], ra[k % 3]) and torch.equal(ob[k], rb[k % 3]), k
 
 
-def test_fused_block_tail_equals_the_separate_residual_pass(monkeypatch):
+def test_fused_block_tail_equals_the_separate_residual_pass():
     """conv1 of the next block computes relu(GN2(conv2) + skip) while staging (conv_bf16.hip MODE 2) and writes the block
-    output; PNVO_BF16_NOFUSE=1 keeps the separate residual kernel.  Same float32 expression, same bf16 rounding: the
+    output; option bf16_fuse=off keeps the separate residual kernel.  Same float32 expression, same bf16 rounding: the
     network outputs must be identical bit for bit (identity and downsample skips, strided and compression consumers)."""
     rec = load_golden("model_default_341x192_b2.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
     with torch.no_grad():
         fused = model(tobs).clone()
-        monkeypatch.setenv("PNVO_BF16_NOFUSE", "1")
+        model.set_option("bf16_fuse", "off")
         plain = model(tobs).clone()
-        monkeypatch.delenv("PNVO_BF16_NOFUSE")
+        model.set_option("bf16_fuse", "on")
     assert torch.equal(fused, plain), (fused, plain)

@@ -84,13 +84,10 @@ def test_fused_pool_and_block_tails_are_bit_identical_at_full_size():
     model.eval()
     outs = []
     with torch.no_grad():
-        for env in ({}, {}, {"PNVO_TAIL": "separate", "PNVO_POOL": "separate"}):
-            os.environ.update(env)
-            try:
-                outs.append(model(obs).clone())
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
+        for opts in ({}, {}, {"tail": "separate", "pool": "separate"}):
+            for k, v in opts.items():
+                model.set_option(k, v)
+            outs.append(model(obs).clone())
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
@@ -113,21 +110,18 @@ def test_large_batch_equals_its_small_batches_at_full_resolution():
 
 def test_both_stem_weight_gradient_kernels_agree_at_full_resolution():
     """The stem's weight gradient on the bf16 matrix cores (exact three-piece operands, wgrad_stem_mx.hip) against the
-    float32-MFMA kernel (PNVO_WGRAD_STEM=fp32) on 16 pairs at 341x192, whitening on: the products are exact in both, only the
+    float32-MFMA kernel (option wgrad_stem=fp32) on 16 pairs at 341x192, whitening on: the products are exact in both, only the
     float32 summation order differs — 2e-6 of the tensor's norm (measured 9e-7); every other tensor is bit-identical."""
     obs = bench.make_inputs(16, torch.device(DEV), 4)
     tgt = (torch.rand((16, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) - 0.5) * 0.5
     grads = {}
     for sel in ("mx", "fp32"):
-        os.environ["PNVO_WGRAD_STEM"] = sel
-        try:
-            model, _ = default_model(dropout_p=0.0)
-            ts = VOTrainStep(model)
-            ts.forward_backward(obs, target=tgt)
-            grads[sel] = {n: ts.grad[o:o + k].double().cpu().numpy() for n, (o, k) in ts.offsets.items()}
-            del ts, model
-        finally:
-            os.environ.pop("PNVO_WGRAD_STEM", None)
+        model, _ = default_model(dropout_p=0.0)
+        model.set_option("wgrad_stem", sel)
+        ts = VOTrainStep(model)
+        ts.forward_backward(obs, target=tgt)
+        grads[sel] = {n: ts.grad[o:o + k].double().cpu().numpy() for n, (o, k) in ts.offsets.items()}
+        del ts, model
     stem = "visual_encoder.backbone.conv1.0.weight"
     for n in grads["mx"]:
         a, b = grads["mx"][n], grads["fp32"][n]

@@ -40,6 +40,17 @@ def test_two_ranks_sharing_one_gpu_train_step_equals_the_step_on_the_concatenate
     _run("train", "--shared-gpu")
 
 
+def test_two_ranks_sharing_one_gpu_action_models_absent_on_one_rank():
+    """GeoInvarianceTrainStep when an action model has entries on one rank only: the set of models that run their
+    collectives is decided globally (all-reduced presence mask), the absent rank contributes zeros."""
+    _run("geo", "--shared-gpu")
+
+
+@need2
+def test_two_gpu_action_models_absent_on_one_rank():
+    _run("geo")
+
+
 @need2
 def test_two_gpu_sharded_inference_equals_one_gpu():
     _run("infer")

@@ -122,20 +122,21 @@ def test_full_batch_256_properties():
     np.testing.assert_array_equal(obs["top_down_view"][0, ..., 1].cpu().numpy(), oracle.topdown_view(d0[..., 1], c)[..., 0])
 
 
-def test_three_stems_agree(monkeypatch):
+def test_three_stems_agree():
     """The default model's stem runs on the bf16 matrix cores with the float32 weights split into three exact bf16
-    pieces (stem_mx.hip, the default); PNVO_STEM=dd selects the one-hot table-gather stem (stem_dd.hip), PNVO_STEM=dense
+    pieces (stem_mx.hip, the default); option stem=dd selects the one-hot table-gather stem (stem_dd.hip), stem=dense
     the all-fp32-MFMA stem (stem_lds.hip).  All three compute the same products exactly; they must agree to float32
     summation-order noise at every output pixel, borders (zero padding after whitening) included, and match the reference."""
     rec = load_golden("model_default_341x192_b2.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
     with torch.no_grad():
         out_mx, stem_mx = model.tap("stem_conv", tobs)
-        monkeypatch.setenv("PNVO_STEM", "dd")
+        assert model.get_option("stem") == "auto"
+        model.set_option("stem", "dd")
         out_dd, stem_dd = model.tap("stem_conv", tobs)
-        monkeypatch.setenv("PNVO_STEM", "dense")
+        model.set_option("stem", "dense")
         out_dense, stem_dense = model.tap("stem_conv", tobs)
-        monkeypatch.delenv("PNVO_STEM")
+        model.set_option("stem", "auto")
         model.check_inputs()
     a, d, b = stem_mx.cpu().numpy(), stem_dd.cpu().numpy(), stem_dense.cpu().numpy()
     assert a.shape == b.shape == d.shape and np.abs(b).max() > 0.1
@@ -150,29 +151,57 @@ def test_three_stems_agree(monkeypatch):
         assert pair_rel_err(o.cpu().numpy(), rec["out64"]).max() < TOL
 
 
-def test_fractional_rgb_is_reported_not_silently_wrong():
-    """The split-weight stem relies on rgb being uint8-valued (exact in bf16); a fractional value must raise
-    PNVO_ERR_INPUT, never a silently rounded result.  PNVO_STEM=dense accepts such input."""
+def _contract_breakers(tobs):
+    frac = dict(tobs)
+    frac["rgb"] = tobs["rgb"].clone()
+    frac["rgb"][0, 3, 4, 1] = 17.3
+    frac["rgb"][2, 20, 11, 5] = 200.125
+    soft = dict(tobs)
+    soft["discretized_depth"] = tobs["discretized_depth"].clone()
+    soft["discretized_depth"][1, 5, 7, :] = 0.1
+    return {"fractional rgb": frac, "soft depth code": soft}
+
+
+@pytest.mark.parametrize("kind", ["fractional rgb", "soft depth code"])
+@pytest.mark.parametrize("stem", ["auto", "dd"])
+def test_input_outside_the_stem_contract_is_rerun_on_the_dense_stem(kind, stem):
+    """The fused stems rely on uint8-valued rgb and one-hot depth (the reference's own observation construction,
+    base_trainer_with_vo.py:163,196-207); the reference MODEL takes any float tensor (vo_cnn.py:110-176).  A forward that
+    meets a value outside the contract must return the CORRECT result from that very call (re-run on the dense fp32 stem),
+    leave the handle usable — now on the dense stem — and say so once."""
     rec = load_golden("model_default_45x37_b3.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
-    bad = dict(tobs)
-    bad["rgb"] = tobs["rgb"].clone()
-    bad["rgb"][0, 3, 4, 1] = 17.3
+    if stem != "auto":
+        model.set_option("stem", stem)
+    bad = _contract_breakers(tobs)[kind]
     with torch.no_grad():
-        model(bad)
-        torch.cuda.synchronize()
-        with pytest.raises(_lib.PnvoError, match="contract"):
-            model.check_inputs()
+        clean0 = model(tobs).cpu().numpy()
+        assert model.get_option("stem") == stem
+        out = model(bad).cpu().numpy()                    # the offending call itself
+        ref = oracle.forward(sd, {k: v.cpu().numpy() for k, v in bad.items()}, ngroups=cfg.ngroups, dtype=np.float64)
+        assert pair_rel_err(out, ref).max() < TOL, pair_rel_err(out, ref)
+        # (the one-hot stem multiplies rgb on the fp32 pipe: fractional rgb is inside ITS contract, no fallback needed)
+        fell_back = not (stem == "dd" and kind == "fractional rgb")
+        assert model.get_option("stem") == ("dense (fallback)" if fell_back else "dd")
+        assert ("dense" in model.last_note()) == fell_back
+        model.check_inputs()                              # nothing pending: the handle is not poisoned
+        again = model(bad).cpu().numpy()                  # stays correct, no second fallback needed
+        np.testing.assert_array_equal(again, out)
+        clean1 = model(tobs).cpu().numpy()                # and contract inputs still evaluate (dense stem now)
+    assert pair_rel_err(clean1, rec["out64"]).max() < TOL and pair_rel_err(clean0, rec["out64"]).max() < TOL
+    # an explicit stem choice lifts the fallback
+    model.set_option("stem", "mx")
+    with torch.no_grad():
+        np.testing.assert_array_equal(model(tobs).cpu().numpy(), clean0)
 
 
-def test_non_onehot_depth_is_reported_not_silently_wrong():
-    """base_trainer_with_vo.py:163 asserts the discretised depth is one-hot; the fused stem relies on it and must say so
-    loudly when the contract is broken (PNVO_ERR_INPUT), while PNVO_STEM=dense accepts soft codes."""
+def test_input_fallback_off_reports_instead():
+    """input_fallback=off keeps the forward free of any host wait: the stem raises a flag, check_inputs() and every later
+    forward fail with PNVO_ERR_INPUT (never a silently rounded result that looks fine)."""
     rec = load_golden("model_default_45x37_b3.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
-    bad = dict(tobs)
-    bad["discretized_depth"] = tobs["discretized_depth"].clone()
-    bad["discretized_depth"][1, 5, 7, :] = 0.1
+    model.set_option("input_fallback", "off")
+    bad = _contract_breakers(tobs)["soft depth code"]
     with torch.no_grad():
         model(tobs)
         torch.cuda.synchronize()
@@ -185,10 +214,20 @@ def test_non_onehot_depth_is_reported_not_silently_wrong():
             model(tobs)
 
 
-def test_soft_depth_codes_on_the_dense_stem(monkeypatch):
+def test_unknown_option_is_refused():
     rec = load_golden("model_default_45x37_b3.npz")
-    monkeypatch.setenv("PNVO_STEM", "dense")
+    model, *_ = build(rec)
+    model.get_option("conv")
+    with pytest.raises(_lib.PnvoError, match="unknown option"):
+        model.set_option("no_such_knob", "1")
+    with pytest.raises(_lib.PnvoError, match="mx"):
+        model.set_option("stem", "sparse")
+
+
+def test_soft_depth_codes_on_the_dense_stem():
+    rec = load_golden("model_default_45x37_b3.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
+    model.set_option("stem", "dense")
     soft = {k: v.copy() for k, v in obs.items()}
     soft["discretized_depth"] = (0.8 * soft["discretized_depth"] + 0.02).astype(np.float32)
     with torch.no_grad():
@@ -276,6 +315,29 @@ def test_compute_local_delta_states_from_vo_matches_reference():
         assert pair_rel_err(np.array(deltas)[None], want[None]).max() < TOL, (deltas, want)
         prevs.append(prev), curs.append(cur), acts.append(int(act))
     # batched sibling: same numbers in one call
+    batch = t.compute_local_delta_states_batch(prevs, curs, acts)
+    assert pair_rel_err(batch, rec["deltas"]).max() < TOL
+
+
+def test_boundary_with_pretrained_reference_checkpoints(tmp_path):
+    """a13, pretrained branch (base_trainer_with_vo.py:83-99): the three action models come from reference-format files —
+    `forward` from a {"model_state"} file, `left` and `right` from ONE engine-format {"model_states"} file that also holds
+    a config object, optimizer and RNG states — and the boundary call reproduces the reference's deltas."""
+    from test_checkpoint import trainer_cfg, write_reference_checkpoints
+    from pointnav_vo_amd import model_spec as ms
+    rec = load_golden("boundary.npz")
+    H, W, bins = int(rec["height"]), int(rec["width"]), int(rec["bins"])
+    mcfg = ms.config_from_kwargs(observation_space=["rgb", "depth", "discretized_depth", "top_down_view"], observation_size=(W, H),
+                                 hidden_size=512, normalize_visual_inputs=True, output_dim=3, discretized_depth_channels=bins)
+    paths = write_reference_checkpoints(str(tmp_path), mcfg, {k: int(rec[f"seed_{k}"]) for k in ("forward", "left", "right")})
+    t = BaseRLTrainerWithVO(trainer_cfg(W, H, bins, paths), dev())
+    t._set_up_vo_obs_transformer()
+    t._setup_vo_model(t.config)
+    prevs, curs, acts = [], [], []
+    for (pi, ci, act, zb) in rec["steps"]:
+        prevs.append(synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(pi), zero_border=int(zb)))
+        curs.append(synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(ci), zero_border=int(zb)))
+        acts.append(int(act))
     batch = t.compute_local_delta_states_batch(prevs, curs, acts)
     assert pair_rel_err(batch, rec["deltas"]).max() < TOL
 
