@@ -33,6 +33,7 @@ SPACE = ["rgb", "depth", "discretized_depth", "top_down_view"]
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+ORACLE_PAIRS = (0, 1, 63, 127, 128, 190, 254, 255)   # pairs of the headline batch checked against the fp64 oracle
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/round_profile.sh (PMC passes)
 
 
@@ -98,7 +99,8 @@ def cpu_baseline(sd, ngroups, budget_s=15.0):
     obs1 = synth.make_obs_pairs(2, H, W, observation_space=SPACE, dd_bins=BINS, seed=99)
     oracle.forward(sd, obs1, ngroups=ngroups, dtype=np.float32)            # page-in / warm-up
     best = None
-    for thr in sorted({min(cores, t) for t in (8, 16, 32, 64, 128, cores)}):   # OpenMP team size that serves best
+    tried = sorted({min(cores, t) for t in (8, 16, 32, 64, 128, cores)})
+    for thr in tried:                                                          # OpenMP team size that serves best
         oracle.set_threads(thr)
         t0 = time.perf_counter()
         oracle.forward(sd, obs1, ngroups=ngroups, dtype=np.float32)
@@ -114,7 +116,10 @@ def cpu_baseline(sd, ngroups, budget_s=15.0):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frame-pairs/s", "cores": thr, "kind": "port", "host_cores": cores,
             "sample": f"{n} pairs, one batched fp32 forward of the oracle C port (OpenMP, {thr} threads, "
-                      f"best of several team sizes on a {cores}-core host)"}
+                      f"best of several team sizes on a {cores}-core host)",
+            "scaling_note": f"the port does not scale with the host: OpenMP teams of {tried} threads were timed on this {cores}-core "
+                            f"box and {thr} served best (plain loop nests, memory-bound beyond that) — `cores` is that team, not "
+                            "the machine; a baseline figure only"}
 
 
 def preheat(step, dev, cap_s=2.0, tol=0.02):
@@ -168,13 +173,12 @@ def timed_steps(step, steps, sync_all, dev):
     return dt, out
 
 
-def stem_executed(kt_entry, B, per_launch_ms):
+def stem_executed(kt_entry, B, per_launch_ms, sel="auto"):
     """Work the stem kernels EXECUTE (not the algorithmic 30-channel conv): matrix-core FLOPs per launch against the
     peak of the pipe they run on."""
     ho, wo = (H + 1) // 2, (W + 1) // 2
     px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128              # pixels of the 8x16 tiles, padding included
-    sel = os.environ.get("PNVO_STEM", "mx")
-    if sel == "mx":          # stem_mx.hip: 7 x v_mfma_f32_32x32x16_bf16 per tap and 32-pixel tile (3 weight pieces x 2
+    if sel in ("auto", "mx"):          # stem_mx.hip: 7 x v_mfma_f32_32x32x16_bf16 per tap and 32-pixel tile (3 weight pieces x 2
         flops = px / 32 * 49 * 7 * (2.0 * 32 * 32 * 16)       #   K-chunks + 1 chunk of float-modality remainders)
         peak, pipe = PEAK_BF16_TFLOPS, "bf16 MFMA (three exact bf16 weight pieces -> float32 results)"
     elif sel == "dd":        # stem_dd.hip: K = 12 of 30 channels on the fp32 MFMA pipe, the rest gathered from LDS
@@ -185,6 +189,26 @@ def stem_executed(kt_entry, B, per_launch_ms):
         peak, pipe = PEAK_FP32_TFLOPS, "fp32 MFMA"
     tf = flops / (per_launch_ms * 1e-3) / 1e12
     return tf, peak, pipe
+
+
+def slim_secondary(name, full):
+    """The `secondary` entry of the headline line: the figures of a 10-step run of another BASELINE configuration."""
+    if full is None or "error" in full:
+        return full
+    rf = full["roofline"]
+    out = {"workload": full["config"]["workload"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"],
+           "steps": full["steps"], "dtype": full["dtype"], "pairs_per_gpu": full["config"]["pairs_per_gpu"],
+           "ms_per_step_events": full["ms_per_step_events"],
+           "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "pipe")}}
+    if name == "dual_bf16":
+        e = full["pose_abs_err_vs_fp64_oracle"]
+        out["rms_err_vs_fp64"] = e and e["rms_abs_l2"]
+        out["err_note"] = e and f"RMS over {e['forwards']} forwards of ||out - ref||_2, reference norm up to {e['ref_l2']:.2f}"
+    else:
+        out["loss_first_last"] = full["loss_first_last"]
+        out["ms_by_kernel_class"] = full["ms_by_kernel_class"]
+        out["gradient_allreduce"] = full["config"].get("gradient_allreduce")
+    return out
 
 
 def main():
@@ -203,6 +227,10 @@ def main():
                     help="testing aid for 1-GPU boxes: every rank uses cuda:0 (with --backend gloo), so the N > 1 code path runs "
                          "on the real kernels; the value it prints is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline run only: skip the 10-step dual_bf16 / train measurements reported under `secondary`")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="--config train: ONE flat gradient all-reduce after the backward instead of buckets behind it (A/B)")
     ap.add_argument("--no-preheat", action="store_true")
     args = ap.parse_args()
 
@@ -247,10 +275,10 @@ def main():
         rel = None
         if rank == 0:
             from oracle import oracle
-            nchk = 2
-            ref = oracle.forward(sd, {k: v[:nchk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups,
+            chk = sorted({i for i in ORACLE_PAIRS if i < B} | {0, B - 1})     # first / last tile of the batch, mid-batch
+            ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups,
                                  dtype=np.float64)
-            o = out[:nchk].cpu().numpy().astype(np.float64)
+            o = out[chk].cpu().numpy().astype(np.float64)
             rel = float((np.linalg.norm(o - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)).max())
 
         pre = (0.0, 0, None) if args.no_preheat else preheat(step, dev)
@@ -268,6 +296,24 @@ def main():
 
     dt = parallel.max_over_ranks(dt, dev)     # slowest rank
 
+    # ---- BASELINE configs[2] and configs[3] (per-GPU shape) next to the headline: 10 timed steps each under the same contract
+    #      (tools/bench_configs.py), on the headline's own observation tensors; AFTER the headline's timed region, never in it
+    secondary = None
+    if not args.no_secondary and B >= 128:
+        import copy
+        from tools import bench_configs
+        sa = copy.copy(args)
+        sa.steps, sa.warmup, sa.batch = 10, 2, None
+        secondary = {}
+        for name, fn in (("dual_bf16", bench_configs.run_dual_bf16), ("train", bench_configs.run_train)):
+            try:
+                full = fn(sa, rank, world, dist, dev, sync_all, obs=obs, emit=False)
+            except Exception as e:                      # the headline line must survive a failing side measurement
+                full = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if rank == 0:
+                secondary[name] = slim_secondary(name, full)
+        torch.cuda.empty_cache()
+
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / dt
@@ -279,9 +325,15 @@ def main():
         total_kernel_ms = sum(k["total_ms"] for k in kt)
         is_stem = dom["name"].endswith("conv1.0")
         if is_stem:
-            ach, peak, pipe = stem_executed(dom, B, per_launch_ms)
-        else:                                       # every other conv executes exactly its algorithmic FLOPs (fp32 MFMA)
-            ach, peak, pipe = alg, PEAK_FP32_TFLOPS, "fp32 MFMA"
+            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"))
+        else:
+            fam, ex = model.layer_kernel(dom["name"][len("conv:"):], B)
+            if fam in ("x3", "x2"):                  # six bf16 / three float16 MFMA terms per float32 product, tile padding included
+                ach, peak = ex / (per_launch_ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS
+                pipe = ("bf16 MFMA (three-piece operands, six terms per product)" if fam == "x3" else
+                        "float16 MFMA (two-piece operands, three terms per product)")
+            else:                                    # the fp32-MFMA kernels execute the algorithmic FLOPs
+                ach, peak, pipe = alg, PEAK_FP32_TFLOPS, "fp32 MFMA"
         traffic, traffic_note = measured_traffic("fwd_fp32", dom["name"], B)
         res = {
             "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
@@ -293,12 +345,12 @@ def main():
             "ms_per_step_events": per_step,
             "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
             "kernel_ms_per_step": total_kernel_ms / args.steps,
-            "pose_rel_err_vs_fp64_oracle": rel,
+            "pose_rel_err_vs_fp64_oracle": rel, "oracle_checked_pairs": chk,
             "arithmetic": ("float32 activations, weights, accumulators and results; the stem and the sixteen 3x3 convs of the "
                            "residual stages multiply on the bf16 matrix cores with every float32 operand split into three bf16 pieces "
                            "(hi + mid + lo == the float32 value): products exact (stem: inputs exact in bf16) or within 2^-23 (six of "
-                           "the nine cross terms), float32 accumulation; PNVO_CONV=fp32 / PNVO_STEM=dense select the fp32-MFMA kernels"
-                           if os.environ.get("PNVO_CONV", "x3") == "x3" else "float32 (fp32 MFMA convs); stem: see PNVO_STEM"),
+                           "the nine cross terms), float32 accumulation; options conv=fp32 / stem=dense select the fp32-MFMA kernels"
+                           if model.get_option("conv") in ("auto", "x3") else "float32 (fp32 MFMA convs); stem: option `stem`"),
             "model_tflops": value * flops_pair / 1e12,
             "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
@@ -313,6 +365,8 @@ def main():
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
                                for k in kt), key=lambda k: -k["ms_per_step"])[:40],
         }
+        if secondary is not None:
+            res["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)
         print(json.dumps(res))

@@ -221,6 +221,20 @@ int pnvo_train_set_actions(pnvo_handle h, const int64_t *actions);
 /* loss.backward() given dLoss/dOut [B,out_dim]: fills the whole gradient buffer (overwrites; no accumulation). */
 int pnvo_train_backward(pnvo_handle h, const float *grad_out, void *stream);
 
+/*
+ * Gradient-ready hook for data-parallel training (replaces nothing in the reference, whose VO training is single-process;
+ * it is what torch DDP's bucketed all-reduce would do for config 4's RCCL gradient exchange).  During pnvo_train_backward the
+ * library calls fn(user, first, count, stream) on the host each time the gradients of the flat range [first, first + count)
+ * are final — i.e. the launches producing them are enqueued on `stream` — latest layers first: [layer4 .. output head],
+ * [layer2 .. layer3], [stem .. layer1] for the reference's parameter order (other orders: one range at the end).  The caller
+ * records an event and starts the all-reduce of that range on its communication stream while the rest of the backward runs.
+ * pnvo_train_grad_buckets returns the same ranges without running a backward (a rank that must join the collectives of a
+ * step in which it had no data).  fn = NULL removes the hook.
+ */
+typedef void (*pnvo_grad_ready_fn)(void *user, uint64_t first, uint64_t count, void *stream);
+int pnvo_train_set_grad_hook(pnvo_handle h, pnvo_grad_ready_fn fn, void *user);
+int pnvo_train_grad_buckets(pnvo_handle h, uint64_t *first, uint64_t *count, int cap, int *n_out);
+
 /* Per-channel moments of the assembled network input (reference channel order, rgb/255), the statistics behind
  * RunningMeanAndVar's train-mode update: out[c] = mean_{n,pixel} (x_c - center_c)^power, power in {1,2}; center may be
  * NULL (0).  out: device [C].  power 3: both moments about `center` in ONE pass over the observation tensors —
@@ -345,6 +359,12 @@ int pnvo_forward_features(pnvo_handle h, const float *rgb, const float *depth, c
  *     raises a host-visible flag instead and pnvo_check_inputs (definitive after the caller synchronised the stream) as well
  *     as every later forward on the handle return PNVO_ERR_INPUT until the weights are re-loaded. */
 int pnvo_check_inputs(pnvo_handle h);
+
+/* Which kernel family a conv of the residual stages / the compression conv (state_dict prefix, e.g.
+ * "visual_encoder.backbone.layer1.0.convs.0") runs on at batch B with the handle's current options — "x3" (float32 results
+ * from six bf16 MFMA terms per product), "fp32-lds", "fp32-generic" — and the matrix-core FLOPs one launch EXECUTES (tile and
+ * channel padding and the six-term expansion included): what bench.py prices against the peak of that pipe. */
+int pnvo_layer_kernel(pnvo_handle h, const char *name, int B, char *family, size_t cap, double *executed_flops);
 
 int pnvo_timing_mode(pnvo_handle h, int mode);
 int pnvo_timing_read(pnvo_handle h, pnvo_kernel_time *entries, int cap, int *n_out);

@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpnvo.so")
 PNVO_OK = 0
 
 
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)
+
+
 class PnvoError(RuntimeError):
     pass
 
@@ -65,6 +68,8 @@ _SIGNATURES = {
     "pnvo_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_train_set_grad_hook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pnvo_train_grad_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
     "pnvo_input_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p]),
     "pnvo_rmv_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -90,6 +95,7 @@ _SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_policy_destroy": (C.c_int, [C.c_void_p]),
     "pnvo_avgpool2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pnvo_layer_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]),
     "pnvo_timing_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "pnvo_timing_read": (C.c_int, [C.c_void_p, C.POINTER(pnvo_kernel_time), C.c_int, C.POINTER(C.c_int)]),
     "pnvo_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

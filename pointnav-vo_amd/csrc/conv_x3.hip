@@ -23,6 +23,7 @@
 //   3  pooled stem keys (stem_mx.hip POOL): decode, * |scale| + shift, ReLU; pooled activations written to xout.
 // Also covers the 1x1 stride-2 downsample convs (KS = 1: the stager reads only the pixels the conv uses).
 // conv_x3_plan() takes a layer only when its launch has >= 192 workgroups (PNVO_CONV=x3 forces it).
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -43,11 +46,20 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
   const bf16x2 r = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32, round to nearest even
   return __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+  const f16x2 r = __builtin_convertvector(f32x2{a, b}, f16x2);    // v_cvt_pk_f16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
 __device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
-template <int KS, int STRIDE, int MODE, int MW, int NW>
+// NP = 3: three bf16 pieces per operand, six product terms (every kept product exact).  NP = 2: two float16 pieces per operand
+// (22 significant bits each), three terms a1 w0 + a0 w1 + a0 w0 on v_mfma_f32_32x32x16_f16: each product within 3 * 2^-22 of a * w —
+// the size of a few float32 roundings of the accumulation it feeds — at half the matrix-pipe time, two LDS planes instead of
+// three and 5 instead of 11 VALU per channel pair in the stager.  The weights are pre-scaled by a power of two (p.oscale undoes
+// it exactly in the epilogue) so that their second piece stays in float16's normal range.
+template <int KS, int STRIDE, int MODE, int MW, int NW, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3_kernel(const ConvX3Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
@@ -72,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int npix = p.TR * p.TC;
   // pixel table behind the three planes: [0] patch byte offset of tile pixel q's top-left tap; [1] element offset of its output
   // pixel inside the sample's output plane, bit 31 set when the pixel does not exist
-  unsigned *qtab = reinterpret_cast<unsigned *>(lds + 3 * plane);
+  unsigned *qtab = reinterpret_cast<unsigned *>(lds + NP * plane);
   unsigned *otab = qtab + p.MT * 32;
   if ((int)threadIdx.x < p.MT * 32) {
     const int q = min((int)threadIdx.x, npix - 1);
@@ -196,6 +208,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *reinterpret_cast<f32x4 *>(dst) = f32x4{f[0], f[1], f[2], f[3]};
             *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{f[4], f[5], f[6], f[7]};
           }
+          if (NP == 2) {                                                 // two float16 pieces of the eight channels
+            u32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = f[2 * e], b = f[2 * e + 1];
+              const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+              o0[e] = __builtin_bit_cast(unsigned, h);
+              o1[e] = pack2h(a - (float)h[0], b - (float)h[1]);
+            }
+            *reinterpret_cast<u32x4 *>(lds + r.off[k]) = o0;
+            *reinterpret_cast<u32x4 *>(lds + plane + r.off[k]) = o1;
+            continue;
+          }
           u32x4 o0, o1, o2;                                              // the three bf16 pieces of the eight channels
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nsteps = KS * KS * kcc;
     // The step being fetched (one ahead of the one being multiplied), kept as running offsets: a division per step costs the
     // wave ~50 scalar instructions between two MFMA groups, and with one wave per SIMD (6 x 11 maps) nobody fills that gap.
-    const unsigned kstep = (unsigned)ntt * 3072u;                        // bytes of one k-chunk of B (all N-tiles, three pieces)
+    const unsigned kstep = (unsigned)ntt * (NP * 1024u);                 // bytes of one k-chunk of B (all N-tiles, NP pieces)
     const char *wb_n = reinterpret_cast<const char *>(p.wpk) + (long)(ck0 >> 4) * kstep;
     unsigned toff_n = 0;                                                 // patch byte offset of the step's (tap, k-chunk)
     int kc_n = 0, kw_n = 0;
@@ -278,17 +303,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     unsigned voff[NW];                                                   // lane's byte offset inside a k-chunk of B
 #pragma unroll
-    for (int j = 0; j < NW; ++j) voff[j] = (unsigned)min(wave_n * NW + j, ntt - 1) * 3072u + (unsigned)lane * 16u;   // (N-tiles past the layer's repeat the last one)
+    for (int j = 0; j < NW; ++j) voff[j] = (unsigned)min(wave_n * NW + j, ntt - 1) * (NP * 1024u) + (unsigned)lane * 16u;   // (N-tiles past the layer's repeat the last one)
     // A fragments of M-tile i (three planes) / B fragments (three weight pieces per N-tile) of the step being fetched
     auto loadA = [&](int i, u32x4 (*a)[MW]) {
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) a[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + toff_n);
+      for (int pc = 0; pc < NP; ++pc) a[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + toff_n);
     };
     auto loadB = [&](u32x4 (*b)[NW]) {
 #pragma unroll
       for (int j = 0; j < NW; ++j)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wb_n + (size_t)voff[j] + pc * 1024);
+        for (int pc = 0; pc < NP; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wb_n + (size_t)voff[j] + pc * 1024);
     };
     // One step: M-tile by M-tile; as soon as an M-tile's MFMAs are issued its A registers take the NEXT step's fragments, so
     // the LDS latency hides behind the other M-tiles' MFMAs
@@ -297,19 +322,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < MW; ++i) {
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-          // smallest terms first: a1 w1, a2 w0, a0 w2, a1 w0, a0 w1, a0 w0
-          constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+          if (NP == 2) {                                                 // a1 w0, a0 w1, a0 w0 (float16 pieces)
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
 #pragma unroll
-          for (int t = 0; t < 6; ++t)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[TA[t]][i]),
-                                                                __builtin_bit_cast(bf16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
+            for (int t = 0; t < 3; ++t)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
+                                                                 __builtin_bit_cast(f16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
+          } else {
+            // smallest terms first: a1 w1, a2 w0, a0 w2, a1 w0, a0 w1, a0 w0
+            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[TA[t]][i]),
+                                                                  __builtin_bit_cast(bf16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         loadA(i, a);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    u32x4 a[3][MW], b0[3][NW], b1[3][NW];
+    u32x4 a[NP][MW], b0[NP][NW], b1[NP][NW];
     loadB(b0);
 #pragma unroll
     for (int i = 0; i < MW; ++i) loadA(i, a);
@@ -331,6 +364,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned long long t_e = __builtin_readcyclecounter();
 
   // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).
+  if (NP == 2) {                                                         // undo the weights' power-of-two scale (exact)
+    const float os = p.oscale;
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= os;
+  }
   const int rr16 = lane >> 5;
   const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
   float t1[NW], t2[NW];
@@ -416,12 +458,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int NP>
 hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, size_t ldsb, hipStream_t s) {
-#define PNVO_X3(MODE_, MW_, NW_)                                                                      \
-  if (mode == MODE_ && mw == MW_ && nw == NW_) {                                                      \
-    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_>), grid, dim3(256), ldsb, s, a);   \
-    return hipGetLastError();                                                                         \
+#define PNVO_X3(MODE_, MW_, NW_)                                                                          \
+  if (mode == MODE_ && mw == MW_ && nw == NW_) {                                                          \
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_, NP>), grid, dim3(256), ldsb, s, a);   \
+    return hipGetLastError();                                                                             \
   }
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
   PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2) PNVO_X3(3, 1, 1) PNVO_X3(3, 2, 1) PNVO_X3(3, 2, 2) PNVO_X3(3, 3, 2)
@@ -503,10 +545,11 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   if ((4 / a.wn) * *mw < a.MT) return false;
   // channel chunk: the largest multiple-of-32 divisor of CIN (power-of-two steps) whose three planes fit 72 KB
   // (a power of two: the stager's thread -> (pixel, 8-channel group) split uses masks; 32 always divides CIN)
+  const size_t np = a.np == 2 ? 2 : 3;                          // operand pieces = LDS planes (tiles are sized for three: same plan)
   int ck = 32;
   while (ck < 256 && a.CIN % (2 * ck) == 0) ck *= 2;
-  while (ck > 32 && (size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)72 * 1024) ck /= 2;
-  if ((size_t)3 * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
+  while (ck > 32 && np * a.PR * a.PC * (ck * 2 + 16) > (size_t)72 * 1024) ck /= 2;
+  if (np * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
   if (a.CIN % ck) return false;
   a.CK = ck;
   // Few workgroups (small batches: the reference's navigation loop calls with ONE pair): a workgroup walks its whole K loop alone
@@ -518,7 +561,7 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
     if (wgs < 192 && !force) return false;
   }
   a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
-  *lds_bytes = (size_t)3 * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
+  *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
   return true;
 }
 
@@ -547,9 +590,15 @@ hipError_t launch_conv_x3(const ConvX3Args &a0, int ks, int stride, int mode, in
   const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
   const int ntt = a.COUTP / 32, per_wg = a.wn * nw;   // N-tiles one workgroup covers
   dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((ntt + per_wg - 1) / per_wg), 1u);
-  if (ks == 3 && stride == 1) return launch_ks<3, 1>(a, mode, mw, nw, grid, lds_bytes, s);
-  if (ks == 3 && stride == 2) return launch_ks<3, 2>(a, mode, mw, nw, grid, lds_bytes, s);
-  if (ks == 1 && stride == 2) return launch_ks<1, 2>(a, mode, mw, nw, grid, lds_bytes, s);
+  if (a.np == 2) {
+    if (ks == 3 && stride == 1) return launch_ks<3, 1, 2>(a, mode, mw, nw, grid, lds_bytes, s);
+    if (ks == 3 && stride == 2) return launch_ks<3, 2, 2>(a, mode, mw, nw, grid, lds_bytes, s);
+    if (ks == 1 && stride == 2) return launch_ks<1, 2, 2>(a, mode, mw, nw, grid, lds_bytes, s);
+    return hipErrorInvalidValue;
+  }
+  if (ks == 3 && stride == 1) return launch_ks<3, 1, 3>(a, mode, mw, nw, grid, lds_bytes, s);
+  if (ks == 3 && stride == 2) return launch_ks<3, 2, 3>(a, mode, mw, nw, grid, lds_bytes, s);
+  if (ks == 1 && stride == 2) return launch_ks<1, 2, 3>(a, mode, mw, nw, grid, lds_bytes, s);
   return hipErrorInvalidValue;
 }
 
@@ -587,6 +636,44 @@ void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int cou
             out[base + 64 * 8] = m;
             out[base + 2 * 64 * 8] = l;
           }
+}
+
+// Two float16 pieces of scale * W (scale = a power of two that puts the layer's largest weight near 2^12: the second piece of
+// any weight within 2^-9 of the largest stays a normal float16; smaller ones keep an absolute resolution of 2^-36 of the
+// largest).  Layout as above with two pieces per N-tile.  Returns the scale's inverse (the kernel's p.oscale).
+static unsigned short f32_to_f16_rne(float f) {
+  const _Float16 h = (_Float16)f;                                  // host conversion: round to nearest even
+  unsigned short u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+static float f16_to_f32(unsigned short u) {
+  _Float16 h;
+  std::memcpy(&h, &u, 2);
+  return (float)h;
+}
+float pack_conv_x2_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh_, int kw_, unsigned short *out) {
+  const int T = kh_ * kw_, kct = cinp / 16, ntt = coutp / 32;
+  float mx = 0.f;
+  for (size_t k = 0; k < (size_t)cout * cin * T; ++k) mx = std::fmax(mx, std::fabs(oihw[k]));
+  int e = 0;
+  if (mx > 0.f) std::frexp(mx, &e);                                // mx = f * 2^e, f in [0.5, 1)
+  const float scale = std::ldexp(1.0f, 12 - e), inv = std::ldexp(1.0f, e - 12);
+  for (int tap = 0; tap < T; ++tap)
+    for (int kc = 0; kc < kct; ++kc)
+      for (int nt = 0; nt < ntt; ++nt)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
+            float v = 0.f;
+            if (co < cout && ci < cin) v = oihw[((size_t)co * cin + ci) * T + tap] * scale;
+            const unsigned short h = f32_to_f16_rne(v);
+            const unsigned short m = f32_to_f16_rne(v - f16_to_f32(h));
+            const size_t base = ((((size_t)tap * kct + kc) * ntt + nt) * 2) * 64 * 8 + (size_t)ln * 8 + j;
+            out[base] = h;
+            out[base + 64 * 8] = m;
+          }
+  return inv;
 }
 
 // The same packing on the device from an OIHW float32 weight (the training step's flat parameter buffer: after an optimiser

@@ -447,9 +447,13 @@ bool x3_layer(pnvo_handle m, const Layer &l) {
   const bool k1 = l.k == 1 && l.kw == 1 && l.pad == 0 && s2;      // the 1x1 stride-2 downsample convs (resnet.py:192-195)
   return (k3 || k1) && !l.host_w.empty() && m->opt.conv <= 1;
 }
+bool x3_two_pieces(pnvo_handle m, const Layer &l) {
+  return m->opt.pieces == 2 && m->train == nullptr && !m->bottleneck && l.in_bound < 6.0e4f;
+}
 bool x3_args(pnvo_handle m, const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
   std::memset(&xa, 0, sizeof(xa));
   xa.force = m->opt.conv == 1;
+  xa.np = x3_two_pieces(m, l) ? 2 : 3;
   xa.B = B;
   xa.H = l.hin;
   xa.W = l.win;
@@ -539,9 +543,23 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     xa.COUTP = l.coutp;
     int mw = 0, nw = 0;
     size_t ldsb = 0;
+    // operand pieces: two float16 pieces (three product terms) at inference when the layer's input is provably inside float16's
+    // range; three bf16 pieces (six exact terms) otherwise, on request (option pieces=3) and whenever a training step is attached
+    // (its device-side re-pack builds the three-piece operand from the flat parameters)
+    const bool two = x3_two_pieces(m, l);
+    xa.np = two ? 2 : 3;
     if (conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
-      if (!lm.wpk_x3 || lm.x3_gen != m->weights_gen) {           // (re)build the three-piece operand of this layer
+      if (two && (!lm.wpk_x2 || lm.x2_gen != m->weights_gen)) {  // (re)build the two-piece operand of this layer
+        const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 2;
+        if (!lm.wpk_x2) HIPCHK(m, hipMalloc((void **)&lm.wpk_x2, nel * 2));
+        std::vector<unsigned short> pk(nel);
+        lm.x2_oscale = pack_conv_x2_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pk.data());
+        HIPCHK(m, hipMemcpyAsync(lm.wpk_x2, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(m, hipStreamSynchronize(s));
+        lm.x2_gen = m->weights_gen;
+      }
+      if (!two && (!lm.wpk_x3 || lm.x3_gen != m->weights_gen)) {   // (re)build the three-piece operand of this layer
         const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 3;
         if (!lm.wpk_x3) HIPCHK(m, hipMalloc((void **)&lm.wpk_x3, nel * 2));
         const float *dev_w = m->train ? pnvo_train_weight_ptr(m, l.name + ".weight") : nullptr;
@@ -556,7 +574,8 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         lm.x3_gen = m->weights_gen;
       }
       xa.x = x;
-      xa.wpk = lm.wpk_x3;
+      xa.wpk = two ? lm.wpk_x2 : lm.wpk_x3;
+      xa.oscale = lm.x2_oscale;
       xa.y = y;
       xa.in_scale = in_scale;
       xa.in_shift = in_shift;
@@ -819,6 +838,7 @@ struct OptDef {
 const OptDef kOptions[] = {
     {"stem", "PNVO_STEM", &PnvoOptions::stem, false, {{"auto", 0}, {"mx", 1}, {"dd", 2}, {"dense", 3}, {nullptr, 0}}},
     {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
+    {"pieces", "PNVO_PIECES", &PnvoOptions::pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
     {"pool", "PNVO_POOL", &PnvoOptions::pool, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
@@ -959,6 +979,36 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
   }
   for (Layer &l : h->convs)
     if ((rc = load_conv(h, t, l, true)) != PNVO_OK) return rc;
+  if (!h->bottleneck) {
+    // Upper bounds of |activation| entering each conv of the residual stages, from the GroupNorm parameters alone: a group of N
+    // elements normalised to unit variance has |x^| <= sqrt(N), so |relu(GN(x))| <= max_c (|gamma_c| sqrt(N) + |beta_c|); a block
+    // output adds its skip branch.  The two-piece float16 operands of conv_x3 need the bound below 65504 (pnvo_run_conv).
+    auto gn_bound = [&](const Layer &l) {
+      const float *g = find_tensor(h, t, l.gn + ".weight", {l.cout}, &rc), *b = find_tensor(h, t, l.gn + ".bias", {l.cout}, &rc);
+      if (!g || !b) return 3.0e38f;
+      const double rootn = std::sqrt((double)(l.cout / l.groups) * l.hout * l.wout);
+      double mx = 0.0;
+      for (int c2 = 0; c2 < l.cout; ++c2) mx = std::fmax(mx, std::fabs((double)g[c2]) * rootn + std::fabs((double)b[c2]));
+      return (float)std::fmin(mx, 3.0e38);
+    };
+    float bin = gn_bound(h->convs[0]);                         // pooled stem output
+    size_t li = 1;
+    for (int stage = 1; stage <= 4; ++stage)
+      for (int bi = 0; bi < h->nblocks[stage - 1]; ++bi) {
+        Layer &c1 = h->convs[li++];
+        Layer &c2 = h->convs[li++];
+        const bool ds = li < h->convs.size() && h->convs[li].name.find("downsample") != std::string::npos;
+        c1.in_bound = bin;
+        c2.in_bound = gn_bound(c1);
+        float skip = bin;
+        if (ds) {
+          Layer &cd = h->convs[li++];
+          cd.in_bound = bin;
+          skip = gn_bound(cd);
+        }
+        bin = gn_bound(c2) + skip;
+      }
+  }
   {
     // fused stem: re-pack conv1 with its input channels in observation-tensor order, and fold /255 and the
     // RunningMeanAndVar whitening into x*sc+sh:  (x/255 - mean)/std = x * 1/(255 std) - mean/std
@@ -1175,10 +1225,11 @@ int pnvo_set_option(pnvo_handle h, const char *key, const char *value) {
     for (const OptChoice *c = d->choices; !d->numeric && c->word != nullptr; ++c) msg += std::string(c == d->choices ? "" : " | ") + c->word;
     return fail(h, PNVO_ERR_ARG, msg + ")");
   }
-  if (h->opt.*(d->field) == v) return PNVO_OK;
+  const bool lift = d->field == &PnvoOptions::stem && h->dense_sticky;   // an explicit stem choice lifts the fallback
+  if (h->opt.*(d->field) == v && !lift) return PNVO_OK;
   h->opt.*(d->field) = v;
   pnvo_drop_graphs(h);                       // captured launches encode the kernel selection
-  if (d->field == &PnvoOptions::stem) h->dense_sticky = false;   // an explicit choice lifts the fallback
+  if (lift) h->dense_sticky = false;
   return PNVO_OK;
 }
 
@@ -1625,6 +1676,7 @@ int pnvo_destroy(pnvo_handle m) {
   for (Layer &l : m->convs) {
     free_dev(l.wpk);
     free_dev(reinterpret_cast<float *&>(l.wpk_x3));
+    free_dev(reinterpret_cast<float *&>(l.wpk_x2));
     free_dev(l.gamma);
     free_dev(l.beta);
   }
@@ -1706,6 +1758,29 @@ int pnvo_tap_shape(pnvo_handle h, const char *name, int B, int64_t shape[4]) {
     return set(B, hh, ww, c.baseplanes << (li - 1));
   }
   return fail(h, PNVO_ERR_ARG, "unknown tap '" + n + "'");
+}
+
+int pnvo_layer_kernel(pnvo_handle h, const char *name, int B, char *family, size_t cap, double *executed_flops) {
+  if (!h || !name || !family || cap == 0 || B <= 0) return fail(h, PNVO_ERR_ARG, "bad argument");
+  for (size_t li = 1; li < h->convs.size(); ++li) {
+    const Layer &l = h->convs[li];
+    if (l.name != name) continue;
+    const double alg = 2.0 * B * l.hout * l.wout * (double)l.cout * l.cin * l.k * l.kw;
+    ConvX3Args xa;
+    int mw, nw;
+    size_t ldsb;
+    if (x3_layer(h, l) && l.groups > 0 && x3_args(h, l, B, xa, &mw, &nw, &ldsb)) {
+      std::snprintf(family, cap, xa.np == 2 ? "x2" : "x3");
+      // tiles x M-tiles x 32 pixels x padded outputs x K, six bf16 (x3) or three float16 (x2) MFMA terms per float32 product
+      if (executed_flops)
+        *executed_flops = (xa.np == 2 ? 3.0 : 6.0) * 2.0 * (double)B * xa.tiles_r * xa.tiles_c * xa.MT * 32.0 * l.coutp * (double)l.cinp * l.k * l.kw;
+      return PNVO_OK;
+    }
+    std::snprintf(family, cap, "%s", layer_on_lds(h, l, nullptr) ? "fp32-lds" : "fp32-generic");
+    if (executed_flops) *executed_flops = alg;
+    return PNVO_OK;
+  }
+  return fail(h, PNVO_ERR_ARG, std::string("no residual-stage conv named '") + name + "'");
 }
 
 int pnvo_timing_mode(pnvo_handle h, int mode) {

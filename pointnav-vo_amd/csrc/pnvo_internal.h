@@ -123,12 +123,15 @@ struct ConvX3Args {
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_x3_plan
   unsigned long long *prof;          // PNVO_X3_PROF=1: phase cycles of one workgroup (nullptr otherwise)
   int force;                         // conv_x3_plan: take the layer at any launch size (option conv=x3)
+  int np;                            // operand pieces: 3 = bf16 (six exact product terms; 0 means 3), 2 = float16 (three terms)
+  float oscale;                      // np == 2: inverse of the power-of-two scale folded into the packed weights
 };
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
 hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,
                                  unsigned short *out, hipStream_t s);
 void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);
+float pack_conv_x2_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);   // -> oscale
 
 // Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).
 struct ConvBArgs {

@@ -21,12 +21,19 @@ struct Layer {
   // float32-on-bf16-pipe path (conv_x3.hip): three-piece packed weights, built on first use after a (re)load
   unsigned short *wpk_x3 = nullptr;
   unsigned long long x3_gen = 0;
+  // two-piece float16 form of the same kernel (inference): packed weights, the inverse of their power-of-two scale, and an
+  // upper bound of |input activation| from the producers' GroupNorm parameters (float16 pieces need it below 65504)
+  unsigned short *wpk_x2 = nullptr;
+  unsigned long long x2_gen = 0;
+  float x2_oscale = 1.f;
+  float in_bound = 3.0e38f;
 };
 
 // Per-handle options (pnvo_set_option; defaults from the PNVO_* environment, read ONCE in pnvo_create).
 struct PnvoOptions {
   int stem = 0;        // 0 auto (bf16-matrix-core stem when the model's modalities fit it, else one-hot-aware, else dense), 1 mx, 2 dd, 3 dense
   int conv = 0;        // 0 auto (conv_x3 for launches of >= 192 workgroups, fp32-MFMA kernels below), 1 x3 at any size, 2 fp32, 3 generic
+  int pieces = 2;      // operand pieces of conv_x3 at inference: 2 float16 (three product terms) or 3 bf16 (six exact terms)
   int x3_s2 = 1;       // stride-2 convs on conv_x3
   int tail = 1;        // BasicBlock tails fused into the next conv's stager (0: residual_kernel)
   int pool = 1;        // max-pool fused into the stem's epilogue (0: gn_relu_maxpool_kernel)

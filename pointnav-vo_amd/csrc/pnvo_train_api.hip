@@ -75,6 +75,11 @@ struct TrainState {
   int *embed_err = nullptr;             // host-mapped flag: action outside the embedding table
   size_t w1_off = 0, b1_off = 0, emb_off = 0;
   long w1_pitch = 0;
+  // gradient-ready hook (pnvo_train_set_grad_hook): the backward reports flat ranges [first, first + count) whose gradients
+  // are final while the rest of it is still being enqueued; bucket_first = lower bounds of the ranges, latest layers first
+  pnvo_grad_ready_fn hook = nullptr;
+  void *hook_user = nullptr;
+  std::vector<size_t> bucket_first;     // e.g. {offset of layer4's first parameter, offset of layer2's, 0}
 };
 
 TrainState *TS(pnvo_handle m) { return reinterpret_cast<TrainState *>(m->train); }
@@ -676,7 +681,50 @@ int pnvo_train_attach(pnvo_handle m, float *params, float *grads, size_t n_float
     pnvo_train_free(m);
     return rc;
   }
+  {
+    // Buckets of the gradient-ready hook.  The backward finishes the parameters in the order head, hidden layer, compression,
+    // layer4 ... layer1, stem; a range can be reported early when everything at or above its first offset belongs to layers
+    // the backward has left (true for the reference's state_dict order; any other order falls back to one final range).
+    auto stage_of = [](const std::string &nm) {          // 5: after the residual stages, 1..4: residual stage, 0: stem / other
+      const std::string bb = "visual_encoder.backbone.layer";
+      if (nm.rfind(bb, 0) == 0 && nm.size() > bb.size()) return nm[bb.size()] - '0';
+      if (nm.rfind("visual_encoder.backbone.", 0) == 0 || nm.rfind("action_embedding", 0) == 0) return 0;
+      return 5;
+    };
+    t->bucket_first.clear();
+    for (int lo_stage : {4, 2}) {
+      size_t first = n_floats, below_end = 0;
+      for (auto &kv : t->toc) {
+        const int st = stage_of(kv.first);
+        if (st >= lo_stage) first = std::min(first, kv.second.off);
+        else below_end = std::max(below_end, kv.second.off + kv.second.numel);
+      }
+      if (first < n_floats && below_end <= first && (t->bucket_first.empty() || first < t->bucket_first.back()) && first > 0)
+        t->bucket_first.push_back(first);
+    }
+    t->bucket_first.push_back(0);
+  }
   return pnvo_train_refresh(m, nullptr);
+}
+
+int pnvo_train_set_grad_hook(pnvo_handle m, pnvo_grad_ready_fn fn, void *user) {
+  if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  TS(m)->hook = fn;
+  TS(m)->hook_user = user;
+  return PNVO_OK;
+}
+
+int pnvo_train_grad_buckets(pnvo_handle m, uint64_t *first, uint64_t *count, int cap, int *n_out) {
+  if (!m || !m->train || !n_out) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
+  TrainState *t = TS(m);
+  *n_out = (int)t->bucket_first.size();
+  size_t end = t->n;
+  for (int k = 0; k < *n_out && k < cap && first && count; ++k) {
+    first[k] = t->bucket_first[k];
+    count[k] = end - t->bucket_first[k];
+    end = t->bucket_first[k];
+  }
+  return PNVO_OK;
 }
 
 // device pointer of a parameter inside the caller's flat buffer (nullptr: not attached / unknown name)
@@ -860,7 +908,22 @@ static int train_forward_body(pnvo_handle m, const float *rgb, const float *dept
   return PNVO_OK;
 }
 
+static int train_backward_body(pnvo_handle m, const float *grad_out, void *stream);
+
+// bucket k of the gradient-ready hook is final: report it (host callback; the launches that produce it are enqueued on `s`)
+static void report_bucket(TrainState *t, size_t k, hipStream_t s) {
+  if (!t->hook || k >= t->bucket_first.size()) return;
+  const size_t end = k == 0 ? t->n : t->bucket_first[k - 1];
+  t->hook(t->hook_user, (uint64_t)t->bucket_first[k], (uint64_t)(end - t->bucket_first[k]), (void *)s);
+}
+
 int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
+  const int rc = train_backward_body(m, grad_out, stream);
+  if (rc == PNVO_OK && m->train) report_bucket(TS(m), TS(m)->bucket_first.size() - 1, (hipStream_t)stream);   // [0, ...): everything
+  return rc;
+}
+
+static int train_backward_body(pnvo_handle m, const float *grad_out, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   TrainState *t = TS(m);
   if (t->lastB <= 0 || !grad_out) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_forward first");
@@ -1022,6 +1085,11 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
       HIPCHK(m, launch_add(dX, t->G, nin, dX, s));
     }
     std::swap(dY, dX);
+    // leaving residual stage 4 / stage 2: every parameter from that stage's first offset upwards has its final gradient
+    if (t->bucket_first.size() == 3) {
+      if (blk - 1 == m->nblocks[0] + m->nblocks[1] + m->nblocks[2]) report_bucket(t, 0, s);
+      if (blk - 1 == m->nblocks[0]) report_bucket(t, 1, s);
+    }
   }
   // ---- stem: maxpool <- dY, GroupNorm + ReLU, weight gradient (no input gradient)
   {

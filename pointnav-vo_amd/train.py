@@ -9,8 +9,9 @@ Mirrors, for one action model, the body of the reference's training iteration
 
 Forward, backward, loss and Adam are HIP kernels behind the C ABI (pnvo_train_*); this class only owns the flat
 device buffers and performs the collectives the reference semantics call for when torch.distributed is initialised:
-RunningMeanAndVar's three all-reduces (running_mean_and_var.py:27-38) and ONE all-reduce of the flat gradient buffer
-(RCCL over xGMI on the GPU box; 15.85 MB for the default model).  Dropout (the reference trains with p = 0.2 before both
+RunningMeanAndVar's all-reduces (running_mean_and_var.py:27-38; batch sum and count travel as one buffer, the variance
+needs the global mean and is the second round) and the all-reduce of the flat gradient buffer (RCCL over xGMI on the GPU box;
+15.85 MB for the default model, in three buckets that start while the backward is still running: pnvo_train_set_grad_hook).  Dropout (the reference trains with p = 0.2 before both
 Linear layers) uses a counter-based hash mask instead of torch's RNG stream — same distribution and arithmetic, a different
 but reproducible random draw (pnvo_train_set_dropout; `dropout_masks()` returns the masks of the last step for checkers).
 """
@@ -82,6 +83,14 @@ class VOTrainStep:
         self._m12 = torch.empty(2 * Cc, device=self.dev)
         self._loss = torch.zeros(1, device=self.dev)
         self._psig = self._param_sig()
+        # data parallel: the gradient all-reduce travels in buckets that start while the backward is still running
+        # (pnvo_train_set_grad_hook; layer4..head first — 80 % of the bytes — then layer2-3, then stem + layer1);
+        # bucketed = False: ONE flat all-reduce after the backward (bench.py --no-overlap, the A/B of the two schedules)
+        self.bucketed = True
+        self._pending = []                     # (work handle, first, count) of the all-reduces in flight
+        self._comm = None
+        self._hook = _lib.GRAD_READY_FN(self._on_grad_ready)
+        _lib.check(_lib.lib.pnvo_train_set_grad_hook(model._handle, C.cast(self._hook, C.c_void_p), None), model._handle)
 
     # ------------------------------------------------------------------ parameter / optimizer state
     def _param_sig(self):
@@ -296,6 +305,52 @@ class VOTrainStep:
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
             _lib.check(_lib.lib.pnvo_train_backward(h, _ptr(grad_out), stream), h)
 
+    # ------------------------------------------------------------------ gradient all-reduce
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _allreduce_bucket(self, first, count):
+        """Start the all-reduce of grad[first : first + count] behind everything enqueued on the current stream so far, on the
+        communication stream (RCCL runs next to the rest of the backward); optimizer_step waits for it."""
+        main = torch.cuda.current_stream(self.dev)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(ev)
+            work = dist.all_reduce(self.grad[first:first + count], async_op=True)
+        self._pending.append((work, first, count))
+
+    def _on_grad_ready(self, user, first, count, stream):
+        """pnvo_grad_ready_fn: called by pnvo_train_backward on the host when a flat gradient range is final."""
+        if self.bucketed and self._distributed():
+            self._allreduce_bucket(int(first), int(count))
+
+    def _bucket_ranges(self):
+        first, count, n = (C.c_uint64 * 8)(), (C.c_uint64 * 8)(), C.c_int(0)
+        _lib.check(_lib.lib.pnvo_train_grad_buckets(self.model._handle, first, count, 8, C.byref(n)), self.model._handle)
+        return [(int(first[k]), int(count[k])) for k in range(n.value)]
+
+    def _finish_gradient_allreduce(self):
+        """Mean of the gradient over the ranks: wait for the buckets the backward started (or issue the same sequence now — a
+        rank that had no backward this step — or the one flat all-reduce when bucketing is off), then divide."""
+        if not self._distributed():
+            return
+        world = dist.get_world_size()
+        if self.bucketed:
+            if not self._pending:
+                for first, count in self._bucket_ranges():
+                    self._allreduce_bucket(first, count)
+            for work, _, _ in self._pending:
+                work.wait()                    # the current stream waits for the collective (no host block with RCCL)
+            if self._comm is not None:
+                torch.cuda.current_stream(self.dev).wait_stream(self._comm)
+            self._pending = []
+            self.grad /= world
+        else:
+            parallel.allreduce_mean_(self.grad)
+
     def participate_absent(self):
         """Data-parallel training, a rank whose batch holds NO entry of this action model while another rank's does: issue
         the same collectives a forward_train would (RunningMeanAndVar's two rounds, with zero contributions — every rank
@@ -308,11 +363,21 @@ class VOTrainStep:
                 self._update_running_stats(None, 0, stream)
                 self.model._loaded_sig = None
             self.grad.zero_()
+            self._pending = []                  # (no backward ran: optimizer_step issues the bucket sequence itself)
 
-    def optimizer_step(self):
+    def absent_backward(self):
+        """The point of the collective sequence where this model's backward would start its bucket all-reduces, on a rank that
+        ran participate_absent() instead of a forward (zero gradient)."""
+        if self._distributed():
+            if self.bucketed:
+                for first, count in self._bucket_ranges():
+                    self._allreduce_bucket(first, count)
+
+    def optimizer_step(self, allreduce=True):
         """All-reduce (mean) of the flat gradient buffer across ranks, Adam, re-pack of the kernel operands."""
         h = self.model._handle
-        parallel.allreduce_mean_(self.grad)                           # ONE RCCL collective, 15.85 MB
+        if allreduce:
+            self._finish_gradient_allreduce()                             # RCCL over xGMI: 15.85 MB in three buckets (or one)
         self.step_count += 1
         with torch.cuda.device(self.dev):
             stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -460,15 +525,18 @@ class GeoInvarianceTrainStep:
                     full.index_copy_(0, dv, ginv)
                     for act, di in idx_of.items():
                         grads[act] += full.index_select(0, di)
-            for act, di in idx_of.items():
-                self.steps[act].backward(grads[act])
+            for act, st in self.steps.items():                   # one fixed order on every rank: the bucket all-reduces of a
+                if act in idx_of:                                #   model start inside its backward ...
+                    st.backward(grads[act])
+                elif present_anywhere[act]:                      #   ... and at the same point of the sequence on a rank without
+                    st.absent_backward()                         #   entries for it (zero gradient)
             for act, st in self.steps.items():
-                if act in idx_of or present_anywhere[act]:       # (absent here, present elsewhere: zero gradient, same all-reduce)
+                if act in idx_of or present_anywhere[act]:
                     st.optimizer_step()
                 elif st.step_count > 0:
                     # the reference zero_grad()s and step()s EVERY action model each iteration (:855-901); a model without
                     # entries in this batch has all-zero gradients once it has had a backward, so Adam still decays and
                     # applies its moments (torch 1.x zero_grad keeps zero tensors, environment.yml)
                     st.grad.zero_()
-                    st.optimizer_step()
+                    st.optimizer_step(allreduce=False)           # no rank holds entries: the gradient is zero everywhere
         return total, preds

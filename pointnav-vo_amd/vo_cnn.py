@@ -264,6 +264,14 @@ class VisualOdometryCNNBase(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.lib.pnvo_check_inputs(self._handle), self._handle)
 
+    def layer_kernel(self, name, batch):
+        """(kernel family, matrix-core FLOPs one launch executes) of a residual-stage conv at this batch size."""
+        dev = next(self.parameters()).device
+        self._ensure_handle(dev)
+        buf, fl = C.create_string_buffer(32), C.c_double(0.0)
+        _lib.check(_lib.lib.pnvo_layer_kernel(self._handle, name.encode(), int(batch), buf, 32, C.byref(fl)), self._handle)
+        return buf.value.decode(), float(fl.value)
+
     def timing(self, enable):
         dev = next(self.parameters()).device
         self._ensure_handle(dev)

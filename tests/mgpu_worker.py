@@ -109,6 +109,7 @@ def geo(rank, world, dev):
              synth.make_obs_pairs(n, H, W, observation_space=SPACE, dd_bins=BINS, seed=30 + rank).items()}
     tgt = torch.from_numpy(np.random.default_rng(5 + rank).normal(size=(n, 3)).astype(np.float32) * 0.2)
     mine = TURN_LEFT if rank == 0 else TURN_RIGHT
+    count0 = {act: float(st.model.visual_encoder.running_mean_and_var._count) for act, st in steps.items()}
     for it in range(2):                                   # second iteration: every model has stepped once on every rank
         total, preds = eng.step(batch, [mine] * n, [CUR_REL_TO_PREV] * n, tgt)
         assert torch.isfinite(total).all() and torch.isfinite(preds).all()
@@ -119,7 +120,7 @@ def geo(rank, world, dev):
             parts = [torch.empty_like(t.cpu()) for _ in range(world)]
             dist.all_gather(parts, t.cpu().contiguous())
             assert torch.equal(parts[0], parts[1]), (rank, act)
-        assert float(rmv._count) == 2 * n                 # the entries of ONE rank per iteration, seen by both
+        assert float(rmv._count) == count0[act] + 2 * n                 # the entries of ONE rank per iteration, seen by both
     dist.barrier()
     dist.destroy_process_group()
 

@@ -89,6 +89,37 @@ def test_two_steps_reduce_loss_on_a_fixed_batch():
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
 
 
+def test_gradient_ready_hook_reports_final_ranges_latest_layers_first():
+    """pnvo_train_set_grad_hook (the bucketed RCCL all-reduce of the data-parallel step hangs off it): during the backward the
+    library reports [layer4 .. head], [layer2 .. layer3], [stem .. layer1]; the ranges tile the flat buffer exactly, equal
+    pnvo_train_grad_buckets, and a range's gradient — copied on the launch stream at the moment it is reported — already
+    equals the final gradient."""
+    from pointnav_vo_amd import _lib
+    import ctypes as C
+    rec = load_golden("train_default_96x64_b3_f32.npz")
+    model, cfg, sd, obs, tobs = build(rec)
+    ts = VOTrainStep(model)
+    seen, snaps = [], []
+
+    def hook(user, first, count, stream):
+        seen.append((int(first), int(count)))
+        snaps.append(ts.grad[first:first + count].clone())       # enqueued behind the launches that produced the range
+
+    cb = _lib.GRAD_READY_FN(hook)
+    _lib.check(_lib.lib.pnvo_train_set_grad_hook(model._handle, C.cast(cb, C.c_void_p), None), model._handle)
+    target = torch.from_numpy(rec["target"]).to("cuda:0")
+    ts.forward_backward(tobs, target=target)
+    torch.cuda.synchronize()
+    n = ts.grad.numel()
+    assert len(seen) == 3 and seen == ts._bucket_ranges()
+    assert seen[0][0] == ts.offsets["visual_encoder.backbone.layer4.0.convs.0.weight"][0] and sum(seen[0]) == n
+    assert seen[1][0] == ts.offsets["visual_encoder.backbone.layer2.0.convs.0.weight"][0] and sum(seen[1]) == seen[0][0]
+    assert seen[2][0] == 0 and seen[2][1] == seen[1][0]
+    assert seen[0][1] > 0.7 * n                                   # most of the bytes can start before layers 3..1 run
+    for (first, count), snap in zip(seen, snaps):
+        assert torch.equal(snap, ts.grad[first:first + count])
+
+
 def test_dropout_step_matches_checker_given_the_same_masks():
     """The reference trains with nn.Dropout(0.2) before both Linear layers (vo_cnn.py:216-227).  torch's random draw
     cannot be reproduced, so the HIP step draws its masks from a counter-based hash; given THOSE masks the forward, the

@@ -50,7 +50,10 @@ def _cpu_baseline_dual(sds, ngroups, budget_s=12.0):
             "sample": f"{n} pairs through both models (fp32 oracle C port, OpenMP {thr} threads; the reference has no bf16 CPU path)"}
 
 
-def run_dual_bf16(args, rank, world, dist, dev, sync_all):
+def run_dual_bf16(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
+    """emit=False: called by the headline run for its `secondary` record — returns the result dictionary on rank 0 (None on
+    the others) instead of printing it, re-uses the caller's observation tensors, skips the CPU baseline and leaves the
+    process group alone."""
     B = args.batch or 256
     models, sds = [], []
     for seed in (0, 1):                               # the two action models of act_left_right_inv_joint
@@ -58,7 +61,8 @@ def run_dual_bf16(args, rank, world, dist, dev, sync_all):
         models.append(m.set_precision("bfloat16"))
         sds.append(sd)
     ma, mb = models
-    obs = bench.make_inputs(B, dev, rank)
+    if obs is None:
+        obs = bench.make_inputs(B, dev, rank)
     step = lambda: vo_cnn.dual_forward(ma, mb, obs)
 
     with torch.no_grad():
@@ -74,7 +78,8 @@ def run_dual_bf16(args, rank, world, dist, dev, sync_all):
             ea = np.linalg.norm(oa[:nchk].cpu().numpy().astype(np.float64) - ra, axis=1)
             eb = np.linalg.norm(ob[:nchk].cpu().numpy().astype(np.float64) - rb, axis=1)
             err = {"abs_l2_model_a": float(ea.max()), "abs_l2_model_b": float(eb.max()),
-                   "ref_l2": float(max(np.linalg.norm(ra, axis=1).max(), np.linalg.norm(rb, axis=1).max()))}
+                   "ref_l2": float(max(np.linalg.norm(ra, axis=1).max(), np.linalg.norm(rb, axis=1).max())),
+                   "rms_abs_l2": float(np.sqrt(np.mean(np.concatenate([ea, eb]) ** 2))), "forwards": int(2 * nchk)}
         pre = (0.0, 0, None) if args.no_preheat else bench.preheat(step, dev)
         for _ in range(args.warmup):
             step()
@@ -118,15 +123,19 @@ def run_dual_bf16(args, rank, world, dist, dev, sync_all):
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
                                for k in kt), key=lambda k: -k["ms_per_step"])[:40],
         }
+        if not emit:
+            return res
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = _cpu_baseline_dual(sds, ma.cfg.ngroups)
         print(json.dumps(res))
+    if not emit:
+        return None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def run_train(args, rank, world, dist, dev, sync_all):
+def run_train(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
     from pointnav_vo_amd.train import VOTrainStep
     B = args.batch or 128
     model = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
@@ -136,7 +145,11 @@ def run_train(args, rank, world, dist, dev, sync_all):
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to(dev)
     ts = VOTrainStep(model)
-    obs = bench.make_inputs(B, dev, rank)
+    ts.bucketed = not getattr(args, "no_overlap", False)     # A/B knob: gradient all-reduce in buckets behind the backward, or one flat one after it
+    if obs is None:
+        obs = bench.make_inputs(B, dev, rank)
+    elif next(iter(obs.values())).shape[0] != B:
+        obs = {k: v[:B].contiguous() for k, v in obs.items()}
     g = torch.Generator(device=dev)
     g.manual_seed(7 + rank)
     tgt = (torch.rand((B, 3), device=dev, generator=g) - 0.5) * 0.5
@@ -167,7 +180,7 @@ def run_train(args, rank, world, dist, dev, sync_all):
         dom = max((k for k in kt if k["flops"]), key=lambda k: k["total_ms"])
         launch_ms = dom["total_ms"] / dom["launches"]
         alg = dom["flops"] / dom["launches"] / (launch_ms * 1e-3) / 1e12
-        stem_mx = dom["name"].endswith("conv1.0.weight") and os.environ.get("PNVO_WGRAD_STEM") != "fp32"
+        stem_mx = dom["name"].endswith("conv1.0.weight") and model.get_option("wgrad_stem") == "mx"
         if stem_mx:
             # the stem's weight gradient runs on the bf16 matrix cores (wgrad_stem_mx.hip): EXECUTED work = tiles (6 x 13 outputs)
             # x 49 taps x 3 K-chunks x 18 v_mfma_f32_16x16x32_bf16 (3 M-tiles x 2 N-tiles x 3 dY pieces) of 16384 FLOP
@@ -195,7 +208,12 @@ def run_train(args, rank, world, dist, dev, sync_all):
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
                                for k in kt), key=lambda k: -k["ms_per_step"])[:70],
         }
+        res["config"]["gradient_allreduce"] = "bucketed behind the backward" if ts.bucketed else "one flat buffer after the backward"
+        if not emit:
+            return res
         print(json.dumps(res))
+    if not emit:
+        return None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
