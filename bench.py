@@ -173,12 +173,15 @@ def timed_steps(step, steps, sync_all, dev):
     return dt, out
 
 
-def stem_executed(kt_entry, B, per_launch_ms, sel="auto"):
+def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2"):
     """Work the stem kernels EXECUTE (not the algorithmic 30-channel conv): matrix-core FLOPs per launch against the
     peak of the pipe they run on."""
     ho, wo = (H + 1) // 2, (W + 1) // 2
     px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128              # pixels of the 8x16 tiles, padding included
-    if sel in ("auto", "mx"):          # stem_mx.hip: 7 x v_mfma_f32_32x32x16_bf16 per tap and 32-pixel tile (3 weight pieces x 2
+    if sel in ("auto", "mx") and pieces == "2":   # stem_mx.hip, float16 pieces: 5 x v_mfma_f32_32x32x16_f16 per tap and 32-pixel
+        flops = px / 32 * 49 * 5 * (2.0 * 32 * 32 * 16)       #   tile (2 weight pieces x 2 K-chunks + 1 chunk of float-modality remainders)
+        peak, pipe = PEAK_BF16_TFLOPS, "float16 MFMA (two float16 weight pieces, inputs exact in float16 -> float32-grade results)"
+    elif sel in ("auto", "mx"):        # stem_mx.hip: 7 x v_mfma_f32_32x32x16_bf16 per tap and 32-pixel tile (3 weight pieces x 2
         flops = px / 32 * 49 * 7 * (2.0 * 32 * 32 * 16)       #   K-chunks + 1 chunk of float-modality remainders)
         peak, pipe = PEAK_BF16_TFLOPS, "bf16 MFMA (three exact bf16 weight pieces -> float32 results)"
     elif sel == "dd":        # stem_dd.hip: K = 12 of 30 channels on the fp32 MFMA pipe, the rest gathered from LDS
@@ -325,7 +328,7 @@ def main():
         total_kernel_ms = sum(k["total_ms"] for k in kt)
         is_stem = dom["name"].endswith("conv1.0")
         if is_stem:
-            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"))
+            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"), model.get_option("pieces"))
         else:
             fam, ex = model.layer_kernel(dom["name"][len("conv:"):], B)
             if fam in ("x3", "x2"):                  # six bf16 / three float16 MFMA terms per float32 product, tile padding included

@@ -684,8 +684,12 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     StemMXArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int k = 0; k < 4; ++k) a.src[k] = src[k];
+    // two float16 weight pieces at inference (5 MFMAs per tap); three bf16 pieces (7, every product exact) on request and
+    // whenever a training step is attached (its device-side re-pack builds the three-piece operand)
+    const int pieces = (m->opt.pieces == 2 && m->train == nullptr && m->mx_wpk2 != nullptr) ? 2 : 3;
     a.zero_page = m->mx_pages;
-    a.wpk = m->mx_wpk3;
+    a.wpk = pieces == 2 ? m->mx_wpk2 : m->mx_wpk3;
+    a.oscale = m->mx_oscale;
     a.bad_input = m->dd_flag;
     const int ntn = stem.cout / 32;
     for (int g = 0; g < ntn; ++g) {
@@ -716,7 +720,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     {
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
               4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
-      HIPCHK(m, launch_stem_mx(a, 3, ntn, false, s));
+      HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     {
@@ -1158,6 +1162,13 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
       if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_wpk3), reinterpret_cast<const float *>(pk.data()), pk.size() / 2)) !=
           PNVO_OK)
         return rc;
+      {
+        std::vector<unsigned short> pk2(stem_mx_packed_u16(2, st.cout / 32));
+        h->mx_oscale = pack_stem_mx_weight_h(h->mx_wk.data(), st.cout, h->mx_xslot, pk2.data());
+        if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_wpk2), reinterpret_cast<const float *>(pk2.data()), pk2.size() / 2)) !=
+            PNVO_OK)
+          return rc;
+      }
       {
         std::vector<float> pages(64, 0.f);
         if ((rc = upload(h, h->mx_pages, pages.data(), pages.size())) != PNVO_OK) return rc;
@@ -1688,6 +1699,7 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->stem_sh);
   free_dev(m->stem_wpk16);
   free_dev(reinterpret_cast<float *&>(m->mx_wpk3));
+  free_dev(reinterpret_cast<float *&>(m->mx_wpk2));
   free_dev(m->mx_pages);
   free_dev(m->dd_wpk);
   free_dev(m->dd_table);

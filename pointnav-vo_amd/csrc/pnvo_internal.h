@@ -99,11 +99,13 @@ struct StemMXArgs {
   int *pool;
   const float *pool_gamma;    // GroupNorm weight of the stem [cout] (its sign decides max or min)
   int Hp, Wp;
+  float oscale;               // PIECES = 2: inverse of the power-of-two scale folded into the packed weights
 };
 constexpr int STEM_POOL_INIT = (int)0x807fffffu;   // key of -inf
 int stem_mx_slots(int Ho, int Wo);
 size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);
+float pack_stem_mx_weight_h(const float *wk, int cout, const int *xslot, unsigned short *out);   // two float16 pieces -> oscale
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                  const int *slot_new, const int *xslot, unsigned short *wpk3, hipStream_t s);

@@ -85,6 +85,8 @@ struct pnvo_model_s {
   // stem on the bf16 matrix cores (stem_mx.hip): exact three-piece bf16 weights -> float32 results (inference default)
   bool mx_ok = false;
   unsigned short *mx_wpk3 = nullptr;         // device: three-piece packing (float32 results)
+  unsigned short *mx_wpk2 = nullptr;         // device: two float16 pieces (inference default) and the inverse of their scale
+  float mx_oscale = 1.f;
   std::vector<float> mx_wk, mx_wk_swapped;   // host [cout][32 slots][49]: whitening-folded weights, as is / for the
                                              //   (cur, prev) channel-swapped pair (geometric-invariance dual forward)
   int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels

@@ -16,6 +16,11 @@
 //       K-steps (768 cycles) for the dense fp32 stem.  A value that is NOT exact in bf16 where the contract says it is
 //       (rgb that is not an integer, a soft depth code) raises the host-visible flag (pnvo_check_inputs) — such callers
 //       select PNVO_STEM=dense.
+//   PIECES = 2  ("f32h": float32-grade results from the float16 pipe, the inference default).  The same raw values are exact in
+//       float16 too (integers up to 2048, {0,1}); the weight is split into TWO float16 pieces (22 significant bits, after a
+//       power-of-two scale that keeps the second piece a normal number; rgb slots carry 2^-8 on the A side and 2^8 on the B
+//       side for the same reason), the float modalities into two pieces on the A side: x0 w0 + x0 w1 + x1 w0, each product
+//       within 3 * 2^-22.  5 MFMAs per tap instead of 7, the scale is undone exactly on the accumulators.
 //   PIECES = 1  (native bf16, BASELINE config 3): one bf16 weight piece, bf16-rounded float modalities, 2 MFMAs per tap;
 //       the indicator weight keeps two pieces (slots 30 and 31) because it carries -sum_c W mean_c/std_c, a large
 //       cancelling term.
@@ -32,6 +37,7 @@
 // split over the 4 waves (K split): every wave keeps 4 x NT accumulators (all M-tiles), streams its taps' B fragments
 // from L2 (one 1 KiB fragment feeds 4 MFMAs) and the partial sums meet in LDS in a fixed order (deterministic).
 // 67 KB LDS -> 2 workgroups per CU: one stages (HBM -> registers -> bf16 -> LDS) while the other computes.
+#include <cmath>
 #include <cstring>
 
 #include "pnvo_internal.h"
@@ -43,6 +49,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -60,6 +68,14 @@ constexpr int NTHREADS = 256;
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const bf16x2 r = __builtin_convertvector(f32x2{a, b}, bf16x2);   // v_cvt_pk_bf16_f32 (round to nearest even)
   return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const f16x2 r = __builtin_convertvector(f32x2{a, b}, f16x2);     // v_cvt_pk_f16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, r);
+}
+template <bool H>
+__device__ __forceinline__ unsigned pack_pair(float a, float b) {
+  return H ? pack_f16(a, b) : pack_bf16(a, b);
 }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -89,7 +105,8 @@ __constant__ const TapOffsets TAPOFF{};
 
 template <int PIECES, int NT, bool BF16OUT, bool POOL = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_mx_kernel(const StemMXArgs p) {
-  constexpr bool EXTRA = PIECES == 3;
+  constexpr bool EXTRA = PIECES >= 2;                      // float32(-grade) results: float modalities split on the A side too
+  constexpr bool H = PIECES == 2;                          // float16 pieces (else bf16)
   constexpr int NFT = PIECES * 2 + (EXTRA ? 1 : 0);        // B fragments per (tap, N-tile)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float *red = reinterpret_cast<float *>(lds + RED_OFF);       // [4 waves][NT*32][2]
@@ -168,31 +185,42 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         unsigned w[16];
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-          w[2 * c] = pack_bf16(vdd[rr][c][0], vdd[rr][c][1]);
-          w[2 * c + 1] = pack_bf16(vdd[rr][c][2], vdd[rr][c][3]);
+          w[2 * c] = pack_pair<H>(vdd[rr][c][0], vdd[rr][c][1]);
+          w[2 * c + 1] = pack_pair<H>(vdd[rr][c][2], vdd[rr][c][3]);
           if (EXTRA) {
             const float f0 = vdd[rr][c][0], f1 = vdd[rr][c][1], f2 = vdd[rr][c][2], f3 = vdd[rr][c][3];
             lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
             lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
           }
         }
-        w[10] = pack_bf16(vr4[rr][0], vr4[rr][1]);
-        w[11] = pack_bf16(vr4[rr][2], vr4[rr][3]);
-        w[12] = pack_bf16(vr2[rr][0], vr2[rr][1]);
+        if (H) {                                                       // rgb * 2^-8 here, 2^8 in the packed weights (exact)
+          w[10] = pack_f16(vr4[rr][0] * 0.00390625f, vr4[rr][1] * 0.00390625f);
+          w[11] = pack_f16(vr4[rr][2] * 0.00390625f, vr4[rr][3] * 0.00390625f);
+          w[12] = pack_f16(vr2[rr][0] * 0.00390625f, vr2[rr][1] * 0.00390625f);
+        } else {
+          w[10] = pack_bf16(vr4[rr][0], vr4[rr][1]);
+          w[11] = pack_bf16(vr4[rr][2], vr4[rr][3]);
+          w[12] = pack_bf16(vr2[rr][0], vr2[rr][1]);
+        }
         if (EXTRA) {
           const float f0 = vr4[rr][0], f1 = vr4[rr][1], f2 = vr4[rr][2], f3 = vr4[rr][3], f4 = vr2[rr][0], f5 = vr2[rr][1];
           lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
           lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
           lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
         }
-        w[13] = pack_bf16(vd[rr][0], vd[rr][1]);
-        w[14] = pack_bf16(vt[rr][0], vt[rr][1]);
-        w[15] = inb[rr] ? 0x3f803f80u : 0u;                            // indicator (two slots)
+        w[13] = pack_pair<H>(vd[rr][0], vd[rr][1]);
+        w[14] = pack_pair<H>(vt[rr][0], vt[rr][1]);
+        w[15] = inb[rr] ? (H ? 0x3c003c00u : 0x3f803f80u) : 0u;        // indicator (two slots): 1.0 in float16 / bf16
         unsigned char *dst = lds + ldsoff[rr];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<u32x4 *>(dst + 16 * q) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-        if (EXTRA) {                                                   // float modalities: x - hi = mid + lo (exact)
+        if (H) {                                                       // float modalities: x = x0 + x1 to 22 bits
+          const f16x2 hd = __builtin_bit_cast(f16x2, w[13]), ht = __builtin_bit_cast(f16x2, w[14]);
+          const unsigned md = pack_f16(vd[rr][0] - (float)hd[0], vd[rr][1] - (float)hd[1]);
+          const unsigned mt = pack_f16(vt[rr][0] - (float)ht[0], vt[rr][1] - (float)ht[1]);
+          *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{md, mt, 0u, 0u};
+        } else if (EXTRA) {                                            // float modalities: x - hi = mid + lo (exact)
           const float d0 = vd[rr][0] - bf16_lo(w[13]), d1 = vd[rr][1] - bf16_hi(w[13]);
           const float t0 = vt[rr][0] - bf16_lo(w[14]), t1 = vt[rr][1] - bf16_hi(w[14]);
           const unsigned md = pack_bf16(d0, d1), mt = pack_bf16(t0, t1);
@@ -202,7 +230,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
     }
-    if (EXTRA && (lowbits & 0xffffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
+    // exact in bf16: low 16 mantissa bits clear; exact in float16 (normal range — the contract's values are integers <= 255
+    // and {0, 1}): low 13 bits clear
+    if (EXTRA && (lowbits & (H ? 0x1fffu : 0xffffu)) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
   }
   const unsigned long long tp1 = prof ? __builtin_readcyclecounter() : 0;
   __syncthreads();
@@ -260,9 +290,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
-            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m]),
-                                                                 __builtin_bit_cast(bf16x8, b[(pc * 2 + q) * NT + nt]),
-                                                                 acc[m][nt], 0, 0, 0);
+            acc[m][nt] = H ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]),
+                                                                    __builtin_bit_cast(f16x8, b[(pc * 2 + q) * NT + nt]), acc[m][nt], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m]),
+                                                                     __builtin_bit_cast(bf16x8, b[(pc * 2 + q) * NT + nt]), acc[m][nt], 0, 0, 0);
     };
     auto mfmas_x = [&](const u32x4 *b) {
       if (EXTRA) {
@@ -270,9 +301,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
-            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[m]),
-                                                                 __builtin_bit_cast(bf16x8, b[(PIECES * 2) * NT + nt]),
-                                                                 acc[m][nt], 0, 0, 0);
+            acc[m][nt] = H ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ax[m]),
+                                                                    __builtin_bit_cast(f16x8, b[(PIECES * 2) * NT + nt]), acc[m][nt], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[m]),
+                                                                     __builtin_bit_cast(bf16x8, b[(PIECES * 2) * NT + nt]), acc[m][nt], 0, 0, 0);
       }
     };
     auto tapof = [&](int i) { return i < 12 ? wave + 4 * i : (wave == 3 ? 48 : wave + 44); };   // (past the end: harmless repeats)
@@ -331,6 +363,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? t[e] : tot[4 * rq + e] + t[e];
       }
+    if (H) {                                              // undo the weights' power-of-two scale (exact)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[r] *= p.oscale;
+    }
     // epilogue of M-tile `wave`: rows 2*wave, 2*wave+1 of the tile; lane = output channel, registers = pixels
     const int g = gy * NT + nt;                           // N-tile of the launch
     const int co = p.y_coff[g] + (lane & 31);
@@ -468,7 +504,55 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 int stem_mx_slots(int Ho, int Wo) { return ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW); }
 
-size_t stem_mx_packed_u16(int pieces, int ntiles) { return (size_t)49 * (pieces * 2 + (pieces == 3 ? 1 : 0)) * ntiles * 64 * 8; }
+size_t stem_mx_packed_u16(int pieces, int ntiles) { return (size_t)49 * (pieces * 2 + (pieces >= 2 ? 1 : 0)) * ntiles * 64 * 8; }
+
+// pieces = 2: float16 pieces of scale * wk (rgb slots 20..25 times 2^8: the stager hands rgb * 2^-8 over); the extra fragment
+// pairs the A bytes [x1(4) | 0] with [w0(x0..x3) | 0] in the first K half.  Returns 1 / scale (StemMXArgs::oscale).
+float pack_stem_mx_weight_h(const float *wk, int cout, const int *xslot, unsigned short *out) {
+  const int ntl = cout / 32, nft = 5;
+  auto slotw = [&](int co, int slot, int tap) {
+    const float v = wk[((size_t)co * 32 + slot) * 49 + tap];
+    return (slot >= 20 && slot <= 25) ? v * 256.f : v;
+  };
+  float mx = 0.f;
+  for (int co = 0; co < cout; ++co)
+    for (int slot = 0; slot < 31; ++slot)
+      for (int tap = 0; tap < 49; ++tap) mx = std::fmax(mx, std::fabs(slotw(co, slot, tap)));
+  int e = 0;
+  if (mx > 0.f) std::frexp(mx, &e);
+  const float scale = std::ldexp(1.0f, 12 - e), inv = std::ldexp(1.0f, e - 12);
+  auto h16 = [](float f) {
+    const _Float16 h = (_Float16)f;
+    unsigned short u;
+    std::memcpy(&u, &h, 2);
+    return u;
+  };
+  auto f32 = [](unsigned short u) {
+    _Float16 h;
+    std::memcpy(&h, &u, 2);
+    return (float)h;
+  };
+  auto piece = [&](float v, int pc) {
+    const unsigned short a = h16(v);
+    return pc == 0 ? a : h16(v - f32(a));
+  };
+  for (int tap = 0; tap < 49; ++tap)
+    for (int f = 0; f < nft; ++f)
+      for (int nt = 0; nt < ntl; ++nt)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int kh = ln >> 5, co = nt * 32 + (ln & 31);
+            unsigned short val = 0;
+            if (f < 4) {
+              const int pc = f / 2, q = f % 2, slot = 16 * q + 8 * kh + j;
+              if (slot < 31) val = piece(slotw(co, slot, tap) * scale, pc);
+            } else if (kh == 0 && j < 4 && xslot[j] >= 0) {
+              val = piece(slotw(co, xslot[j], tap) * scale, 0);
+            }
+            out[((((size_t)tap * nft + f) * ntl + nt) * 64 + ln) * 8 + j] = val;
+          }
+  return inv;
+}
 
 // B operand of the stem:  out[tap][fragment][N-tile][lane = kh*32 + n][8 bf16]  (kh = K half of the lane)
 //   fragment (piece pc, chunk q):  value = piece pc of  wk[co][slot 16q + 8kh + j][tap]
@@ -572,7 +656,13 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
   p.tiles_y = (a.Ho + TH - 1) / TH;
   const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
   const unsigned gx = (unsigned)(((ntiles + 7) / 8) * 8);
-  if (pieces == 3 && !bf16_out && a.pool != nullptr) {   // pooled keys instead of the raw output (inference)
+  if (pieces == 2 && !bf16_out) {                        // float16 pieces (inference default), pooled keys or raw output
+    const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
+    if (a.pool != nullptr)
+      hipLaunchKernelGGL((stem_mx_kernel<2, 1, false, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+    else
+      hipLaunchKernelGGL((stem_mx_kernel<2, 1, false>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+  } else if (pieces == 3 && !bf16_out && a.pool != nullptr) {   // pooled keys instead of the raw output (inference)
     const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
     hipLaunchKernelGGL((stem_mx_kernel<3, 1, false, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
   } else if (pieces == 3 && !bf16_out) {
