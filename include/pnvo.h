@@ -108,6 +108,25 @@ int pnvo_set_option(pnvo_handle h, const char *key, const char *value);
 int pnvo_get_option(pnvo_handle h, const char *key, char *buf, size_t cap);
 
 /*
+ * The same forward from the SENSOR frames (SURVEY.md section 8(b) sketch): replaces the observation construction of
+ * BaseRLTrainerWithVO._compute_local_delta_states_from_vo (base_trainer_with_vo.py:172-269) AND the model call (:286-291)
+ * without materialising obs_pairs — pair concatenation, the uint8 -> float cast and _discretize_depth_func (:135-167) happen in
+ * the stem's operand fetch (7.86 MB per pair of float32 observation tensors are neither written nor read).
+ *   rgb_frames   device uint8   [B][2][H][W][3]  (prev frame, cur frame; NULL for models without rgb)
+ *   depth_frames device float32 [B][2][H][W]     values 0..1 (feeds the depth and the discretised-depth modality)
+ *   tdv          device float32 [B][H][W][2]     the two top-down views (pnvo_topdown_view with out_pstride 2), NULL without it
+ *   err_flag     device int32, may be NULL: set to 1 when a depth lies outside [0, 1] (the reference asserts, :136-137)
+ * Results are bit-identical to pnvo_build_obs_pairs + pnvo_forward.  Configurations the frame-reading stem does not cover
+ * (option stem / pieces away from their defaults, an attached training step, models outside its K-slot layout) are served by
+ * materialising the pairs into a workspace of the handle first: same results, the cost of the separate path.
+ */
+int pnvo_forward_raw(pnvo_handle h, const uint8_t *rgb_frames, const float *depth_frames, const float *tdv, const int64_t *actions,
+                     int B, float *out, int32_t *err_flag, void *stream);
+/* pnvo_forward_dual (bfloat16, two action models, the second on the swapped pair) from the sensor frames. */
+int pnvo_forward_dual_raw(pnvo_handle ha, pnvo_handle hb, const uint8_t *rgb_frames, const float *depth_frames, const float *tdv, int B,
+                          float *out_a, float *out_b, int32_t *err_flag, void *stream);
+
+/*
  * Arithmetic of pnvo_forward for this handle: 0 = float32 (default: exact-float32 products on the matrix cores), 1 = bfloat16
  * (BASELINE config 3: bf16 operands and bf16 activations in HBM, float32 accumulation / GroupNorm statistics / Linear layers).
  * The reference has no such switch (it would be model.bfloat16(), which also rounds the normalisation and the head);

@@ -45,6 +45,10 @@ _SIGNATURES = {
     "pnvo_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(pnvo_tensor_desc), C.c_int]),
     "pnvo_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_void_p]),
+    "pnvo_forward_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "pnvo_forward_dual_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "pnvo_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pnvo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "pnvo_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),

@@ -59,8 +59,12 @@ __device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(fl
 // the size of a few float32 roundings of the accumulation it feeds — at half the matrix-pipe time, two LDS planes instead of
 // three and 5 instead of 11 VALU per channel pair in the stager.  The weights are pre-scaled by a power of two (p.oscale undoes
 // it exactly in the epilogue) so that their second piece stays in float16's normal range.
+// Waves per SIMD: the two-plane patch of the small wave tiles (32- / 64-channel stages) is <= 54 KB, so three workgroups fit a
+// CU; their accumulators are few, so 168 registers do.
+constexpr int x3_wpe(int mw, int nw, int np) { return (np == 2 && mw * nw <= 2) ? 3 : 2; }
+
 template <int KS, int STRIDE, int MODE, int MW, int NW, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3_kernel(const ConvX3Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, NW, NP), x3_wpe(MW, NW, NP)))) void conv_x3_kernel(const ConvX3Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
   constexpr int CS = KS == 1 ? 1 : STRIDE;         // patch pixels per output pixel
@@ -237,8 +241,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           *reinterpret_cast<u32x4 *>(lds + 2 * plane + r.off[k]) = o2;
         }
       };
-      constexpr bool PIPE = !(MODE == 2 && MW * NW >= 6);              // (the block-tail stager of the 96-accumulator tile would spill)
-      if (MW * NW <= 2) {
+      constexpr bool PIPE = !(MODE == 2 && (MW * NW >= 6 || x3_wpe(MW, NW, NP) == 3));   // (the block-tail stager of the 96-accumulator tile /
+                                                                                         //  of the 168-register small tiles would spill)
+      if (MW * NW <= 2 && !(MODE == 2 && x3_wpe(MW, NW, NP) == 3)) {
         // few accumulators: registers for three rounds in flight — the whole patch of the 32- / 64-channel stages is ONE memory
         // latency instead of three (their staging phase is as long as their MFMA phase)
         for (int pix = pl; pix < nppix; pix += 6 * PS) {

@@ -655,6 +655,19 @@ inline int run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const 
 
 // The fused stem: input assembly + /255 + whitening gathered in the operand fetch (LDS-staged kernel when the channel
 // count allows, else MODE 2 of the generic kernel), raw output + GroupNorm scale/shift (+ optional mean/rstd).
+void pnvo_stem_raw_args(pnvo_handle m, StemMXArgs &a) {
+  if (m->raw_depth == nullptr) return;
+  a.raw_rgb = m->raw_rgb;
+  a.raw_depth = m->raw_depth;
+  a.raw_flags = (m->cfg.n_depth > 0 ? 1 : 0) | (m->cfg.n_dd > 0 ? 2 : 0);
+  a.raw_err = m->raw_err;
+  const int bins = 10;                                             // the mx stem's K-slot layout (n_dd == 20)
+  for (int i = 0; i < bins; ++i) a.edges[i] = (float)((double)i * 1.0 / (double)bins);   // base_trainer_with_vo.py:105-115
+  a.edges[bins] = 1.0f;
+  a.edges[bins + 1] = 1.0f;
+  a.src[0] = a.src[1] = a.src[2] = nullptr;
+}
+
 bool pnvo_stem_on_mx(pnvo_handle m) {
   return m->mx_ok && !m->dense_sticky && (!m->in_train_forward || m->train_mx) && m->opt.stem <= 1;
 }
@@ -663,6 +676,7 @@ bool pnvo_stem_on_mx(pnvo_handle m) {
 // (an event recorded into a graph cannot be waited for: such forwards keep the deferred check of pnvo_check_inputs).
 int pnvo_mark_stem(pnvo_handle m, hipStream_t s) {
   if (!m->opt.input_fallback || m->dense_sticky || !m->dd_flag) return PNVO_OK;
+  if (m->raw_depth != nullptr) return PNVO_OK;      // sensor frames: uint8 rgb, one-hot derived in the stager — inside the contract by construction
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return PNVO_OK;
   if (!m->stem_ev) HIPCHK(m, hipEventCreateWithFlags(&m->stem_ev, hipEventDisableTiming));
@@ -684,6 +698,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     StemMXArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int k = 0; k < 4; ++k) a.src[k] = src[k];
+    pnvo_stem_raw_args(m, a);
     // two float16 weight pieces at inference (5 MFMAs per tap); three bf16 pieces (7, every product exact) on request and
     // whenever a training step is attached (its device-side re-pack builds the three-piece operand)
     const int pieces = (m->opt.pieces == 2 && m->train == nullptr && m->mx_wpk2 != nullptr) ? 2 : 3;
@@ -718,8 +733,10 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     }
     const double M = (double)B * m->Hs * m->Ws;
     {
+      // algorithmic bytes: the observation tensors (or, RAW: 6 B of rgb + 8 B of depth + 8 B of top-down view per pixel) once
+      const double in_bytes = (double)B * c.height * c.width * (m->raw_depth ? (c.n_rgb ? 6.0 : 0.0) + 8.0 + (c.n_tdv ? 8.0 : 0.0) : 4.0 * stem.cin);
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
-              4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
+              in_bytes + 4.0 * (M * stem.cout + (double)stem.cout * stem.cin * 49));
       HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
@@ -1348,7 +1365,7 @@ int forward_dispatch(pnvo_handle m, const float *rgb, const float *depth, const 
   if (plain) return forward_body(m, rgb, depth, dd, tdv, actions, B, out, s);
 
   // ---- graph replay: key = everything the captured kernel arguments depend on
-  const void *key[8] = {rgb, depth, dd, tdv, actions, nullptr, nullptr, nullptr};   // (pnvo_set_option drops the captured graphs)
+  const void *key[8] = {rgb, depth, dd, tdv, actions, m->raw_rgb, m->raw_depth, m->raw_err};   // (pnvo_set_option drops the captured graphs)
   const size_t out_bytes = (size_t)B * c.out_dim * sizeof(float);
   for (auto &g : m->graphs)
     if (g.B == B && std::memcmp(g.key, key, sizeof(key)) == 0) {
@@ -1565,6 +1582,104 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
 }
 }  // namespace
 
+namespace {
+// Can this call run on the RAW stager (frames straight into the stem)?  Else the raw entry materialises the observation pairs
+// (pnvo_build_obs_pairs into a workspace of the handle) and takes the ordinary path: same results, the old cost.
+bool raw_direct(pnvo_handle m, const float *depth_frames) {
+  if (depth_frames == nullptr || !m->mx_ok || m->dense_sticky || m->opt.stem > 1 || m->tap_dst != nullptr) return false;
+  if (m->precision == 1) return true;                                // bf16 path: its stem is the mx kernel (PIECES = 1)
+  return m->opt.pieces == 2 && m->train == nullptr && m->mx_wpk2 != nullptr;
+}
+
+int raw_materialise(pnvo_handle m, const uint8_t *rgb_frames, const float *depth_frames, int B, int32_t *err_flag, hipStream_t s) {
+  const pnvo_config &c = m->cfg;
+  if (B > m->rawws_cap) {
+    for (float *&q : m->rawws) pnvo_free_dev(q);
+    const size_t px = (size_t)B * c.height * c.width;
+    if (c.n_rgb) HIPCHK(m, hipMalloc((void **)&m->rawws[0], px * 6 * sizeof(float)));
+    HIPCHK(m, hipMalloc((void **)&m->rawws[1], px * 2 * sizeof(float)));
+    if (c.n_dd) HIPCHK(m, hipMalloc((void **)&m->rawws[2], px * (size_t)c.n_dd * sizeof(float)));
+    m->rawws_cap = B;
+  }
+  HIPCHK(m, launch_frame_pairs(c.n_rgb ? rgb_frames : nullptr, depth_frames, B, c.height, c.width, c.n_dd / 2, m->rawws[0], m->rawws[1],
+                               m->rawws[2], err_flag, s));
+  return PNVO_OK;
+}
+}  // namespace
+
+int pnvo_forward_raw(pnvo_handle m, const uint8_t *rgb_frames, const float *depth_frames, const float *tdv, const int64_t *actions, int B,
+                     float *out, int32_t *err_flag, void *stream) {
+  if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
+  if (!m->loaded) return fail(m, PNVO_ERR_STATE, "pnvo_forward_raw before pnvo_load_weights");
+  if (B <= 0 || !out) return fail(m, PNVO_ERR_ARG, "bad batch / null output");
+  const pnvo_config &c = m->cfg;
+  if ((c.n_rgb > 0) != (rgb_frames != nullptr) || ((c.n_depth > 0 || c.n_dd > 0) && depth_frames == nullptr) ||
+      (c.n_tdv > 0) != (tdv != nullptr))
+    return fail(m, PNVO_ERR_ARG, "sensor frames do not match the model's observation_space");
+  if (c.act_embed && !actions) return fail(m, PNVO_ERR_ARG, "act_embed model needs actions");
+  if (int rc0 = pnvo_check_inputs(m)) return rc0;
+  HIPCHK(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!raw_direct(m, depth_frames)) {
+    int rc = raw_materialise(m, rgb_frames, depth_frames, B, err_flag, s);
+    if (rc != PNVO_OK) return rc;
+    return pnvo_forward(m, c.n_rgb ? m->rawws[0] : nullptr, c.n_depth ? m->rawws[1] : nullptr, c.n_dd ? m->rawws[2] : nullptr, tdv,
+                        actions, B, out, stream);
+  }
+  m->raw_rgb = rgb_frames;
+  m->raw_depth = depth_frames;
+  m->raw_err = err_flag;
+  int rc;
+  if (m->precision == 1) {
+    pnvo_handle hs[1] = {m};
+    float *outs[1] = {out};
+    rc = pnvo_forward_bf16(hs, 1, nullptr, nullptr, nullptr, tdv, actions, B, outs, s);
+  } else {
+    rc = ensure_workspace(m, B);
+    // (frames are uint8 / the one-hot is derived in the stager: nothing for the input-contract check to find — no stem event)
+    if (rc == PNVO_OK) rc = forward_dispatch(m, nullptr, nullptr, nullptr, tdv, actions, B, out, s);
+    m->stem_ev_pending = false;
+  }
+  m->raw_rgb = nullptr;
+  m->raw_depth = nullptr;
+  m->raw_err = nullptr;
+  return rc;
+}
+
+int pnvo_forward_dual_raw(pnvo_handle ha, pnvo_handle hb, const uint8_t *rgb_frames, const float *depth_frames, const float *tdv, int B,
+                          float *out_a, float *out_b, int32_t *err_flag, void *stream) {
+  if (!ha || !hb) return fail(ha, PNVO_ERR_ARG, "null handle");
+  if (!ha->loaded || !hb->loaded) return fail(ha, PNVO_ERR_STATE, "pnvo_forward_dual_raw before pnvo_load_weights");
+  if (B <= 0 || !out_a || !out_b) return fail(ha, PNVO_ERR_ARG, "bad batch / null output");
+  if (ha->precision != 1 || hb->precision != 1)
+    return fail(ha, PNVO_ERR_STATE, "pnvo_forward_dual_raw runs the bfloat16 path: call pnvo_set_precision(h, 1) on both models");
+  if (std::memcmp(&ha->cfg, &hb->cfg, sizeof(pnvo_config)) != 0 || ha->device != hb->device)
+    return fail(ha, PNVO_ERR_ARG, "the two models of a dual forward must share architecture and device");
+  const pnvo_config &c = ha->cfg;
+  if (c.act_embed) return fail(ha, PNVO_ERR_ARG, "pnvo_forward_dual_raw covers the separate-action models");
+  if ((c.n_rgb > 0) != (rgb_frames != nullptr) || ((c.n_depth > 0 || c.n_dd > 0) && depth_frames == nullptr) ||
+      (c.n_tdv > 0) != (tdv != nullptr))
+    return fail(ha, PNVO_ERR_ARG, "sensor frames do not match the model's observation_space");
+  HIPCHK(ha, hipSetDevice(ha->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!raw_direct(ha, depth_frames)) {
+    int rc = raw_materialise(ha, rgb_frames, depth_frames, B, err_flag, s);
+    if (rc != PNVO_OK) return rc;
+    return pnvo_forward_dual(ha, hb, c.n_rgb ? ha->rawws[0] : nullptr, c.n_depth ? ha->rawws[1] : nullptr,
+                             c.n_dd ? ha->rawws[2] : nullptr, tdv, B, out_a, out_b, stream);
+  }
+  ha->raw_rgb = rgb_frames;
+  ha->raw_depth = depth_frames;
+  ha->raw_err = err_flag;
+  pnvo_handle hs[2] = {ha, hb};
+  float *outs[2] = {out_a, out_b};
+  const int rc = pnvo_forward_bf16(hs, 2, nullptr, nullptr, nullptr, tdv, nullptr, B, outs, s);
+  ha->raw_rgb = nullptr;
+  ha->raw_depth = nullptr;
+  ha->raw_err = nullptr;
+  return rc;
+}
+
 int pnvo_forward_features(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
                           const int64_t *actions, int B, float *hidden_out, void *stream) {
   if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
@@ -1727,6 +1842,7 @@ int pnvo_destroy(pnvo_handle m) {
   }
   free_dev(m->zero_page);
   free_dev(m->kpart);
+  for (float *&q : m->rawws) free_dev(q);
   for (auto &r : m->trecs) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);

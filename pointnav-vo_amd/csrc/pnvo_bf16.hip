@@ -205,6 +205,7 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     a.src[1] = depth;
     a.src[2] = dd;
     a.src[3] = tdv;
+    pnvo_stem_raw_args(m, a);                                    // (pnvo_forward_raw: sensor frames instead of src[0..2])
     a.zero_page = m->mx_pages;
     a.wpk = nm == 2 ? bs[0]->dual_stem : bs[0]->stem_wpk;
     for (int z = 0; z < nm; ++z) {
@@ -222,8 +223,8 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     a.slots = stem_mx_slots(m->Hs, m->Ws);
     const double M = (double)B * m->Hs * m->Ws;
     {
-      PnvoTimed t(m, s, "bf16:stem", 2.0 * nm * M * stem.cout * stem.cin * 49,
-                  4.0 * (double)B * c.height * c.width * stem.cin + 2.0 * nm * M * stem.cout);
+      const double in_bytes = (double)B * c.height * c.width * (m->raw_depth ? (c.n_rgb ? 6.0 : 0.0) + 8.0 + (c.n_tdv ? 8.0 : 0.0) : 4.0 * stem.cin);
+      PnvoTimed t(m, s, "bf16:stem", 2.0 * nm * M * stem.cout * stem.cin * 49, in_bytes + 2.0 * nm * M * stem.cout);
       if (m->opt.bf16_stem3 == 1 && nm == 1) {                 // experiment: exact three-piece stem in front of the bf16 stages
         a.wpk = m->mx_wpk3;
         HIPCHK(m, launch_stem_mx(a, 3, 1, true, s));

@@ -100,6 +100,12 @@ struct StemMXArgs {
   const float *pool_gamma;    // GroupNorm weight of the stem [cout] (its sign decides max or min)
   int Hp, Wp;
   float oscale;               // PIECES = 2: inverse of the power-of-two scale folded into the packed weights
+  // RAW staging (pnvo_forward_raw): sensor frames instead of src[0..2]; src[3] stays the top-down view pair tensor
+  const unsigned char *raw_rgb;   // [B][2][H][W][3] uint8 or nullptr (model without rgb)
+  const float *raw_depth;         // [B][2][H][W] float32; non-null selects the RAW stager
+  int raw_flags;                  // bit 0: the model has the depth modality, bit 1: discretised depth
+  int *raw_err;                   // device flag: a depth outside [0, 1]
+  float edges[12];                // bin edges e_0 .. e_10 of the one-hot depth (float32(i / 10))
 };
 constexpr int STEM_POOL_INIT = (int)0x807fffffu;   // key of -inf
 int stem_mx_slots(int Ho, int Wo);

@@ -100,6 +100,12 @@ struct pnvo_model_s {
   int fallback_count = 0;                    // forwards re-run on the dense stem
   hipEvent_t stem_ev = nullptr;              // recorded behind a contract-checking stem launch (pnvo_mark_stem)
   bool stem_ev_pending = false;
+  // pnvo_forward_raw / pnvo_forward_dual_raw: sensor frames of the call in flight (the stem's RAW stager reads them)
+  const unsigned char *raw_rgb = nullptr;
+  const float *raw_depth = nullptr;
+  int *raw_err = nullptr;
+  float *rawws[3] = {nullptr, nullptr, nullptr};   // rgb / depth / dd pair tensors of the materialising fallback of the raw entry
+  int rawws_cap = 0;
   int precision = 0;                         // pnvo_set_precision: 0 float32 (default), 1 bfloat16 (BASELINE config 3)
   unsigned long long load_gen = 0;           // bumped by pnvo_load_weights (operands derived lazily are rebuilt)
   unsigned long long weights_gen_at_load = 0;  // weights_gen as pnvo_load_weights left it
@@ -169,6 +175,7 @@ void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, 
 int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float *ss[2], float *mu_out, float *rstd_out,
                   hipStream_t s, int *pool_keys = nullptr);
 bool pnvo_stem_on_mx(pnvo_handle m);
+void pnvo_stem_raw_args(pnvo_handle m, pnvo::StemMXArgs &a);   // fills the RAW-stager fields of a stem launch when m->raw_depth is set
 int pnvo_mark_stem(pnvo_handle m, hipStream_t s);
 int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun);   // after the forward is enqueued: wait for the stem, re-run on the dense stem?
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip

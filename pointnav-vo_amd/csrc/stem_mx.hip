@@ -103,7 +103,13 @@ struct TapOffsets {
 };
 __constant__ const TapOffsets TAPOFF{};
 
-template <int PIECES, int NT, bool BF16OUT, bool POOL = false>
+// RAW: the stager reads the SENSOR frames — uint8 rgb [B][2][H][W][3], float32 depth [B][2][H][W] (prev frame, cur frame) —
+// and the 2-channel top-down view instead of the float32 observation-pair tensors: the pair concatenation, the uint8 -> float
+// cast and _discretize_depth_func (base_trainer_with_vo.py:135-167,196-229) happen while staging, the 7.86 MB per pair of
+// observation tensors are never written or read (0.92 MB of frames + 0.52 MB of top-down view instead).  The one-hot depth
+// becomes two 2-byte LDS writes into a zeroed row: bin = the reference's (e_i <= d < e_{i+1}, last bin closed) from an
+// 11-entry edge table in LDS, bit-identical to discretize_depth_kernel.
+template <int PIECES, int NT, bool BF16OUT, bool POOL = false, bool RAW = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_mx_kernel(const StemMXArgs p) {
   constexpr bool EXTRA = PIECES >= 2;                      // float32(-grade) results: float modalities split on the A side too
   constexpr bool H = PIECES == 2;                          // float16 pieces (else bf16)
@@ -139,7 +145,114 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   //   slots 0-19 discretised depth | 20-25 rgb | 26-27 depth | 28-29 top-down view | 30-31 indicator
   // Out-of-image pixels read a page of zeros (zero padding AFTER whitening); a value that must be exact in bf16 and is not
   // (low 16 bits set) raises the host-visible flag.
-  {
+  if (RAW) {
+    float *etab = reinterpret_cast<float *>(lds + RED_OFF + 4 * NT * 32 * 2 * 4);   // bin edges e_0 .. e_10 (+ 1 pad)
+    if (threadIdx.x < 12) etab[threadIdx.x] = p.edges[threadIdx.x];
+    __syncthreads();
+    const float *zp = p.zero_page;
+    const unsigned char *zpb = reinterpret_cast<const unsigned char *>(zp);
+    const long fpix = (long)p.H * p.W;
+    const bool use_rgb = p.raw_rgb != nullptr, use_d = (p.raw_flags & 1) != 0, use_dd = (p.raw_flags & 2) != 0;
+    const float *b_t = p.src[3] ? p.src[3] + (long)n * fpix * 2 : nullptr;
+    bool bad_depth = false;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; r0 += 2) {
+      unsigned rgbw[2][2];
+      float dv[2][2];
+      f32x2 vt[2];
+      bool inb[2];
+      unsigned ldsoff[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int pix = (r0 + rr) * NTHREADS + (int)threadIdx.x;
+        const int py = pix / PW, px = pix - py * PW;
+        const int hi = hi_base + py, wi = wi_base + px;
+        const bool in = pix < NPIX && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const int e = in ? hi * p.W + wi : 0;
+        inb[rr] = in;
+        ldsoff[rr] = (unsigned)(py * ROW + (px & 1) * PAR + (px >> 1) * PITCH);
+        if (r0 + rr == 3 && wave != 0) continue;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const long gi = ((long)n * 2 + f) * fpix + e;                  // pixel index over all frames
+          // three bytes at 3 gi, fetched as ONE (unaligned) dword that starts a byte early except at the very first pixel of
+          // the tensor: never before its start, never past its end
+          const long boff = 3 * gi - (gi > 0 ? 1 : 0);
+          const unsigned char *a_rgb = (in && use_rgb) ? p.raw_rgb + boff : zpb;
+          unsigned wv;
+          __builtin_memcpy(&wv, a_rgb, 4);
+          rgbw[rr][f] = (in && use_rgb && gi > 0) ? (wv >> 8) : wv;
+          const float *a_d = in ? p.raw_depth + gi : zp;
+          dv[rr][f] = *a_d;
+        }
+        const float *a_t = (in && b_t) ? b_t + (long)e * 2 : zp;
+        vt[rr] = *reinterpret_cast<const f32x2 *>(a_t);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        if (r0 + rr == 3 && wave != 0) continue;
+        const int pix = (r0 + rr) * NTHREADS + (int)threadIdx.x;
+        if (pix >= NPIX) continue;
+        // bins of the two frames (valid only inside the image and for depth in [0, 1])
+        int bidx[2];
+        bool bok[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const float d = dv[rr][f];
+          int g = (int)(d * 10.0f);
+          g = min(max(g, 0), 9);
+          const float lo = etab[g], hi = etab[g + 1];
+          bidx[f] = g - (d < lo ? 1 : 0) + ((d >= hi && g < 9) ? 1 : 0);
+          bok[f] = d >= 0.f && d <= 1.f;
+          bad_depth = bad_depth || (inb[rr] && !bok[f]);
+        }
+        unsigned w[16];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) w[c] = 0u;
+        {
+          const unsigned a0 = rgbw[rr][0], a1 = rgbw[rr][1];
+          const float pr = (float)(a0 & 0xffu), pg = (float)((a0 >> 8) & 0xffu), pb = (float)((a0 >> 16) & 0xffu);
+          const float cr = (float)(a1 & 0xffu), cg = (float)((a1 >> 8) & 0xffu), cb = (float)((a1 >> 16) & 0xffu);
+          if (H) {
+            w[10] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
+            w[11] = pack_f16(pb * 0.00390625f, cr * 0.00390625f);
+            w[12] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
+          } else {
+            w[10] = pack_bf16(pr, pg);
+            w[11] = pack_bf16(pb, cr);
+            w[12] = pack_bf16(cg, cb);
+          }
+        }
+        const float d0 = use_d ? dv[rr][0] : 0.f, d1 = use_d ? dv[rr][1] : 0.f;
+        w[13] = pack_pair<H>(d0, d1);
+        w[14] = pack_pair<H>(vt[rr][0], vt[rr][1]);
+        w[15] = inb[rr] ? (H ? 0x3c003c00u : 0x3f803f80u) : 0u;
+        unsigned char *dst = lds + ldsoff[rr];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<u32x4 *>(dst + 16 * q) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        if (use_dd && inb[rr]) {                                       // the one-hot depth: one 1.0 per frame
+          const unsigned short one = H ? 0x3c00 : 0x3f80;
+          if (bok[0]) *reinterpret_cast<unsigned short *>(dst + 2 * bidx[0]) = one;
+          if (bok[1]) *reinterpret_cast<unsigned short *>(dst + 20 + 2 * bidx[1]) = one;
+        }
+        if (H) {
+          const f16x2 hd = __builtin_bit_cast(f16x2, w[13]), ht = __builtin_bit_cast(f16x2, w[14]);
+          const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
+          const unsigned mt = pack_f16(vt[rr][0] - (float)ht[0], vt[rr][1] - (float)ht[1]);
+          *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{md, mt, 0u, 0u};
+        } else if (EXTRA) {
+          const float e0 = d0 - bf16_lo(w[13]), e1 = d1 - bf16_hi(w[13]);
+          const float t0 = vt[rr][0] - bf16_lo(w[14]), t1 = vt[rr][1] - bf16_hi(w[14]);
+          const unsigned md = pack_bf16(e0, e1), mt = pack_bf16(t0, t1);
+          const unsigned ld = pack_bf16(e0 - bf16_lo(md), e1 - bf16_hi(md));
+          const unsigned lt = pack_bf16(t0 - bf16_lo(mt), t1 - bf16_hi(mt));
+          *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{md, mt, ld, lt};
+        }
+      }
+    }
+    if (bad_depth && p.raw_err != nullptr) *p.raw_err = 1;              // the reference asserts depth in [0, 1] (:136-137)
+  } else {
     const float *zp = p.zero_page;
     const float *b_rgb = p.src[0] ? p.src[0] + (long)n * p.H * p.W * 6 : nullptr;
     const float *b_d = p.src[1] ? p.src[1] + (long)n * p.H * p.W * 2 : nullptr;
@@ -656,7 +769,23 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
   p.tiles_y = (a.Ho + TH - 1) / TH;
   const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
   const unsigned gx = (unsigned)(((ntiles + 7) / 8) * 8);
-  if (pieces == 2 && !bf16_out) {                        // float16 pieces (inference default), pooled keys or raw output
+  if (a.raw_depth != nullptr) {                          // sensor frames in (pnvo_forward_raw): the RAW stager (+ 64 B: bin edges)
+    if (pieces == 2 && !bf16_out) {
+      const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float) + 64;
+      if (a.pool != nullptr)
+        hipLaunchKernelGGL((stem_mx_kernel<2, 1, false, true, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+      else
+        hipLaunchKernelGGL((stem_mx_kernel<2, 1, false, false, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+    } else if (pieces == 1 && bf16_out && ntiles_n % 2 == 0) {
+      const size_t ldsb = RED_OFF + 4 * 2 * 32 * 2 * sizeof(float) + 64;
+      hipLaunchKernelGGL((stem_mx_kernel<1, 2, true, false, true>), dim3(gx, (unsigned)(ntiles_n / 2)), dim3(NTHREADS), ldsb, s, p);
+    } else if (pieces == 1 && bf16_out) {
+      const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float) + 64;
+      hipLaunchKernelGGL((stem_mx_kernel<1, 1, true, false, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (pieces == 2 && !bf16_out) {                 // float16 pieces (inference default), pooled keys or raw output
     const size_t ldsb = RED_OFF + 4 * 1 * 32 * 2 * sizeof(float);
     if (a.pool != nullptr)
       hipLaunchKernelGGL((stem_mx_kernel<2, 1, false, true>), dim3(gx, (unsigned)ntiles_n), dim3(NTHREADS), ldsb, s, p);

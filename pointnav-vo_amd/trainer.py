@@ -212,19 +212,21 @@ class BaseRLTrainerWithVO:
     def _boundary_buffers(self, n, H, W, bins, want_rgb, want_tdv):
         """Reusable staging for n pairs: pinned host frames, their device twins, the observation-pair tensors, the
         top-down workspace and a pinned error flag — allocated once per (capacity, shape)."""
+        pairs = self.config.VO.REGRESS_MODEL.mode != "det"
         st = getattr(self, "_bstage", None)
-        if st is None or st["cap"] < n or st["shape"] != (H, W, bins, want_rgb, want_tdv):
-            same = st is not None and st["shape"] == (H, W, bins, want_rgb, want_tdv)
+        if st is None or st["cap"] < n or st["shape"] != (H, W, bins, want_rgb, want_tdv, pairs):
+            same = st is not None and st["shape"] == (H, W, bins, want_rgb, want_tdv, pairs)
             cap = max(n, 2 * st["cap"]) if same else n        # grow geometrically for callers with a varying pair count
             dev = self.device
-            st = dict(cap=cap, shape=(H, W, bins, want_rgb, want_tdv),
+            st = dict(cap=cap, shape=(H, W, bins, want_rgb, want_tdv, pairs),
                       h_rgb=torch.empty((cap, 2, H, W, 3), dtype=torch.uint8).pin_memory() if want_rgb else None,
                       h_dep=torch.empty((cap, 2, H, W), dtype=torch.float32).pin_memory(),
                       d_rgb=torch.empty((cap, 2, H, W, 3), dtype=torch.uint8, device=dev) if want_rgb else None,
                       d_dep=torch.empty((cap, 2, H, W), dtype=torch.float32, device=dev),
-                      rgb=torch.empty((cap, H, W, 6), dtype=torch.float32, device=dev) if want_rgb else None,
-                      depth=torch.empty((cap, H, W, 2), dtype=torch.float32, device=dev),
-                      dd=torch.empty((cap, H, W, 2 * bins), dtype=torch.float32, device=dev) if bins else None,
+                      # (the float32 observation-pair tensors exist for mode 'rnd' only: 'det' feeds the frames to the model)
+                      rgb=torch.empty((cap, H, W, 6), dtype=torch.float32, device=dev) if (want_rgb and pairs) else None,
+                      depth=torch.empty((cap, H, W, 2), dtype=torch.float32, device=dev) if pairs else None,
+                      dd=torch.empty((cap, H, W, 2 * bins), dtype=torch.float32, device=dev) if (bins and pairs) else None,
                       tdv=torch.empty((cap, H, W, 2), dtype=torch.float32, device=dev) if want_tdv else None,
                       work=torch.empty(int(_lib.lib.pnvo_topdown_workspace_bytes(cap, H, W)), dtype=torch.uint8, device=dev)
                       if want_tdv else None,
@@ -245,10 +247,12 @@ class BaseRLTrainerWithVO:
 
     def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts):
         """Batched sibling of _compute_local_delta_states_from_vo: lists of observation dicts and actions ->
-        float32 array [N,3].  Host side: the 2N raw frames are gathered into pinned staging by pnvo_stage_frames (parallel
-        memcpy), shipped in two async transfers, and turned into the observation-pair tensors (pair concatenation, uint8 ->
-        float, one-hot depth, both top-down views — base_trainer_with_vo.py:172-269) by pnvo_build_obs_pairs; pairs are
-        grouped per action model (sep_act) and each group is one forward; one host synchronisation at the end."""
+        float32 array [N,3].  The 2N raw frames are gathered into pinned staging by pnvo_stage_frames (parallel memcpy) and
+        cross PCIe in 1-4 chunks on a copy stream; behind each chunk the two top-down views of its frames are built on the
+        caller's stream.  Mode 'det': the frames then go STRAIGHT into the model (pnvo_forward_raw: pair concatenation, uint8 ->
+        float and the one-hot depth of base_trainer_with_vo.py:172-269 happen in the stem's operand fetch; no observation-pair
+        tensors are built), one forward per action model (sep_act) over all of its pairs.  Mode 'rnd' (train-mode forwards with
+        dropout, :295-308) builds the observation pairs (pnvo_build_obs_pairs).  One host synchronisation at the end."""
         assert len(prev_obs_list) == len(cur_obs_list) == len(acts)
         n = len(acts)
         H, W = prev_obs_list[0]["depth"].shape[:2]
@@ -267,9 +271,9 @@ class BaseRLTrainerWithVO:
         out = np.zeros((n, 3), dtype=np.float32)
         std = np.zeros((n, 3), dtype=np.float32)
         keys = ["all"] * n if rm.regress_type == "unified_act" else [ACT_IDX2NAME[a] for a in acts]
-        # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, chunk
-        # c-1 is pre-processed and evaluated on the caller's stream (host staging, transfer and device work overlap).
-        nchunks = 1 if n < 32 else (2 if n < 128 else 4)
+        # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, the
+        # top-down views of chunk c-1 are built on the caller's stream (host staging, transfer and device work overlap).
+        nchunks = 1 if n < 24 else (2 if n < 48 else 4)
         bounds = [(n * c // nchunks, n * (c + 1) // nchunks) for c in range(nchunks)]
         main = torch.cuda.current_stream(dev)
         if nchunks > 1 and getattr(self, "_copy_stream", None) is None:
@@ -294,42 +298,43 @@ class BaseRLTrainerWithVO:
                     st["d_dep"][lo:hi].copy_(st["h_dep"][lo:hi], non_blocking=True)
                 if nchunks > 1:
                     main.wait_stream(copy)
-                _lib.check(_lib.lib.pnvo_build_obs_pairs(
-                    p(st["d_rgb"], lo), p(st["d_dep"], lo), int(m), int(H), int(W), int(bins), gen._consts if gen else None,
-                    int(gen._rows_around_center) if gen else 0, p(st["work"]), p(st["rgb"], lo), p(st["depth"], lo),
-                    p(st["dd"], lo), p(st["tdv"], lo), p(st["flag"]), _stream(dev)))
-                obs_pairs = {"depth": st["depth"][lo:hi]}
-                if want_rgb:
-                    obs_pairs["rgb"] = st["rgb"][lo:hi]
-                if bins:
-                    obs_pairs["discretized_depth"] = st["dd"][lo:hi]
-                if want_tdv:
-                    obs_pairs["top_down_view"] = st["tdv"][lo:hi]
-                obs_pairs = {k: v for k, v in obs_pairs.items() if k in vis}
-                ckeys = keys[lo:hi]
-                for key in sorted(set(ckeys)):
-                    idx = [i for i, k in enumerate(ckeys) if k == key]
-                    if len(idx) == m:
-                        sub = obs_pairs
-                    else:
-                        sel = torch.as_tensor(idx, device=dev)
-                        sub = {k: v.index_select(0, sel) for k, v in obs_pairs.items()}
-                    gidx = [lo + i for i in idx]
-                    model = self.vo_model[key]
-                    a = torch.as_tensor([acts[i] for i in gidx], dtype=torch.long, device=dev) if "act_embed" in name else None
-                    if rm.mode == "det":                      # :285-294
-                        if model.training:                    # (eval() walks ~75 sub-modules: only when it changes anything)
-                            model.eval()
-                        pending.append((gidx, model(sub, a) if a is not None else model(sub)))
-                    else:                                     # 'rnd', :295-308: rnd_mode_n train-mode (dropout) forwards
-                        model.train()
-                        samples = np.stack([(model(sub, a) if a is not None else model(sub)).cpu().numpy()
-                                            for _ in range(int(rm.rnd_mode_n))])
-                        out[gidx] = samples.mean(axis=0)
-                        std[gidx] = samples.std(axis=0)
+                if rm.mode == "rnd":                      # the train-mode forward takes observation pairs
+                    _lib.check(_lib.lib.pnvo_build_obs_pairs(
+                        p(st["d_rgb"], lo), p(st["d_dep"], lo), int(m), int(H), int(W), int(bins), gen._consts if gen else None,
+                        int(gen._rows_around_center) if gen else 0, p(st["work"]), p(st["rgb"], lo), p(st["depth"], lo),
+                        p(st["dd"], lo), p(st["tdv"], lo), p(st["flag"]), _stream(dev)))
+                elif want_tdv:                            # :239-249: prev frames -> channel 0, cur frames -> channel 1
+                    for k in range(2):
+                        gen.gen_top_down_view_batch(st["d_dep"][lo:hi, k], out=st["tdv"][lo:hi], out_channel=k)
+            for key in sorted(set(keys)):
+                idx = [i for i, k in enumerate(keys) if k == key]
+                whole = len(idx) == n
+                sel = None if whole else torch.as_tensor(idx, device=dev)
+                pick = lambda t: None if t is None else (t[:n] if whole else t.index_select(0, sel))
+                model = self.vo_model[key]
+                a = torch.as_tensor([acts[i] for i in idx], dtype=torch.long, device=dev) if "act_embed" in name else None
+                if rm.mode == "det":                      # :285-294
+                    if model.training:                    # (eval() walks ~75 sub-modules: only when it changes anything)
+                        model.eval()
+                    pending.append((idx, model.forward_raw(pick(st["d_rgb"]) if want_rgb else None, pick(st["d_dep"]),
+                                                           pick(st["tdv"]) if want_tdv else None, a, err_flag=st["flag"])))
+                else:                                     # 'rnd', :295-308: rnd_mode_n train-mode (dropout) forwards
+                    sub = {"depth": pick(st["depth"])}
+                    if want_rgb:
+                        sub["rgb"] = pick(st["rgb"])
+                    if bins:
+                        sub["discretized_depth"] = pick(st["dd"])
+                    if want_tdv:
+                        sub["top_down_view"] = pick(st["tdv"])
+                    sub = {k: v for k, v in sub.items() if k in vis}
+                    model.train()
+                    samples = np.stack([(model(sub, a) if a is not None else model(sub)).cpu().numpy()
+                                        for _ in range(int(rm.rnd_mode_n))])
+                    out[idx] = samples.mean(axis=0)
+                    std[idx] = samples.std(axis=0)
             st["h_flag"].copy_(st["flag"], non_blocking=True)
-            for gidx, res in pending:                     # the first .cpu() is the one synchronisation of the call
-                out[gidx] = res.cpu().numpy()
+            for idx, res in pending:                      # the first .cpu() is the one synchronisation of the call
+                out[idx] = res.cpu().numpy()
         if not pending:
             torch.cuda.current_stream(dev).synchronize()
         assert int(st["h_flag"][0]) == 0, "depth must lie in [0, 1]"      # the reference's asserts (:136-137)

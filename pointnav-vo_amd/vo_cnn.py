@@ -238,6 +238,54 @@ class VisualOdometryCNNBase(nn.Module):
                                              C.c_void_p(out.data_ptr()), C.c_void_p(stream)), self._handle)
         return out
 
+    def forward_raw(self, rgb_frames, depth_frames, top_down_view=None, actions=None, err_flag=None):
+        """The eval forward from the SENSOR frames (pnvo_forward_raw): rgb_frames uint8 [B,2,H,W,3] (prev, cur; None for models
+        without rgb), depth_frames float32 [B,2,H,W] in 0..1, top_down_view float32 [B,H,W,2] (None without that modality) —
+        CUDA tensors.  Pair concatenation, the uint8 -> float cast and the one-hot depth happen in the stem's operand fetch: no
+        observation-pair tensors are built.  err_flag: optional int32 CUDA tensor [1], set when a depth is outside [0, 1]."""
+        if self.training:
+            raise RuntimeError("forward_raw is the eval-mode forward (train-mode forwards take observation pairs)")
+        ref = next(self.parameters())
+        if ref.device.type != "cuda":
+            raise RuntimeError("pointnav_vo_amd VO models run on an MI355X only (there is no CPU fallback)")
+        dev = ref.device
+        self._ensure_handle(dev)
+        self._sync_weights()
+        c = self.cfg
+        B = depth_frames.shape[0]
+        keep = []
+
+        def ptr(t, dtype, shape, what):
+            if t is None:
+                return None
+            if t.device != dev or t.dtype != dtype or tuple(t.shape) != shape:
+                raise ValueError(f"{what}: expected {dtype} {shape} on {dev}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+            t = t.contiguous()
+            keep.append(t)
+            return C.c_void_p(t.data_ptr())
+
+        p_rgb = ptr(rgb_frames if c.n_rgb else None, torch.uint8, (B, 2, c.height, c.width, 3), "rgb_frames")
+        p_dep = ptr(depth_frames, torch.float32, (B, 2, c.height, c.width), "depth_frames")
+        p_tdv = ptr(top_down_view if c.n_tdv else None, torch.float32, (B, c.height, c.width, 2), "top_down_view")
+        if c.n_rgb and p_rgb is None:
+            raise ValueError("this model has the rgb modality: rgb_frames is required")
+        if c.n_tdv and p_tdv is None:
+            raise ValueError("this model has the top_down_view modality: top_down_view is required")
+        act_ptr = None
+        if c.act_embed:
+            if actions is None:
+                raise TypeError("forward_raw() missing required argument 'actions' (act_embed model)")
+            a = actions.to(device=dev, dtype=torch.int64).contiguous().reshape(-1)
+            keep.append(a)
+            act_ptr = C.c_void_p(a.data_ptr())
+        out = torch.empty((B, c.out_dim), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(_lib.lib.pnvo_forward_raw(self._handle, p_rgb, p_dep, p_tdv, act_ptr, int(B), C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(err_flag.data_ptr()) if err_flag is not None else None,
+                                                 C.c_void_p(stream)), self._handle)
+        return out
+
     # ------------------------------------------------------------------ introspection (tests / bench)
     def tap(self, name, observation_pairs, actions=None):
         """Run a forward and return (output, intermediate activation `name` as an NHWC tensor)."""
@@ -327,6 +375,35 @@ def dual_forward(model_a, model_b, observation_pairs):
         _lib.check(_lib.lib.pnvo_forward_dual(model_a._handle, model_b._handle, ptrs[0], ptrs[1], ptrs[2], ptrs[3], int(B),
                                               C.c_void_p(oa.data_ptr()), C.c_void_p(ob.data_ptr()), C.c_void_p(stream)),
                    model_a._handle)
+    return oa, ob
+
+
+def dual_forward_raw(model_a, model_b, rgb_frames, depth_frames, top_down_view=None, err_flag=None):
+    """dual_forward from the sensor frames (pnvo_forward_dual_raw; tensor contract as VisualOdometryCNNBase.forward_raw)."""
+    ref = next(model_a.parameters())
+    if ref.device.type != "cuda" or next(model_b.parameters()).device != ref.device:
+        raise RuntimeError("dual_forward_raw: both models must be on the same MI355X (there is no CPU fallback)")
+    if model_a.training or model_b.training:
+        raise RuntimeError("dual_forward_raw is the eval-mode forward of both models")
+    dev = ref.device
+    for m in (model_a, model_b):
+        m._ensure_handle(dev)
+        m._sync_weights()
+    c = model_a.cfg
+    B = depth_frames.shape[0]
+    rgb = rgb_frames.contiguous() if c.n_rgb else None
+    dep = depth_frames.contiguous()
+    tdv = top_down_view.contiguous() if c.n_tdv else None
+    assert dep.dtype == torch.float32 and tuple(dep.shape) == (B, 2, c.height, c.width) and dep.device == dev
+    assert rgb is None or (rgb.dtype == torch.uint8 and tuple(rgb.shape) == (B, 2, c.height, c.width, 3) and rgb.device == dev)
+    assert tdv is None or (tdv.dtype == torch.float32 and tuple(tdv.shape) == (B, c.height, c.width, 2) and tdv.device == dev)
+    oa = torch.empty((B, c.out_dim), device=dev, dtype=torch.float32)
+    ob = torch.empty_like(oa)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.pnvo_forward_dual_raw(model_a._handle, model_b._handle, p(rgb), p(dep), p(tdv), int(B), p(oa), p(ob),
+                                                  p(err_flag), C.c_void_p(stream)), model_a._handle)
     return oa, ob
 
 
