@@ -194,6 +194,26 @@ def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2"):
     return tf, peak, pipe
 
 
+def frames_of(obs):
+    """The sensor frames behind synthetic observation pairs: uint8 rgb [B,2,H,W,3], float32 depth [B,2,H,W] (the pair tensors
+    hold [prev | cur] on the channel axis)."""
+    B = obs["depth"].shape[0]
+    rgb = obs["rgb"].to(torch.uint8).reshape(B, H, W, 2, 3).permute(0, 3, 1, 2, 4).contiguous()
+    dep = obs["depth"].permute(0, 3, 1, 2).contiguous()
+    return rgb, dep
+
+
+def time_steps_simple(step, steps, sync_all):
+    for _ in range(3):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    return (time.perf_counter() - t0) / steps
+
+
 def slim_secondary(name, full):
     """The `secondary` entry of the headline line: the figures of a 10-step run of another BASELINE configuration."""
     if full is None or "error" in full:
@@ -205,6 +225,7 @@ def slim_secondary(name, full):
            "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "pipe")}}
     if name == "dual_bf16":
         e = full["pose_abs_err_vs_fp64_oracle"]
+        out["from_sensor_frames"] = full.get("from_sensor_frames")
         out["rms_err_vs_fp64"] = e and e["rms_abs_l2"]
         out["err_note"] = e and f"RMS over {e['forwards']} forwards of ||out - ref||_2, reference norm up to {e['ref_l2']:.2f}"
     else:
@@ -302,6 +323,18 @@ def main():
     # ---- BASELINE configs[2] and configs[3] (per-GPU shape) next to the headline: 10 timed steps each under the same contract
     #      (tools/bench_configs.py), on the headline's own observation tensors; AFTER the headline's timed region, never in it
     secondary = None
+    raw_rec = None
+    if not args.no_secondary:
+        # the same forward from the SENSOR frames (pnvo_forward_raw: no observation-pair tensors): bit-identical results
+        with torch.no_grad():
+            rgb_f, dep_f = frames_of(obs)
+            o_raw = model.forward_raw(rgb_f, dep_f, obs["top_down_view"])
+            same = bool(torch.equal(o_raw, out))
+            t_raw = parallel.max_over_ranks(time_steps_simple(lambda: model.forward_raw(rgb_f, dep_f, obs["top_down_view"]), 10, sync_all), dev)
+        raw_rec = {"workload": "the headline batch handed over as sensor frames (uint8 rgb + float32 depth + top-down view: 1.44 MB per "
+                               "pair instead of 7.86 MB of float32 observation tensors)", "value": world * B / t_raw,
+                   "unit": "frame-pairs/s", "ms_per_step": 1e3 * t_raw, "steps": 10, "bit_identical_to_headline_outputs": same}
+        del rgb_f, dep_f
     if not args.no_secondary and B >= 128:
         import copy
         from tools import bench_configs
@@ -370,6 +403,8 @@ def main():
         }
         if secondary is not None:
             res["secondary"] = secondary
+        if raw_rec is not None:
+            res.setdefault("secondary", {})["fwd_fp32_from_sensor_frames"] = raw_rec
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)
         print(json.dumps(res))

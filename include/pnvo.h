@@ -185,6 +185,9 @@ int pnvo_build_obs_pairs(const uint8_t *rgb_frames, const float *depth_frames, i
 /* Host helper of the same boundary: gathers n separately allocated host frames (each bytes_each long) into one (pinned)
  * staging buffer with `threads` copy threads — the per-frame numpy copies were what bounded the batched boundary call. */
 int pnvo_stage_frames(const void *const *src, int n, size_t bytes_each, void *dst, int threads);
+/* Two frame lists (the rgb frames and the depth frames of a chunk) in one call: one wake-up of the copy workers. */
+int pnvo_stage_frames2(const void *const *src_a, size_t bytes_a, void *dst_a, const void *const *src_b, size_t bytes_b, void *dst_b,
+                       int n, int threads);
 
 /* ---- VO dataset input pipeline on the device: what StatePairRegressionDataset._process_data
  * does per sample on 20 CPU workers (pointnav_vo/vo/dataset/regression_geo_invariance_iter_dataset.py:205-454), per chunk

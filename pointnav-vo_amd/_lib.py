@@ -57,6 +57,7 @@ _SIGNATURES = {
     "pnvo_build_obs_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_stage_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int]),
+    "pnvo_stage_frames2": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]),
     "pnvo_discretize_depth": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
     "pnvo_topdown_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -563,7 +563,9 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   {
     const bool force = a.force != 0;
     const long wgs = (long)a.B * a.tiles_r * a.tiles_c * ((ntt + a.wn * *nw - 1) / (a.wn * *nw));
-    if (wgs < 192 && !force) return false;
+    // (break-even measured at ~200 workgroups for the six-term form; the three-term float16 form halves the K loop: batch 64
+    //  — 128 workgroups on the deep stages — 1.09 ms with it against 1.18 without, batch 32 — 64 workgroups — 0.82 against 0.78)
+    if (wgs < (a.np == 2 ? 112 : 192) && !force) return false;
   }
   a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
   *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;

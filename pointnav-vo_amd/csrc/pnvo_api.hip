@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -1754,21 +1755,104 @@ int pnvo_dataset_pairs(const uint8_t *prev_rgb, const uint8_t *cur_rgb, const ui
   return PNVO_OK;
 }
 
+namespace {
+// Persistent copy workers of pnvo_stage_frames: a per-call std::thread spawn costs more than the copy of a small chunk, and the
+// gather of 2N simulator frames into pinned staging is the host-side critical path of the batched boundary call (59 MB at 64
+// pairs).  Heap-allocated and never destroyed: workers may still be parked on the condition variable at process exit.
+struct StagePool {
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> workers;
+  // current job: items [0, n) of array 0 then items [0, n) of array 1 (rgb frames and depth frames of a chunk in ONE wake-up)
+  const void *const *src[2] = {nullptr, nullptr};
+  char *dst[2] = {nullptr, nullptr};
+  size_t bytes[2] = {0, 0};
+  int n = 0, narr = 1;
+  std::atomic<int> next{0};
+  int active = 0;            // workers still inside the current job
+  int want = 0;              // workers the current job admits
+  unsigned long long gen = 0;
+  void run(int nworkers, int narr_, const void *const *s0, size_t b0, void *d0, const void *const *s1, size_t b1, void *d1, int n_) {
+    std::unique_lock<std::mutex> lk(mu);
+    while ((int)workers.size() < nworkers) {
+      const int id = (int)workers.size();
+      workers.emplace_back([this, id] { loop(id); });
+      workers.back().detach();
+    }
+    src[0] = s0;
+    dst[0] = static_cast<char *>(d0);
+    bytes[0] = b0;
+    src[1] = s1;
+    dst[1] = static_cast<char *>(d1);
+    bytes[1] = b1;
+    narr = narr_;
+    n = n_;
+    next.store(0);
+    want = nworkers;
+    active = nworkers;
+    ++gen;
+    cv_work.notify_all();
+    lk.unlock();
+    copy_items();                                   // the caller works too
+    lk.lock();
+    cv_done.wait(lk, [this] { return active == 0; });
+  }
+  void copy_items() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n * narr) return;
+      const int a = i / n, k = i - a * n;
+      std::memcpy(dst[a] + (size_t)k * bytes[a], src[a][k], bytes[a]);
+    }
+  }
+  void loop(int id) {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&] { return gen != seen; });
+      seen = gen;
+      if (id >= want) continue;                     // this job runs on fewer workers
+      lk.unlock();
+      copy_items();
+      lk.lock();
+      if (--active == 0) cv_done.notify_all();
+    }
+  }
+};
+StagePool *stage_pool() {
+  static StagePool *p = new StagePool();
+  return p;
+}
+std::mutex g_stage_call;                            // one gather at a time (the pool holds one job)
+}  // namespace
+
 int pnvo_stage_frames(const void *const *src, int n, size_t bytes_each, void *dst, int threads) {
   if (!src || !dst || n < 0) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
   if (threads < 1) threads = 1;
+  if (threads > 32) threads = 32;
   if (threads > n) threads = n > 0 ? n : 1;
-  auto work = [&](int t) {
-    for (int i = t; i < n; i += threads) std::memcpy(static_cast<char *>(dst) + (size_t)i * bytes_each, src[i], bytes_each);
-  };
-  if (threads == 1 || (size_t)n * bytes_each < ((size_t)1 << 21)) {      // small jobs: thread start-up would dominate
+  if (threads == 1 || (size_t)n * bytes_each < ((size_t)1 << 20)) {      // small jobs: a wake-up would dominate
     for (int i = 0; i < n; ++i) std::memcpy(static_cast<char *>(dst) + (size_t)i * bytes_each, src[i], bytes_each);
     return PNVO_OK;
   }
-  std::vector<std::thread> pool;
-  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
-  work(0);
-  for (auto &th : pool) th.join();
+  std::lock_guard<std::mutex> lk(g_stage_call);
+  stage_pool()->run(threads - 1, 1, src, bytes_each, dst, nullptr, 0, nullptr, n);   // threads - 1 workers + the caller
+  return PNVO_OK;
+}
+
+int pnvo_stage_frames2(const void *const *src_a, size_t bytes_a, void *dst_a, const void *const *src_b, size_t bytes_b, void *dst_b, int n,
+                       int threads) {
+  if (!src_a || !dst_a || !src_b || !dst_b || n < 0) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (threads < 1) threads = 1;
+  if (threads > 32) threads = 32;
+  if (threads > 2 * n) threads = n > 0 ? 2 * n : 1;
+  if (threads == 1 || (size_t)n * (bytes_a + bytes_b) < ((size_t)1 << 20)) {
+    for (int i = 0; i < n; ++i) std::memcpy(static_cast<char *>(dst_a) + (size_t)i * bytes_a, src_a[i], bytes_a);
+    for (int i = 0; i < n; ++i) std::memcpy(static_cast<char *>(dst_b) + (size_t)i * bytes_b, src_b[i], bytes_b);
+    return PNVO_OK;
+  }
+  std::lock_guard<std::mutex> lk(g_stage_call);
+  stage_pool()->run(threads - 1, 2, src_a, bytes_a, dst_a, src_b, bytes_b, dst_b, n);
   return PNVO_OK;
 }
 

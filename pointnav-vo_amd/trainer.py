@@ -109,6 +109,9 @@ class BaseRLTrainerWithVO:
     """Mirror of BaseRLTrainerWithVO.  Subclass it (or mix it in) exactly as the reference trainers do; it needs
     ``self.config`` (attribute-style VO / TASK_CONFIG tree) and ``self.device``."""
 
+    boundary_chunks = None    # None: chosen from the pair count (1 below 24 pairs, 2 below 48, else 4); an integer forces it
+    stage_threads = 12        # host threads that gather the simulator's frames into pinned staging (batched boundary call)
+
     def __init__(self, config=None, device=None):
         self.config = config
         self.device = device
@@ -240,9 +243,10 @@ class BaseRLTrainerWithVO:
         need = 1
         for d in shape:
             need *= int(d)
-        keep = [f if (type(f) is np.ndarray and f.dtype == dtype and f.size == need and f.flags.c_contiguous)
+        dt = np.dtype(dtype)
+        keep = [f if (type(f) is np.ndarray and f.dtype == dt and f.size == need and f.flags.c_contiguous)
                 else np.ascontiguousarray(np.asarray(f, dtype=dtype).reshape(shape)) for f in frames]
-        arr = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        arr = (C.c_void_p * len(keep))(*[k.__array_interface__["data"][0] for k in keep])   # (.ctypes builds an object per frame)
         return arr, keep
 
     def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts):
@@ -273,7 +277,7 @@ class BaseRLTrainerWithVO:
         keys = ["all"] * n if rm.regress_type == "unified_act" else [ACT_IDX2NAME[a] for a in acts]
         # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, the
         # top-down views of chunk c-1 are built on the caller's stream (host staging, transfer and device work overlap).
-        nchunks = 1 if n < 24 else (2 if n < 48 else 4)
+        nchunks = self.boundary_chunks or (1 if n < 24 else (2 if n < 48 else 4))
         bounds = [(n * c // nchunks, n * (c + 1) // nchunks) for c in range(nchunks)]
         main = torch.cuda.current_stream(dev)
         if nchunks > 1 and getattr(self, "_copy_stream", None) is None:
@@ -281,20 +285,26 @@ class BaseRLTrainerWithVO:
         copy = self._copy_stream if nchunks > 1 else main
         pending = []
         frames = [o for pc in zip(prev_obs_list, cur_obs_list) for o in pc]
+        # address tables over all 2N frames, once (frames are used in place when they are contiguous arrays of the right type)
+        pd_all, keep_d = self._frame_ptrs([f["depth"] for f in frames], np.float32, (H, W))
+        pr_all, keep_r = self._frame_ptrs([f["rgb"] for f in frames], np.uint8, (H, W, 3)) if want_rgb else (None, None)
+        vp = C.sizeof(C.c_void_p)
         with torch.cuda.device(dev), torch.no_grad():
             st["flag"].zero_()
             if nchunks > 1:
                 copy.wait_stream(main)
             for lo, hi in bounds:
                 m = hi - lo
-                threads = min(4, max(1, m // 8))          # measured: 4 copy threads saturate the host side
+                threads = min(self.stage_threads, 2 * m)  # persistent copy workers of libpnvo (pnvo_stage_frames)
+                pd_c = C.c_void_p(C.addressof(pd_all) + 2 * lo * vp)
                 with torch.cuda.stream(copy):
                     if want_rgb:
-                        ptrs, keep_r = self._frame_ptrs([f["rgb"] for f in frames[2 * lo:2 * hi]], np.uint8, (H, W, 3))
-                        _lib.check(_lib.lib.pnvo_stage_frames(ptrs, 2 * m, H * W * 3, p(st["h_rgb"], lo), threads))
+                        pr_c = C.c_void_p(C.addressof(pr_all) + 2 * lo * vp)
+                        _lib.check(_lib.lib.pnvo_stage_frames2(pr_c, H * W * 3, p(st["h_rgb"], lo), pd_c, H * W * 4, p(st["h_dep"], lo),
+                                                               2 * m, threads))
                         st["d_rgb"][lo:hi].copy_(st["h_rgb"][lo:hi], non_blocking=True)
-                    ptrs, keep_d = self._frame_ptrs([f["depth"] for f in frames[2 * lo:2 * hi]], np.float32, (H, W))
-                    _lib.check(_lib.lib.pnvo_stage_frames(ptrs, 2 * m, H * W * 4, p(st["h_dep"], lo), threads))
+                    else:
+                        _lib.check(_lib.lib.pnvo_stage_frames(pd_c, 2 * m, H * W * 4, p(st["h_dep"], lo), threads))
                     st["d_dep"][lo:hi].copy_(st["h_dep"][lo:hi], non_blocking=True)
                 if nchunks > 1:
                     main.wait_stream(copy)
