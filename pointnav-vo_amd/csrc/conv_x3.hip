@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
 
   // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).
   if (NP == 2) {                                                         // undo the weights' power-of-two scale (exact)
-    const float os = p.oscale;
+    const float os = p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -708,6 +708,60 @@ __global__ __launch_bounds__(256) void conv_x3_repack_kernel(const float *w, int
   out[base] = (unsigned short)h;
   out[base + 512] = (unsigned short)m;
   out[base + 1024] = (unsigned short)l;
+}
+
+// ---- the two-piece float16 operand on the device (training forward: the weights move every optimiser step)
+// One block per segment of the flat parameter buffer: max |w| -> out[2 seg] = scale = 2^(12 - e), out[2 seg + 1] = 1 / scale,
+// mx = f * 2^e with f in [0.5, 1)  (pack_conv_x2_weight's rule, on the device).
+__global__ __launch_bounds__(1024) void conv_x2_scale_kernel(const float *params, const long *seg, float *out) {
+  __shared__ float red[16];
+  const long off = seg[2 * blockIdx.x], n = seg[2 * blockIdx.x + 1];
+  float mx = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(params[off + i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+    int e = 0;
+    if (mx > 0.f) e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu) - 126;
+    out[2 * blockIdx.x] = __builtin_bit_cast(float, (unsigned)(12 - e + 127) << 23);
+    out[2 * blockIdx.x + 1] = __builtin_bit_cast(float, (unsigned)(e - 12 + 127) << 23);
+  }
+}
+
+hipError_t launch_conv_x2_scales(const float *params, const long *seg_dev, int nseg, float *out, hipStream_t s) {
+  if (nseg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(conv_x2_scale_kernel, dim3((unsigned)nseg), dim3(1024), 0, s, params, seg_dev, out);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void conv_x2_repack_kernel(const float *w, int cout, int cin, int cinp, int coutp, int T,
+                                                           const float *scale, unsigned short *out, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e & 7), ln = (int)((e >> 3) & 63);
+  long r = e >> 9;
+  const int ntt = coutp / 32, kct = cinp / 16;
+  const int nt = (int)(r % ntt);
+  r /= ntt;
+  const int kc = (int)(r % kct), tap = (int)(r / kct);
+  const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
+  const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * T + tap] * scale[0] : 0.f;
+  const _Float16 h = (_Float16)v;
+  const _Float16 m = (_Float16)(v - (float)h);
+  const long base = ((((long)tap * kct + kc) * ntt + nt) * 2) * 512 + (long)ln * 8 + j;
+  out[base] = __builtin_bit_cast(unsigned short, h);
+  out[base + 512] = __builtin_bit_cast(unsigned short, m);
+}
+
+hipError_t launch_conv_x2_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, const float *scale_dev,
+                                 unsigned short *out, hipStream_t s) {
+  const long total = (long)kh * kw * (cinp / 16) * (coutp / 32) * 512;
+  hipLaunchKernelGGL(conv_x2_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cout, cin, cinp, coutp,
+                     kh * kw, scale_dev, out, total);
+  return hipGetLastError();
 }
 
 hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,

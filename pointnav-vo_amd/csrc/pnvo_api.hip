@@ -449,7 +449,10 @@ bool x3_layer(pnvo_handle m, const Layer &l) {
   return (k3 || k1) && !l.host_w.empty() && m->opt.conv <= 1;
 }
 bool x3_two_pieces(pnvo_handle m, const Layer &l) {
-  return m->opt.pieces == 2 && m->train == nullptr && !m->bottleneck && l.in_bound < 6.0e4f;
+  if (m->bottleneck || !(l.in_bound < 6.0e4f)) return false;
+  if (m->train != nullptr)             // a training step is attached: operands are rebuilt on the device from the flat parameters
+    return m->opt.train_pieces == 2 && pnvo_train_x2_scale(m, l.name + ".weight") != nullptr;
+  return m->opt.pieces == 2;
 }
 bool x3_args(pnvo_handle m, const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
   std::memset(&xa, 0, sizeof(xa));
@@ -554,10 +557,16 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       if (two && (!lm.wpk_x2 || lm.x2_gen != m->weights_gen)) {  // (re)build the two-piece operand of this layer
         const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 2;
         if (!lm.wpk_x2) HIPCHK(m, hipMalloc((void **)&lm.wpk_x2, nel * 2));
-        std::vector<unsigned short> pk(nel);
-        lm.x2_oscale = pack_conv_x2_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pk.data());
-        HIPCHK(m, hipMemcpyAsync(lm.wpk_x2, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
-        HIPCHK(m, hipStreamSynchronize(s));
+        const float *dev_w = m->train ? pnvo_train_weight_ptr(m, l.name + ".weight") : nullptr;
+        if (dev_w != nullptr) {          // training attached: weight and scale live on the device (pnvo_train_refresh)
+          HIPCHK(m, launch_conv_x2_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pnvo_train_x2_scale(m, l.name + ".weight"),
+                                          lm.wpk_x2, s));
+        } else {
+          std::vector<unsigned short> pk(nel);
+          lm.x2_oscale = pack_conv_x2_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pk.data());
+          HIPCHK(m, hipMemcpyAsync(lm.wpk_x2, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
+          HIPCHK(m, hipStreamSynchronize(s));
+        }
         lm.x2_gen = m->weights_gen;
       }
       if (!two && (!lm.wpk_x3 || lm.x3_gen != m->weights_gen)) {   // (re)build the three-piece operand of this layer
@@ -577,6 +586,10 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       xa.x = x;
       xa.wpk = two ? lm.wpk_x2 : lm.wpk_x3;
       xa.oscale = lm.x2_oscale;
+      if (two && m->train != nullptr) {
+        const float *sp = pnvo_train_x2_scale(m, l.name + ".weight");
+        xa.oscale_ptr = sp ? sp + 1 : nullptr;
+      }
       xa.y = y;
       xa.in_scale = in_scale;
       xa.in_shift = in_shift;
@@ -702,10 +715,17 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     pnvo_stem_raw_args(m, a);
     // two float16 weight pieces at inference (5 MFMAs per tap); three bf16 pieces (7, every product exact) on request and
     // whenever a training step is attached (its device-side re-pack builds the three-piece operand)
-    const int pieces = (m->opt.pieces == 2 && m->train == nullptr && m->mx_wpk2 != nullptr) ? 2 : 3;
+    // (an eval forward of a handle with a training step attached takes the float16 operand too when it is current: packed by the
+    //  pnvo_load_weights that followed the last optimiser step)
+    //  pnvo_load_weights that followed the last optimiser step — or kept current by the training step's device-side re-pack)
+    const bool h2_current = m->train == nullptr || m->mx_wpk2_dev || (!m->in_train_forward && m->weights_gen == m->weights_gen_at_load);
+    const bool want2 = m->in_train_forward ? m->opt.train_pieces == 2 : m->opt.pieces == 2;
+    const int pieces = (want2 && h2_current && m->mx_wpk2 != nullptr) ? 2 : 3;
     a.zero_page = m->mx_pages;
     a.wpk = pieces == 2 ? m->mx_wpk2 : m->mx_wpk3;
     a.oscale = m->mx_oscale;
+    // (after a device-side re-pack the scale lives on the device; a later pnvo_load_weights re-packs on the host with its own)
+    a.oscale_ptr = m->mx_wpk2_dev ? m->mx_scale2_dev + 1 : nullptr;
     a.bad_input = m->dd_flag;
     const int ntn = stem.cout / 32;
     for (int g = 0; g < ntn; ++g) {
@@ -861,6 +881,7 @@ const OptDef kOptions[] = {
     {"stem", "PNVO_STEM", &PnvoOptions::stem, false, {{"auto", 0}, {"mx", 1}, {"dd", 2}, {"dense", 3}, {nullptr, 0}}},
     {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
     {"pieces", "PNVO_PIECES", &PnvoOptions::pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
+    {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
     {"pool", "PNVO_POOL", &PnvoOptions::pool, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
@@ -1183,6 +1204,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
       {
         std::vector<unsigned short> pk2(stem_mx_packed_u16(2, st.cout / 32));
         h->mx_oscale = pack_stem_mx_weight_h(h->mx_wk.data(), st.cout, h->mx_xslot, pk2.data());
+        h->mx_wpk2_dev = false;
         if ((rc = upload(h, reinterpret_cast<float *&>(h->mx_wpk2), reinterpret_cast<const float *>(pk2.data()), pk2.size() / 2)) !=
             PNVO_OK)
           return rc;
@@ -1589,7 +1611,7 @@ namespace {
 bool raw_direct(pnvo_handle m, const float *depth_frames) {
   if (depth_frames == nullptr || !m->mx_ok || m->dense_sticky || m->opt.stem > 1 || m->tap_dst != nullptr) return false;
   if (m->precision == 1) return true;                                // bf16 path: its stem is the mx kernel (PIECES = 1)
-  return m->opt.pieces == 2 && m->train == nullptr && m->mx_wpk2 != nullptr;
+  return m->opt.pieces == 2 && m->mx_wpk2 != nullptr && (m->train == nullptr || m->weights_gen == m->weights_gen_at_load);
 }
 
 int raw_materialise(pnvo_handle m, const uint8_t *rgb_frames, const float *depth_frames, int B, int32_t *err_flag, hipStream_t s) {
@@ -1899,6 +1921,7 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->stem_wpk16);
   free_dev(reinterpret_cast<float *&>(m->mx_wpk3));
   free_dev(reinterpret_cast<float *&>(m->mx_wpk2));
+  if (m->mx_scale2_dev) (void)hipFree(m->mx_scale2_dev);
   free_dev(m->mx_pages);
   free_dev(m->dd_wpk);
   free_dev(m->dd_table);

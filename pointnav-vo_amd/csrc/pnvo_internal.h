@@ -100,6 +100,7 @@ struct StemMXArgs {
   const float *pool_gamma;    // GroupNorm weight of the stem [cout] (its sign decides max or min)
   int Hp, Wp;
   float oscale;               // PIECES = 2: inverse of the power-of-two scale folded into the packed weights
+  const float *oscale_ptr;    //   ... or where it lives on the device (training: the scale follows the weights)
   // RAW staging (pnvo_forward_raw): sensor frames instead of src[0..2]; src[3] stays the top-down view pair tensor
   const unsigned char *raw_rgb;   // [B][2][H][W][3] uint8 or nullptr (model without rgb)
   const float *raw_depth;         // [B][2][H][W] float32; non-null selects the RAW stager
@@ -113,6 +114,8 @@ size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);
 float pack_stem_mx_weight_h(const float *wk, int cout, const int *xslot, unsigned short *out);   // two float16 pieces -> oscale
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
+hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
+                                   const int *slot_new, const int *xslot, float *scale2, unsigned short *wpk2, hipStream_t s);
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                  const int *slot_new, const int *xslot, unsigned short *wpk3, hipStream_t s);
 
@@ -133,12 +136,16 @@ struct ConvX3Args {
   int force;                         // conv_x3_plan: take the layer at any launch size (option conv=x3)
   int np;                            // operand pieces: 3 = bf16 (six exact product terms; 0 means 3), 2 = float16 (three terms)
   float oscale;                      // np == 2: inverse of the power-of-two scale folded into the packed weights
+  const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
 };
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
 hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,
                                  unsigned short *out, hipStream_t s);
 void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);
+hipError_t launch_conv_x2_scales(const float *params, const long *seg_dev, int nseg, float *out, hipStream_t s);   // [nseg][2]: scale, 1/scale
+hipError_t launch_conv_x2_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, const float *scale_dev,
+                                 unsigned short *out, hipStream_t s);
 float pack_conv_x2_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);   // -> oscale
 
 // Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).

@@ -34,6 +34,8 @@ struct PnvoOptions {
   int stem = 0;        // 0 auto (bf16-matrix-core stem when the model's modalities fit it, else one-hot-aware, else dense), 1 mx, 2 dd, 3 dense
   int conv = 0;        // 0 auto (conv_x3 for launches of >= 192 workgroups, fp32-MFMA kernels below), 1 x3 at any size, 2 fp32, 3 generic
   int pieces = 2;      // operand pieces of conv_x3 at inference: 2 float16 (three product terms) or 3 bf16 (six exact terms)
+  int train_pieces = 2;  // the same choice for the TRAINING forward's convs (their backward-data convs keep three bf16 pieces:
+                         //   gradients do not fit float16's range)
   int x3_s2 = 1;       // stride-2 convs on conv_x3
   int tail = 1;        // BasicBlock tails fused into the next conv's stager (0: residual_kernel)
   int pool = 1;        // max-pool fused into the stem's epilogue (0: gn_relu_maxpool_kernel)
@@ -87,6 +89,8 @@ struct pnvo_model_s {
   unsigned short *mx_wpk3 = nullptr;         // device: three-piece packing (float32 results)
   unsigned short *mx_wpk2 = nullptr;         // device: two float16 pieces (inference default) and the inverse of their scale
   float mx_oscale = 1.f;
+  float *mx_scale2_dev = nullptr;            // training: {scale, 1/scale} of mx_wpk2 as the device-side re-pack chose it
+  bool mx_wpk2_dev = false;                  // mx_wpk2 currently holds the device-side re-pack (scale in mx_scale2_dev), not the host's
   std::vector<float> mx_wk, mx_wk_swapped;   // host [cout][32 slots][49]: whitening-folded weights, as is / for the
                                              //   (cur, prev) channel-swapped pair (geometric-invariance dual forward)
   int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels
@@ -180,6 +184,7 @@ int pnvo_mark_stem(pnvo_handle m, hipStream_t s);
 int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun);   // after the forward is enqueued: wait for the stem, re-run on the dense stem?
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
 const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name);   // pnvo_train_api.hip: device pointer or nullptr
+const float *pnvo_train_x2_scale(pnvo_handle m, const std::string &name);     // device {scale, 1/scale} of that conv weight's float16 pieces, or nullptr
 void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip
 int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *depth, const float *dd, const float *tdv,
                       const int64_t *actions, int B, float *const *outs, hipStream_t s);

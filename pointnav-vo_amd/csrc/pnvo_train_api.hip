@@ -80,6 +80,11 @@ struct TrainState {
   pnvo_grad_ready_fn hook = nullptr;
   void *hook_user = nullptr;
   std::vector<size_t> bucket_first;     // e.g. {offset of layer4's first parameter, offset of layer2's, 0}
+  // two-piece float16 operands of the training forward's convs: per conv weight {scale, 1/scale}, recomputed from the flat
+  // parameters by ONE launch per pnvo_train_refresh (conv_x3.hip conv_x2_scale_kernel)
+  std::map<std::string, int> x2_index;  // conv weight name -> row of x2_scale
+  long *x2_seg = nullptr;               // device [rows][2]: flat offset, element count
+  float *x2_scale = nullptr;            // device [rows][2]
 };
 
 TrainState *TS(pnvo_handle m) { return reinterpret_cast<TrainState *>(m->train); }
@@ -319,8 +324,14 @@ int refresh_stem_dd(pnvo_handle m, TrainState *t, hipStream_t s) {
   if (m->train_mx) {
     HIPCHK(m, launch_stem_mx_repack(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_mxmaps, t->d_mxmaps + 32,
                                     t->d_mxmaps + 64, m->mx_wpk3, s));
-    return PNVO_OK;
-  }
+    if (m->opt.train_pieces == 2 && m->mx_wpk2 != nullptr) {      // the float16 operand of the training forward, with its own scale
+      if (!m->mx_scale2_dev) HIPCHK(m, hipMalloc((void **)&m->mx_scale2_dev, 2 * sizeof(float)));
+      HIPCHK(m, launch_stem_mx_repack_h(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_mxmaps, t->d_mxmaps + 32,
+                                        t->d_mxmaps + 64, m->mx_scale2_dev, m->mx_wpk2, s));
+      m->mx_wpk2_dev = true;
+    }
+    if (!(m->dd_ok && m->opt.stem == 2)) return PNVO_OK;       // (option stem=dd on a model that trains on the mx stem: keep the
+  }                                                             //  one-hot stem's operands current as well)
   if (!m->dd_ok) return PNVO_OK;
   const int bins = m->dd_bins;
   HIPCHK(m, launch_stem_dd_repack(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_ddmaps,
@@ -644,6 +655,8 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->d_mxmaps);
   for (unsigned short *&q : t->dgrad_x3) dfree(q);
   dfree(t->d_segs);
+  dfree(t->x2_seg);
+  dfree(t->x2_scale);
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
   if (t->embed_err) (void)hipHostFree(t->embed_err);
@@ -728,6 +741,13 @@ int pnvo_train_grad_buckets(pnvo_handle m, uint64_t *first, uint64_t *count, int
 }
 
 // device pointer of a parameter inside the caller's flat buffer (nullptr: not attached / unknown name)
+extern "C++" const float *pnvo_train_x2_scale(pnvo_handle m, const std::string &name) {
+  if (!m || !m->train) return nullptr;
+  TrainState *t = TS(m);
+  auto it = t->x2_index.find(name);
+  return it == t->x2_index.end() || !t->x2_scale ? nullptr : t->x2_scale + 2 * it->second;
+}
+
 extern "C++" const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name) {
   if (!m || !m->train) return nullptr;
   TrainState *t = TS(m);
@@ -754,6 +774,24 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
     HIPCHK(m, hipMemcpy(t->d_segs, segs.data(), segs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice));
   }
   HIPCHK(m, launch_gather_all(t->params, t->d_segs, t->nseg, t->seg_total, (hipStream_t)stream));
+  if (!t->x2_seg && !m->bottleneck) {       // the 3x3 / strided convs conv_x3.hip may take: one scale row each
+    std::vector<long> seg;
+    for (size_t li = 1; li < m->convs.size(); ++li) {
+      const Layer &l = m->convs[li];
+      auto it = t->toc.find(l.name + ".weight");
+      if (it == t->toc.end()) continue;
+      t->x2_index[l.name + ".weight"] = (int)(seg.size() / 2);
+      seg.push_back((long)it->second.off);
+      seg.push_back((long)it->second.numel);
+    }
+    if (!seg.empty()) {
+      int rc0 = dmalloc(m, (void **)&t->x2_seg, seg.size() * sizeof(long));
+      if (rc0 != PNVO_OK) return rc0;
+      if ((rc0 = dmalloc(m, (void **)&t->x2_scale, seg.size() * sizeof(float))) != PNVO_OK) return rc0;
+      HIPCHK(m, hipMemcpy(t->x2_seg, seg.data(), seg.size() * sizeof(long), hipMemcpyHostToDevice));
+    }
+  }
+  if (t->x2_seg) HIPCHK(m, launch_conv_x2_scales(t->params, t->x2_seg, (int)t->x2_index.size(), t->x2_scale, (hipStream_t)stream));
   if (m->cfg.act_embed) {      // eval-mode bias rows bias[a][o] = b1[o] + W1[o][flat:] . emb[a]  (pnvo_load_weights does this on the host)
     const pnvo_config &c = m->cfg;
     const int rows = c.n_acts + 1, flat = m->comp_c * m->fh * m->fw;

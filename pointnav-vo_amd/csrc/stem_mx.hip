@@ -457,6 +457,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   // M-tile `wave` in wave order 0,1,2,3 — no data-dependent register selection, bit-reproducible.
   const int rr16 = lane >> 5;                             // accumulator row = (r & 3) + 8 (r >> 2) + 4 rr16
   const bool full = ho0 + TH <= p.Ho && wo0 + TW <= p.Wo; // the whole tile is inside the output (wave-uniform)
+  const float oscale = (H && p.oscale_ptr != nullptr) ? *p.oscale_ptr : p.oscale;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     __syncthreads();                                      // patch (or the previous N-tile's exchange) no longer read
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     if (H) {                                              // undo the weights' power-of-two scale (exact)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot[r] *= p.oscale;
+      for (int r = 0; r < 16; ++r) tot[r] *= oscale;
     }
     // epilogue of M-tile `wave`: rows 2*wave, 2*wave+1 of the tile; lane = output channel, registers = pixels
     const int g = gy * NT + nt;                           // N-tile of the launch
@@ -753,6 +754,80 @@ __global__ __launch_bounds__(256) void stem_mx_repack_kernel(const float *w, int
     }
   }
   out[e] = val;
+}
+
+// The two-piece float16 operand of the same weights (pack_stem_mx_weight_h on the device), for the training forward.
+// Folded weight of (co, slot, tap) exactly as above (double products rounded to float once); rgb slots times 2^8.
+__device__ __forceinline__ float stem_folded_weight(const float *w, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
+                                                    const int *slot_new, int co, int slot, int tap) {
+  float v;
+  if (slot == 30) {
+    double ind = 0.0;
+    for (int k = 0; k < 30; ++k)
+      if (slot_ref[k] >= 0) ind += (double)w[((long)co * cin + slot_ref[k]) * 49 + tap] * (double)sh_new[slot_new[k]];
+    v = (float)ind;
+  } else if (slot > 30 || slot_ref[slot] < 0) {
+    v = 0.f;
+  } else {
+    v = (float)((double)w[((long)co * cin + slot_ref[slot]) * 49 + tap] * (double)sc_new[slot_new[slot]]);
+  }
+  return (slot >= 20 && slot <= 25) ? v * 256.f : v;
+}
+
+// one block: max |folded weight| -> scale2[0] = 2^(12 - e), scale2[1] = 1 / scale
+__global__ __launch_bounds__(1024) void stem_mx_scale_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
+                                                           const int *slot_ref, const int *slot_new, float *scale2) {
+  __shared__ float red[16];
+  float mx = 0.f;
+  for (int e = threadIdx.x; e < 32 * 31 * 49; e += 1024) {
+    const int tap = e % 49, slot = (e / 49) % 31, co = e / (49 * 31);
+    mx = fmaxf(mx, fabsf(stem_folded_weight(w, cin, sc_new, sh_new, slot_ref, slot_new, co, slot, tap)));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
+    int e = 0;
+    if (mx > 0.f) e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu) - 126;
+    scale2[0] = __builtin_bit_cast(float, (unsigned)(12 - e + 127) << 23);
+    scale2[1] = __builtin_bit_cast(float, (unsigned)(e - 12 + 127) << 23);
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_mx_repack_h_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
+                                                             const int *slot_ref, const int *slot_new, const int *xslot,
+                                                             const float *scale2, unsigned short *out, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = e & 7, ln = (e >> 3) & 63;
+  const int r = e >> 9;
+  const int f = r % 5, tap = r / 5;                  // (one N-tile: cout = 32)
+  const int kh = ln >> 5, co = ln & 31;
+  const float sc = scale2[0];
+  auto piece = [&](float v, int pc) -> unsigned short {
+    const _Float16 a = (_Float16)v;
+    if (pc == 0) return __builtin_bit_cast(unsigned short, a);
+    return __builtin_bit_cast(unsigned short, (_Float16)(v - (float)a));
+  };
+  unsigned short val = 0;
+  if (f < 4) {
+    const int pc = f / 2, q = f % 2, slot = 16 * q + 8 * kh + j;
+    if (slot < 31) val = piece(stem_folded_weight(w, cin, sc_new, sh_new, slot_ref, slot_new, co, slot, tap) * sc, pc);
+  } else if (kh == 0 && j < 4 && xslot[j] >= 0) {
+    val = piece(stem_folded_weight(w, cin, sc_new, sh_new, slot_ref, slot_new, co, xslot[j], tap) * sc, 0);
+  }
+  out[e] = val;
+}
+
+hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
+                                   const int *slot_new, const int *xslot, float *scale2, unsigned short *wpk2, hipStream_t s) {
+  hipLaunchKernelGGL(stem_mx_scale_kernel, dim3(1), dim3(1024), 0, s, w_oihw, cin, sc_new, sh_new, slot_ref, slot_new, scale2);
+  const int total = 49 * 5 * 64 * 8;
+  hipLaunchKernelGGL(stem_mx_repack_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cin, sc_new, sh_new,
+                     slot_ref, slot_new, xslot, scale2, wpk2, total);
+  return hipGetLastError();
 }
 
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
