@@ -890,6 +890,7 @@ const OptDef kOptions[] = {
     {"stem_dbg", nullptr, &PnvoOptions::stem_dbg, true, {{nullptr, 0}}},
     {"stem_dbg_pad", nullptr, &PnvoOptions::stem_dbg_pad, true, {{nullptr, 0}}},
     {"wgrad_stem", "PNVO_WGRAD_STEM", &PnvoOptions::wgrad_stem, false, {{"mx", 0}, {"fp32", 1}, {nullptr, 0}}},
+    {"wgrad3", "PNVO_WGRAD3", &PnvoOptions::wgrad3, false, {{"x3", 1}, {"fp32", 0}, {nullptr, 0}}},
     {"pool_bwd", "PNVO_POOL_BWD", &PnvoOptions::pool_bwd, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
     {"dgrad", "PNVO_DGRAD", &PnvoOptions::dgrad, false, {{"phase", 1}, {"masked", 0}, {nullptr, 0}}},
     {"bf16_fuse", nullptr, &PnvoOptions::bf16_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},

@@ -264,7 +264,11 @@ struct WgradArgs {
   // workgroups = pair groups x wg_chunks, LDS buffers
   int cs, os, rs, wg_chunks, nbuf;
   long grad_pitch;          // row pitch of the OIHW gradient tensor (0: cin_out * KH * KW)
+  // bf16-matrix-core path (wgrad_x3.hip, lds3 = 6): row segments per strip; use_x3 = 0 keeps wgrad_plan off it
+  int xr_rsegs, use_x3;
 };
+bool wgrad_x3_plan(WgradArgs &a);
+hipError_t launch_wgrad_x3(const WgradArgs &a, hipStream_t s);
 // Weight gradient of the 7x7 stem on the bf16 matrix cores (wgrad_stem_mx.hip): exact three-piece bf16 on both operands.
 struct WgradStemMXArgs {
   const float *src[4];        // rgb, depth, discretised depth, top-down view observation tensors (nullptr if absent)

@@ -43,6 +43,7 @@ struct PnvoOptions {
   int graph = 0;       // forward replayed from a captured hipGraph
   int stem_dbg = 0, stem_dbg_pad = 0;   // developer instrumentation of the stem kernels
   int wgrad_stem = 0;  // 0 bf16 matrix cores, 1 fp32
+  int wgrad3 = 1;      // weight gradient of the 3x3 stride-1 convs: 1 bf16 matrix cores (wgrad_x3.hip), 0 fp32 kernels
   int pool_bwd = 1;    // max-pool backward fused into the stem's GroupNorm backward
   int dgrad = 1;       // stride-2 backward-data as four parity-phase convs (0: masked taps)
   int bf16_fuse = 1;   // bf16 path: block tails fused

@@ -379,9 +379,12 @@ void free_train_ws(TrainState *t) {
 }
 
 // weight-gradient launch descriptor of conv `l` for batch B (input geometry = the forward conv's)
+thread_local int g_wgrad_x3 = 1;          // option wgrad3 of the handle whose call is in flight (set at the entry points)
+
 WgradArgs wgrad_args(const Layer &l, int B, int cin_kernel, int dyc, int mode = 0) {
   WgradArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.use_x3 = g_wgrad_x3;
   a.mode = mode;                 // wgrad_plan picks the kernel by mode
   a.B = B;
   a.H = l.hin;
@@ -400,6 +403,7 @@ WgradArgs wgrad_args(const Layer &l, int B, int cin_kernel, int dyc, int mode = 
 }
 
 int ensure_train_ws(pnvo_handle m, TrainState *t, int B) {
+  g_wgrad_x3 = m->opt.wgrad3;
   if (B <= t->capB) return PNVO_OK;
   free_train_ws(t);
   int rc = pnvo_ensure_workspace(m, B);    // stats buffer etc. of the inference path are reused
@@ -964,6 +968,7 @@ int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
 static int train_backward_body(pnvo_handle m, const float *grad_out, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   TrainState *t = TS(m);
+  g_wgrad_x3 = m->opt.wgrad3;
   if (t->lastB <= 0 || !grad_out) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_forward first");
   HIPCHK(m, hipSetDevice(m->device));
   const pnvo_config &c = m->cfg;

@@ -697,6 +697,7 @@ static bool wgrad_plan_mw(WgradArgs &a) {
 
 void wgrad_plan(WgradArgs &a) {
   a.lds3 = 0;
+  if (a.use_x3 && wgrad_x3_plan(a)) return;              // 3x3 stride-1 convs: three-piece operands on the bf16 matrix cores
   static const bool no_lds = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "generic") == 0;
   static const bool nine = std::getenv("PNVO_WGRAD") && std::strcmp(std::getenv("PNVO_WGRAD"), "lds9") == 0;
   if (!no_lds && !nine && a.mode != 2 && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.CIN % 32 == 0 && a.DYC >= (a.COUT + 31) / 32 * 32 &&
@@ -784,6 +785,12 @@ size_t wgrad_partial_floats(const WgradArgs &a) { return (size_t)a.chunks * a.pa
 
 hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int cin_out, hipStream_t s) {
   hipError_t e;
+  if (a.lds3 == 6) {
+    e = launch_wgrad_x3(a, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.pairs * 9 * 32)), dim3(256), 0, s, a, a.TG, grad, ci_perm, cin_out);
+    return hipGetLastError();
+  }
   if (a.lds3 == 2) {
     const size_t lds = (size_t)(13 * 37 + 64) * 36 * 4;
     hipLaunchKernelGGL(wgrad_stem_lds_kernel, dim3((unsigned)a.chunks), dim3(448), lds, s, a);
