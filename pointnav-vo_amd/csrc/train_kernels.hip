@@ -900,6 +900,66 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *x, cons
   }
 }
 
+// The same reduction with FOUR consecutive channels per thread (16-byte loads; C % 4 == 0 and C / 4 divides 256 or is a multiple
+// of it — every GroupNorm of these models): a quarter of the load instructions of the kernel above.
+__global__ __launch_bounds__(256) void gn_bwd_reduce4_kernel(const float *x, const float *dout, const float *scale,
+                                                           const float *shift, const float *mu, const float *rstd, int C,
+                                                           int Creal, int G, long P, int chunks, int mask, float *part) {
+  __shared__ float red[256 * 8];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long ppc = (P + chunks - 1) / chunks;
+  const long p0 = (long)chunk * ppc;
+  long p1 = p0 + ppc;
+  if (p1 > P) p1 = P;
+  const int cpg = Creal / G;
+  const int Q = C / 4;                                     // channel quads
+  for (int qb = 0; qb < Q; qb += 256) {
+    const int lanes_q = Q - qb < 256 ? Q - qb : 256;       // quads handled in this pass
+    const int c0 = 4 * (qb + (int)(threadIdx.x % lanes_q));
+    const int pl = threadIdx.x / lanes_q, pstep = 256 / lanes_q;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float m_[4], r_[4];
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = c0 + t < Creal ? c0 + t : Creal - 1;   // (pad channels: any valid statistics; their sums are never read)
+      m_[t] = mu[n * G + c / cpg];
+      r_[t] = rstd[n * G + c / cpg];
+    }
+    if (mask) {
+      sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + c0);
+      sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + c0);
+    }
+    for (long p = p0 + pl; p < p1; p += pstep) {
+      const long idx = ((long)n * P + p) * C + c0;
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + idx), gv = *reinterpret_cast<const f32x4 *>(dout + idx);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float g = gv[t];
+        if (mask && !(__builtin_fmaf(xv[t], sc[t], sh[t]) > 0.f)) g = 0.f;
+        s1[t] += g;
+        s2[t] = __builtin_fmaf(g, (xv[t] - m_[t]) * r_[t], s2[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      red[threadIdx.x * 8 + 2 * t] = s1[t];
+      red[threadIdx.x * 8 + 2 * t + 1] = s2[t];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < lanes_q) {
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < pstep; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += red[(k * lanes_q + threadIdx.x) * 8 + e];
+      float *dst = part + (((long)n * chunks + chunk) * C + c0) * 2;
+      *reinterpret_cast<f32x4 *>(dst) = f32x4{a[0], a[1], a[2], a[3]};
+      *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{a[4], a[5], a[6], a[7]};
+    }
+    __syncthreads();
+  }
+}
+
 // stage A: per (n, channel) sum of the chunk partials (fixed order) -> nc[n][c][2]
 __global__ __launch_bounds__(256) void gn_bwd_sum_chunks_kernel(const float *part, int B, int C, int chunks, float *nc) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -918,9 +978,25 @@ __global__ __launch_bounds__(256) void gn_bwd_sum_chunks_kernel(const float *par
 // stage B: per (n, group): c1 = S1/N, c2 = S2/N;  per channel: dgamma, dbeta (sum over n in a fixed order, fp64).
 // Blocks [0, nb_coef) do the coefficients (one thread per (n, group)); the following blocks take one channel per WAVE:
 // lane l sums samples l, l+64, ... and a fixed xor-shuffle tree combines the lanes.
+// (chunks > 0: `nc` holds the CHUNK partials [B][chunks][C][2] and the sum over chunks — stage A — happens here, in fp64, in
+// chunk order: one launch fewer per GroupNorm; chunks == 0: nc is stage A's output.)
+__device__ __forceinline__ void gn_nc(const float *nc, int chunks, int C, int n, int c, double &a1, double &a2) {
+  if (chunks <= 0) {
+    a1 = (double)nc[((long)n * C + c) * 2];
+    a2 = (double)nc[((long)n * C + c) * 2 + 1];
+    return;
+  }
+  a1 = a2 = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const float *src = nc + (((long)n * chunks + ch) * C + c) * 2;
+    a1 += (double)src[0];
+    a2 += (double)src[1];
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, int B, int C, int Creal, int G, long P,
                                                             const float *gamma, float *coef, float *dgamma, float *dbeta,
-                                                            int nb_coef) {
+                                                            int nb_coef, int chunks = 0) {
   const int cpg = Creal / G;
   if ((int)blockIdx.x >= nb_coef) {               // per-channel parameter gradients
     const int c = ((int)blockIdx.x - nb_coef) * 4 + (int)(threadIdx.x >> 6);
@@ -928,8 +1004,10 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, i
     if (c >= Creal) return;
     double dg = 0.0, db = 0.0;
     for (int n = lane; n < B; n += 64) {
-      db += (double)nc[((long)n * C + c) * 2];
-      dg += (double)nc[((long)n * C + c) * 2 + 1];
+      double a1, a2;
+      gn_nc(nc, chunks, C, n, c, a1, a2);
+      db += (double)(float)a1;                    // (rounded to float as stage A stores it: same bits either way)
+      dg += (double)(float)a2;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -949,8 +1027,10 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, i
     double S1 = 0.0, S2 = 0.0;
     for (int k = 0; k < cpg; ++k) {
       const int c = g * cpg + k;
-      S1 += (double)gamma[c] * (double)nc[((long)n * C + c) * 2];
-      S2 += (double)gamma[c] * (double)nc[((long)n * C + c) * 2 + 1];
+      double a1, a2;
+      gn_nc(nc, chunks, C, n, c, a1, a2);
+      S1 += (double)gamma[c] * (double)(float)a1;
+      S2 += (double)gamma[c] * (double)(float)a2;
     }
     coef[((long)n * G + g) * 2] = (float)(S1 / N);
     coef[((long)n * G + g) * 2 + 1] = (float)(S2 / N);
@@ -1120,11 +1200,9 @@ hipError_t launch_gn_bwd_pool(const float *x, const float *dpool, const unsigned
   q.Wp = Wp;
   hipLaunchKernelGGL(gn_bwd_reduce_pool_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, q, scale, shift, mu, rstd, C, G, P,
                      chunks, part);
-  float *nc = part + (size_t)B * chunks * C * 2;
-  hipLaunchKernelGGL(gn_bwd_sum_chunks_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, s, part, B, C, chunks, nc);
   const int nb_coef = (B * G + 255) / 256;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)(nb_coef + (C + 3) / 4)), dim3(256), 0, s, nc, B, C, C, G, P, gamma, coef,
-                     dgamma, dbeta, nb_coef);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)(nb_coef + (C + 3) / 4)), dim3(256), 0, s, part, B, C, C, G, P, gamma, coef,
+                     dgamma, dbeta, nb_coef, chunks);
   const long total4 = (long)B * P * C / 4;
   hipLaunchKernelGGL(gn_bwd_apply_pool_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, q, scale, shift, mu, rstd,
                      gamma, coef, C, G, P, total4, dx);
@@ -1141,14 +1219,16 @@ hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, 
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
   // the reduce kernel walks channels 0..C-1 of the padded tensor; pad channels are never read by finalize
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, dout, scale, shift, mu, rstd,
-                     C, Creal, G, P, chunks, mask, part);
-  float *nc = part + (size_t)B * chunks * C * 2;     // [B][C][2] right behind the chunk partials
-  hipLaunchKernelGGL(gn_bwd_sum_chunks_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, s, part, B, C, chunks,
-                     nc);
-  const int nb_coef = (B * G + 255) / 256;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)(nb_coef + (Creal + 3) / 4)), dim3(256), 0, s, nc, B, C, Creal,
-                     G, P, gamma, coef, dgamma, dbeta, nb_coef);
+  const int Q = C / 4;
+  if (C % 4 == 0 && (256 % Q == 0 || Q % 256 == 0))
+    hipLaunchKernelGGL(gn_bwd_reduce4_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, dout, scale, shift, mu, rstd,
+                       C, Creal, G, P, chunks, mask, part);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, s, x, dout, scale, shift, mu, rstd,
+                       C, Creal, G, P, chunks, mask, part);
+  const int nb_coef = (B * G + 255) / 256;           // (stage A — the sum over chunks — happens inside the finalisation)
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)(nb_coef + (Creal + 3) / 4)), dim3(256), 0, s, part, B, C, Creal,
+                     G, P, gamma, coef, dgamma, dbeta, nb_coef, chunks);
   const long total4 = (long)B * P * C / 4;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, dout, scale, shift, mu,
                      rstd, gamma, coef, C, Creal, G, P, total4, mask, dx);

@@ -92,23 +92,26 @@ def run_dual_bf16(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
         ma.timing(False)
     dt = parallel.max_over_ranks(dt, dev)
     # the same dual forward from the sensor frames (pnvo_forward_dual_raw): bit-identical outputs, 5.5x fewer input bytes
-    with torch.no_grad():
-        rgb_f, dep_f = bench.frames_of(obs)
-        ra, rb = vo_cnn.dual_forward_raw(ma, mb, rgb_f, dep_f, obs["top_down_view"])
-        same = bool(torch.equal(ra, oa) and torch.equal(rb, ob))
-        t_raw = parallel.max_over_ranks(
-            bench.time_steps_simple(lambda: vo_cnn.dual_forward_raw(ma, mb, rgb_f, dep_f, obs["top_down_view"]), 10, sync_all), dev)
-        ma.timing(True)
-        for _ in range(5):
-            vo_cnn.dual_forward_raw(ma, mb, rgb_f, dep_f, obs["top_down_view"])
-        sync_all()
-        kr = ma.timing_read()
-        ma.timing(False)
-    stem_raw = [k for k in kr if k["name"] == "bf16:stem"]
-    raw_rec = {"value": world * B / t_raw, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t_raw, "steps": 10,
-               "bit_identical_outputs": same, "stem_launch_ms": stem_raw[0]["total_ms"] / stem_raw[0]["launches"] if stem_raw else None,
-               "stem_algorithmic_gbs": (stem_raw[0]["bytes"] / (stem_raw[0]["total_ms"] * 1e-3) / 1e9) if stem_raw else None}
-    del rgb_f, dep_f
+    raw_rec = None
+    if not getattr(args, "no_secondary", False):
+        with torch.no_grad():
+            rgb_f, dep_f = bench.frames_of(obs)
+            ra, rb = vo_cnn.dual_forward_raw(ma, mb, rgb_f, dep_f, obs["top_down_view"])
+            same = bool(torch.equal(ra, oa) and torch.equal(rb, ob))
+            t_raw = parallel.max_over_ranks(
+                bench.time_steps_simple(lambda: vo_cnn.dual_forward_raw(ma, mb, rgb_f, dep_f, obs["top_down_view"]), 10, sync_all), dev)
+            ma.timing(True)
+            for _ in range(5):
+                vo_cnn.dual_forward_raw(ma, mb, rgb_f, dep_f, obs["top_down_view"])
+            sync_all()
+            kr = ma.timing_read()
+            ma.timing(False)
+        stem_raw = [k for k in kr if k["name"] == "bf16:stem"]
+        raw_rec = {"value": world * B / t_raw, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t_raw, "steps": 10,
+                   "bit_identical_outputs": same,
+                   "stem_launch_ms": stem_raw[0]["total_ms"] / stem_raw[0]["launches"] if stem_raw else None,
+                   "stem_algorithmic_gbs": (stem_raw[0]["bytes"] / (stem_raw[0]["total_ms"] * 1e-3) / 1e9) if stem_raw else None}
+        del rgb_f, dep_f
     if rank == 0:
         value = world * B * args.steps / dt
         dom = max((k for k in kt if k["name"].startswith("bf16:")), key=lambda k: k["total_ms"])

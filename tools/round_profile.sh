@@ -8,11 +8,11 @@ python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 300 $O/${
 python bench.py --config dual_bf16 > $O/${tag}_bench_dual_bf16.json 2> $O/${tag}_bench_dual_bf16.err; tail -c 300 $O/${tag}_bench_dual_bf16.json; echo
 python bench.py --config train --steps 10 --warmup 3 > $O/${tag}_bench_train.json 2> $O/${tag}_bench_train.err; tail -c 300 $O/${tag}_bench_train.json; echo
 for cfg in fwd_fp32 dual_bf16; do
-  rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_$cfg -o p -- python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $O/${tag}_trace_$cfg.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_$cfg -o p -- python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/${tag}_trace_$cfg.log 2>&1
   python tools/rocprof_summary.py $O/${tag}_trace_$cfg/p_results.db > $O/${tag}_kernel_trace_$cfg.md 2>&1
   for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
     n=$(echo $set | cut -d" " -f1)
-    rocprofv3 --kernel-trace --pmc $set -d $O/${tag}_pmc_${cfg}_$n -o p -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-preheat > $O/${tag}_pmc_${cfg}_$n.log 2>&1
+    rocprofv3 --kernel-trace --pmc $set -d $O/${tag}_pmc_${cfg}_$n -o p -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-preheat --no-secondary > $O/${tag}_pmc_${cfg}_$n.log 2>&1
     python tools/rocprof_summary.py $O/${tag}_pmc_${cfg}_$n/p_results.db --pmc 2>&1 | awk '/## counters/{f=1} f' > $O/${tag}_pmc_${cfg}_$n.md
   done
   python tools/make_traffic.py $cfg 256 $O/${tag}_pmc_${cfg}_FETCH_SIZE/p_results.db $O/${tag}_pmc_${cfg}_WRITE_SIZE/p_results.db $O/${tag}_traffic.json
@@ -25,6 +25,10 @@ rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_train -o p -- python bench.p
 python tools/rocprof_summary.py $O/${tag}_trace_train/p_results.db > $O/${tag}_kernel_trace_train.md 2>&1
 rm -rf $O/${tag}_trace_train
 PNVO_WSM_PROF=1 python bench.py --config train --steps 10 --warmup 3 2>&1 >/dev/null | grep "pnvo\]" > $O/${tag}_wgrad_stem_phases.txt
-PNVO_X3_PROF=1 python bench.py --steps 1 --warmup 0 --no-preheat --no-cpu-baseline 2>&1 >/dev/null | grep "pnvo\] conv_x3" | sort -u -t: -k1,1 > $O/${tag}_conv_x3_phases.txt
-PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-preheat --no-cpu-baseline 2>&1 >/dev/null | grep "pnvo\] stem_mx" > $O/${tag}_stem_phases.txt
+PNVO_X3_PROF=1 python bench.py --steps 1 --warmup 0 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] conv_x3" | sort -u -t: -k1,1 > $O/${tag}_conv_x3_phases.txt
+PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] stem_mx" > $O/${tag}_stem_phases.txt
+python tools/bench_boundary.py > $O/${tag}_bench_boundary.json 2>/dev/null
+python tools/bench_boundary_phases.py 64 > $O/${tag}_boundary_phases.json 2>/dev/null
+python tools/bench_batch_sweep.py > $O/${tag}_batch_sweep.txt 2>/dev/null
+python bench.py --config train --steps 10 --warmup 3 --no-overlap > $O/${tag}_bench_train_no_overlap.json 2>/dev/null
 head -14 $O/${tag}_kernel_trace_fwd_fp32.md
