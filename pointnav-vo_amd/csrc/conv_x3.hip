@@ -111,6 +111,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // a gradient input (backward-data, NP = 2): power-of-two scale 2^(14 - e) from the tensor's absolute maximum = f * 2^e
+  float in_mul = 1.f, in_div = 1.f;
+  const bool in_scaled = NP == 2 && p.in_absmax != nullptr;
+  if (in_scaled) {
+    unsigned mb = p.in_absmax[(threadIdx.x & 63) * 16];                 // maximum of the 64 slots: one per lane, butterfly
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, d));
+    const int e = mb != 0u ? (int)((mb >> 23) & 0xffu) - 126 : 14;
+    in_mul = __builtin_bit_cast(float, (unsigned)(14 - e + 127) << 23);
+    in_div = __builtin_bit_cast(float, (unsigned)(e - 14 + 127) << 23);
+  }
   // staging role: thread -> (pixel lane, 8-channel group); G groups per pixel, 256 / G pixels per step
   const int G = CK >> 3;
   const int cg = threadIdx.x & (G - 1), pl = threadIdx.x / G, PS = 256 / G;
@@ -213,6 +224,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
             *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{f[4], f[5], f[6], f[7]};
           }
           if (NP == 2) {                                                 // two float16 pieces of the eight channels
+            if (in_scaled) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= in_mul;
+            }
             u32x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
 
   // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).
   if (NP == 2) {                                                         // undo the weights' power-of-two scale (exact)
-    const float os = p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
+    const float os = (p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale) * in_div;
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -737,7 +752,7 @@ hipError_t launch_conv_x2_scales(const float *params, const long *seg_dev, int n
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void conv_x2_repack_kernel(const float *w, int cout, int cin, int cinp, int coutp, int T,
+__global__ __launch_bounds__(256) void conv_x2_repack_kernel(const float *w, int cout, int cin, int cinp, int coutp, int T, int transposed,
                                                            const float *scale, unsigned short *out, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
@@ -748,7 +763,9 @@ __global__ __launch_bounds__(256) void conv_x2_repack_kernel(const float *w, int
   r /= ntt;
   const int kc = (int)(r % kct), tap = (int)(r / kct);
   const int co = nt * 32 + (ln & 31), ci = 16 * kc + 8 * (ln >> 5) + j;
-  const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * T + tap] * scale[0] : 0.f;
+  // transposed = 1: the operand of the backward-data conv (w is [cin][cout][T] as seen from here, taps flipped)
+  const float v = (co < cout && ci < cin) ? (transposed ? w[((long)ci * cout + co) * T + (T - 1 - tap)] : w[((long)co * cin + ci) * T + tap]) * scale[0]
+                                          : 0.f;
   const _Float16 h = (_Float16)v;
   const _Float16 m = (_Float16)(v - (float)h);
   const long base = ((((long)tap * kct + kc) * ntt + nt) * 2) * 512 + (long)ln * 8 + j;
@@ -757,10 +774,10 @@ __global__ __launch_bounds__(256) void conv_x2_repack_kernel(const float *w, int
 }
 
 hipError_t launch_conv_x2_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, const float *scale_dev,
-                                 unsigned short *out, hipStream_t s) {
+                                 unsigned short *out, hipStream_t s, int transposed) {
   const long total = (long)kh * kw * (cinp / 16) * (coutp / 32) * 512;
   hipLaunchKernelGGL(conv_x2_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cout, cin, cinp, coutp,
-                     kh * kw, scale_dev, out, total);
+                     kh * kw, transposed, scale_dev, out, total);
   return hipGetLastError();
 }
 

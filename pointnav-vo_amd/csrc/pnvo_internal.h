@@ -5,6 +5,8 @@
 
 namespace pnvo {
 
+constexpr int PNVO_ABSMAX_UINTS = 64 * 16;      // an absolute-maximum record: 64 atomicMax slots, one cache line apart
+
 // A 2-channel slice of one observation tensor feeding the fused stem (MODE 2 of conv_mfma_kernel).
 struct SrcPiece {
   const float *base;   // tensor base (nullptr: zero padding piece)
@@ -134,6 +136,9 @@ struct ConvX3Args {
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_x3_plan
   unsigned long long *prof;          // PNVO_X3_PROF=1: phase cycles of one workgroup (nullptr otherwise)
   int force;                         // conv_x3_plan: take the layer at any launch size (option conv=x3)
+  // np == 2 on a GRADIENT input (backward-data): float bits of max |x| over the input tensor (gn_bwd_apply's absmax); the stager
+  // multiplies by 2^(14 - e) before the float16 split, the epilogue divides again (both exact)
+  const unsigned *in_absmax;         //   (64 slots of 16 uints: readers take the maximum, absmax_of())
   int np;                            // operand pieces: 3 = bf16 (six exact product terms; 0 means 3), 2 = float16 (three terms)
   float oscale;                      // np == 2: inverse of the power-of-two scale folded into the packed weights
   const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
@@ -145,7 +150,7 @@ hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cin
 void pack_conv_x3_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);
 hipError_t launch_conv_x2_scales(const float *params, const long *seg_dev, int nseg, float *out, hipStream_t s);   // [nseg][2]: scale, 1/scale
 hipError_t launch_conv_x2_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, const float *scale_dev,
-                                 unsigned short *out, hipStream_t s);
+                                 unsigned short *out, hipStream_t s, int transposed = 0);
 float pack_conv_x2_weight(const float *oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, unsigned short *out);   // -> oscale
 
 // Native-bf16 convs of the residual stages (conv_bf16.hip); index [z] = model of the launch (dual forward: two).
@@ -266,6 +271,10 @@ struct WgradArgs {
   long grad_pitch;          // row pitch of the OIHW gradient tensor (0: cin_out * KH * KW)
   // bf16-matrix-core path (wgrad_x3.hip, lds3 = 6): row segments per strip; use_x3 = 0 keeps wgrad_plan off it
   int xr_rsegs, use_x3;
+  // np = 2: two float16 pieces per operand, three terms (X bounded by the forward's range check; dY scaled by 2^(14 - e) from
+  // dy_absmax, un-scaled on the accumulators); np = 3 (or 0): three bf16 pieces, six terms
+  int np;
+  const unsigned *dy_absmax;
 };
 bool wgrad_x3_plan(WgradArgs &a);
 hipError_t launch_wgrad_x3(const WgradArgs &a, hipStream_t s);
@@ -289,7 +298,7 @@ hipError_t launch_wgrad(const WgradArgs &a, float *grad, const int *ci_perm, int
 
 hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
                          const float *rstd, const float *gamma, int B, long P, int C, int Creal, int G, int mask,
-                         float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s);
+                         float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s, unsigned *absmax = nullptr);
 hipError_t launch_gn_bwd_pool(const float *x, const float *dpool, const unsigned char *idx, int Hs, int Ws, int Hp, int Wp,
                               const float *scale, const float *shift, const float *mu, const float *rstd, const float *gamma, int B, int C,
                               int G, float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s);

@@ -41,6 +41,9 @@ struct TrainState {
   std::vector<std::array<float *, 4>> dgrad_wph;   // stride-2 3x3 convs: one sub-kernel per output parity phase (ph*2 + pw)
   std::vector<unsigned short *> dgrad_x3;          // 3x3 stride-1 convs: three-piece operand of the backward-data conv (conv_x3.hip)
   std::vector<unsigned long long> dgrad_x3_gen;    //   ... built from the flat parameters when m->weights_gen moved
+  std::vector<unsigned short *> dgrad_x2;          //   ... and its two-piece float16 form (option train_pieces = 2)
+  std::vector<unsigned long long> dgrad_x2_gen;
+  unsigned *dmax = nullptr;                        // per conv: float bits of max |dRaw| of the backward in flight (gn_bwd_apply)
   float *fc_t = nullptr, *head_t = nullptr;
   int *d_ref_of_new = nullptr, *d_tensor_of_new = nullptr, *d_ciperm = nullptr;
   GatherSeg *d_segs = nullptr;      // all re-pack maps as one segment table (pnvo_train_refresh)
@@ -147,6 +150,8 @@ int build_maps(pnvo_handle m, TrainState *t) {
   t->dgrad_wph.assign(m->convs.size(), std::array<float *, 4>{nullptr, nullptr, nullptr, nullptr});
   t->dgrad_x3.assign(m->convs.size(), nullptr);
   t->dgrad_x3_gen.assign(m->convs.size(), 0);
+  t->dgrad_x2.assign(m->convs.size(), nullptr);
+  t->dgrad_x2_gen.assign(m->convs.size(), 0);
   for (size_t li = 0; li < m->convs.size(); ++li) {
     Layer &l = m->convs[li];
     const TocEnt *w = need(m, t, l.name + ".weight", &rc);
@@ -566,7 +571,30 @@ int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw,
     int mw = 0, nw = 0;
     size_t ldsb = 0;
     auto it = t->toc.find(l.name + ".weight");
+    // two float16 pieces (three terms) when the training forward uses them: the gradient is scaled by a power of two from its
+    // absolute maximum (tracked by the GroupNorm backward that produced it), the weights carry the forward's per-tensor scale
+    const float *wsc = m->opt.train_pieces == 2 && t->dmax != nullptr ? pnvo_train_x2_scale(m, l.name + ".weight") : nullptr;
+    xa.np = wsc != nullptr ? 2 : 3;
     if (it != t->toc.end() && conv_x3_plan(xa, 3, 1, &mw, &nw, &ldsb)) {
+      if (wsc != nullptr) {
+        if (!t->dgrad_x2[li] || t->dgrad_x2_gen[li] != m->weights_gen) {
+          const size_t nel = (size_t)9 * l.coutp * l.cin * 2;
+          if (!t->dgrad_x2[li]) {
+            int rc = dmalloc(m, (void **)&t->dgrad_x2[li], nel * 2);
+            if (rc != PNVO_OK) return rc;
+          }
+          HIPCHK(m, launch_conv_x2_repack(t->params + it->second.off, l.cin, l.cout, l.coutp, l.cin, 3, 3, wsc, t->dgrad_x2[li], s, 1));
+          t->dgrad_x2_gen[li] = m->weights_gen;
+        }
+        xa.x = draw;
+        xa.wpk = t->dgrad_x2[li];
+        xa.y = dx;
+        xa.oscale_ptr = wsc + 1;
+        xa.in_absmax = t->dmax + li * PNVO_ABSMAX_UINTS;
+        PnvoTimed tm(m, s, "dgrad:" + l.name, 2.0 * (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw, 0.0);
+        HIPCHK(m, launch_conv_x3(xa, 3, 1, 0, mw, nw, ldsb, s));
+        return PNVO_OK;
+      }
       if (!t->dgrad_x3[li] || t->dgrad_x3_gen[li] != m->weights_gen) {
         const size_t nel = (size_t)9 * l.coutp * l.cin * 3;
         if (!t->dgrad_x3[li]) {
@@ -638,7 +666,7 @@ int run_gn_bwd(pnvo_handle m, TrainState *t, size_t li, int B, const float *dout
   if (!db) return rc;
   PnvoTimed tm(m, s, "gn_bwd", 0.0, 0.0);
   HIPCHK(m, launch_gn_bwd(c.raw, dout, c.ss[0], c.ss[1], c.mu, c.rstd, l.gamma, B, (long)l.hout * l.wout, l.coutp, l.cout,
-                          l.groups, mask, t->gn_part, t->gn_coef, dg, db, dx, s));
+                          l.groups, mask, t->gn_part, t->gn_coef, dg, db, dx, s, t->dmax ? t->dmax + li * PNVO_ABSMAX_UINTS : nullptr));
   return PNVO_OK;
 }
 
@@ -650,6 +678,8 @@ void pnvo_train_free(pnvo_handle m) {
   free_train_ws(t);
   for (auto &pm : t->maps) dfree(pm.map);
   for (auto &p : t->dgrad_w) dfree(p);
+  for (auto &p : t->dgrad_x2) dfree(p);
+  dfree(t->dmax);
   for (auto &q : t->dgrad_wph)
     for (auto &p : q) dfree(p);
   dfree(t->fc_t);
@@ -977,6 +1007,10 @@ static int train_backward_body(pnvo_handle m, const float *grad_out, void *strea
   int rc = PNVO_OK;
 
   const int nblk_total = m->nblocks[0] + m->nblocks[1] + m->nblocks[2] + m->nblocks[3];
+  if (!t->dmax && !m->bottleneck) {
+    if ((rc = dmalloc(m, (void **)&t->dmax, m->convs.size() * PNVO_ABSMAX_UINTS * sizeof(unsigned))) != PNVO_OK) return rc;
+  }
+  if (t->dmax) HIPCHK(m, hipMemsetAsync(t->dmax, 0, m->convs.size() * PNVO_ABSMAX_UINTS * sizeof(unsigned), s));   // maxima of this backward's gradients
   // ---- output head: out = hid . W2^T + b2
   HIPCHK(m, launch_padcopy(grad_out, B, c.out_dim, 8, t->dout8, s));
   {
@@ -1110,6 +1144,10 @@ static int train_backward_body(pnvo_handle m, const float *grad_out, void *strea
         a.mode = 0;
       }
       a.dy = t->dRaw;
+      if (a.lds3 == 6 && m->opt.train_pieces == 2 && t->dmax != nullptr && ck.in_bound < 6.0e4f) {
+        a.np = 2;                     // float16 pieces: X inside float16's range (the forward's bound), dY scaled from its maximum
+        a.dy_absmax = t->dmax + ik[k] * PNVO_ABSMAX_UINTS;
+      }
       if ((rc = run_wgrad(m, t, a, ck.name + ".weight", nullptr, ck.cin, s)) != PNVO_OK) return rc;
       if ((rc = run_dgrad(m, t, ik[k], B, t->dRaw, k ? t->dA : dX, false, s)) != PNVO_OK) return rc;
       din = t->dA;

@@ -1038,38 +1038,60 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *nc, i
 }
 
 // dx for 4 consecutive channels per thread (C % 4 == 0; the 4 channels may straddle groups when C/G < 4)
+// absmax (optional, device uint[PNVO_ABSMAX_SLOTS * 16]): the float bits of max |dx| over the tensor, spread over 64 slots by
+// atomicMax (non-negative floats order like their bit patterns; readers take the maximum of the slots) — the power-of-two scale the float16 forms of the backward-data conv and of the weight gradient
+// put on this gradient before they split it (conv_x3.hip in_absmax, wgrad_x3.hip dy_absmax).
+__device__ __forceinline__ void block_absmax(float v, unsigned *absmax) {
+  __shared__ float wmax[4];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // 64 slots, one cache line apart (the workgroups of a launch would serialise on one address: measured +1.3 ms per step), and
+    // no atomic at all when the slot already holds a value at least as large (most workgroups after the first few)
+    const unsigned m = __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+    unsigned *slot = absmax + (blockIdx.x & 63u) * 16u;
+    if (m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+  }
+}
+
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, const float *dout, const float *scale,
                                                          const float *shift, const float *mu, const float *rstd,
                                                          const float *gamma, const float *coef, int C, int Creal, int G,
-                                                         long P, long total4, int mask, float *dx) {
+                                                         long P, long total4, int mask, float *dx, unsigned *absmax) {
   const long e4 = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e4 >= total4) return;
-  const long e = e4 * 4;
-  const int c0 = (int)(e % C);
-  const int n = (int)(e / (P * C));
-  const int cpg = Creal / G;
-  const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + e), gv = *reinterpret_cast<const f32x4 *>(dout + e);
-  f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if (mask) {
-    sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + c0);
-    sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + c0);
-  }
-  f32x4 out;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = c0 + t;
-    float o = 0.f;
-    if (c < Creal) {
-      const int g = c / cpg;
-      float gd = gv[t];
-      if (mask && !(__builtin_fmaf(xv[t], sc[t], sh[t]) > 0.f)) gd = 0.f;
-      const float r_ = rstd[n * G + g];
-      const float xh = (xv[t] - mu[n * G + g]) * r_;
-      o = r_ * (gamma[c] * gd - coef[((long)n * G + g) * 2] - xh * coef[((long)n * G + g) * 2 + 1]);
+  float amax = 0.f;
+  if (e4 < total4) {
+    const long e = e4 * 4;
+    const int c0 = (int)(e % C);
+    const int n = (int)(e / (P * C));
+    const int cpg = Creal / G;
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + e), gv = *reinterpret_cast<const f32x4 *>(dout + e);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (mask) {
+      sc = *reinterpret_cast<const f32x4 *>(scale + (long)n * C + c0);
+      sh = *reinterpret_cast<const f32x4 *>(shift + (long)n * C + c0);
     }
-    out[t] = o;                                   // channel-pad lanes (compression 31 -> 32) get 0
+    f32x4 out;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = c0 + t;
+      float o = 0.f;
+      if (c < Creal) {
+        const int g = c / cpg;
+        float gd = gv[t];
+        if (mask && !(__builtin_fmaf(xv[t], sc[t], sh[t]) > 0.f)) gd = 0.f;
+        const float r_ = rstd[n * G + g];
+        const float xh = (xv[t] - mu[n * G + g]) * r_;
+        o = r_ * (gamma[c] * gd - coef[((long)n * G + g) * 2] - xh * coef[((long)n * G + g) * 2 + 1]);
+      }
+      out[t] = o;                                   // channel-pad lanes (compression 31 -> 32) get 0
+      amax = fmaxf(amax, __builtin_fabsf(o));
+    }
+    *reinterpret_cast<f32x4 *>(dx + e) = out;
   }
-  *reinterpret_cast<f32x4 *>(dx + e) = out;
+  if (absmax != nullptr) block_absmax(amax, absmax);   // (wave-uniform condition: the whole workgroup takes part)
 }
 
 // ---- the stem's GroupNorm backward with the max-pool backward folded in: dOut of the stem's GN+ReLU is the gather of the
@@ -1211,7 +1233,7 @@ hipError_t launch_gn_bwd_pool(const float *x, const float *dpool, const unsigned
 
 hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, const float *shift, const float *mu,
                          const float *rstd, const float *gamma, int B, long P, int C, int Creal, int G, int mask,
-                         float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s) {
+                         float *part, float *coef, float *dgamma, float *dbeta, float *dx, hipStream_t s, unsigned *absmax) {
   // pixel chunks per sample: >= 64 pixels each, and enough workgroups to fill the chip on the small late stages too
   // (one chunk per sample left the 12x22 / 6x11 stages on 128 workgroups: 33 us for 17 MB)
   int chunks = (int)(P / 256);
@@ -1231,7 +1253,7 @@ hipError_t launch_gn_bwd(const float *x, const float *dout, const float *scale, 
                      G, P, gamma, coef, dgamma, dbeta, nb_coef, chunks);
   const long total4 = (long)B * P * C / 4;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, dout, scale, shift, mu,
-                     rstd, gamma, coef, C, Creal, G, P, total4, mask, dx);
+                     rstd, gamma, coef, C, Creal, G, P, total4, mask, dx, absmax);
   return hipGetLastError();
 }
 

@@ -30,6 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -54,12 +56,31 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned 
   p2 = pack2(ra - lo_f(p1), rb - hi_f(p1));
 }
 
+// two float16 pieces of a pair of float32 values (22 significant bits; NP = 2)
+__device__ __forceinline__ void split2(float a, float b, unsigned &p0, unsigned &p1) {
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  p0 = __builtin_bit_cast(unsigned, h);
+  const f16x2 m = __builtin_convertvector(f32x2{a - (float)h[0], b - (float)h[1]}, f16x2);
+  p1 = __builtin_bit_cast(unsigned, m);
+}
+template <int NP>
+__device__ __forceinline__ void splitn(float a, float b, unsigned (&q)[NP]) {
+  if constexpr (NP == 2)
+    split2(a, b, q[0], q[1]);
+  else
+    split3(a, b, q[0], q[1], q[2]);
+}
+
+template <int NP>
 struct XRow {          // one X row of the window: 10 pixels (columns cb - 1 .. cb + 8) as 5 packed pairs per piece
-  unsigned p[3][5];
+  unsigned p[NP][5];
 };
 }  // namespace
 
-template <int MODE>
+// NP = 3: three bf16 pieces per operand, six exact product terms.  NP = 2 (option train_pieces = 2): two float16 pieces, three
+// terms — X is a forward activation (inside float16's range by the forward's own bound), dY is multiplied by 2^(14 - e) from its
+// tensor's absolute maximum before the split (gn_bwd_apply tracks it) and the accumulators are divided by it at the end (exact).
+template <int MODE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wgrad3_x3_kernel(const WgradArgs p) {
   __shared__ __attribute__((aligned(16))) float red[3 * 64 * 16];
   const int lane = threadIdx.x & 63;
@@ -82,6 +103,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dmul = 1.f, ddiv = 1.f;
+  if (NP == 2 && p.dy_absmax != nullptr) {
+    unsigned mb = p.dy_absmax[lane * 16];                               // maximum of the 64 slots: one per lane, butterfly
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, d));
+    const int e = mb != 0u ? (int)((mb >> 23) & 0xffu) - 126 : 14;
+    dmul = __builtin_bit_cast(float, (unsigned)(14 - e + 127) << 23);
+    ddiv = __builtin_bit_cast(float, (unsigned)(e - 14 + 127) << 23);
+  }
 
   for (int u = u0; u < u1; ++u) {
     int q = u;
@@ -123,7 +153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     };
     // the producer's GroupNorm + ReLU (MODE 1), zero padding AFTER it, then the three-piece split
-    auto convX = [&](int yy, const float (&raw)[10], XRow &row) {
+    auto convX = [&](int yy, const float (&raw)[10], XRow<NP> &row) {
       const unsigned rinv = inv31(yy, H);
       float v[10];
 #pragma unroll
@@ -137,10 +167,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         v[k] = t;
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) split3(v[2 * j], v[2 * j + 1], row.p[0][j], row.p[1][j], row.p[2][j]);
+      for (int j = 0; j < 5; ++j) {
+        unsigned q[NP];
+        splitn<NP>(v[2 * j], v[2 * j + 1], q);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) row.p[pc][j] = q[pc];
+      }
     };
     // A fragment (8 bf16 = 4 dwords) of a window row for tap column kw: pixels kw .. kw + 7 of the 10 held
-    auto afrag = [&](const XRow &row, int pc, int kw) -> u32x4 {
+    auto afrag = [&](const XRow<NP> &row, int pc, int kw) -> u32x4 {
       const unsigned *r = row.p[pc];
       if (kw == 0) return u32x4{r[0], r[1], r[2], r[3]};
       if (kw == 2) return u32x4{r[1], r[2], r[3], r[4]};
@@ -148,12 +183,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    __builtin_amdgcn_alignbit(r[3], r[2], 16), __builtin_amdgcn_alignbit(r[4], r[3], 16)};
     };
     // the 18 MFMAs of one kernel row kh: three kw taps x six product terms, against dY pieces d[3][4]
-    auto mfma_row = [&](const XRow &row, int kh, const unsigned (&d)[3][4]) {
-      const u32x4 b0 = u32x4{d[0][0], d[0][1], d[0][2], d[0][3]}, b1 = u32x4{d[1][0], d[1][1], d[1][2], d[1][3]},
-                  b2 = u32x4{d[2][0], d[2][1], d[2][2], d[2][3]};
+    auto mfma_row = [&](const XRow<NP> &row, int kh, const unsigned (&d)[NP][4]) {
+      const u32x4 b0 = u32x4{d[0][0], d[0][1], d[0][2], d[0][3]}, b1 = u32x4{d[1][0], d[1][1], d[1][2], d[1][3]};
+      if constexpr (NP == 2) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const u32x4 a0 = afrag(row, 0, kw), a1 = afrag(row, 1, kw);
+          f32x16 &c = acc[kh * 3 + kw];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), c, 0, 0, 0);
+        }
+        return;
+      }
+      const u32x4 b2 = u32x4{d[NP - 1][0], d[NP - 1][1], d[NP - 1][2], d[NP - 1][3]};
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const u32x4 a0 = afrag(row, 0, kw), a1 = afrag(row, 1, kw), a2 = afrag(row, 2, kw);
+        const u32x4 a0 = afrag(row, 0, kw), a1 = afrag(row, 1, kw), a2 = afrag(row, NP - 1, kw);
         f32x16 &c = acc[kh * 3 + kw];
         // smallest terms first: a1 b1, a2 b0, a0 b2, a1 b0, a0 b1, a0 b0
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b1), c, 0, 0, 0);
@@ -165,12 +211,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     };
 
-    XRow win[3];
-    unsigned dpk[3][4];
+    XRow<NP> win[3];
+    unsigned dpk[NP][4];
     float xr[10], dr[8];
-    auto convD = [&](const float (&raw)[8], unsigned (&d)[3][4]) {
+    auto convD = [&](const float (&raw)[8], unsigned (&d)[NP][4]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) split3(raw[2 * j], raw[2 * j + 1], d[0][j], d[1][j], d[2][j]);
+      for (int j = 0; j < 4; ++j) {
+        unsigned q[NP];
+        if constexpr (NP == 2)
+          splitn<NP>(raw[2 * j] * dmul, raw[2 * j + 1] * dmul, q);
+        else
+          splitn<NP>(raw[2 * j], raw[2 * j + 1], q);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) d[pc][j] = q[pc];
+      }
     };
     // prologue of the unit: rows ya - 1, ya, ya + 1 converted; row ya + 2 and dY row ya in flight
     {                                                       // (all three rows in flight at once: one memory latency, not three)
@@ -210,6 +264,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // the four waves of the workgroup meet in LDS, tap by tap, in wave order; wave 0 writes the workgroup's partial
   // (C/D layout: col j (= co) = lane & 31, row i (= ci) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  if (NP == 2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= ddiv;
+  }
   const long unit = (long)pair * p.chunks + chunk;
   float *dst = p.partial + unit * 9 * 1024;
 #pragma unroll
@@ -274,10 +334,14 @@ bool wgrad_x3_plan(WgradArgs &a) {
 
 hipError_t launch_wgrad_x3(const WgradArgs &a, hipStream_t s) {
   dim3 grid((unsigned)(a.pairs * a.chunks));
-  if (a.mode == 1)
-    hipLaunchKernelGGL((wgrad3_x3_kernel<1>), grid, dim3(256), 0, s, a);
+  if (a.np == 2 && a.mode == 1)
+    hipLaunchKernelGGL((wgrad3_x3_kernel<1, 2>), grid, dim3(256), 0, s, a);
+  else if (a.np == 2)
+    hipLaunchKernelGGL((wgrad3_x3_kernel<0, 2>), grid, dim3(256), 0, s, a);
+  else if (a.mode == 1)
+    hipLaunchKernelGGL((wgrad3_x3_kernel<1, 3>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((wgrad3_x3_kernel<0>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wgrad3_x3_kernel<0, 3>), grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
