@@ -61,6 +61,30 @@ def test_two_gpu_train_step_equals_one_gpu_step_on_the_concatenated_batch():
     _run("train")
 
 
+def test_bench_headline_with_its_secondary_runs_as_two_ranks_sharing_one_gpu():
+    """The driver's default command at N = 2: the headline plus its `secondary` measurements (dual bf16, training step with the
+    bucketed gradient all-reduce and the statistics collectives, sensor-frame variants) — every rank walks the same collectives."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--backend", "gloo", "--shared-gpu", "--no-cpu-baseline", "--batch", "128"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    sec = rec["secondary"]
+    assert rec["n_gpus"] == 2 and set(sec) >= {"dual_bf16", "train", "fwd_fp32_from_sensor_frames"}
+    for k in ("dual_bf16", "train"):
+        assert "error" not in sec[k], sec[k]
+        assert sec[k]["value"] > 0
+    assert sec["fwd_fp32_from_sensor_frames"]["bit_identical_to_headline_outputs"] is True
+    assert sec["train"]["gradient_allreduce"].startswith("bucketed")
+
+
 @pytest.mark.parametrize("config", ["fwd_fp32", "train"])
 def test_bench_two_ranks_sharing_one_gpu(config):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run), both ranks on cuda:0 over gloo: the real timed
