@@ -350,6 +350,19 @@ def main():
                 secondary[name] = slim_secondary(name, full)
         torch.cuda.empty_cache()
 
+    navloop = None
+    if not args.no_secondary and rank == 0 and B >= 128:
+        # BASELINE configs[4] cannot run here (no habitat-sim / Gibson scenes): its GPU side — policy step + batched VO through the
+        # boundary (host numpy frames in, PCIe included) + goal update per simulator step, 8 environments of one process
+        try:
+            from tools import bench_navloop
+            nl = bench_navloop.run([8], 20, 150.0, dev)
+            navloop = {"workload": "GPU side of BASELINE configs[4]'s loop per simulator step (policy.act + VO boundary call + goal update; "
+                                   "the simulator itself is not emulated), 8 environments, host numpy observations",
+                       **nl["results"][0], "unit": nl["unit"], "note": nl["note"]}
+        except Exception as e:
+            navloop = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / dt
@@ -405,6 +418,8 @@ def main():
             res["secondary"] = secondary
         if raw_rec is not None:
             res.setdefault("secondary", {})["fwd_fp32_from_sensor_frames"] = raw_rec
+        if navloop is not None:
+            res.setdefault("secondary", {})["navloop_gpu_side"] = navloop
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)
         print(json.dumps(res))

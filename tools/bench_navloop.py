@@ -48,7 +48,14 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--episode-steps", type=float, default=150.0, help="mean steps per episode used for the extrapolation")
     a = ap.parse_args()
-    dev = torch.device("cuda", 0)
+    print(json.dumps(run(a.envs, a.steps, a.episode_steps, torch.device("cuda", 0))))
+
+
+def run(envs, steps, episode_steps=150.0, dev=None):
+    """-> the result record (also what bench.py reports under secondary["navloop_gpu_side"])."""
+    import types
+    a = types.SimpleNamespace(envs=envs, steps=steps, episode_steps=episode_steps)
+    dev = dev if dev is not None else torch.device("cuda", 0)
     cfg = AttrDict(
         VO=dict(VO_TYPE="REGRESS", OBS_TRANSFORM="none", VIS_SIZE_W=W, VIS_SIZE_H=H,
                 REGRESS_MODEL=dict(name="vo_cnn_rgb_d_dd_top_down", visual_backbone="resnet18", hidden_size=512,
@@ -104,7 +111,7 @@ def main():
                                "gpu_side_minutes_for_994_episodes": 994 * a.episode_steps / (E / dt) / 60.0})
     res["note"] = (f"extrapolation assumes {a.episode_steps:.0f} steps per episode on one GPU; the reference's 4.5 h includes "
                    "the simulator, which is not emulated here")
-    print(json.dumps(res))
+    return res
 
 
 if __name__ == "__main__":
