@@ -688,6 +688,13 @@ bool pnvo_stem_on_mx(pnvo_handle m) {
 
 // An event behind a contract-checking stem launch (see pnvo_input_fallback); nothing while a stream capture is under way
 // (an event recorded into a graph cannot be waited for: such forwards keep the deferred check of pnvo_check_inputs).
+// Does the stem kernel pnvo_run_stem would launch leave per-tile statistics ([B][slots][CP][2]) in m->stats?
+bool stem_writes_slots(pnvo_handle m) {
+  const Layer &stem = m->convs[0];
+  const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
+  return pnvo_stem_on_mx(m) || (m->dd_ok && m->opt.stem != 3 && !m->dense_sticky) || lds_stem;
+}
+
 int pnvo_mark_stem(pnvo_handle m, hipStream_t s) {
   if (!m->opt.input_fallback || m->dense_sticky || !m->dd_flag) return PNVO_OK;
   if (m->raw_depth != nullptr) return PNVO_OK;      // sensor frames: uint8 rgb, one-hot derived in the stager — inside the contract by construction
@@ -761,7 +768,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
-    {
+    m->stem_slots_out = a.slots;
+    if (!m->stem_skip_finalize) {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
                                    stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
@@ -810,7 +818,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       HIPCHK(m, launch_stem_dd(a, s));
     }
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
-    {
+    m->stem_slots_out = a.slots;
+    if (!m->stem_skip_finalize) {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
                                    stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
@@ -849,7 +858,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
               4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
       HIPCHK(m, launch_stem_lds(a, stem.coutp, s));
     }
-    {
+    m->stem_slots_out = a.slots;
+    if (!m->stem_skip_finalize) {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
                                    stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
@@ -896,7 +906,10 @@ const OptDef kOptions[] = {
     {"bf16_fuse", nullptr, &PnvoOptions::bf16_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"bf16_stem3", "PNVO_BF16_STEM3", &PnvoOptions::bf16_stem3, true, {{nullptr, 0}}},
     {"input_fallback", "PNVO_INPUT_FALLBACK", &PnvoOptions::input_fallback, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
-    {"small_tail", "PNVO_SMALL_TAIL", &PnvoOptions::small_tail, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"small_net", "PNVO_SMALL_NET", &PnvoOptions::small_net, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"small_max", "PNVO_SMALL_MAX", &PnvoOptions::small_max, true, {{nullptr, 0}}},
+    {"small_coop", "PNVO_SMALL_COOP", &PnvoOptions::small_coop, true, {{nullptr, 0}}},
+    {"small_prof", "PNVO_SMALL_PROF", &PnvoOptions::small_prof, true, {{nullptr, 0}}},
 };
 
 const OptDef *find_option(const char *key) {
@@ -1231,6 +1244,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     std::vector<float> vis((size_t)c.hidden * flat);
     for (int o = 0; o < c.hidden; ++o) std::memcpy(&vis[(size_t)o * flat], w1 + (size_t)o * fc_in, sizeof(float) * flat);
     std::vector<float> pk;
+    h->fc.host_w = vis;                                    // (smallnet.hip packs its own layout from these)
     pack_conv_weight_cinp(vis.data(), c.hidden, h->comp_c, h->comp_cp, h->fh, h->fw, pk);
     if ((rc = upload(h, h->fc.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
     const int rows = c.act_embed ? c.n_acts + 1 : 1;
@@ -1255,6 +1269,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
   if (!b2) return rc;
   {
     std::vector<float> pk;
+    h->head.host_w.assign(w2, w2 + (size_t)c.out_dim * c.hidden);
     pack_conv_weight_cinp(w2, c.out_dim, c.hidden, c.hidden, 1, 1, pk);
     if ((rc = upload(h, h->head.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
     if ((rc = upload(h, h->head_bias, b2, c.out_dim)) != PNVO_OK) return rc;
@@ -1474,6 +1489,17 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   float *cur = m->bufY[0], *nxt = m->bufY[1];
   const bool pool_fused = !m->bottleneck && pnvo_stem_on_mx(m) && m->opt.pool && m->convs.size() > 1 &&
                           stem.coutp == stem.cout && pnvo_conv_takes_tail(m, m->convs[1], B);
+  // Batches of the navigation loop (one or two pairs): everything behind the stem conv is ONE persistent launch (smallnet.hip),
+  // which also reduces the stem's GroupNorm statistics itself.
+  const bool small = !pool_fused && stem_writes_slots(m) && pnvo_small_usable(m, B);
+  if (small) {
+    const float *src[4] = {rgb, depth, dd, tdv};
+    m->stem_skip_finalize = true;
+    rc = pnvo_run_stem(m, B, src, m->stem_raw, m->ssA, nullptr, nullptr, s, nullptr);
+    m->stem_skip_finalize = false;
+    if (rc != PNVO_OK) return rc;
+    return pnvo_small_forward(m, B, c.act_embed ? actions : nullptr, out, s);
+  }
   {
     const float *src[4] = {rgb, depth, dd, tdv};
     if (pool_fused) {
@@ -1903,6 +1929,7 @@ int pnvo_destroy(pnvo_handle m) {
   (void)hipSetDevice(m->device);
   pnvo_train_free(m);
   pnvo_bf16_free(m);
+  pnvo_small_free(m);
   free_workspace(m);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   if (m->stem_ev) (void)hipEventDestroy(m->stem_ev);

@@ -49,7 +49,10 @@ struct PnvoOptions {
   int bf16_fuse = 1;   // bf16 path: block tails fused
   int bf16_stem3 = 0;  // bf16 path: exact three-piece stem (experiment)
   int input_fallback = 1;   // contract-breaking input (fractional rgb, soft depth codes): re-run on the dense stem and stay on it
-  int small_tail = 1;  // small batches: stages 3-4 + compression + Linear layers in one persistent kernel
+  int small_net = 1;   // batches of <= small_max pairs: everything behind the stem conv in ONE persistent launch (smallnet.hip)
+  int small_max = 2;   // largest batch the persistent kernel takes (it handles up to 4)
+  int small_prof = 0;  // developer instrumentation: per-phase times of the persistent kernel on stderr
+  int small_coop = 1;  // its launch is cooperative (hipLaunchCooperativeKernel); 0: plain launch of <= one workgroup per CU
 };
 
 struct TimingRec {
@@ -135,6 +138,9 @@ struct pnvo_model_s {
 
   bool features_only = false;        // pnvo_forward_features: stop after the hidden layer
   void *train = nullptr;             // TrainState (pnvo_train_api.hip), present after pnvo_train_attach
+  void *small = nullptr;             // SmallNet (smallnet.hip): the persistent small-batch kernel's operands, built on first use
+  int stem_slots_out = 0;            // statistics slots per sample the last stem launch wrote into `stats` ([B][slots][CP][2])
+  bool stem_skip_finalize = false;   // the consumer of this forward's stem reduces those slots itself (smallnet.hip)
 
   // Opt-in (PNVO_GRAPH=1): the whole forward (~60 launches) captured once per (batch, tensor addresses, kernel
   // selection) into a hipGraph and replayed (see pnvo_forward for the measurement that keeps it off by default).
@@ -187,6 +193,9 @@ void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
 const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name);   // pnvo_train_api.hip: device pointer or nullptr
 const float *pnvo_train_x2_scale(pnvo_handle m, const std::string &name);     // device {scale, 1/scale} of that conv weight's float16 pieces, or nullptr
 void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip
+bool pnvo_small_usable(pnvo_handle m, int B);   // smallnet.hip: does this call shape take the persistent kernel?
+int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out, hipStream_t s);
+void pnvo_small_free(pnvo_handle m);
 int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *depth, const float *dd, const float *tdv,
                       const int64_t *actions, int B, float *const *outs, hipStream_t s);
 int pnvo_fail(pnvo_handle h, int code, const std::string &msg);
