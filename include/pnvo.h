@@ -98,6 +98,11 @@ int pnvo_forward(pnvo_handle h, const float *rgb, const float *depth, const floa
  *   "x3_s2"           on | off                               stride-2 convs on the 3-piece kernel
  *   "tail", "pool"    fused | separate                       BasicBlock tails / the max-pool folded into neighbouring kernels
  *   "input_fallback"  on | off                               see pnvo_check_inputs
+ *   "small_net"       on | off                               batches of <= small_max pairs (the navigation loop's call shape,
+ *   "small_max"       4 (1..4)                               rl/ppo/ppo_trainer.py:836-841): everything behind the stem conv in ONE
+ *   "small_coop"      0 | 1                                  persistent launch (smallnet.hip) — default models with BasicBlock
+ *                                                            backbones, options conv/tail/pool at their defaults, no tap.
+ *                                                            small_coop = 1 launches it with hipLaunchCooperativeKernel
  *   "graph"           0 | 1                                  replay the forward from a captured hipGraph
  *   "wgrad_stem"      mx | fp32        "pool_bwd" fused | separate        "dgrad" phase | masked        (training step)
  *   "bf16_fuse"       on | off         "bf16_stem3" 0 | 1    "conv3_nt" 0 | 1   "stem_dbg" <int>            (experiments)
@@ -383,8 +388,9 @@ int pnvo_forward_features(pnvo_handle h, const float *rgb, const float *depth, c
 int pnvo_check_inputs(pnvo_handle h);
 
 /* Which kernel family a conv of the residual stages / the compression conv (state_dict prefix, e.g.
- * "visual_encoder.backbone.layer1.0.convs.0") runs on at batch B with the handle's current options — "x3" (float32 results
- * from six bf16 MFMA terms per product), "fp32-lds", "fp32-generic" — and the matrix-core FLOPs one launch EXECUTES (tile and
+ * "visual_encoder.backbone.layer1.0.convs.0") runs on at batch B with the handle's current options — "x2" / "x3" (float32 results
+ * from three float16 / six bf16 MFMA terms per product), "fp32-lds", "fp32-generic", "smallnet" (a phase of the persistent
+ * small-batch kernel: option small_net, batches <= small_max) — and the matrix-core FLOPs one launch EXECUTES (tile and
  * channel padding and the six-term expansion included): what bench.py prices against the peak of that pipe. */
 int pnvo_layer_kernel(pnvo_handle h, const char *name, int B, char *family, size_t cap, double *executed_flops);
 

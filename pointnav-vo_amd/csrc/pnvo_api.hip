@@ -2029,6 +2029,14 @@ int pnvo_layer_kernel(pnvo_handle h, const char *name, int B, char *family, size
     const Layer &l = h->convs[li];
     if (l.name != name) continue;
     const double alg = 2.0 * B * l.hout * l.wout * (double)l.cout * l.cin * l.k * l.kw;
+    if (stem_writes_slots(h) && pnvo_small_usable(h, B)) {      // a phase of the persistent small-batch kernel (fp32 MFMA)
+      std::snprintf(family, cap, "smallnet");
+      if (executed_flops) {
+        const int mb = l.cinp >= 128 ? 1 : l.cinp >= 64 ? 2 : 4, th = mb == 4 ? 8 : 4, tw = mb == 1 ? 4 : 8;
+        *executed_flops = 2.0 * B * ((l.hout + th - 1) / th) * ((l.wout + tw - 1) / tw) * (th * tw) * (double)rup(l.cout, 16) * l.cinp * l.k * l.kw;
+      }
+      return PNVO_OK;
+    }
     ConvX3Args xa;
     int mw, nw;
     size_t ldsb;

@@ -50,9 +50,9 @@ struct PnvoOptions {
   int bf16_stem3 = 0;  // bf16 path: exact three-piece stem (experiment)
   int input_fallback = 1;   // contract-breaking input (fractional rgb, soft depth codes): re-run on the dense stem and stay on it
   int small_net = 1;   // batches of <= small_max pairs: everything behind the stem conv in ONE persistent launch (smallnet.hip)
-  int small_max = 2;   // largest batch the persistent kernel takes (it handles up to 4)
+  int small_max = 4;   // largest batch the persistent kernel takes (1..4: faster than the per-layer launches up to there)
   int small_prof = 0;  // developer instrumentation: per-phase times of the persistent kernel on stderr
-  int small_coop = 1;  // its launch is cooperative (hipLaunchCooperativeKernel); 0: plain launch of <= one workgroup per CU
+  int small_coop = 0;  // 1: its launch is cooperative (hipLaunchCooperativeKernel, +17 us); 0: plain launch of <= 144 workgroups (two fit per CU)
 };
 
 struct TimingRec {

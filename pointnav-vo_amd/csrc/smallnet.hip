@@ -77,6 +77,7 @@ struct SnArgs {
   int *err;
   const int64_t *bias_row;   // [B] or nullptr (act-embed variants: row of the first Linear layer's bias table)
   float *final_out;          // the caller's [B, out_dim]
+  int final_n;               // B * out_dim (a barrier that times out leaves NaNs there: never a plausible wrong pose)
   int dbg;                   // small_prof = 2: barriers only; 3: barriers without the cache write-back / invalidate (timing experiments)
   unsigned long long *prof;  // option small_prof: per phase {block 0 start, block 0 end, max phase time, max barrier wait} (10 ns ticks)
 };
@@ -94,17 +95,38 @@ __device__ __forceinline__ T *sn_uni(T *q) {            // a pointer read from t
   return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 
+// Data that crosses workgroups inside the launch (conv outputs, GroupNorm partials, block outputs, the hidden vector) is written
+// and read with AGENT-scope accesses (sc1: write-through / coherent across the per-XCD L2s), so the grid barrier needs no L2
+// write-back or invalidate — and weights, the instruction stream and the phase table stay cached across phases.
+typedef __amdgpu_buffer_rsrc_t sn_rsrc_t;
+constexpr int SN_SC1 = 16;
+__device__ __forceinline__ sn_rsrc_t sn_rsrc(const void *q) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(q), 0, 0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ sn_f32x4 sn_ld4(sn_rsrc_t r, unsigned fidx) {
+  return __builtin_bit_cast(sn_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, fidx * 4u, 0, SN_SC1));
+}
+__device__ __forceinline__ float2 sn_ld2(sn_rsrc_t r, unsigned fidx) {
+  return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, fidx * 4u, 0, SN_SC1));
+}
+__device__ __forceinline__ void sn_st4(sn_rsrc_t r, unsigned fidx, sn_f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, fidx * 4u, 0, SN_SC1);
+}
+__device__ __forceinline__ void sn_st2(sn_rsrc_t r, unsigned fidx, float2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, v), r, fidx * 4u, 0, SN_SC1);
+}
+__device__ __forceinline__ void sn_st1(sn_rsrc_t r, unsigned fidx, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, fidx * 4u, 0, SN_SC1);
+}
+
 // Grid barrier in two halves.  ARRIVE as soon as a phase's last store is issued: every wave waits for its own stores, the
-// workgroup meets, thread 0 writes the XCD's L2 back and bumps the device-scope counter.  Then the workgroup prepares the
+// workgroup meets, thread 0 bumps the device-scope counter.  Then the workgroup prepares the
 // next phase (tile, weight fragments, addresses: nothing that depends on other workgroups) and only then WAITS: thread 0 polls
-// the counter, invalidates, the workgroup meets again.  A bounded spin turns an impossible wait into an error flag.
+// the counter, the workgroup meets again.  A bounded spin turns an impossible wait into an error flag.
 __device__ __forceinline__ void sn_grid_arrive(unsigned *ctr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool sn_grid_wait(unsigned *ctr, unsigned target, int *err, int *flag) {
   if (threadIdx.x == 0) {
@@ -117,7 +139,6 @@ __device__ __forceinline__ bool sn_grid_wait(unsigned *ctr, unsigned target, int
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (bad) *err = 1;
     *flag = bad;
   }
@@ -153,6 +174,7 @@ __device__ __forceinline__ void sn_gn_rows(const SnGN &g, int gi, int n, bool ac
   const float g_inv = __builtin_bit_cast(float, sn_uni(__builtin_bit_cast(int, g.inv_cnt)));
   const int nk = g_layout == 0 ? g_slots : g_slots << g_lgcpg;
   const float2 *pp = reinterpret_cast<const float2 *>(sn_uni(g.part)) + (g_layout == 0 ? 0u : (unsigned)(n * g_slots * g_CP));
+  const sn_rsrc_t rp = sn_rsrc(pp);          // layout 0: partials written by other workgroups of this launch
   const unsigned row0 = g_layout == 0 ? (unsigned)((n * g_G + gi) * g_slots) : 0u;
   float2 v[NJ];
   float gm[2] = {0.f, 0.f}, bt[2] = {0.f, 0.f};
@@ -167,7 +189,7 @@ __device__ __forceinline__ void sn_gn_rows(const SnGN &g, int gi, int n, bool ac
       const int slot = kc >> g_lgcpg;
       idx = (unsigned)(slot * g_CP + (gi << g_lgcpg) + (kc - (slot << g_lgcpg)));
     }
-    v[j] = pp[idx];
+    v[j] = sn_ld2(rp, idx * 2u);
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -193,7 +215,7 @@ __device__ __forceinline__ void sn_gn_rows(const SnGN &g, int gi, int n, bool ac
         idx = (unsigned)(slot * g_CP + (gi << g_lgcpg) + (kk - (slot << g_lgcpg)));
       }
       if (act) {
-        const float2 u = pp[idx];
+        const float2 u = sn_ld2(rp, idx * 2u);
         s1 += (double)u.x;
         s2 += (double)u.y;
       }
@@ -213,6 +235,14 @@ __device__ __forceinline__ void sn_gn_rows(const SnGN &g, int gi, int n, bool ac
       const float sv = rstd * gm[h];
       sc[ch] = ch < g_C ? sv : 0.f;
       sh[ch] = ch < g_C ? __builtin_fmaf(-muf, sv, bt[h]) : 0.f;
+    }
+  }
+  for (int c = l16 + 32; c < g_cpg; c += 16) {       // groups of more than 32 channels (GroupNorm(1, C) of a 64-channel compression)
+    const int ch = (gi << g_lgcpg) + c;
+    if (act) {
+      const float sv = ch < g_C ? rstd * g_gamma[ch] : 0.f;
+      sc[ch] = sv;
+      sh[ch] = ch < g_C ? __builtin_fmaf(-muf, sv, g_beta[ch]) : 0.f;
     }
   }
 }
@@ -239,8 +269,6 @@ __device__ __forceinline__ void sn_gn_tables(const SnGN &ga, float *sca, float *
     const int nk = sn_uni(g.layout) == 0 ? sn_uni(g.slots) : sn_uni(g.slots) << sn_uni(g.lgcpg);
     if (nk <= 32)
       sn_gn_rows<2>(g, gi, n, act, l16, sc, sh);
-    else if (nk <= 80)
-      sn_gn_rows<5>(g, gi, n, act, l16, sc, sh);
     else
       sn_gn_rows<17>(g, gi, n, act, l16, sc, sh);
   }
@@ -272,6 +300,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
   const float *p_in = sn_uni(p.in), *p_res = sn_uni(p.res), *p_w = sn_uni(p.w), *p_wds = sn_uni(p.w_ds);
   float *p_blk = sn_uni(p.blk_out), *p_out = sn_uni(p.out), *p_part = sn_uni(p.part), *p_outds = sn_uni(p.out_ds), *p_partds = sn_uni(p.part_ds);
   const int *p_tiles = sn_uni(p.tiles);
+  const sn_rsrc_t r_in = sn_rsrc(p_in), r_res = sn_rsrc(p_res), r_blk = sn_rsrc(p_blk);
   const bool has_ds = ST == 2 && p_wds != nullptr;
 
   int n = 0, nt = 0, txi = 0, tyi = 0;
@@ -284,14 +313,27 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
     txi = (tw >> 8) & 255;
     tyi = (tw >> 16) & 255;
     n = tw >> 24;
-    const float *wp = p_w + (size_t)nt * (9 * C4 * 64) + lane;
+    // (weights are packed per wave in the order of its K walk, four steps per lane and load: sn_pack_conv)
+    const sn_f32x4 *wp = reinterpret_cast<const sn_f32x4 *>(p_w) + ((size_t)(nt * KS + ks) * (NSTEP / 4)) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < NSTEP; ++j) b[j] = wp[((j / SPT) * C4 + ks + (j % SPT) * KS) * 64];
+    for (int j = 0; j < NSTEP / 4; ++j) {
+      const sn_f32x4 q = wp[j * 64];
+      b[4 * j] = q[0];
+      b[4 * j + 1] = q[1];
+      b[4 * j + 2] = q[2];
+      b[4 * j + 3] = q[3];
+    }
     if (ST == 2) {
       if (has_ds) {
-        const float *wd = p_wds + (size_t)nt * (C4 * 64) + lane;
+        const sn_f32x4 *wd = reinterpret_cast<const sn_f32x4 *>(p_wds) + ((size_t)(nt * KS + ks) * (SPT / 4)) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) bd[i] = wd[(ks + i * KS) * 64];
+        for (int j = 0; j < SPT / 4; ++j) {
+          const sn_f32x4 q = wd[j * 64];
+          bd[4 * j] = q[0];
+          bd[4 * j + 1] = q[1];
+          bd[4 * j + 2] = q[2];
+          bd[4 * j + 3] = q[3];
+        }
       }
     }
     const int iy0 = tyi * (TH * ST) - 1, ix0 = txi * (TW * ST) - 1;
@@ -337,12 +379,12 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
     sn_f32x4 va[NIT], vr[NIT];
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {          // (unconditional: out-of-image items read offset 0 and are zeroed below)
-      va[j] = *reinterpret_cast<const sn_f32x4 *>(p_in + gofs[j]);
+      va[j] = sn_ld4(r_in, gofs[j]);
       vr[j] = sn_f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (mode >= 2) {
 #pragma unroll
-      for (int j = 0; j < NIT; ++j) vr[j] = *reinterpret_cast<const sn_f32x4 *>(p_res + gofs[j]);
+      for (int j = 0; j < NIT; ++j) vr[j] = sn_ld4(r_res, gofs[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
     SN_STAMP(0);
@@ -381,7 +423,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          if (mode >= 2 && p_blk != nullptr && ((own >> j) & 1u)) *reinterpret_cast<sn_f32x4 *>(p_blk + gofs[j]) = v;
+          if (mode >= 2 && p_blk != nullptr && ((own >> j) & 1u)) sn_st4(r_blk, gofs[j], v);
         }
         *reinterpret_cast<sn_f32x4 *>(patch + pp * CS + c4 * 4) = v;
       }
@@ -428,8 +470,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += u[e];
       }
-      float *out = which ? p_outds : p_out;
-      float *part = which ? p_partds : p_part;
+      const sn_rsrc_t r_out = sn_rsrc(which ? p_outds : p_out), r_part = sn_rsrc(which ? p_partds : p_part);
       const int col = lane & 15, rg = lane >> 4;
       const int oy0 = tyi * TH, ox0 = txi * TW;
       float s1 = 0.f, s2 = 0.f;
@@ -438,7 +479,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
         const int pl = mbe * 16 + rg * 4 + e;
         const int oy = oy0 + (pl >> LGTW), ox = ox0 + (pl & (TW - 1));
         if (oy < Ho && ox < Wo) {
-          out[(unsigned)(((n * Ho + oy) * Wo + ox) * coutp + nt * 16 + col)] = v[e];
+          sn_st1(r_out, (unsigned)(((n * Ho + oy) * Wo + ox) * coutp + nt * 16 + col), v[e]);
           s1 += v[e];
           s2 = __builtin_fmaf(v[e], v[e], s2);
         }
@@ -466,7 +507,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
         float2 pr;
         pr.x = s1;
         pr.y = s2;
-        reinterpret_cast<float2 *>(part)[(unsigned)((n * out_G + g) * out_slots + slot)] = pr;
+        sn_st2(r_part, (unsigned)((n * out_G + g) * out_slots + slot) * 2u, pr);
       }
     }
   }
@@ -490,6 +531,7 @@ __device__ void sn_pool_phase(const SnPhase &p, int B, float *lds) {
   __syncthreads();
   const int Q = p.cinp >> 2;
   const int total = B * p.Ho * p.Wo * Q;
+  const sn_rsrc_t r_out = sn_rsrc(sn_uni(p.out));
   for (int g = blockIdx.x * SN_THREADS + tid; g < total; g += gridDim.x * SN_THREADS) {
     const int q = g % Q;
     int r = g / Q;
@@ -515,7 +557,7 @@ __device__ void sn_pool_phase(const SnPhase &p, int B, float *lds) {
     for (int k = 0; k < 9; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], __builtin_fmaf(v[k][e], a[e], b[e]));
-    reinterpret_cast<sn_f32x4 *>(p.out)[g] = m;
+    sn_st4(r_out, (unsigned)g * 4u, m);
   }
 }
 
@@ -549,6 +591,7 @@ __device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int
     t0 = wall_clock64();
     if (blockIdx.x == 0) a.prof[pi * 4 + 0] = t0;
   }
+  const sn_rsrc_t r_lin = sn_rsrc(sn_uni(p.in));
   if ((int)blockIdx.x < p.ntiles) {
     if (p.in_mode == 1) {
       for (int n = 0; n < B; ++n) sn_gn_tables(p.gin, sc + n * p.cinp, sh + n * p.cinp, false, p.gin, nullptr, nullptr, n, tid);
@@ -557,7 +600,7 @@ __device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int
     {
       const int C4 = p.cinp >> 2;
       for (int it = tid; it < B * K4; it += SN_THREADS) {
-        sn_f32x4 v = reinterpret_cast<const sn_f32x4 *>(p.in)[it];
+        sn_f32x4 v = sn_ld4(r_lin, (unsigned)it * 4u);
         if (p.in_mode == 1) {
           const int n = it / K4, c4 = (it - n * K4) & (C4 - 1);
           const sn_f32x4 s = *reinterpret_cast<const sn_f32x4 *>(sc + n * p.cinp + c4 * 4);
@@ -625,8 +668,10 @@ __device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int
           for (int k = 0; k < SN_KP; ++k) v += red[(k * 4 + ol2) * SN_MAXB + b];
           if (p.bias != nullptr) v += p.bias[(size_t)(a.bias_row != nullptr && p.use_row ? a.bias_row[b] : 0) * p.cout + o2];
           if (p.relu_out) v = fmaxf(v, 0.f);
-          float *dst = p.out != nullptr ? p.out : a.final_out;
-          dst[(size_t)b * p.coutp + o2] = v;
+          if (p.out != nullptr)
+            sn_st1(sn_rsrc(p.out), (unsigned)(b * p.coutp + o2), v);   // the hidden vector: read by the head phase of other workgroups
+          else
+            a.final_out[(size_t)b * p.coutp + o2] = v;
         }
       }
     }
@@ -702,21 +747,29 @@ __global__ __launch_bounds__(SN_THREADS) void smallnet_kernel(SnArgs a) {
     } else {
       ok = sn_linear(a, p, pi, sn_lds, &flag);
     }
-    if (!ok) return;
+    if (!ok) {
+      if ((int)threadIdx.x < a.final_n) a.final_out[threadIdx.x] = __builtin_nanf("");
+      return;
+    }
     if (pi + 1 < a.nph) sn_grid_arrive(a.bar);
   }
 }
 
-// [NT][taps * cinp/4][64]: lane (j = lane & 15, kk = lane >> 4) of K-step (tap, cq) holds W[nt*16 + j][cq*4 + kk][tap]
+// Weights of a conv phase in the order sn_conv's waves walk K: [cout tile nt][wave ks][step group j/4][lane][4], step
+// j = tap * SPT + i of wave ks being K-step (tap, cq = ks + i * KS); lane (col = lane & 15, kk = lane >> 4) holds
+// W[nt*16 + col][cq*4 + kk][tap].  k = 1 (the downsample conv): one tap.
 void sn_pack_conv(const float *oihw, int cout, int cin, int cinp, int k, std::vector<float> &out) {
-  const int T = k * k, C4 = cinp / 4, Q = T * C4, NT = (cout + 15) / 16;
-  out.assign((size_t)NT * Q * 64, 0.f);
+  const int T = k * k, C4 = cinp / 4, NT = (cout + 15) / 16;
+  const int KS = std::min(SN_WAVES, C4 / 4), SPT = C4 / KS, NSTEP = T * SPT;
+  out.assign((size_t)NT * KS * NSTEP * 64, 0.f);
   for (int nt = 0; nt < NT; ++nt)
-    for (int tap = 0; tap < T; ++tap)
-      for (int cq = 0; cq < C4; ++cq)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int j = 0; j < NSTEP; ++j)
         for (int lane = 0; lane < 64; ++lane) {
+          const int tap = j / SPT, cq = ks + (j % SPT) * KS;
           const int co = nt * 16 + (lane & 15), ci = cq * 4 + (lane >> 4);
-          if (co < cout && ci < cin) out[((size_t)(nt * Q + tap * C4 + cq)) * 64 + lane] = oihw[((size_t)co * cin + ci) * T + tap];
+          if (co < cout && ci < cin)
+            out[((((size_t)(nt * KS + ks) * (NSTEP / 4) + j / 4) * 64) + lane) * 4 + j % 4] = oihw[((size_t)co * cin + ci) * T + tap];
         }
 }
 
@@ -777,6 +830,7 @@ bool pnvo_small_usable(pnvo_handle m, int B) {
   if (!m->opt.small_net || B < 1 || B > m->opt.small_max || B > SN_MAXB) return false;
   if (m->bottleneck || m->tap_dst != nullptr || m->features_only || m->train != nullptr || m->graph_mode > 0) return false;
   if (m->precision != 0) return false;
+  if (m->opt.conv != 0 || !m->opt.tail || !m->opt.pool || m->opt.conv3_nt) return false;   // an explicit kernel selection is honoured
   SmallNet *sn = static_cast<SmallNet *>(m->small);
   if (sn && (sn->unsupported || sn->failed)) return false;
   const pnvo_config &c = m->cfg;
@@ -1112,6 +1166,7 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
   a.err = sn->err;
   a.bias_row = actions;
   a.final_out = out;
+  a.final_n = B * m->cfg.out_dim;
   a.prof = nullptr;
   a.dbg = m->opt.small_prof;
   if (m->opt.small_prof) {

@@ -34,3 +34,16 @@ with torch.no_grad():
             model.set_option("small_prof", lvl)
             model(obs); model(obs)
         model.set_option("small_prof", "0")
+    if os.environ.get("STRESS"):
+        # coherence stress: alternate inputs, every result against the per-layer path's
+        obs_list = [{k: v[i:i + 1].contiguous() for k, v in full.items()} for i in range(4)]
+        model.set_option("small_net", "off")
+        refs = [model(o).clone() for o in obs_list]
+        model.set_option("small_net", "on")
+        worst = 0.0
+        for it in range(int(os.environ["STRESS"])):
+            i = (it * 7 + it // 3) % 4
+            out = model(obs_list[i])
+            err = ((out - refs[i]).abs().max() / refs[i].abs().max()).item()
+            worst = max(worst, err)
+        print(f"stress: worst rel err over {os.environ['STRESS']} alternating forwards = {worst:.3e}", flush=True)
