@@ -350,6 +350,27 @@ def main():
                 secondary[name] = slim_secondary(name, full)
         torch.cuda.empty_cache()
 
+    latency = None
+    if not args.no_secondary and rank == 0:
+        # the reference's own call shape (rl/ppo/ppo_trainer.py:836-841: ONE pair per environment step): model-only latency of a
+        # batch-1 forward, observation tensors resident, with the persistent small-batch kernel (csrc/smallnet.hip) and with the
+        # per-layer launches it replaces; outputs of the two compared
+        try:
+            with torch.no_grad():
+                o1 = {k: v[:1].contiguous() for k, v in obs.items()}
+                fam = model.layer_kernel("visual_encoder.backbone.layer1.0.convs.0", 1)[0]
+                y_small = model(o1).clone()
+                t_small = time_steps_simple(lambda: model(o1), 200, lambda: torch.cuda.synchronize(dev))
+                model.set_option("small_net", "off")
+                y_layers = model(o1).clone()
+                t_layers = time_steps_simple(lambda: model(o1), 200, lambda: torch.cuda.synchronize(dev))
+                model.set_option("small_net", "on")
+            latency = {"workload": "one frame pair per call (the navigation loop's call shape), observation tensors resident",
+                       "ms_per_call": 1e3 * t_small, "kernel_family": fam, "ms_per_call_per_layer_launches": 1e3 * t_layers,
+                       "calls": 200, "max_abs_diff_between_the_two": float((y_small - y_layers).abs().max())}
+        except Exception as e:
+            latency = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     navloop = None
     if not args.no_secondary and rank == 0 and B >= 128:
         # BASELINE configs[4] cannot run here (no habitat-sim / Gibson scenes): its GPU side — policy step + batched VO through the
@@ -420,6 +441,8 @@ def main():
             res.setdefault("secondary", {})["fwd_fp32_from_sensor_frames"] = raw_rec
         if navloop is not None:
             res.setdefault("secondary", {})["navloop_gpu_side"] = navloop
+        if latency is not None:
+            res.setdefault("secondary", {})["batch1_latency"] = latency
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, model.cfg.ngroups)
         print(json.dumps(res))
