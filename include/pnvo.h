@@ -100,9 +100,14 @@ int pnvo_forward(pnvo_handle h, const float *rgb, const float *depth, const floa
  *   "input_fallback"  on | off                               see pnvo_check_inputs
  *   "small_net"       on | off                               batches of <= small_max pairs (the navigation loop's call shape,
  *   "small_max"       4 (1..4)                               rl/ppo/ppo_trainer.py:836-841): everything behind the stem conv in ONE
- *   "small_coop"      0 | 1                                  persistent launch (smallnet.hip) — default models with BasicBlock
+ *   "small_coop"      1 | 0                                  persistent launch (smallnet.hip) — default models with BasicBlock
  *                                                            backbones, options conv/tail/pool at their defaults, no tap.
- *                                                            small_coop = 1 launches it with hipLaunchCooperativeKernel
+ *                                                            small_coop = 1: hipLaunchCooperativeKernel (all workgroups resident
+ *                                                            by the runtime's guarantee); 0: plain launch, 17 us less per call,
+ *                                                            for a process that has the GPU to itself (one workgroup per CU, 144
+ *                                                            of 256: two such kernels started at the same instant from different
+ *                                                            queues could each hold half the chip — the barrier's bounded spin
+ *                                                            then leaves NaN poses and fails the handle's next call)
  *   "graph"           0 | 1                                  replay the forward from a captured hipGraph
  *   "wgrad_stem"      mx | fp32        "pool_bwd" fused | separate        "dgrad" phase | masked        (training step)
  *   "bf16_fuse"       on | off         "bf16_stem3" 0 | 1    "conv3_nt" 0 | 1   "stem_dbg" <int>            (experiments)

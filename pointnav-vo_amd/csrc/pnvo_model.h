@@ -52,7 +52,8 @@ struct PnvoOptions {
   int small_net = 1;   // batches of <= small_max pairs: everything behind the stem conv in ONE persistent launch (smallnet.hip)
   int small_max = 4;   // largest batch the persistent kernel takes (1..4: faster than the per-layer launches up to there)
   int small_prof = 0;  // developer instrumentation: per-phase times of the persistent kernel on stderr
-  int small_coop = 0;  // 1: its launch is cooperative (hipLaunchCooperativeKernel, +17 us); 0: plain launch of <= 144 workgroups (two fit per CU)
+  int small_coop = 1;  // cooperative launch (hipLaunchCooperativeKernel): every workgroup resident by the runtime's guarantee, also next to other
+                       // processes' kernels (+17 us); 0: plain launch of <= 144 workgroups (one per CU) for a process that owns the GPU
 };
 
 struct TimingRec {
