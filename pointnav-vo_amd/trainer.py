@@ -275,6 +275,16 @@ class BaseRLTrainerWithVO:
         out = np.zeros((n, 3), dtype=np.float32)
         std = np.zeros((n, 3), dtype=np.float32)
         keys = ["all"] * n if rm.regress_type == "unified_act" else [ACT_IDX2NAME[a] for a in acts]
+        # pairs travel grouped by action model (stable order): every model then reads ONE contiguous slice of the staged frames —
+        # no gather kernels between the copy and the forwards; results go back to the caller's order on the host
+        order = sorted(range(n), key=lambda i: keys[i])
+        if order != list(range(n)):
+            prev_obs_list = [prev_obs_list[i] for i in order]
+            cur_obs_list = [cur_obs_list[i] for i in order]
+            acts = [acts[i] for i in order]
+            keys = [keys[i] for i in order]
+        else:
+            order = None
         # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, the
         # top-down views of chunk c-1 are built on the caller's stream (host staging, transfer and device work overlap).
         nchunks = self.boundary_chunks or (1 if n < 24 else (2 if n < 48 else 4))
@@ -317,10 +327,9 @@ class BaseRLTrainerWithVO:
                     for k in range(2):
                         gen.gen_top_down_view_batch(st["d_dep"][lo:hi, k], out=st["tdv"][lo:hi], out_channel=k)
             for key in sorted(set(keys)):
-                idx = [i for i, k in enumerate(keys) if k == key]
-                whole = len(idx) == n
-                sel = None if whole else torch.as_tensor(idx, device=dev)
-                pick = lambda t: None if t is None else (t[:n] if whole else t.index_select(0, sel))
+                idx = [i for i, k in enumerate(keys) if k == key]            # contiguous: the pairs are sorted by key
+                lo_k, hi_k = idx[0], idx[-1] + 1
+                pick = lambda t: None if t is None else t[lo_k:hi_k]
                 model = self.vo_model[key]
                 a = torch.as_tensor([acts[i] for i in idx], dtype=torch.long, device=dev) if "act_embed" in name else None
                 if rm.mode == "det":                      # :285-294
@@ -348,6 +357,10 @@ class BaseRLTrainerWithVO:
         if not pending:
             torch.cuda.current_stream(dev).synchronize()
         assert int(st["h_flag"][0]) == 0, "depth must lie in [0, 1]"      # the reference's asserts (:136-137)
+        if order is not None:                             # back to the caller's order
+            inv = np.empty(n, dtype=np.int64)
+            inv[np.asarray(order)] = np.arange(n)
+            out, std = out[inv], std[inv]
         self._last_std = std
         return out
 

@@ -35,3 +35,15 @@ def test_global_state_composes_with_goal_update():
         rinv = np.array([-rot[0], -rot[1], -rot[2], rot[3]])
         np.testing.assert_allclose(goal_local, g._quat_rotate(rinv, goal_world - pos), atol=1e-10)
     assert abs(np.linalg.norm(rot) - 1.0) < 1e-12
+
+
+def test_batched_goal_update_is_the_per_environment_one():
+    rng = np.random.default_rng(3)
+    goals = rng.normal(size=(17, 3)) * 4.0
+    deltas = np.stack([rng.normal(size=17) * 0.2, rng.normal(size=17) * 0.3, rng.uniform(-np.pi, np.pi, size=17)], axis=1)
+    deltas[0] = 0.0
+    out = g.compute_goal_pos_batch(goals, deltas)
+    for e in range(17):
+        one = g.compute_goal_pos(goals[e], deltas[e])
+        assert np.allclose(out["cartesian"][e], one["cartesian"], rtol=0, atol=1e-15)
+        assert np.array_equal(out["polar"][e], one["polar"]) or np.allclose(out["polar"][e], one["polar"], rtol=0, atol=1e-7)

@@ -88,14 +88,13 @@ def run(envs, steps, episode_steps=150.0, dev=None):
         def step(s):
             nonlocal hid, prev_a, prev_obs
             depth = torch.from_numpy(np.stack([o["depth"] for o in prev_obs])).to(dev, non_blocking=True)
-            polar = np.stack([geometry.compute_goal_pos(g, (0.0, 0.0, 0.0))["polar"] for g in goals]).astype(np.float32)
+            polar = geometry.compute_goal_pos_batch(np.stack(goals), np.zeros((E, 3)))["polar"]
             obs = {"depth": depth, "pointgoal_with_gps_compass": torch.from_numpy(polar).to(dev)}
             _, act, _, hid = pol.act(obs, hid, prev_a, masks, deterministic=False)
             acts = (act.view(-1).cpu().numpy() % 3 + 1).tolist()          # STOP never ends a synthetic episode here
             cur_obs = [frames[(e + s + 1) % 96] for e in range(E)]
             deltas = t.compute_local_delta_states_batch(prev_obs, cur_obs, acts)
-            for e in range(E):
-                goals[e] = geometry.compute_goal_pos(goals[e], deltas[e])["cartesian"]
+            goals[:] = list(geometry.compute_goal_pos_batch(np.stack(goals), deltas)["cartesian"])
             prev_a = torch.as_tensor(acts, device=dev).view(E, 1)
             prev_obs = cur_obs
 
