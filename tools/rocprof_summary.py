@@ -13,6 +13,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "").replace("pnvo::", "")
     return name if len(name) < 70 else name[:67] + "..."

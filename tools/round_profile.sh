@@ -32,7 +32,9 @@ python tools/bench_boundary_phases.py 64 > $O/${tag}_boundary_phases.json 2>/dev
 python tools/bench_batch_sweep.py > $O/${tag}_batch_sweep.txt 2>/dev/null
 python bench.py --config train --steps 10 --warmup 3 --no-overlap > $O/${tag}_bench_train_no_overlap.json 2>/dev/null
 # one pair per call: the persistent small-batch kernel, its per-phase times, and the per-layer launches it replaces
-rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_b1 -o p -- python bench.py --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $O/${tag}_trace_b1.log 2>&1
+# (traced with the plain launch: rocprofv3 7.2 crashes in its exit handler after a process used hipLaunchCooperativeKernel; the trace
+#  itself is complete either way and the kernel time is the same)
+PNVO_SMALL_COOP=0 rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_b1 -o p -- python bench.py --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $O/${tag}_trace_b1.log 2>&1
 python tools/rocprof_summary.py $O/${tag}_trace_b1/p_results.db > $O/${tag}_kernel_trace_b1.md 2>&1
 PNVO_SMALL_NET=off rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_b1l -o p -- python bench.py --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $O/${tag}_trace_b1l.log 2>&1
 python tools/rocprof_summary.py $O/${tag}_trace_b1l/p_results.db > $O/${tag}_kernel_trace_b1_layers.md 2>&1
