@@ -174,6 +174,12 @@ int pnvo_discretize_depth(const float *depth, int64_t n, int64_t in_stride, int 
  *   work: device scratch of pnvo_topdown_workspace_bytes(N,H,W) bytes.
  */
 size_t pnvo_topdown_workspace_bytes(int N, int H, int W);
+/* Both top-down views of n_pairs (prev, cur) frame pairs in ONE pass of the three kernels (the boundary call's shape:
+ * base_trainer_with_vo.py:239-249 builds them one after the other): depth_frames device float32 [n_pairs][2][H][W] ->
+ * tdv_pairs [n_pairs][H][W][2] (channel 0 = prev frame).  work >= pnvo_topdown_workspace_bytes(2 * n_pairs, H, W).  Same values as
+ * two pnvo_topdown_view calls with out_pstride 2. */
+int pnvo_topdown_view_pairs(const float *depth_frames, int n_pairs, int H, int W, const float *consts, int rows_around_center,
+                            float *tdv_pairs, void *work, void *stream);
 int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                       const float *consts, int rows_around_center, float *out, int64_t out_fstride,
                       int64_t out_pstride, void *work, void *stream);

@@ -65,6 +65,8 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "pnvo_half_to_float": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pnvo_dataset_pairs": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p] * 7),
+    "pnvo_topdown_view_pairs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     "pnvo_topdown_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                     C.c_void_p]),

@@ -446,15 +446,18 @@ __global__ __launch_bounds__(256) void topdown_project_kernel(const float *depth
     atomicMax(&work[n].maxcnt, now);
 }
 
+// out_pair > 0: frames come as (prev, cur) pairs and frame n goes to channel n & 1 of pair n >> 1:
+//   out[(n >> 1) * ofstride + (n & 1) * out_pair + p * opstride]   (both top-down views of a pair tensor in one pass)
 __global__ __launch_bounds__(256) void topdown_normalize_kernel(int H, int W, const TopdownWork *work, const int *cnt,
-                                                              float *out, long ofstride, long opstride) {
+                                                              float *out, long ofstride, long opstride, long out_pair) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= H * W) return;
   const int mx = work[n].maxcnt;
   float v = 0.f;
   if (mx > 0) v = fminf(div_rn((float)cnt[(long)n * H * W + p], (float)mx), 1.0f);   // :543-554
-  out[(long)n * ofstride + (long)p * opstride] = v;
+  const long base = out_pair > 0 ? (long)(n >> 1) * ofstride + (long)(n & 1) * out_pair : (long)n * ofstride;
+  out[base + (long)p * opstride] = v;
 }
 
 // The dataset-side twin NormalizedDepth2TopDownViewHabitat (numpy, geometry_utils.py:275-470) does the same projection
@@ -525,7 +528,7 @@ hipError_t launch_topdown_f64(const float *depth, int N, int H, int W, int64_t i
   hipLaunchKernelGGL(topdown_project_f64_kernel, dim3((unsigned)((band * W + 255) / 256), (unsigned)N), dim3(256), 0, s,
                      depth, (long)in_fstride, (long)in_pstride, H, W, tc, rows_around_center, tw, cnt);
   hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N), dim3(256), 0, s, H, W, tw,
-                     cnt, out, (long)out_fstride, (long)out_pstride);
+                     cnt, out, (long)out_fstride, (long)out_pstride, 0L);
   return hipGetLastError();
 }
 
@@ -693,7 +696,7 @@ hipError_t launch_frame_pairs(const unsigned char *rgb, const float *depth, int 
 
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const float *consts, int rows_around_center, float *out, int64_t out_fstride,
-                          int64_t out_pstride, void *work, hipStream_t s) {
+                          int64_t out_pstride, void *work, hipStream_t s, int64_t out_pair) {
   TopdownWork *tw = reinterpret_cast<TopdownWork *>(work);
   int *cnt = reinterpret_cast<int *>(tw + N);
   hipError_t e = hipMemsetAsync(work, 0, topdown_workspace_bytes(N, H, W), s);   // counts, bbox encodings, maxima
@@ -708,7 +711,7 @@ hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fs
   hipLaunchKernelGGL(topdown_project_kernel, dim3((unsigned)((band * W + 255) / 256), (unsigned)N), dim3(256), 0, s,
                      depth, (long)in_fstride, (long)in_pstride, H, W, tc, rows_around_center, tw, cnt);
   hipLaunchKernelGGL(topdown_normalize_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N), dim3(256), 0, s, H, W, tw,
-                     cnt, out, (long)out_fstride, (long)out_pstride);
+                     cnt, out, (long)out_fstride, (long)out_pstride, (long)out_pair);
   return hipGetLastError();
 }
 

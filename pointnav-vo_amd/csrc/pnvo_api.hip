@@ -1773,6 +1773,17 @@ int pnvo_topdown_view(const float *depth, int N, int H, int W, int64_t in_fstrid
   return PNVO_OK;
 }
 
+int pnvo_topdown_view_pairs(const float *depth_frames, int n_pairs, int H, int W, const float *consts, int rows_around_center,
+                            float *tdv_pairs, void *work, void *stream) {
+  if (!depth_frames || !tdv_pairs || !consts || !work || n_pairs < 0 || H <= 0 || W <= 0)
+    return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if (n_pairs == 0) return PNVO_OK;
+  const int64_t hw = (int64_t)H * W;
+  HIPCHK(nullptr, launch_topdown(depth_frames, 2 * n_pairs, H, W, hw, 1, consts, rows_around_center, tdv_pairs, 2 * hw, 2, work,
+                                 (hipStream_t)stream, 1));
+  return PNVO_OK;
+}
+
 int pnvo_topdown_view_f64(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const double *consts, int rows_around_center, float *out, int64_t out_fstride,
                           int64_t out_pstride, void *work, void *stream) {

@@ -243,7 +243,7 @@ hipError_t launch_frame_pairs(const unsigned char *rgb, const float *depth, int 
 size_t topdown_workspace_bytes(int N, int H, int W);
 hipError_t launch_topdown(const float *depth, int N, int H, int W, int64_t in_fstride, int64_t in_pstride,
                           const float *consts_host, int rows_around_center, float *out, int64_t out_fstride,
-                          int64_t out_pstride, void *work, hipStream_t s);
+                          int64_t out_pstride, void *work, hipStream_t s, int64_t out_pair = 0);
 
 // ---- training step (train_kernels.hip) ---------------------------------------------------------------------------
 struct SrcLane {            // stem weight gradient: the observation-tensor slot feeding input channel (lane) i

@@ -98,6 +98,20 @@ class NormalizedDepth2TopDownViewHabitatTorch:
                 C.c_void_p(work.data_ptr()), _stream(dev)))
         return res
 
+    def gen_top_down_view_pairs(self, depth_frames, out):
+        """Both views of n (prev, cur) pairs in one pass of the kernels: depth_frames CUDA float32 [n,2,H,W] (contiguous) ->
+        out [n,H,W,2] (contiguous), channel 0 = prev frame.  The values of two gen_top_down_view_batch calls."""
+        H, W = self._vis_size_h, self._vis_size_w
+        n, dev = depth_frames.shape[0], depth_frames.device
+        assert depth_frames.is_cuda and depth_frames.dtype == torch.float32 and depth_frames.shape[1:] == (2, H, W)
+        assert depth_frames.is_contiguous() and out.is_contiguous() and out.shape == (n, H, W, 2) and out.dtype == torch.float32
+        work = self._workspace(2 * n, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.pnvo_topdown_view_pairs(C.c_void_p(depth_frames.data_ptr()), int(n), H, W, self._consts,
+                                                        int(self._rows_around_center), C.c_void_p(out.data_ptr()),
+                                                        C.c_void_p(work.data_ptr()), _stream(dev)))
+        return out
+
     def gen_top_down_view(self, normalized_depth):
         """normalized_depth: [H, W, 1] -> [H, W, 1]   (geometry_utils.py:516-556)."""
         d = normalized_depth.to(torch.float32)
@@ -324,8 +338,7 @@ class BaseRLTrainerWithVO:
                         int(gen._rows_around_center) if gen else 0, p(st["work"]), p(st["rgb"], lo), p(st["depth"], lo),
                         p(st["dd"], lo), p(st["tdv"], lo), p(st["flag"]), _stream(dev)))
                 elif want_tdv:                            # :239-249: prev frames -> channel 0, cur frames -> channel 1
-                    for k in range(2):
-                        gen.gen_top_down_view_batch(st["d_dep"][lo:hi, k], out=st["tdv"][lo:hi], out_channel=k)
+                    gen.gen_top_down_view_pairs(st["d_dep"][lo:hi], st["tdv"][lo:hi])
             for key in sorted(set(keys)):
                 idx = [i for i, k in enumerate(keys) if k == key]            # contiguous: the pairs are sorted by key
                 lo_k, hi_k = idx[0], idx[-1] + 1

@@ -282,6 +282,25 @@ def test_topdown_view_batched_strided_matches_single():
             np.testing.assert_array_equal(tdv[b, ..., k].cpu().numpy(), oracle.topdown_view(pair[b, ..., k].cpu().numpy(), c)[..., 0])
 
 
+def test_topdown_views_of_frame_pairs_in_one_pass_match_the_oracle():
+    """pnvo_topdown_view_pairs: frames [n,2,H,W] -> pair tensor [n,H,W,2] in one pass of the three kernels (what the boundary
+    call uses), bit-exact against the oracle and against the per-channel calls."""
+    H, W = 192, 341
+    gen = NormalizedDepth2TopDownViewHabitatTorch(min_depth=0.1, max_depth=10.0, vis_size_h=H, vis_size_w=W, hfov_rad=70)
+    frames = torch.from_numpy(np.stack([synth.make_raw_obs(H, W, seed=4, index=i, zero_border=2 * (i % 3))["depth"][..., 0]
+                                        for i in range(10)]).reshape(5, 2, H, W).copy()).to(dev())
+    tdv = torch.full((5, H, W, 2), -1.0, device=dev())
+    gen.gen_top_down_view_pairs(frames, tdv)
+    ref = torch.zeros((5, H, W, 2), device=dev())
+    for k in range(2):
+        gen.gen_top_down_view_batch(frames[:, k], out=ref, out_channel=k)
+    assert torch.equal(tdv, ref)
+    c = oracle.topdown_consts(H, W, 70, 0.1, 10.0)
+    for b in (0, 4):
+        for k in range(2):
+            np.testing.assert_array_equal(tdv[b, ..., k].cpu().numpy(), oracle.topdown_view(frames[b, k].cpu().numpy(), c)[..., 0])
+
+
 # ----------------------------------------------------------------------------- the drop-in boundary (a1 / a13)
 def make_trainer(rec):
     cfg = AttrDict(

@@ -51,8 +51,7 @@ for thr in (2, 8, 12, 16, 24):
                                                    _lib.lib.pnvo_stage_frames(pd, 2 * N, H * W * 4, p(st["h_dep"]), thr)))
 timed("H2D (pinned -> device)", lambda: (st["d_rgb"][:N].copy_(st["h_rgb"][:N], non_blocking=True), st["d_dep"][:N].copy_(st["h_dep"][:N], non_blocking=True)))
 def tdv():
-    for k in range(2):
-        gen.gen_top_down_view_batch(st["d_dep"][:N, k], out=st["tdv"][:N], out_channel=k)
+    gen.gen_top_down_view_pairs(st["d_dep"][:N], st["tdv"][:N])
 timed("top-down views of 2N frames", tdv)
 with torch.no_grad():
     timed("forward_raw over N pairs", lambda: model.forward_raw(st["d_rgb"][:N], st["d_dep"][:N], st["tdv"][:N], err_flag=st["flag"]))
