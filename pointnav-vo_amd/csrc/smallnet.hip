@@ -841,6 +841,16 @@ bool pnvo_small_usable(pnvo_handle m, int B) {
     if (m->nblocks[st] < 2) return false;
   if (B * std::max(m->convs[0].coutp, m->comp_cp) > SN_TAB) return false;
   if (m->comp_cp != 32 && m->comp_cp != 64) return false;
+  // LDS: the largest patch of a conv phase, or the activation vectors of the Linear layers for the whole batch (large frames)
+  size_t floats = (size_t)B * std::max((size_t)m->fh * m->fw * m->comp_cp, (size_t)c.hidden);
+  for (size_t k = 1; k < m->convs.size(); ++k) {
+    const Layer &l = m->convs[k];
+    if (l.k != 3) continue;
+    const int mb = SN_WAVES / std::min(SN_WAVES, l.cinp / 16), th = mb == 4 ? 8 : 4, tw = mb == 1 ? 4 : 8;
+    floats = std::max(floats, (size_t)((th - 1) * l.stride + 3) * ((tw - 1) * l.stride + 3) * (l.cinp + 4));
+  }
+  if (((size_t)SN_FIXED_FLOATS + floats) * sizeof(float) > (size_t)156 * 1024) return false;
+  if (1 + (int)m->convs.size() - 1 + 2 > SN_MAXPH) return false;
   return true;
 }
 

@@ -75,6 +75,33 @@ def test_model_variants_at_a_size_the_kernel_takes(name, space, bins):
     assert pair_rel_err(small, run(model, tobs, tact).astype(np.float64)).max() < 2e-5
 
 
+def test_large_frames_take_the_kernel_while_the_batch_fits_its_lds():
+    """640 x 480 frames: 15 x 20 final map, 9600 activations per pair in front of the Linear layer — three pairs fit the kernel's
+    LDS, four do not (they keep the per-layer launches); 1200 GroupNorm slots per group exercise the consumers' slot loop."""
+    from pointnav_vo_amd import model_spec as ms
+    from pointnav_vo_amd import synth
+    from pointnav_vo_amd.registry import baseline_registry
+    W, H = 640, 480
+    space = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    model = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=space, observation_size=(W, H), hidden_size=512, backbone="resnet18", normalize_visual_inputs=True,
+        output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(model.cfg), seed=2)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model = model.to(dev()).eval()
+    assert model.layer_kernel(FIRST_CONV, 3)[0] == "smallnet" and model.layer_kernel(FIRST_CONV, 4)[0] != "smallnet"
+    obs = synth.make_obs_pairs(4, H, W, observation_space=space, dd_bins=10, seed=8)
+    tobs = {k: torch.from_numpy(v).to(dev()) for k, v in obs.items()}
+    sub = {k: v[:3].contiguous() for k, v in tobs.items()}
+    small = run(model, sub, None)
+    four = run(model, tobs, None)                                   # per-layer launches
+    model.set_option("small_net", "off")
+    layers = run(model, sub, None)
+    assert np.isfinite(small).all()
+    assert pair_rel_err(small, layers.astype(np.float64)).max() < 2e-5
+    assert pair_rel_err(four[:3], layers.astype(np.float64)).max() < 2e-5
+
+
 def test_models_it_does_not_fit_keep_the_per_layer_launches():
     for fname in ("model_wider_64x48_b2.npz",          # 512 channels in the last stage: above the kernel's 256
                   "model_deeper_64x48_b2.npz",         # Bottleneck blocks
