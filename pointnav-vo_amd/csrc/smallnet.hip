@@ -38,6 +38,7 @@ namespace pnvo {
 typedef float sn_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SN_THREADS = 512, SN_WAVES = 8, SN_TAB = 512, SN_MAXB = 4;
+constexpr int sn_mblocks(int c4) { return c4 <= 8 ? 4 : c4 <= 16 ? 2 : 1; }   // M-blocks (16 output pixels) of a conv tile, by input channels / 4
 constexpr int SN_KP = SN_WAVES / 4, SN_WPRE = 6;                  // linear layers: K parts per output, weight vectors fetched ahead
 constexpr int SN_RED_FLOATS = 2 * SN_WAVES * 256;                 // K-split partials: two convs x 16 waves x (64 lanes x 4)
 constexpr int SN_MAXPH = 40;                                      // phases (BasicBlock nets up to resnet34: 36)
@@ -52,19 +53,19 @@ struct SnGN {              // GroupNorm of a producer phase: partial statistics 
   float inv_cnt;           // 1 / (pixels x real channels per group)
 };
 
-struct SnPhase {
+struct SnPhase {            // 70 dwords; GroupNorms first (their fields are read with a run-time base), then pointers, then integers
+  SnGN gin, gres;
+  const int *tiles;        // [ntiles] n << 24 | tile row << 16 | tile column << 8 | cout tile
+  const float *in, *res;
+  float *blk_out;
+  const float *w, *w_ds, *bias;
+  float *out, *part, *out_ds, *part_ds;
   int kind;                // 0 conv3x3 (+ optional 1x1 stride-2 conv on the centre tap), 1 GN+ReLU+max-pool, 2 linear
   int type;                // conv: stride * 8 + log2(cinp / 4) — selects the compiled variant
   int cinp, coutp, cout, Hin, Win, Ho, Wo;
   int tiles_y, tiles_x, NT, ntiles;
   int in_mode;             // 0 final activations; 1 relu(x*sc+sh); 2 relu(x*sc+sh + r), r = res; 3: r = res*sc2+sh2.  2/3: owner writes blk_out
   int out_cpg, out_G, out_slots, relu_out, K, use_row;
-  const int *tiles;        // [ntiles] n << 24 | tile row << 16 | tile column << 8 | cout tile
-  const float *in, *res;
-  float *blk_out;
-  const float *w, *w_ds, *bias;
-  float *out, *part, *out_ds, *part_ds;
-  SnGN gin, gres;
 };
 
 static_assert(sizeof(SnPhase) <= 72 * 4, "SnPhase outgrew its LDS slot");
@@ -95,6 +96,50 @@ __device__ __forceinline__ T *sn_uni(T *q) {            // a pointer read from t
   return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 
+// The thread index inside phase code: wave index (a scalar, set once at kernel start) * 64 + the lane id from mbcnt.  Nothing
+// derived from the threadIdx register has to live across the phases (it would be spilled to scratch memory and re-loaded — one
+// memory round trip — at every phase entry).
+__device__ __forceinline__ int sn_lane() {   // (volatile: computed where it is used, never hoisted out of the phase loop and spilled)
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+#define SN_TID (sn_wave * 64 + sn_lane())
+
+// A phase's descriptor in registers: lane k of d0 holds dword k of the LDS copy (d1: dwords 64..71).  One LDS read per phase; a
+// field is a v_readlane with a constant (or, for the two GroupNorm blocks, scalar) lane index — no per-field LDS round trips.
+struct SnRegs {
+  int d0, d1;
+};
+__device__ __forceinline__ SnRegs sn_regs(const SnPhase *lp, int lane) {
+  const int *q = reinterpret_cast<const int *>(lp);
+  SnRegs r;
+  r.d0 = q[lane];
+  r.d1 = q[64 + (lane & 7)];
+  return r;
+}
+template <int K>
+__device__ __forceinline__ int sn_geti(const SnRegs &r) {
+  return K < 64 ? __builtin_amdgcn_readlane(r.d0, K < 64 ? K : 0) : __builtin_amdgcn_readlane(r.d1, K < 64 ? 0 : K - 64);
+}
+template <int K, typename T>
+__device__ __forceinline__ T *sn_getp(const SnRegs &r) {
+  const unsigned lo = (unsigned)sn_geti<K>(r), hi = (unsigned)sn_geti<K + 1>(r);
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int sn_geti_at(const SnRegs &r, int k) { return __builtin_amdgcn_readlane(r.d0, k); }   // k < 64, uniform
+template <typename T>
+__device__ __forceinline__ T *sn_getp_at(const SnRegs &r, int k) {
+  const unsigned lo = (unsigned)sn_geti_at(r, k), hi = (unsigned)sn_geti_at(r, k + 1);
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+#define SN_I(r, f) sn_geti<(int)(offsetof(SnPhase, f) / 4)>(r)
+#define SN_P(T, r, f) sn_getp<(int)(offsetof(SnPhase, f) / 4), T>(r)
+// dword offsets inside an SnGN block (base = 0 for gin, 14 for gres)
+constexpr int GN_PART = 0, GN_GAMMA = 2, GN_BETA = 4, GN_G = 6, GN_LGCPG = 8, GN_C = 9, GN_CP = 10, GN_SLOTS = 11, GN_LAYOUT = 12,
+              GN_INV = 13, GN_DWORDS = 14;
+static_assert(sizeof(SnGN) == 4 * GN_DWORDS && offsetof(SnGN, inv_cnt) == 4 * GN_INV && offsetof(SnGN, G) == 4 * GN_G, "SnGN layout");
+
 // Data that crosses workgroups inside the launch (conv outputs, GroupNorm partials, block outputs, the hidden vector) is written
 // and read with AGENT-scope accesses (sc1: write-through / coherent across the per-XCD L2s), so the grid barrier needs no L2
 // write-back or invalidate — and weights, the instruction stream and the phase table stay cached across phases.
@@ -123,13 +168,13 @@ __device__ __forceinline__ void sn_st1(sn_rsrc_t r, unsigned fidx, float v) {
 // workgroup meets, thread 0 bumps the device-scope counter.  Then the workgroup prepares the
 // next phase (tile, weight fragments, addresses: nothing that depends on other workgroups) and only then WAITS: thread 0 polls
 // the counter, the workgroup meets again.  A bounded spin turns an impossible wait into an error flag.
-__device__ __forceinline__ void sn_grid_arrive(unsigned *ctr) {
+__device__ __forceinline__ void sn_grid_arrive(unsigned *ctr, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool sn_grid_wait(unsigned *ctr, unsigned target, int *err, int *flag) {
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ bool sn_grid_wait(unsigned *ctr, unsigned target, int *err, int *flag, int tid) {
+  if (tid == 0) {
     unsigned spins = 0;
     int bad = 0;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
@@ -167,13 +212,13 @@ __device__ __forceinline__ double sn_row_sum(double v) {
 
 // One group per 16-lane row: NJ slot pairs per lane, all loads in flight together with gamma / beta.
 template <int NJ>
-__device__ __forceinline__ void sn_gn_rows(const SnGN &g, int gi, int n, bool act, int l16, float *sc, float *sh) {
-  const int g_slots = sn_uni(g.slots), g_lgcpg = sn_uni(g.lgcpg), g_layout = sn_uni(g.layout), g_CP = sn_uni(g.CP), g_C = sn_uni(g.C),
-            g_G = sn_uni(g.G), g_cpg = 1 << g_lgcpg;
-  const float *g_gamma = sn_uni(g.gamma), *g_beta = sn_uni(g.beta);
-  const float g_inv = __builtin_bit_cast(float, sn_uni(__builtin_bit_cast(int, g.inv_cnt)));
+__device__ __forceinline__ void sn_gn_rows(const SnRegs &r, int gb, int gi, int n, bool act, int l16, float *sc, float *sh) {
+  const int g_slots = sn_geti_at(r, gb + GN_SLOTS), g_lgcpg = sn_geti_at(r, gb + GN_LGCPG), g_layout = sn_geti_at(r, gb + GN_LAYOUT),
+            g_CP = sn_geti_at(r, gb + GN_CP), g_C = sn_geti_at(r, gb + GN_C), g_G = sn_geti_at(r, gb + GN_G), g_cpg = 1 << g_lgcpg;
+  const float *g_gamma = sn_getp_at<const float>(r, gb + GN_GAMMA), *g_beta = sn_getp_at<const float>(r, gb + GN_BETA);
+  const float g_inv = __builtin_bit_cast(float, sn_geti_at(r, gb + GN_INV));
   const int nk = g_layout == 0 ? g_slots : g_slots << g_lgcpg;
-  const float2 *pp = reinterpret_cast<const float2 *>(sn_uni(g.part)) + (g_layout == 0 ? 0u : (unsigned)(n * g_slots * g_CP));
+  const float2 *pp = reinterpret_cast<const float2 *>(sn_getp_at<const float>(r, gb + GN_PART)) + (g_layout == 0 ? 0u : (unsigned)(n * g_slots * g_CP));
   const sn_rsrc_t rp = sn_rsrc(pp);          // layout 0: partials written by other workgroups of this launch
   const unsigned row0 = g_layout == 0 ? (unsigned)((n * g_G + gi) * g_slots) : 0u;
   float2 v[NJ];
@@ -250,31 +295,31 @@ __device__ __forceinline__ void sn_gn_rows(const SnGN &g, int gi, int n, bool ac
 // scale / shift of every channel of sample n into LDS tables for one or two GroupNorms (the input's, the skip branch's):
 // one group per 16-lane row, 32 groups per pass of the workgroup, double-precision sums in a fixed order.
 // (Groups of one table fill whole waves: G is 1 or a multiple of 4.)
-__device__ __forceinline__ void sn_gn_tables(const SnGN &ga, float *sca, float *sha, bool use_b, const SnGN &gb, float *scb, float *shb,
-                                             int n, int tid) {
+__device__ __forceinline__ void sn_gn_tables(const SnRegs &r, float *sca, float *sha, bool use_b, float *scb, float *shb, int n, int tid) {
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15;
-  const int Ga = sn_uni(ga.G), Gb = use_b ? sn_uni(gb.G) : 0;
+  const int Ga = sn_geti_at(r, GN_G), Gb = use_b ? sn_geti_at(r, GN_DWORDS + GN_G) : 0;
   const int total = Ga + Gb;
   for (int base = 0; base < total; base += 4 * SN_WAVES) {
     const int it0 = base + w * 4;
     if (it0 >= total) break;
     const bool sel = it0 >= Ga;
-    const SnGN &g = sel ? gb : ga;
+    const int gb = sel ? GN_DWORDS : 0;
     const int Gg = sel ? Gb : Ga;
     int gi = it0 - (sel ? Ga : 0) + (lane >> 4);
     const bool act = gi < Gg;
     gi = act ? gi : Gg - 1;                        // (inactive rows compute a valid group and drop it)
     float *sc = sel ? scb : sca, *sh = sel ? shb : sha;
-    const int nk = sn_uni(g.layout) == 0 ? sn_uni(g.slots) : sn_uni(g.slots) << sn_uni(g.lgcpg);
+    const int slots = sn_geti_at(r, gb + GN_SLOTS);
+    const int nk = sn_geti_at(r, gb + GN_LAYOUT) == 0 ? slots : slots << sn_geti_at(r, gb + GN_LGCPG);
     if (nk <= 32)
-      sn_gn_rows<2>(g, gi, n, act, l16, sc, sh);
+      sn_gn_rows<2>(r, gb, gi, n, act, l16, sc, sh);
     else
-      sn_gn_rows<17>(g, gi, n, act, l16, sc, sh);
+      sn_gn_rows<17>(r, gb, gi, n, act, l16, sc, sh);
   }
 }
 
-#define SN_STAMP(k) do { if (pf != nullptr && threadIdx.x == 0 && blockIdx.x == 0) pf[k] = wall_clock64(); } while (0)
+#define SN_STAMP(k) do { if (pf != nullptr && tid == 0 && blockIdx.x == 0) pf[k] = wall_clock64(); } while (0)
 
 // One 3x3 conv layer (pad 1) as a phase.  ST stride, LGC4 = log2(input channels / 4).
 //   K split: KS = min(8, C4/4) waves per M-block, MB = 8 / KS M-blocks (16 output pixels each) per tile, SPT = C4 / KS K-steps per tap
@@ -282,24 +327,26 @@ __device__ __forceinline__ void sn_gn_tables(const SnGN &ga, float *sca, float *
 // Everything that does not depend on the previous phase — the tile, the B fragments of the whole K walk, the addresses and
 // bounds of this thread's patch items — is computed BEFORE the grid barrier; behind it: loads, GroupNorm tables, patch, MFMAs.
 template <int ST, int LGC4>
-__device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int pi, int mytile, float *lds, int *flag, unsigned long long *pf) {
-  constexpr int C4 = 1 << LGC4, CIN = 4 * C4, KS = C4 / 4 < SN_WAVES ? C4 / 4 : SN_WAVES, MB = SN_WAVES / KS, SPT = C4 / KS;
+__device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p_lds, int pi, int mytile, float *lds, int *flag, unsigned long long *pf, int sn_wave) {
+  constexpr int C4 = 1 << LGC4, CIN = 4 * C4, MB = sn_mblocks(C4), KS = SN_WAVES / MB, SPT = C4 / KS;
   constexpr int TH = MB == 4 ? 8 : 4, TW = MB == 1 ? 4 : 8, LGTW = MB == 1 ? 2 : 3;
   constexpr int PH = (TH - 1) * ST + 3, PW = (TW - 1) * ST + 3, CS = CIN + 4, ITEMS = PH * PW * C4;
   constexpr int NIT = (ITEMS + SN_THREADS - 1) / SN_THREADS, NSTEP = 9 * SPT;
   float *sc_in = lds, *sh_in = lds + SN_TAB, *sc_res = lds + 2 * SN_TAB, *sh_res = lds + 3 * SN_TAB;
   float *red = lds + 4 * SN_TAB;
   float *patch = lds + SN_FIXED_FLOATS;
-  int tid = threadIdx.x;
+  int tid = SN_TID;
   asm volatile("" : "+v"(tid));             // (per-thread constants of a phase stay inside the phase: no hoisting out of the phase loop)
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const SnRegs r = sn_regs(&p_lds, lane);   // (read here, inside the variant: held across the variant switch it is spilled to scratch)
   const int mb = w % MB, ks = w / MB;
-  // the phase's parameters: LDS table -> scalar registers, once, before the barrier
-  const int Hin = sn_uni(p.Hin), Win = sn_uni(p.Win), Ho = sn_uni(p.Ho), Wo = sn_uni(p.Wo), coutp = sn_uni(p.coutp), ntiles = sn_uni(p.ntiles);
-  const int mode = sn_uni(p.in_mode), tiles_x = sn_uni(p.tiles_x), out_cpg = sn_uni(p.out_cpg), out_G = sn_uni(p.out_G), out_slots = sn_uni(p.out_slots);
-  const float *p_in = sn_uni(p.in), *p_res = sn_uni(p.res), *p_w = sn_uni(p.w), *p_wds = sn_uni(p.w_ds);
-  float *p_blk = sn_uni(p.blk_out), *p_out = sn_uni(p.out), *p_part = sn_uni(p.part), *p_outds = sn_uni(p.out_ds), *p_partds = sn_uni(p.part_ds);
-  const int *p_tiles = sn_uni(p.tiles);
+  // the phase's parameters: lanes of the descriptor registers -> scalar registers
+  const int Hin = SN_I(r, Hin), Win = SN_I(r, Win), Ho = SN_I(r, Ho), Wo = SN_I(r, Wo), coutp = SN_I(r, coutp), ntiles = SN_I(r, ntiles);
+  const int mode = SN_I(r, in_mode), tiles_x = SN_I(r, tiles_x), out_cpg = SN_I(r, out_cpg), out_G = SN_I(r, out_G), out_slots = SN_I(r, out_slots);
+  const float *p_in = SN_P(const float, r, in), *p_res = SN_P(const float, r, res), *p_w = SN_P(const float, r, w), *p_wds = SN_P(const float, r, w_ds);
+  float *p_blk = SN_P(float, r, blk_out), *p_out = SN_P(float, r, out), *p_part = SN_P(float, r, part), *p_outds = SN_P(float, r, out_ds),
+        *p_partds = SN_P(float, r, part_ds);
+  const int *p_tiles = SN_P(const int, r, tiles);
   const sn_rsrc_t r_in = sn_rsrc(p_in), r_res = sn_rsrc(p_res), r_blk = sn_rsrc(p_blk);
   const bool has_ds = ST == 2 && p_wds != nullptr;
 
@@ -336,6 +383,8 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    SN_STAMP(7);
     const int iy0 = tyi * (TH * ST) - 1, ix0 = txi * (TW * ST) - 1;
     inimg = own = 0;
 #pragma unroll
@@ -361,9 +410,9 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
     aofs = ((ty * ST) * PW + tx * ST) * CS + (lane >> 4) + ks * 4;
   }
   SN_STAMP(5);
-  if (pi > 0 && !sn_grid_wait(a.bar, a.bar_base + (unsigned)pi * gridDim.x, a.err, flag)) return false;
+  if (pi > 0 && !sn_grid_wait(a.bar, a.bar_base + (unsigned)pi * gridDim.x, a.err, flag, tid)) return false;
   unsigned long long t0 = 0;
-  if (a.prof != nullptr && threadIdx.x == 0) {
+  if (a.prof != nullptr && tid == 0) {
     t0 = wall_clock64();
     if (blockIdx.x == 0) a.prof[pi * 4 + 0] = t0;
   }
@@ -391,7 +440,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
     // ---- (2) GroupNorm tables of this sample (their slot loads fly together with the loads above)
     if (n != cur_n) {
       if (mode >= 1) {
-        sn_gn_tables(p.gin, sc_in, sh_in, mode == 3, p.gres, sc_res, sh_res, n, tid);
+        sn_gn_tables(r, sc_in, sh_in, mode == 3, sc_res, sh_res, n, tid);
         __syncthreads();
       }
       cur_n = n;
@@ -461,8 +510,8 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
     SN_STAMP(4);
     // ---- (5) epilogue: wave (conv, M-block) sums the K-split partials in wave order, stores, writes the group partials
     const int nconv = has_ds ? 2 : 1;
-    if (w < MB * nconv) {
-      const int which = w / MB, mbe = w % MB;
+    for (int slot_w = w; slot_w < MB * nconv; slot_w += SN_WAVES) {
+      const int which = slot_w / MB, mbe = slot_w % MB;
       sn_f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
@@ -513,7 +562,7 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
   }
   if (a.prof != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       const unsigned long long t1 = wall_clock64();
       if (blockIdx.x == 0) a.prof[pi * 4 + 1] = t1;
       atomicMax(&a.prof[pi * 4 + 2], t1 - t0);
@@ -523,11 +572,12 @@ __device__ __forceinline__ bool sn_conv(const SnArgs &a, const SnPhase &p, int p
 }
 
 // GroupNorm + ReLU + MaxPool2d(3, 2, 1) of the stem output (resnet.py:165-168); the affine transform goes BEFORE the max
-__device__ void sn_pool_phase(const SnPhase &p, int B, float *lds) {
+__device__ void sn_pool_phase(const SnPhase &p, int B, float *lds, int sn_wave) {
   float *sc = lds, *sh = lds + SN_TAB;
-  int tid = threadIdx.x;
+  int tid = SN_TID;
   asm volatile("" : "+v"(tid));
-  for (int n = 0; n < B; ++n) sn_gn_tables(p.gin, sc + n * p.cinp, sh + n * p.cinp, false, p.gin, nullptr, nullptr, n, tid);
+  const SnRegs r = sn_regs(&p, tid & 63);
+  for (int n = 0; n < B; ++n) sn_gn_tables(r, sc + n * p.cinp, sh + n * p.cinp, false, nullptr, nullptr, n, tid);
   __syncthreads();
   const int Q = p.cinp >> 2;
   const int total = B * p.Ho * p.Wo * Q;
@@ -564,12 +614,12 @@ __device__ void sn_pool_phase(const SnPhase &p, int B, float *lds) {
 // Linear layer: y[b][o] = act(bias[row(b)][o] + sum_k W[o][k] x[b][k]), x = the input transform of [B][K] activations.
 // Tile = 4 outputs; wave (output ol = w & 3, K part kq = w >> 2); its first SN_WPRE weight vectors per lane are fetched before
 // the grid barrier.
-__device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int pi, float *lds, int *flag) {
+__device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int pi, float *lds, int *flag, int sn_wave) {
   float *sc = lds, *sh = lds + SN_TAB;
   float *red = lds + 4 * SN_TAB;
   float *xs = lds + SN_FIXED_FLOATS;
   const int B = a.B, K = p.K, K4 = K >> 2;
-  int tid = threadIdx.x;
+  int tid = SN_TID;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Kq4 = (K4 + SN_KP - 1) / SN_KP;
@@ -585,16 +635,17 @@ __device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int
       wpre[j] = reinterpret_cast<const sn_f32x4 *>(p.w + (size_t)oc * K)[ic];
     }
   }
-  if (pi > 0 && !sn_grid_wait(a.bar, a.bar_base + (unsigned)pi * gridDim.x, a.err, flag)) return false;
+  if (pi > 0 && !sn_grid_wait(a.bar, a.bar_base + (unsigned)pi * gridDim.x, a.err, flag, tid)) return false;
   unsigned long long t0 = 0;
-  if (a.prof != nullptr && threadIdx.x == 0) {
+  if (a.prof != nullptr && tid == 0) {
     t0 = wall_clock64();
     if (blockIdx.x == 0) a.prof[pi * 4 + 0] = t0;
   }
   const sn_rsrc_t r_lin = sn_rsrc(sn_uni(p.in));
   if ((int)blockIdx.x < p.ntiles) {
     if (p.in_mode == 1) {
-      for (int n = 0; n < B; ++n) sn_gn_tables(p.gin, sc + n * p.cinp, sh + n * p.cinp, false, p.gin, nullptr, nullptr, n, tid);
+      const SnRegs r = sn_regs(&p, tid & 63);
+      for (int n = 0; n < B; ++n) sn_gn_tables(r, sc + n * p.cinp, sh + n * p.cinp, false, nullptr, nullptr, n, tid);
       __syncthreads();
     }
     {
@@ -678,7 +729,7 @@ __device__ __forceinline__ bool sn_linear(const SnArgs &a, const SnPhase &p, int
   }
   if (a.prof != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       const unsigned long long t1 = wall_clock64();
       if (blockIdx.x == 0) a.prof[pi * 4 + 1] = t1;
       atomicMax(&a.prof[pi * 4 + 2], t1 - t0);
@@ -692,6 +743,7 @@ __global__ __launch_bounds__(SN_THREADS) void smallnet_kernel(SnArgs a) {
   __shared__ int flag;
   // the phase table and this workgroup's first tile of every phase: global -> LDS once (nothing behind a grid barrier waits for
   // a descriptor or a tile list to arrive from memory)
+  const int sn_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   SnPhase *phl = reinterpret_cast<SnPhase *>(sn_lds + 4 * SN_TAB + SN_RED_FLOATS);
   int *mytiles = reinterpret_cast<int *>(sn_lds + 4 * SN_TAB + SN_RED_FLOATS + SN_MAXPH * 72);
   {
@@ -731,27 +783,30 @@ __global__ __launch_bounds__(SN_THREADS) void smallnet_kernel(SnArgs a) {
     const int kind = sn_uni(p.kind);
     if (kind == 0) {
       switch (sn_uni(p.type)) {
-        case 8 + 3: ok = sn_conv<1, 3>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        case 8 + 4: ok = sn_conv<1, 4>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        case 8 + 5: ok = sn_conv<1, 5>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        case 8 + 6: ok = sn_conv<1, 6>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        case 16 + 3: ok = sn_conv<2, 3>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        case 16 + 4: ok = sn_conv<2, 4>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        case 16 + 5: ok = sn_conv<2, 5>(a, p, pi, mytile, sn_lds, &flag, pf); break;
-        default: ok = sn_conv<2, 6>(a, p, pi, mytile, sn_lds, &flag, pf); break;
+        case 8 + 3: ok = sn_conv<1, 3>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        case 8 + 4: ok = sn_conv<1, 4>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        case 8 + 5: ok = sn_conv<1, 5>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        case 8 + 6: ok = sn_conv<1, 6>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        case 16 + 3: ok = sn_conv<2, 3>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        case 16 + 4: ok = sn_conv<2, 4>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        case 16 + 5: ok = sn_conv<2, 5>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
+        default: ok = sn_conv<2, 6>(a, p, pi, mytile, sn_lds, &flag, pf, sn_wave); break;
       }
     } else if (kind == 1) {
-      if (a.prof != nullptr && threadIdx.x == 0 && blockIdx.x == 0) a.prof[pi * 4 + 0] = wall_clock64();
-      sn_pool_phase(p, a.B, sn_lds);
-      if (a.prof != nullptr && threadIdx.x == 0 && blockIdx.x == 0) a.prof[pi * 4 + 1] = wall_clock64();
+      if (a.prof != nullptr && SN_TID == 0 && blockIdx.x == 0) a.prof[pi * 4 + 0] = wall_clock64();
+      sn_pool_phase(p, a.B, sn_lds, sn_wave);
+      if (a.prof != nullptr && SN_TID == 0 && blockIdx.x == 0) a.prof[pi * 4 + 1] = wall_clock64();
     } else {
-      ok = sn_linear(a, p, pi, sn_lds, &flag);
+      ok = sn_linear(a, p, pi, sn_lds, &flag, sn_wave);
     }
     if (!ok) {
-      if ((int)threadIdx.x < a.final_n) a.final_out[threadIdx.x] = __builtin_nanf("");
+      if (SN_TID < a.final_n) a.final_out[SN_TID] = __builtin_nanf("");
       return;
     }
-    if (pi + 1 < a.nph) sn_grid_arrive(a.bar);
+    if (pi + 1 < a.nph) {
+      sn_grid_arrive(a.bar, SN_TID);
+      if (a.prof != nullptr && SN_TID == 0 && blockIdx.x == 0) a.prof[256 + (pi + 1) * 8 + 6] = wall_clock64();
+    }
   }
 }
 
@@ -760,7 +815,7 @@ __global__ __launch_bounds__(SN_THREADS) void smallnet_kernel(SnArgs a) {
 // W[nt*16 + col][cq*4 + kk][tap].  k = 1 (the downsample conv): one tap.
 void sn_pack_conv(const float *oihw, int cout, int cin, int cinp, int k, std::vector<float> &out) {
   const int T = k * k, C4 = cinp / 4, NT = (cout + 15) / 16;
-  const int KS = std::min(SN_WAVES, C4 / 4), SPT = C4 / KS, NSTEP = T * SPT;
+  const int KS = SN_WAVES / sn_mblocks(C4), SPT = C4 / KS, NSTEP = T * SPT;
   out.assign((size_t)NT * KS * NSTEP * 64, 0.f);
   for (int nt = 0; nt < NT; ++nt)
     for (int ks = 0; ks < KS; ++ks)
@@ -846,7 +901,7 @@ bool pnvo_small_usable(pnvo_handle m, int B) {
   for (size_t k = 1; k < m->convs.size(); ++k) {
     const Layer &l = m->convs[k];
     if (l.k != 3) continue;
-    const int mb = SN_WAVES / std::min(SN_WAVES, l.cinp / 16), th = mb == 4 ? 8 : 4, tw = mb == 1 ? 4 : 8;
+    const int mb = sn_mblocks(l.cinp / 4), th = mb == 4 ? 8 : 4, tw = mb == 1 ? 4 : 8;
     floats = std::max(floats, (size_t)((th - 1) * l.stride + 3) * ((tw - 1) * l.stride + 3) * (l.cinp + 4));
   }
   if (((size_t)SN_FIXED_FLOATS + floats) * sizeof(float) > (size_t)156 * 1024) return false;
@@ -891,9 +946,8 @@ struct SnGeom {
   int MB, TH, TW, PH, PW, CS;
 };
 SnGeom sn_geom(const Layer &l) {
-  const int C4 = l.cinp / 4, KS = std::min(SN_WAVES, C4 / 4);
   SnGeom g;
-  g.MB = SN_WAVES / KS;
+  g.MB = sn_mblocks(l.cinp / 4);
   g.TH = g.MB == 4 ? 8 : 4;
   g.TW = g.MB == 1 ? 4 : 8;
   g.PH = (g.TH - 1) * l.stride + 3;
@@ -1208,7 +1262,8 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
       std::fprintf(stderr, "[pnvo] smallnet %2d k%d t%2d %4d | %7.2f %7.2f | %6.2f %6.2f", pi, sn->ph[pi].kind, sn->ph[pi].type, sn->ph[pi].ntiles,
                    (hp[pi * 4] - z) * 0.01, (hp[pi * 4 + 1] - z) * 0.01, hp[pi * 4 + 2] * 0.01, hp[pi * 4 + 3] * 0.01);
       if (sn->ph[pi].kind == 0) {
-        std::fprintf(stderr, " | pre %5.2f barrier %5.2f", pi > 0 ? (hp[256 + pi * 8 + 5] - hp[(pi - 1) * 4 + 1]) * 0.01 : 0.0,
+        std::fprintf(stderr, " | arrive %5.2f weights %5.2f items %5.2f wait %5.2f", pi > 0 ? (hp[256 + pi * 8 + 6] - hp[(pi - 1) * 4 + 1]) * 0.01 : 0.0,
+                     (hp[256 + pi * 8 + 7] - hp[256 + pi * 8 + 6]) * 0.01, (hp[256 + pi * 8 + 5] - hp[256 + pi * 8 + 7]) * 0.01,
                      (hp[pi * 4] - hp[256 + pi * 8 + 5]) * 0.01);
         std::fprintf(stderr, " | loads issued %5.2f tables %5.2f patch %5.2f K loop %5.2f sync %5.2f epilogue %5.2f", (hp[256 + pi * 8] - hp[pi * 4]) * 0.01,
                      (hp[256 + pi * 8 + 1] - hp[256 + pi * 8]) * 0.01, (hp[256 + pi * 8 + 2] - hp[256 + pi * 8 + 1]) * 0.01,
