@@ -330,7 +330,10 @@ int refresh_stem_dd(pnvo_handle m, TrainState *t, hipStream_t s) {
     HIPCHK(m, launch_stem_mx_repack(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_mxmaps, t->d_mxmaps + 32,
                                     t->d_mxmaps + 64, m->mx_wpk3, s));
     if (m->opt.train_pieces == 2 && m->mx_wpk2 != nullptr) {      // the float16 operand of the training forward, with its own scale
-      if (!m->mx_scale2_dev) HIPCHK(m, hipMalloc((void **)&m->mx_scale2_dev, 2 * sizeof(float)));
+      if (!m->mx_scale2_dev) {                    // {scale, 1/scale, integer maximum of the folded weights (zero between calls)}
+        HIPCHK(m, hipMalloc((void **)&m->mx_scale2_dev, 4 * sizeof(float)));
+        HIPCHK(m, hipMemset(m->mx_scale2_dev, 0, 4 * sizeof(float)));
+      }
       HIPCHK(m, launch_stem_mx_repack_h(t->params + t->stem_w_off, m->convs[0].cin, m->stem_sc, m->stem_sh, t->d_mxmaps, t->d_mxmaps + 32,
                                         t->d_mxmaps + 64, m->mx_scale2_dev, m->mx_wpk2, s));
       m->mx_wpk2_dev = true;
@@ -821,7 +824,9 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
     if (!seg.empty()) {
       int rc0 = dmalloc(m, (void **)&t->x2_seg, seg.size() * sizeof(long));
       if (rc0 != PNVO_OK) return rc0;
-      if ((rc0 = dmalloc(m, (void **)&t->x2_scale, seg.size() * sizeof(float))) != PNVO_OK) return rc0;
+      // {scale, 1/scale} per conv + the integer maxima launch_conv_x2_scales reduces into (zero between calls)
+      if ((rc0 = dmalloc(m, (void **)&t->x2_scale, (seg.size() + seg.size() / 2) * sizeof(float))) != PNVO_OK) return rc0;
+      HIPCHK(m, hipMemset(t->x2_scale, 0, (seg.size() + seg.size() / 2) * sizeof(float)));
       HIPCHK(m, hipMemcpy(t->x2_seg, seg.data(), seg.size() * sizeof(long), hipMemcpyHostToDevice));
     }
   }

@@ -774,26 +774,29 @@ __device__ __forceinline__ float stem_folded_weight(const float *w, int cin, con
   return (slot >= 20 && slot <= 25) ? v * 256.f : v;
 }
 
-// one block: max |folded weight| -> scale2[0] = 2^(12 - e), scale2[1] = 1 / scale
-__global__ __launch_bounds__(1024) void stem_mx_scale_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
-                                                           const int *slot_ref, const int *slot_new, float *scale2) {
-  __shared__ float red[16];
+// max |folded weight| -> scale2[0] = 2^(12 - e), scale2[1] = 1 / scale.  One folded weight per thread, the maximum as an integer
+// maximum of float bits in scale2[2]; a one-thread kernel derives the pair and clears the maximum.  (One 1024-thread block walked
+// the 48 608 folded weights alone — the indicator slot sums 30 channels — in 55 us, twice per training step.)
+__global__ __launch_bounds__(256) void stem_mx_absmax_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
+                                                            const int *slot_ref, const int *slot_new, float *scale2) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
   float mx = 0.f;
-  for (int e = threadIdx.x; e < 32 * 31 * 49; e += 1024) {
+  if (e < 32 * 31 * 49) {
     const int tap = e % 49, slot = (e / 49) % 31, co = e / (49 * 31);
-    mx = fmaxf(mx, fabsf(stem_folded_weight(w, cin, sc_new, sh_new, slot_ref, slot_new, co, slot, tap)));
+    mx = fabsf(stem_folded_weight(w, cin, sc_new, sh_new, slot_ref, slot_new, co, slot, tap));
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
-    int e = 0;
-    if (mx > 0.f) e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu) - 126;
-    scale2[0] = __builtin_bit_cast(float, (unsigned)(12 - e + 127) << 23);
-    scale2[1] = __builtin_bit_cast(float, (unsigned)(e - 12 + 127) << 23);
-  }
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned *>(scale2) + 2, __builtin_bit_cast(unsigned, mx));
+}
+__global__ void stem_mx_scale_finish_kernel(float *scale2) {
+  unsigned *bits = reinterpret_cast<unsigned *>(scale2) + 2;
+  const unsigned mb = *bits;
+  *bits = 0u;
+  int e = 0;
+  if (mb != 0u) e = (int)((mb >> 23) & 0xffu) - 126;
+  scale2[0] = __builtin_bit_cast(float, (unsigned)(12 - e + 127) << 23);
+  scale2[1] = __builtin_bit_cast(float, (unsigned)(e - 12 + 127) << 23);
 }
 
 __global__ __launch_bounds__(256) void stem_mx_repack_h_kernel(const float *w, int cin, const float *sc_new, const float *sh_new,
@@ -823,7 +826,9 @@ __global__ __launch_bounds__(256) void stem_mx_repack_h_kernel(const float *w, i
 
 hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                    const int *slot_new, const int *xslot, float *scale2, unsigned short *wpk2, hipStream_t s) {
-  hipLaunchKernelGGL(stem_mx_scale_kernel, dim3(1), dim3(1024), 0, s, w_oihw, cin, sc_new, sh_new, slot_ref, slot_new, scale2);
+  hipLaunchKernelGGL(stem_mx_absmax_kernel, dim3((32 * 31 * 49 + 255) / 256), dim3(256), 0, s, w_oihw, cin, sc_new, sh_new, slot_ref, slot_new,
+                     scale2);
+  hipLaunchKernelGGL(stem_mx_scale_finish_kernel, dim3(1), dim3(1), 0, s, scale2);
   const int total = 49 * 5 * 64 * 8;
   hipLaunchKernelGGL(stem_mx_repack_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cin, sc_new, sh_new,
                      slot_ref, slot_new, xslot, scale2, wpk2, total);
