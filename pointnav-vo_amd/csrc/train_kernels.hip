@@ -987,10 +987,22 @@ __device__ __forceinline__ void gn_nc(const float *nc, int chunks, int C, int n,
     return;
   }
   a1 = a2 = 0.0;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const float *src = nc + (((long)n * chunks + ch) * C + c) * 2;
-    a1 += (double)src[0];
-    a2 += (double)src[1];
+  const float2 *src = reinterpret_cast<const float2 *>(nc) + ((long)n * chunks) * C + c;
+  int ch = 0;
+  for (; ch + 8 <= chunks; ch += 8) {             // eight loads in flight, added in chunk order
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[(long)(ch + k) * C];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a1 += (double)v[k].x;
+      a2 += (double)v[k].y;
+    }
+  }
+  for (; ch < chunks; ++ch) {
+    const float2 v = src[(long)ch * C];
+    a1 += (double)v.x;
+    a2 += (double)v.y;
   }
 }
 
