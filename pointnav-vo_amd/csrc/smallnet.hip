@@ -800,7 +800,7 @@ __global__ __launch_bounds__(SN_THREADS) void smallnet_kernel(SnArgs a) {
       ok = sn_linear(a, p, pi, sn_lds, &flag, sn_wave);
     }
     if (!ok) {
-      if (SN_TID < a.final_n) a.final_out[SN_TID] = __builtin_nanf("");
+      for (int i = SN_TID; i < a.final_n; i += SN_THREADS) a.final_out[i] = __builtin_nanf("");
       return;
     }
     if (pi + 1 < a.nph) {
@@ -848,6 +848,7 @@ struct SmallNet {
   size_t tiles_cap = 0;
   std::vector<SnPhase> ph;
   int B = -1, grid = 0, stem_slots = -1;
+  bool features = false;             // built for pnvo_forward_features (no head phase)
   const void *ws_key[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t lds_bytes = 0;
   unsigned *bar = nullptr;
@@ -883,7 +884,7 @@ void pnvo_small_free(pnvo_handle m) {
 // <= small_max, no taps / per-launch timing / training forward; otherwise the per-layer launches run.)
 bool pnvo_small_usable(pnvo_handle m, int B) {
   if (!m->opt.small_net || B < 1 || B > m->opt.small_max || B > SN_MAXB) return false;
-  if (m->bottleneck || m->tap_dst != nullptr || m->features_only || m->train != nullptr || m->graph_mode > 0) return false;
+  if (m->bottleneck || m->tap_dst != nullptr || m->train != nullptr || m->graph_mode > 0) return false;
   if (m->precision != 0) return false;
   if (m->opt.conv != 0 || !m->opt.tail || !m->opt.pool || m->opt.conv3_nt) return false;   // an explicit kernel selection is honoured
   SmallNet *sn = static_cast<SmallNet *>(m->small);
@@ -895,7 +896,7 @@ bool pnvo_small_usable(pnvo_handle m, int B) {
   for (int st = 0; st < 4; ++st)
     if (m->nblocks[st] < 2) return false;
   if (B * std::max(m->convs[0].coutp, m->comp_cp) > SN_TAB) return false;
-  if (m->comp_cp != 32 && m->comp_cp != 64) return false;
+  if (m->comp_cp != 32 && m->comp_cp != 64 && m->comp_cp != 128) return false;
   // LDS: the largest patch of a conv phase, or the activation vectors of the Linear layers for the whole batch (large frames)
   size_t floats = (size_t)B * std::max((size_t)m->fh * m->fw * m->comp_cp, (size_t)c.hidden);
   for (size_t k = 1; k < m->convs.size(); ++k) {
@@ -1121,7 +1122,7 @@ int sn_build(pnvo_handle m, SmallNet *sn, int B) {
     p.bias = m->fc_bias;
     p.relu_out = 1;
     p.use_row = 1;
-    p.out = m->hid;
+    p.out = m->features_only ? nullptr : m->hid;   // pnvo_forward_features: the hidden vector IS the result (caller's tensor)
     ph.push_back(p);
     patch_floats = std::max(patch_floats, (size_t)B * p.K);
     SnPhase h;
@@ -1138,8 +1139,10 @@ int sn_build(pnvo_handle m, SmallNet *sn, int B) {
     h.bias = m->head_bias;
     h.relu_out = 0;
     h.out = nullptr;                               // the caller's tensor (SnArgs::final_out)
-    ph.push_back(h);
-    patch_floats = std::max(patch_floats, (size_t)B * h.K);
+    if (!m->features_only) {
+      ph.push_back(h);
+      patch_floats = std::max(patch_floats, (size_t)B * h.K);
+    }
   }
   // ---- buffers
   for (int k = 0; k < 4; ++k)
@@ -1173,6 +1176,7 @@ int sn_build(pnvo_handle m, SmallNet *sn, int B) {
   HIPCHK(m, hipMemcpy(sn->ph_dev, ph.data(), ph.size() * sizeof(SnPhase), hipMemcpyHostToDevice));
   sn->ph = ph;
   sn->B = B;
+  sn->features = m->features_only;
   sn->stem_slots = m->stem_slots_out;
   sn->ws_key[0] = m->stem_raw;
   sn->ws_key[1] = m->stats;
@@ -1207,7 +1211,7 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
     if ((rc = sn_pack_weights(m, sn)) != PNVO_OK) return rc;
     sn->B = -1;
   }
-  if (sn->B != B || sn->stem_slots != m->stem_slots_out || sn->ws_key[0] != m->stem_raw || sn->ws_key[1] != m->stats ||
+  if (sn->B != B || sn->features != m->features_only || sn->stem_slots != m->stem_slots_out || sn->ws_key[0] != m->stem_raw || sn->ws_key[1] != m->stats ||
       sn->ws_key[2] != m->rawA || sn->ws_key[3] != m->fc_bias) {
     HIPCHK(m, hipStreamSynchronize(s));            // the table of an in-flight launch is about to be rewritten
     rc = sn_build(m, sn, B);
@@ -1230,7 +1234,7 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
   a.err = sn->err;
   a.bias_row = actions;
   a.final_out = out;
-  a.final_n = B * m->cfg.out_dim;
+  a.final_n = B * (m->features_only ? m->cfg.hidden : m->cfg.out_dim);
   a.prof = nullptr;
   a.dbg = m->opt.small_prof;
   if (m->opt.small_prof) {
