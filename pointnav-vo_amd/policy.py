@@ -226,7 +226,9 @@ class PointNavResNetPolicy(nn.Module):
         """-> (value [B,1], action [B,1] int64, action_log_probs [B,1], rnn_hidden_states)  (policy.py:29-46)."""
         with torch.no_grad():
             _, hout, logits, value = self._net(observations, rnn_hidden_states, prev_actions, masks)
-            dist = torch.distributions.Categorical(logits=logits)
+            # (validate_args=False: the distribution's argument checks are five more launches and a host sync per step; the logits
+            #  come from the kernels above, the sampling call and its generator use are unchanged)
+            dist = torch.distributions.Categorical(logits=logits, validate_args=False)
             action = dist.probs.argmax(dim=-1, keepdim=True) if deterministic else dist.sample().unsqueeze(-1)
             logp = dist.log_prob(action.squeeze(-1)).view(action.size(0), -1).sum(-1).unsqueeze(-1)
         return value, action, logp, hout
