@@ -1,28 +1,26 @@
-// smallnet.hip — the whole network behind the stem in ONE persistent launch, for the batch sizes of the navigation loop.
+// smallnet.hip — the whole network behind the stem conv in ONE persistent launch, for the batch sizes of the navigation loop.
 //
 // The reference calls the VO model once per environment step with a batch of ONE pair (rl/ppo/ppo_trainer.py:836-841,
 // challenge_2020/challenge2020_agent.py:311-394).  At that size the ~58 launches that follow the stem (sixteen 3x3 convs,
 // three 1x1 downsample convs, twenty GroupNorm finalisations, eight residual passes, max-pool, compression, two Linear
 // layers — resnet.py:29-55,153-212, vo_cnn.py:70-176) are a chain of dependent 5–25 µs kernels, each spread over 1–33
-// workgroups: 0.42 ms of latency for 1.2 GFLOP.  Here every layer is a PHASE of one kernel: workgroups (one per CU, 16
-// waves) meet at a grid barrier between phases, every phase spreads its layer over ~100–150 CUs, and what the small passes
-// did rides on the phases themselves:
-//   * GroupNorm finalisation: every producer tile writes {sum, sum of squares} per group; every consumer workgroup reduces
-//     the slots of its sample in double precision (fixed order) into scale / shift tables in LDS;
+// workgroups: 0.42 ms of latency for 1.2 GFLOP.  Here every layer is a PHASE of one kernel: 144 workgroups of 8 waves (one per
+// CU) meet at a grid barrier between phases, every phase spreads its layer over 96–144 of them, and what the small passes did
+// rides on the phases themselves:
+//   * GroupNorm finalisation: every producer tile writes {sum, sum of squares} per group; every consumer workgroup reduces the
+//     slots of its sample in double precision (fixed order) into scale / shift tables in LDS;
 //   * GroupNorm + ReLU, the BasicBlock tail relu(GN2(conv2) + skip) and the stem's GroupNorm + ReLU + max-pool are the input
-//     transform of the consuming phase's stager (the tile that owns a pixel also writes the block output the next skip
-//     branch reads);
+//     transform of the consuming phase (the tile that owns a pixel also writes the block output the next skip branch reads);
 //   * the 1x1 stride-2 downsample conv shares the staged patch of the block's first 3x3 conv (its centre tap).
 // Convs are implicit GEMMs on v_mfma_f32_16x16x4_f32 (float32 in, float32 accumulate): a tile is TH x TW output pixels
-// (16 * MB) x 16 output channels; the MB M-blocks and a 16/MB-way split of K = 9 * Cin go over the 16 waves, the K-split
-// partials meet in LDS in wave order.  A fragments come from the LDS patch, B fragments straight from global memory in
-// fragment order (256 contiguous bytes per wave and K-step; each weight is read by exactly one workgroup per sample-tile row).
-// Linear layers: 4 outputs per workgroup, K split over 4 waves per output.
+// (16 * MB) x 16 output channels; the MB M-blocks and an 8/MB-way split of K = 9 * Cin go over the 8 waves, the K-split partials
+// meet in LDS in wave order.  A fragments come from the LDS patch; a wave's B fragments of the whole K walk sit in registers,
+// fetched in 16-byte loads from a host-side packing in walk order.  Linear layers: 4 outputs per workgroup, K over 2 waves each.
 //
-// Grid barrier: one device-scope counter; arrive = release fence + atomic add by thread 0, wait = polling load + acquire
-// fence (the per-XCD L2s are written back / invalidated by those fences exactly as a kernel boundary would).  The launch is
-// cooperative (all workgroups resident by construction); a bounded spin turns an impossible wait into an error flag instead
-// of a hung device.
+// Grid barrier: one device-scope counter, in two halves — ARRIVE right behind a phase's stores, then the next phase's tile,
+// weights and addresses are prepared, then WAIT.  Tensors that cross workgroups are moved with agent-scope (sc1) loads / stores, so
+// the barrier carries no cache write-back or invalidate.  The launch is cooperative by default; a bounded spin turns an
+// impossible wait into NaN results and an error on the handle, never a hung device.  DESIGN.md section 4 has the measurements.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -40,7 +38,7 @@ typedef float sn_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SN_THREADS = 512, SN_WAVES = 8, SN_TAB = 512, SN_MAXB = 4;
 constexpr int sn_mblocks(int c4) { return c4 <= 8 ? 4 : c4 <= 16 ? 2 : 1; }   // M-blocks (16 output pixels) of a conv tile, by input channels / 4
 constexpr int SN_KP = SN_WAVES / 4, SN_WPRE = 6;                  // linear layers: K parts per output, weight vectors fetched ahead
-constexpr int SN_RED_FLOATS = 2 * SN_WAVES * 256;                 // K-split partials: two convs x 16 waves x (64 lanes x 4)
+constexpr int SN_RED_FLOATS = 2 * SN_WAVES * 256;                 // K-split partials: two convs x 8 waves x (64 lanes x 4)
 constexpr int SN_MAXPH = 40;                                      // phases (BasicBlock nets up to resnet34: 36)
 constexpr int SN_DESC_FLOATS = SN_MAXPH * 72 + 64;                // the phase table (copied to LDS at kernel start) + this workgroup's first tiles
 constexpr int SN_FIXED_FLOATS = 4 * SN_TAB + SN_RED_FLOATS + SN_DESC_FLOATS;   // tables + partials + phase table, then the patch / activation vector
@@ -85,8 +83,6 @@ struct SnArgs {
 
 namespace {
 
-#define SN_C __attribute__((address_space(4)))
-typedef const SN_C SnPhase *SnPhaseC;
 
 __device__ __forceinline__ int sn_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <typename T>
@@ -1280,7 +1276,3 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
   return PNVO_OK;
 }
 
-int pnvo_small_phases(pnvo_handle m) {
-  SmallNet *sn = static_cast<SmallNet *>(m->small);
-  return sn ? (int)sn->ph.size() : 0;
-}
