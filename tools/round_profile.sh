@@ -4,9 +4,6 @@
 tag=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 300 $O/${tag}_bench.json; echo
-python bench.py --config dual_bf16 > $O/${tag}_bench_dual_bf16.json 2> $O/${tag}_bench_dual_bf16.err; tail -c 300 $O/${tag}_bench_dual_bf16.json; echo
-python bench.py --config train --steps 10 --warmup 3 > $O/${tag}_bench_train.json 2> $O/${tag}_bench_train.err; tail -c 300 $O/${tag}_bench_train.json; echo
 for cfg in fwd_fp32 dual_bf16; do
   rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_$cfg -o p -- python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/${tag}_trace_$cfg.log 2>&1
   python tools/rocprof_summary.py $O/${tag}_trace_$cfg/p_results.db > $O/${tag}_kernel_trace_$cfg.md 2>&1
@@ -20,6 +17,12 @@ for cfg in fwd_fp32 dual_bf16; do
   python tools/mfma_util.py $O/${tag}_kernel_trace_$cfg.md $O/${tag}_pmc_$cfg.md > $O/${tag}_mfma_util_$cfg.md
   rm -rf $O/${tag}_pmc_${cfg}_* $O/${tag}_trace_$cfg
 done
+# the three bench lines AFTER the counter passes, with this run's traffic record in place (bench.py reads profiles/traffic.json and
+# accepts it only for the kernel sources it was measured on)
+cp $O/${tag}_traffic.json profiles/traffic.json
+python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 300 $O/${tag}_bench.json; echo
+python bench.py --config dual_bf16 > $O/${tag}_bench_dual_bf16.json 2> $O/${tag}_bench_dual_bf16.err; tail -c 300 $O/${tag}_bench_dual_bf16.json; echo
+python bench.py --config train --steps 10 --warmup 3 > $O/${tag}_bench_train.json 2> $O/${tag}_bench_train.err; tail -c 300 $O/${tag}_bench_train.json; echo
 # training step: kernel trace only (its kernels are MFMA / HBM bound by construction; counters are taken for the forward)
 rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_train -o p -- python bench.py --config train --steps 10 --warmup 3 > $O/${tag}_trace_train.log 2>&1
 python tools/rocprof_summary.py $O/${tag}_trace_train/p_results.db > $O/${tag}_kernel_trace_train.md 2>&1
