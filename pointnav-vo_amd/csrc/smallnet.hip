@@ -1241,11 +1241,20 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
   sn->bar_base += (unsigned)(a.nph - 1) * (unsigned)sn->grid;
   {
     PnvoTimed t(m, s, "smallnet", 0.0, 0.0);
+    bool launched = false;
     if (m->opt.small_coop) {
       void *args[1] = {&a};
-      HIPCHK(m, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(smallnet_kernel), dim3((unsigned)sn->grid), dim3(SN_THREADS),
-                                           args, (unsigned)sn->lds_bytes, s));
-    } else {
+      const hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(smallnet_kernel), dim3((unsigned)sn->grid),
+                                                       dim3(SN_THREADS), args, (unsigned)sn->lds_bytes, s);
+      launched = ce == hipSuccess;
+      if (!launched) {                             // a runtime without cooperative launches for this shape: plain launch from now on
+        (void)hipGetLastError();
+        m->opt.small_coop = 0;
+        m->err = std::string("note: hipLaunchCooperativeKernel refused the small-batch kernel (") + hipGetErrorString(ce) +
+                 "); this handle uses the plain launch (option small_coop = 0)";
+      }
+    }
+    if (!launched) {
       hipLaunchKernelGGL(smallnet_kernel, dim3((unsigned)sn->grid), dim3(SN_THREADS), sn->lds_bytes, s, a);
       HIPCHK(m, hipGetLastError());
     }
