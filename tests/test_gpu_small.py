@@ -102,6 +102,23 @@ def test_large_frames_take_the_kernel_while_the_batch_fits_its_lds():
     assert pair_rel_err(four[:3], layers.astype(np.float64)).max() < 2e-5
 
 
+def test_reloaded_weights_reach_the_kernels_own_packing():
+    """The kernel keeps its own fragment-ordered copy of every weight: a load_state_dict between two forwards must rebuild it."""
+    rec = load_golden("model_default_341x192_b2.npz")
+    model, cfg, sd, obs, tobs, actions, tact = build(rec)
+    one = {k: v[:1].contiguous() for k, v in tobs.items()}
+    before = run(model, one, None)
+    sd2 = {k: torch.from_numpy(np.array(v)).clone() for k, v in sd.items()}
+    for k in ("visual_encoder.backbone.layer3.1.convs.3.weight", "visual_fc.2.weight", "output_head.1.bias",
+              "visual_encoder.backbone.layer2.0.downsample.1.weight"):
+        sd2[k] = sd2[k] * 1.25 + 0.01
+    model.load_state_dict(sd2)
+    after = run(model, one, None)
+    assert np.abs(after - before).max() > 1e-3
+    model.set_option("small_net", "off")
+    assert pair_rel_err(after, run(model, one, None).astype(np.float64)).max() < 2e-5
+
+
 def test_models_it_does_not_fit_keep_the_per_layer_launches():
     for fname in ("model_wider_64x48_b2.npz",          # 512 channels in the last stage: above the kernel's 256
                   "model_deeper_64x48_b2.npz",         # Bottleneck blocks
