@@ -43,4 +43,12 @@ PNVO_SMALL_NET=off rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_b1l -o p 
 python tools/rocprof_summary.py $O/${tag}_trace_b1l/p_results.db > $O/${tag}_kernel_trace_b1_layers.md 2>&1
 rm -rf $O/${tag}_trace_b1 $O/${tag}_trace_b1l
 PROF=1 COOPS=0 python tools/check_small.py 2>&1 | grep -v amdgpu.ids > $O/${tag}_smallnet_phases.txt
+# counters of the one-pair forward (the persistent kernel and the stem in front of it)
+: > $O/${tag}_pmc_b1.md
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE"; do
+  n=$(echo $set | cut -d" " -f1)
+  PNVO_SMALL_COOP=0 rocprofv3 --kernel-trace --pmc $set -d $O/${tag}_pmc_b1_$n -o p -- python bench.py --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-preheat --no-secondary > $O/${tag}_pmc_b1_$n.log 2>&1
+  python tools/rocprof_summary.py $O/${tag}_pmc_b1_$n/p_results.db --pmc 2>&1 | awk '/## counters/{f=1} f' >> $O/${tag}_pmc_b1.md
+  rm -rf $O/${tag}_pmc_b1_$n
+done
 head -14 $O/${tag}_kernel_trace_fwd_fp32.md
