@@ -173,6 +173,49 @@ def timed_steps(step, steps, sync_all, dev):
     return dt, out
 
 
+def arithmetic_text(model):
+    """What the measured forward multiplied with, read from the handle's options (not a fixed string)."""
+    conv, stem, pieces = model.get_option("conv"), model.get_option("stem"), model.get_option("pieces")
+    if conv in ("auto", "x3") and stem in ("auto", "mx"):
+        if pieces == "2":
+            how = ("every float32 operand of the stem and of the sixteen 3x3 convs is split into TWO float16 pieces (22-bit operands; "
+                   "weights pre-scaled by a power of two per tensor, undone exactly on the accumulators) and multiplied on the float16 "
+                   "matrix cores: a*w ~ a0*w0 + a0*w1 + a1*w0, every kept term exact in the float32 accumulator, the dropped a1*w1 "
+                   "below 2^-22 of the product (relative error per product <= 3 * 2^-22 = 7e-7); raw stem inputs (integers <= 255, "
+                   "{0,1}) are exact in float16, only the stem weight and the float-valued channels are split there; float32 "
+                   "accumulation.  NARROWER than the reference's fp32 multiply: `secondary.fwd_fp32_pieces3` (three exact bf16 "
+                   "pieces, products exact or within 2^-23) and `secondary.fwd_fp32_pipe` (every conv on the fp32 MFMA pipe) are the "
+                   "strict forms, measured in the same run with their own error against the fp64 oracle")
+        else:
+            how = ("every float32 operand of the stem and of the sixteen 3x3 convs is split into THREE bf16 pieces (hi + mid + lo == the "
+                   "float32 value) and multiplied on the bf16 matrix cores: products exact (stem: inputs exact in bf16) or within 2^-23 "
+                   "(six of the nine cross terms), float32 accumulation")
+        return "float32 activations, weights, accumulators and results; " + how + "; options conv=fp32 / stem=dense select the fp32-MFMA kernels"
+    return f"float32 (options conv={conv}, stem={stem}, pieces={pieces}): fp32-MFMA convs where conv=fp32, dense fp32 stem where stem=dense"
+
+
+def strict_variant(model, obs, ref, chk, opts, B, world, sync_all, dev, note):
+    """10 timed steps of the headline batch with `opts` set on the handle (the strict-arithmetic forms), their own error against the
+    fp64 oracle on the headline's checked pairs; options restored afterwards."""
+    saved = {k: model.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            model.set_option(k, v)
+        with torch.no_grad():
+            o = model(obs)
+            t = parallel.max_over_ranks(time_steps_simple(lambda: model(obs), 10, sync_all), dev)
+        rec = {"workload": note, "options": dict(opts), "value": world * B / t, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t, "steps": 10}
+        if ref is not None:
+            oc = o[chk].cpu().numpy().astype(np.float64)
+            rec["pose_rel_err_vs_fp64_oracle"] = float((np.linalg.norm(oc - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)).max())
+        return rec
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        for k, v in saved.items():
+            model.set_option(k, v.split(" ")[0])
+
+
 def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2"):
     """Work the stem kernels EXECUTE (not the algorithmic 30-channel conv): matrix-core FLOPs per launch against the
     peak of the pipe they run on."""
@@ -296,7 +339,7 @@ def main():
         # parity on the first pairs of this rank's batch (fp64 oracle on the same tensors)
         out = model(obs)
         torch.cuda.synchronize(dev)
-        rel = None
+        rel = ref = chk = None
         if rank == 0:
             from oracle import oracle
             chk = sorted({i for i in ORACLE_PAIRS if i < B} | {0, B - 1})     # first / last tile of the batch, mid-batch
@@ -324,6 +367,7 @@ def main():
     #      (tools/bench_configs.py), on the headline's own observation tensors; AFTER the headline's timed region, never in it
     secondary = None
     raw_rec = None
+    strict = None
     if not args.no_secondary:
         # the same forward from the SENSOR frames (pnvo_forward_raw: no observation-pair tensors): bit-identical results
         with torch.no_grad():
@@ -335,6 +379,16 @@ def main():
                                "pair instead of 7.86 MB of float32 observation tensors)", "value": world * B / t_raw,
                    "unit": "frame-pairs/s", "ms_per_step": 1e3 * t_raw, "steps": 10, "bit_identical_to_headline_outputs": same}
         del rgb_f, dep_f
+        # the strict forms of the same forward, beside the headline: three exact bf16 pieces (round 2's arithmetic) and the fp32 pipe
+        strict = {
+            "fwd_fp32_pieces3": strict_variant(model, obs, ref if rank == 0 else None, chk if rank == 0 else None, {"pieces": "3"}, B, world,
+                                               sync_all, dev, "the headline batch with option pieces=3: three exact bf16 pieces per float32 "
+                                               "operand, six MFMA terms per product (stem: 7 MFMAs per tap)"),
+            "fwd_fp32_pipe": strict_variant(model, obs, ref if rank == 0 else None, chk if rank == 0 else None,
+                                            {"conv": "fp32", "stem": "dense", "pool": "separate"}, B, world, sync_all, dev,
+                                            "the headline batch with options conv=fp32, stem=dense: every multiply on the fp32 MFMA pipe "
+                                            "(v_mfma_f32_32x32x2_f32 / 16x16x4_f32: an exact fp32 FMA chain)"),
+        }
     if not args.no_secondary and B >= 128:
         import copy
         from tools import bench_configs
@@ -409,6 +463,7 @@ def main():
             "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "float32 storage, accumulation and results; what the multipliers see is stated under `arithmetic`",
             "config": {"workload": "BASELINE configs[1]: act_forward VO inference (vo_cnn_rgb_d_dd_top_down, 30 input "
                                    "channels), 341x192, fp32, seeded random weights", "pairs_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"dp{world} (independent pairs, no collective)"},
@@ -416,11 +471,7 @@ def main():
             "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
             "kernel_ms_per_step": total_kernel_ms / args.steps,
             "pose_rel_err_vs_fp64_oracle": rel, "oracle_checked_pairs": chk,
-            "arithmetic": ("float32 activations, weights, accumulators and results; the stem and the sixteen 3x3 convs of the "
-                           "residual stages multiply on the bf16 matrix cores with every float32 operand split into three bf16 pieces "
-                           "(hi + mid + lo == the float32 value): products exact (stem: inputs exact in bf16) or within 2^-23 (six of "
-                           "the nine cross terms), float32 accumulation; options conv=fp32 / stem=dense select the fp32-MFMA kernels"
-                           if model.get_option("conv") in ("auto", "x3") else "float32 (fp32 MFMA convs); stem: option `stem`"),
+            "arithmetic": arithmetic_text(model),
             "model_tflops": value * flops_pair / 1e12,
             "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
@@ -439,6 +490,8 @@ def main():
             res["secondary"] = secondary
         if raw_rec is not None:
             res.setdefault("secondary", {})["fwd_fp32_from_sensor_frames"] = raw_rec
+        if strict is not None:
+            res.setdefault("secondary", {}).update(strict)
         if navloop is not None:
             res.setdefault("secondary", {})["navloop_gpu_side"] = navloop
         if latency is not None:

@@ -363,6 +363,10 @@ int pnvo_avgpool2(const float *depth, int N, int H, int W, float *out, void *str
 /* Message of the last failing call on this handle (or of the last failing handle-less call if h is NULL). */
 const char *pnvo_last_error(pnvo_handle h);
 
+/* One-line note of the last SUCCESSFUL call that changed the handle's behaviour (the dense-stem fallback of pnvo_check_inputs,
+ * a refused cooperative launch): "" when there is none.  Kept apart from pnvo_last_error, which only ever holds failures. */
+const char *pnvo_last_note(pnvo_handle h);
+
 /* ---- introspection used by tests and bench.py (not part of the drop-in surface) ---- */
 
 /* Copy an intermediate activation of the NEXT pnvo_forward into dst (device, capacity in floats).  Names:
@@ -390,9 +394,12 @@ int pnvo_forward_features(pnvo_handle h, const float *rgb, const float *depth, c
  * asserts, :163).  The reference MODEL, however, accepts any float tensor (vo_cnn.py:110-176), so a drop-in must too:
  *   option input_fallback = on (default): a forward whose stem met a value outside the contract is RE-RUN inside the same
  *     pnvo_forward / pnvo_forward_features / pnvo_train_forward call on the dense fp32 stem — the caller gets the correct
- *     result from that call — and the handle stays on the dense stem from then on (pnvo_last_error holds a one-line note,
+ *     result from that call — and the handle stays on the dense stem from then on (pnvo_last_note holds a one-line note,
  *     pnvo_get_option(h, "stem") reports "dense (fallback)"; pnvo_set_option(h, "stem", ...) lifts it).  Cost for contract
- *     inputs: the call waits for the stem kernel (the first of ~55 launches) before it returns; the rest stays queued.
+ *     inputs: the call waits (hipEventSynchronize) for the stem kernel of THIS forward before it returns — the first of its ~55
+ *     launches, so on an idle stream the wait is over before the enqueue is; on a stream with a backlog (several action models
+ *     enqueued back to back, 'rnd' mode, a training step whose gradient all-reduce should run ahead of the host) the host
+ *     blocks until the earlier work and this stem have run.  Such callers switch the option off and poll pnvo_check_inputs.
  *   option input_fallback = off, or a forward issued while the stream is being captured into a hipGraph: no wait; the stem
  *     raises a host-visible flag instead and pnvo_check_inputs (definitive after the caller synchronised the stream) as well
  *     as every later forward on the handle return PNVO_ERR_INPUT until the weights are re-loaded. */

@@ -91,6 +91,7 @@ _SIGNATURES = {
                                  C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "pnvo_destroy": (C.c_int, [C.c_void_p]),
     "pnvo_last_error": (C.c_char_p, [C.c_void_p]),
+    "pnvo_last_note": (C.c_char_p, [C.c_void_p]),
     "pnvo_set_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "pnvo_tap_shape": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
     "pnvo_check_inputs": (C.c_int, [C.c_void_p]),

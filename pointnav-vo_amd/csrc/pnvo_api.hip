@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <atomic>
 #include <condition_variable>
 #include <map>
@@ -438,6 +439,31 @@ void pnvo_drop_graphs(pnvo_handle m) {
   }
   m->graphs.clear();
   m->seen.clear();
+}
+
+// Upper bound of |activation| entering each conv of the residual stages from per-layer GroupNorm bounds gn_bound(l) =
+// max_c (|gamma_c| sqrt(N) + |beta_c|): a block output adds its skip branch (resnet.py:47-55).  Used at load (host copy of the
+// parameters) and by the training step (bounds tracked on the device after every optimiser step, pnvo_train_api.hip).
+void pnvo_chain_in_bounds(pnvo_handle h, const std::function<float(const Layer &)> &gn_bound) {
+  if (h->bottleneck || h->convs.empty()) return;
+  float bin = gn_bound(h->convs[0]);                         // pooled stem output
+  size_t li = 1;
+  for (int stage = 1; stage <= 4; ++stage)
+    for (int bi = 0; bi < h->nblocks[stage - 1]; ++bi) {
+      if (li + 1 >= h->convs.size()) return;
+      Layer &c1 = h->convs[li++];
+      Layer &c2 = h->convs[li++];
+      const bool ds = li < h->convs.size() && h->convs[li].name.find("downsample") != std::string::npos;
+      c1.in_bound = bin;
+      c2.in_bound = gn_bound(c1);
+      float skip = bin;
+      if (ds) {
+        Layer &cd = h->convs[li++];
+        cd.in_bound = bin;
+        skip = gn_bound(cd);
+      }
+      bin = gn_bound(c2) + skip;
+    }
 }
 
 namespace {
@@ -963,7 +989,7 @@ int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun) {
   m->dense_sticky = true;
   m->fallback_count += 1;
   pnvo_drop_graphs(m);
-  m->err = "note: observation values outside the fused stems' contract (fractional rgb or depth codes that are not one-hot) — "
+  m->note = "note: observation values outside the fused stems' contract (fractional rgb or depth codes that are not one-hot) — "
            "the forward was re-run on the dense fp32 stem and this handle stays on it";
   *rerun = true;
   return PNVO_OK;
@@ -981,6 +1007,8 @@ extern "C" {
 const char *pnvo_version(void) { return "pnvo 0.2 (gfx950: fp32 + bf16 MFMA)"; }
 
 const char *pnvo_last_error(pnvo_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+const char *pnvo_last_note(pnvo_handle h) { return h ? h->note.c_str() : ""; }
 
 int pnvo_create(const pnvo_config *cfg, int device, pnvo_handle *out) {
   if (!cfg || !out) return fail(nullptr, PNVO_ERR_ARG, "null argument");
@@ -1048,23 +1076,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
       for (int c2 = 0; c2 < l.cout; ++c2) mx = std::fmax(mx, std::fabs((double)g[c2]) * rootn + std::fabs((double)b[c2]));
       return (float)std::fmin(mx, 3.0e38);
     };
-    float bin = gn_bound(h->convs[0]);                         // pooled stem output
-    size_t li = 1;
-    for (int stage = 1; stage <= 4; ++stage)
-      for (int bi = 0; bi < h->nblocks[stage - 1]; ++bi) {
-        Layer &c1 = h->convs[li++];
-        Layer &c2 = h->convs[li++];
-        const bool ds = li < h->convs.size() && h->convs[li].name.find("downsample") != std::string::npos;
-        c1.in_bound = bin;
-        c2.in_bound = gn_bound(c1);
-        float skip = bin;
-        if (ds) {
-          Layer &cd = h->convs[li++];
-          cd.in_bound = bin;
-          skip = gn_bound(cd);
-        }
-        bin = gn_bound(c2) + skip;
-      }
+    pnvo_chain_in_bounds(h, gn_bound);
   }
   {
     // fused stem: re-pack conv1 with its input channels in observation-tensor order, and fold /255 and the

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,7 @@ struct pnvo_model_s {
   pnvo_config cfg;
   int device = 0;
   std::string err;
+  std::string note;           // pnvo_last_note: what a SUCCESSFUL call changed on the handle (never an error)
   bool loaded = false;
 
   int C = 0, CP = 0;                 // input channels, padded to 8
@@ -192,6 +194,7 @@ int pnvo_mark_stem(pnvo_handle m, hipStream_t s);
 int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun);   // after the forward is enqueued: wait for the stem, re-run on the dense stem?
 void pnvo_train_free(pnvo_handle m);   // pnvo_train_api.hip
 const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string &name);   // pnvo_train_api.hip: device pointer or nullptr
+void pnvo_chain_in_bounds(pnvo_handle h, const std::function<float(const Layer &)> &gn_bound);   // pnvo_api.hip
 const float *pnvo_train_x2_scale(pnvo_handle m, const std::string &name);     // device {scale, 1/scale} of that conv weight's float16 pieces, or nullptr
 void pnvo_bf16_free(pnvo_handle m);    // pnvo_bf16.hip
 bool pnvo_small_usable(pnvo_handle m, int B);   // smallnet.hip: does this call shape take the persistent kernel?

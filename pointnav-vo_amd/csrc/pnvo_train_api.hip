@@ -83,11 +83,19 @@ struct TrainState {
   pnvo_grad_ready_fn hook = nullptr;
   void *hook_user = nullptr;
   std::vector<size_t> bucket_first;     // e.g. {offset of layer4's first parameter, offset of layer2's, 0}
+  std::vector<char> bucket_done;        // per backward: which ranges have been reported (the end of the backward reports the rest)
   // two-piece float16 operands of the training forward's convs: per conv weight {scale, 1/scale}, recomputed from the flat
   // parameters by ONE launch per pnvo_train_refresh (conv_x3.hip conv_x2_scale_kernel)
   std::map<std::string, int> x2_index;  // conv weight name -> row of x2_scale
   long *x2_seg = nullptr;               // device [rows][2]: flat offset, element count
   float *x2_scale = nullptr;            // device [rows][2]
+  // GroupNorm bounds behind Layer::in_bound (the range guard of the float16 pieces), tracked while gamma / beta move: one small
+  // launch per pnvo_train_refresh writes max_c (|gamma_c| sqrt(N) + |beta_c|) per conv into host-mapped memory; the next training
+  // forward chains them into in_bound without a synchronisation (a value may lag one optimiser step: a step moves gamma by <= lr)
+  struct GnbSeg { long goff, boff; int c; float rootn; };
+  GnbSeg *gnb_seg = nullptr;            // device [convs]
+  float *gnb_host = nullptr;            // host-mapped [convs]; < 0: not computed yet
+  int gnb_n = 0;
 };
 
 TrainState *TS(pnvo_handle m) { return reinterpret_cast<TrainState *>(m->train); }
@@ -697,6 +705,8 @@ void pnvo_train_free(pnvo_handle m) {
   dfree(t->d_tensor_of_new);
   dfree(t->d_ciperm);
   if (t->embed_err) (void)hipHostFree(t->embed_err);
+  dfree(t->gnb_seg);
+  if (t->gnb_host) (void)hipHostFree(t->gnb_host);
   m->train_mx = false;
   delete t;
   m->train = nullptr;
@@ -792,6 +802,27 @@ extern "C++" const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string
   return it == t->toc.end() ? nullptr : t->params + it->second.off;
 }
 
+__global__ __launch_bounds__(64) void gn_bound_kernel(const float *params, const TrainState::GnbSeg *seg, float *out) {
+  const TrainState::GnbSeg sg = seg[blockIdx.x];
+  if (sg.c <= 0) return;
+  float mx = 0.f;
+  for (int c = threadIdx.x; c < sg.c; c += 64) mx = fmaxf(mx, fabsf(params[sg.goff + c]) * sg.rootn + fabsf(params[sg.boff + c]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if (threadIdx.x == 0) __hip_atomic_store(out + blockIdx.x, fminf(mx, 3.0e38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Layer::in_bound from the bounds the device last reported (no-op until every conv has one)
+static void chain_tracked_bounds(pnvo_handle m, TrainState *t) {
+  if (!t->gnb_host || m->bottleneck) return;
+  for (int i = 0; i < t->gnb_n; ++i)
+    if (m->convs[i].gn.size() && !(*(volatile float *)(t->gnb_host + i) >= 0.f)) return;
+  pnvo_chain_in_bounds(m, [&](const Layer &l) {
+    const long i = &l - m->convs.data();
+    return i >= 0 && i < t->gnb_n ? *(volatile float *)(t->gnb_host + i) : 3.0e38f;
+  });
+}
+
 int pnvo_train_refresh(pnvo_handle m, void *stream) {
   if (!m || !m->train) return pnvo_fail(m, PNVO_ERR_STATE, "pnvo_train_attach first");
   HIPCHK(m, hipSetDevice(m->device));
@@ -831,6 +862,26 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
     }
   }
   if (t->x2_seg) HIPCHK(m, launch_conv_x2_scales(t->params, t->x2_seg, (int)t->x2_index.size(), t->x2_scale, (hipStream_t)stream));
+  if (!m->bottleneck) {                // GroupNorm bounds of the CURRENT parameters -> host-mapped table (chain_tracked_bounds)
+    if (!t->gnb_seg) {
+      std::vector<TrainState::GnbSeg> seg(m->convs.size(), TrainState::GnbSeg{0, 0, 0, 0.f});
+      for (size_t li = 0; li < m->convs.size(); ++li) {
+        const Layer &l = m->convs[li];
+        auto g = t->toc.find(l.gn + ".weight"), b = t->toc.find(l.gn + ".bias");
+        if (l.gn.empty() || g == t->toc.end() || b == t->toc.end() || l.groups <= 0) continue;
+        seg[li] = TrainState::GnbSeg{(long)g->second.off, (long)b->second.off, l.cout,
+                                     (float)std::sqrt((double)(l.cout / l.groups) * l.hout * l.wout)};
+      }
+      t->gnb_n = (int)seg.size();
+      int rc0 = dmalloc(m, (void **)&t->gnb_seg, seg.size() * sizeof(TrainState::GnbSeg));
+      if (rc0 != PNVO_OK) return rc0;
+      HIPCHK(m, hipMemcpy(t->gnb_seg, seg.data(), seg.size() * sizeof(TrainState::GnbSeg), hipMemcpyHostToDevice));
+      HIPCHK(m, hipHostMalloc((void **)&t->gnb_host, seg.size() * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+      for (int i = 0; i < t->gnb_n; ++i) t->gnb_host[i] = -1.f;
+    }
+    hipLaunchKernelGGL(gn_bound_kernel, dim3((unsigned)t->gnb_n), dim3(64), 0, (hipStream_t)stream, t->params, t->gnb_seg, t->gnb_host);
+    HIPCHK(m, hipGetLastError());
+  }
   if (m->cfg.act_embed) {      // eval-mode bias rows bias[a][o] = b1[o] + W1[o][flat:] . emb[a]  (pnvo_load_weights does this on the host)
     const pnvo_config &c = m->cfg;
     const int rows = c.n_acts + 1, flat = m->comp_c * m->fh * m->fw;
@@ -866,6 +917,7 @@ static int train_forward_body(pnvo_handle m, const float *rgb, const float *dept
   if (c.normalize && (!run_mean || !run_var)) return pnvo_fail(m, PNVO_ERR_ARG, "running statistics required");
   HIPCHK(m, hipSetDevice(m->device));
   TrainState *t = TS(m);
+  chain_tracked_bounds(m, t);            // float16-piece range guard follows the parameters as they train
   int rc = ensure_train_ws(m, t, B);
   if (rc != PNVO_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -989,14 +1041,22 @@ static int train_backward_body(pnvo_handle m, const float *grad_out, void *strea
 
 // bucket k of the gradient-ready hook is final: report it (host callback; the launches that produce it are enqueued on `s`)
 static void report_bucket(TrainState *t, size_t k, hipStream_t s) {
-  if (!t->hook || k >= t->bucket_first.size()) return;
+  if (k >= t->bucket_first.size()) return;
+  if (t->bucket_done.size() != t->bucket_first.size()) t->bucket_done.assign(t->bucket_first.size(), 0);
+  if (t->bucket_done[k]) return;
+  t->bucket_done[k] = 1;
+  if (!t->hook) return;
   const size_t end = k == 0 ? t->n : t->bucket_first[k - 1];
   t->hook(t->hook_user, (uint64_t)t->bucket_first[k], (uint64_t)(end - t->bucket_first[k]), (void *)s);
 }
 
 int pnvo_train_backward(pnvo_handle m, const float *grad_out, void *stream) {
+  if (m && m->train) TS(m)->bucket_done.assign(TS(m)->bucket_first.size(), 0);
   const int rc = train_backward_body(m, grad_out, stream);
-  if (rc == PNVO_OK && m->train) report_bucket(TS(m), TS(m)->bucket_first.size() - 1, (hipStream_t)stream);   // [0, ...): everything
+  // the end of the backward: every range not reported on the way (whatever the number of split points a parameter order allowed —
+  // with exactly one of them the in-backward reports are skipped and BOTH ranges are due here), latest layers first
+  if (rc == PNVO_OK && m->train)
+    for (size_t k = 0; k < TS(m)->bucket_first.size(); ++k) report_bucket(TS(m), k, (hipStream_t)stream);
   return rc;
 }
 

@@ -1250,7 +1250,7 @@ int pnvo_small_forward(pnvo_handle m, int B, const int64_t *actions, float *out,
       if (!launched) {                             // a runtime without cooperative launches for this shape: plain launch from now on
         (void)hipGetLastError();
         m->opt.small_coop = 0;
-        m->err = std::string("note: hipLaunchCooperativeKernel refused the small-batch kernel (") + hipGetErrorString(ce) +
+        m->note = std::string("note: hipLaunchCooperativeKernel refused the small-batch kernel (") + hipGetErrorString(ce) +
                  "); this handle uses the plain launch (option small_coop = 0)";
       }
     }

@@ -82,11 +82,13 @@ def onehot_depth(depth, bins):
     return out
 
 
-def make_obs_pairs(B, H, W, *, observation_space, dd_bins=10, seed=0, tdv_sparsity=0.7, start=0):
+def make_obs_pairs(B, H, W, *, observation_space, dd_bins=10, seed=0, tdv_sparsity=0.7, start=0, depth_fp16=True):
     """Synthetic observation pairs in the reference's model-input format (NHWC float32):
     rgb [B,H,W,6] in 0..255, depth [B,H,W,2] in [0,1], discretized_depth [B,H,W,2*bins], top_down_view
     [B,H,W,2] (sparse histogram-like values in [0,1]).  `start` offsets the sample index so shards of one
-    global batch can be generated independently (sample i depends only on (seed, start+i))."""
+    global batch can be generated independently (sample i depends only on (seed, start+i)).  `depth_fp16` (default): depth
+    rounded through float16 as the dataset stores it (generate_datasets.py:272,290); False: dense float32 depth, what the simulator
+    hands the navigation loop (base_trainer_with_vo.py:177-190) — every stem operand then has a non-zero low piece."""
     obs = {}
     rgb = np.empty((B, H, W, 6), dtype=np.float32)
     depth = np.empty((B, H, W, 2), dtype=np.float32)
@@ -95,7 +97,7 @@ def make_obs_pairs(B, H, W, *, observation_space, dd_bins=10, seed=0, tdv_sparsi
         tag = f"#{start + i}"
         rgb[i] = (bits(seed, "rgb" + tag, H * W * 6) >> np.uint64(56)).astype(np.float32).reshape(H, W, 6)
         d = uniform(seed, "depth" + tag, (H, W, 2), 0.05, 0.95)
-        depth[i] = d.astype(np.float16).astype(np.float32)
+        depth[i] = d.astype(np.float16).astype(np.float32) if depth_fp16 else d.astype(np.float32)
         t = uniform(seed, "tdv" + tag, (H, W, 2))
         m = uniform(seed, "tdvmask" + tag, (H, W, 2))
         tdv[i] = np.where(m < tdv_sparsity, 0.0, t).astype(np.float32)
@@ -112,13 +114,14 @@ def make_obs_pairs(B, H, W, *, observation_space, dd_bins=10, seed=0, tdv_sparsi
     return obs
 
 
-def make_raw_obs(H, W, seed=0, index=0, zero_border=0):
+def make_raw_obs(H, W, seed=0, index=0, zero_border=0, depth_fp16=True):
     """One simulator-style observation dict: rgb uint8 [H,W,3], depth float32 [H,W,1] in [0,1]
     (what _compute_local_delta_states_from_vo receives,
     /root/reference/pointnav_vo/rl/common/base_trainer_with_vo.py:172-193)."""
     tag = f"#{index}"
     rgb = (bits(seed, "raw_rgb" + tag, H * W * 3) >> np.uint64(56)).astype(np.uint8).reshape(H, W, 3)
-    d = uniform(seed, "raw_depth" + tag, (H, W, 1), 0.0, 1.0).astype(np.float16).astype(np.float32)
+    d = uniform(seed, "raw_depth" + tag, (H, W, 1), 0.0, 1.0)
+    d = d.astype(np.float16).astype(np.float32) if depth_fp16 else d.astype(np.float32)
     if zero_border:
         d[:zero_border] = 0
         d[-zero_border:] = 0

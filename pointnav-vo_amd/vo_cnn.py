@@ -118,10 +118,11 @@ class VisualOdometryCNNBase(nn.Module):
         return buf.value.decode()
 
     def last_note(self):
-        """Text of pnvo_last_error for this model's handle (also carries the one-line note of the dense-stem fallback)."""
+        """pnvo_last_note of this model's handle: the one-line note of a successful call that changed the handle's behaviour
+        (the dense-stem fallback); errors travel separately (exceptions raised from pnvo_last_error)."""
         if self._handle is None:
             return ""
-        msg = _lib.lib.pnvo_last_error(self._handle)
+        msg = _lib.lib.pnvo_last_note(self._handle)
         return msg.decode() if msg else ""
 
     def _tensors(self):

@@ -39,13 +39,15 @@ def golden_case(rec):
         backbone=str(rec["backbone"]) if "backbone" in rec else "resnet18")
     sd = synth.make_state_dict(ms.state_dict_spec(cfg), seed=int(rec["seed"]))
     obs = synth.make_obs_pairs(int(rec["batch"]), cfg.height, cfg.width, observation_space=obs_space,
-                               dd_bins=max(bins, 1), seed=int(rec["seed"]))
+                               dd_bins=max(bins, 1), seed=int(rec["seed"]),
+                               depth_fp16=bool(int(rec["depth_fp16"])) if "depth_fp16" in rec else True)
     actions = rec["actions"] if "actions" in rec else None
     return cfg, sd, obs, actions
 
 
 MODEL_FIXTURES = [
     "model_default_341x192_b2.npz",
+    "model_default_341x192_b2_f32depth.npz",      # dense float32 depth (simulator-style), not float16-exact
     "model_default_45x37_b3.npz",
     "model_vo_cnn_64x48_b2.npz",
     "model_rgb_d_dd_70x40_b2.npz",

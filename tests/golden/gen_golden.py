@@ -160,10 +160,10 @@ def sample_idx(name, n, k=24):
     return (synth.bits(1234, "tap:" + name, k) % np.uint64(n)).astype(np.int64)
 
 
-def model_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, full_taps, extra=None):
+def model_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, full_taps, extra=None, depth_fp16=True):
     W, H = size
     model, cfg, sd = build_ref_model(registry, name, obs_space, size, dd_bins, seed, extra)
-    obs = synth.make_obs_pairs(B, H, W, observation_space=obs_space, dd_bins=max(dd_bins, 1), seed=seed)
+    obs = synth.make_obs_pairs(B, H, W, observation_space=obs_space, dd_bins=max(dd_bins, 1), seed=seed, depth_fp16=depth_fp16)
     actions = None
     if cfg.act_embed:
         actions = (synth.bits(seed, "actions", B) % np.uint64(4)).astype(np.int64)
@@ -173,6 +173,8 @@ def model_fixture(registry, fname, name, obs_space, size, B, dd_bins, seed, full
     rec = dict(model=name, obs_space=",".join(obs_space), width=W, height=H, batch=B, dd_bins=dd_bins, seed=seed,
                baseplanes=cfg.baseplanes, act_embed=int(cfg.act_embed), out64=out64, out32=out32,
                backbone="resnet%d" % cfg.backbone_depth)
+    if not depth_fp16:
+        rec["depth_fp16"] = 0
     if actions is not None:
         rec["actions"] = actions
     for k, v in taps64.items():
@@ -261,7 +263,7 @@ def preproc_fixture(geo):
 
 
 # ----------------------------------------------------------------------------- boundary fixture (a1)
-def boundary_fixture(registry, geo):
+def boundary_fixture(registry, geo, fname="boundary.npz", depth_fp16=True, steps=None):
     """_compute_local_delta_states_from_vo (base_trainer_with_vo.py:169-314) end to end, sep_act, det mode."""
     meths = extract_methods(REF + "/pointnav_vo/rl/common/base_trainer_with_vo.py", "BaseRLTrainerWithVO",
                             ["_discretize_depth_func", "_compute_local_delta_states_from_vo"])
@@ -290,16 +292,17 @@ def boundary_fixture(registry, geo):
         fake.vo_model[k], _, _ = build_ref_model(registry, name, obs_space, (W, H), bins, s)
     rec = dict(width=W, height=H, bins=bins, seed_forward=21, seed_left=22, seed_right=23, obs_seed=5)
     outs = []
-    steps = [(0, 1, 1, 0), (1, 2, 2, 0), (2, 3, 3, 4), (3, 4, 1, 4)]   # (prev idx, cur idx, act, zero_border)
+    steps = steps or [(0, 1, 1, 0), (1, 2, 2, 0), (2, 3, 3, 4), (3, 4, 1, 4)]   # (prev idx, cur idx, act, zero_border)
+    rec["depth_fp16"] = int(depth_fp16)
     for pi, ci, act, zb in steps:
-        prev = synth.make_raw_obs(H, W, seed=5, index=pi, zero_border=zb)
-        cur = synth.make_raw_obs(H, W, seed=5, index=ci, zero_border=zb)
+        prev = synth.make_raw_obs(H, W, seed=5, index=pi, zero_border=zb, depth_fp16=depth_fp16)
+        cur = synth.make_raw_obs(H, W, seed=5, index=ci, zero_border=zb, depth_fp16=depth_fp16)
         d, std, _ = nsd["_compute_local_delta_states_from_vo"](fake, prev, cur, act)
         outs.append(np.array(d, dtype=np.float32))
         assert std == [0, 0, 0]
     rec["steps"] = np.array(steps, dtype=np.int32)
     rec["deltas"] = np.stack(outs)
-    np.savez_compressed(os.path.join(HERE, "boundary.npz"), **rec)
+    np.savez_compressed(os.path.join(HERE, fname), **rec)
     print("boundary deltas:\n", rec["deltas"])
 
 
@@ -482,6 +485,11 @@ def main():
     torch.set_num_threads(8)
     registry, geo = import_reference()
     full = ["rgb", "depth", "discretized_depth", "top_down_view"]
+    if len(sys.argv) > 1 and sys.argv[1] == "f32depth":      # the dense-float32-depth fixtures (simulator-style depth, not float16-exact)
+        model_fixture(registry, "model_default_341x192_b2_f32depth.npz", "vo_cnn_rgb_d_dd_top_down", full, (341, 192), 2, 10, 9, False,
+                      depth_fp16=False)
+        boundary_fixture(registry, geo, "boundary_f32depth.npz", depth_fp16=False, steps=[(5, 6, 2, 0), (6, 7, 1, 3)])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "traindeeper":   # regenerate just the Bottleneck training fixture
         train_fixture(registry, "train_deeper_64x48_b2_f64.npz", "vo_cnn_deeper", ["rgb", "depth"], (64, 48), 2, 0, 34,
                       torch.float64, extra={"backbone": "resnet101"})

@@ -44,7 +44,9 @@ KNOBS = [{}, {"PNVO_CONV": "x3"}, _FP32, {**_FP32, "PNVO_CONV_WSPLIT": "1"}, {**
          {**_FP32, "PNVO_CONV_TILE": "22"}, {**_FP32, "PNVO_WAVE_NT": "2", "PNVO_WAVE_WGS": "4"}, {**_FP32, "PNVO_CONV3": "tile"},
          {**_FP32, "PNVO_CONV3": "wave"}, {"PNVO_CONV": "generic"}, {"PNVO_STEM": "dense"}, {"PNVO_STEM": "dd"}, {"PNVO_GRAPH": "1"},
          {"PNVO_CONV": "x3", "PNVO_TAIL": "separate"}, {"PNVO_CONV": "x3", "PNVO_POOL": "separate"},
-         {"PNVO_CONV": "x3", "PNVO_X3_S2_OFF": "1"}]
+         {"PNVO_CONV": "x3", "PNVO_X3_S2_OFF": "1"},
+         # the exact-product fallbacks the documents advertise: three bf16 pieces everywhere (round 2's arithmetic)
+         {"PNVO_PIECES": "3"}, {"PNVO_CONV": "x3", "PNVO_PIECES": "3"}, {"PNVO_CONV": "x3", "PNVO_PIECES": "3", "PNVO_POOL": "separate"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
@@ -115,7 +117,10 @@ def test_conv_x3_agrees_with_the_fp32_kernels_at_odd_sizes():
             assert err.max() < 2e-5, (other, err.max())
 
 
-TRAIN_KNOBS = [{"PNVO_CONV": "x3"}, {"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"}]
+TRAIN_KNOBS = [{"PNVO_CONV": "x3"}, {"PNVO_WGRAD_STEM": "fp32"}, {"PNVO_WGRAD": "lds9"}, {"PNVO_WGRAD": "generic"},
+               # the exact fallbacks of the training step: three bf16 pieces (forward + backward), 3x3 weight gradients on the fp32 pipe
+               {"PNVO_CONV": "x3", "PNVO_TRAIN_PIECES": "3"}, {"PNVO_CONV": "x3", "PNVO_WGRAD3": "fp32"},
+               {"PNVO_CONV": "x3", "PNVO_TRAIN_PIECES": "3", "PNVO_WGRAD3": "fp32"}]
 
 
 @pytest.mark.parametrize("env", TRAIN_KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))

@@ -98,7 +98,7 @@ def test_deterministic_and_batch_composition_invariant():
 
 def test_full_batch_256_properties():
     """BASELINE configs[1] size: B=256 at 341x192.  Checked through size-independent properties: every pair of the
-    big batch equals the same pair evaluated in a small batch, and a few pairs equal the fp64 oracle."""
+    big batch equals the same pair evaluated in a small batch, and the eight pairs of bench.ORACLE_PAIRS equal the fp64 oracle."""
     import bench
     d = dev()
     model, sd = bench.build_model(d)
@@ -111,9 +111,10 @@ def test_full_batch_256_properties():
     out, sub = out.cpu().numpy(), sub.cpu().numpy()
     assert np.isfinite(out).all()
     assert pair_rel_err(sub, out[idx]).max() < 1e-5
-    ref = oracle.forward(sd, {k: v[idx[:2]].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups,
+    chk = list(bench.ORACLE_PAIRS)                 # the same 8 pairs bench.py checks: first / last tiles, mid-batch, both halves
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups,
                          dtype=np.float64)
-    assert pair_rel_err(out[idx[:2]], ref).max() < TOL
+    assert pair_rel_err(out[chk], ref).max() < TOL
     # the synthetic dd/tdv inputs were produced by the HIP pre-processing kernels: check them against the oracle too
     d0 = obs["depth"][0].cpu().numpy()
     dd_ref, _ = oracle.discretize_depth(d0[..., 0], 10)
@@ -384,3 +385,49 @@ def test_rnd_mode_samples_dropout_and_updates_running_stats():
     t.config.VO.REGRESS_MODEL.mode = "det"
     d2, s2, _ = t._compute_local_delta_states_from_vo(prev, cur, int(act))
     assert s2 == [0, 0, 0] and np.isfinite(d2).all()
+
+
+# ----------------------------------------------------------------------------- dense float32 depth (the path's real input)
+F32_OPTS = [{}, {"conv": "x3"}, {"pieces": "3"}, {"conv": "x3", "pieces": "3"}, {"conv": "fp32", "stem": "dense"}]
+
+
+@pytest.mark.parametrize("opts", F32_OPTS, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()) or "default")
+def test_dense_float32_depth_matches_reference(opts):
+    """Every other model fixture has float16-exact depth (the dataset's storage format), for which the low float16 piece of the
+    stem's depth operand is identically zero.  The navigation loop hands over float32 simulator depth
+    (base_trainer_with_vo.py:177-190): this fixture's depth is uniform float32, so both pieces of every float-valued stem channel
+    are live; checked on the default kernels, with the split 3x3 kernels forced at this size, and on the exact three-piece forms."""
+    rec = load_golden("model_default_341x192_b2_f32depth.npz")
+    model, cfg, sd, obs, tobs, _, _ = build(rec)
+    d = obs["depth"]
+    assert not np.array_equal(d.astype(np.float16).astype(np.float32), d)        # the depth really is not float16-exact
+    for k, v in opts.items():
+        model.set_option(k, v)
+    with torch.no_grad():
+        out = model(tobs).cpu().numpy()
+        model.set_option("small_net", "off")                                     # (2 pairs: also through the per-layer kernels)
+        out_l = model(tobs).cpu().numpy()
+    assert pair_rel_err(out, rec["out64"]).max() < TOL, pair_rel_err(out, rec["out64"])
+    assert pair_rel_err(out_l, rec["out64"]).max() < TOL, pair_rel_err(out_l, rec["out64"])
+
+
+@pytest.mark.parametrize("opts", [{}, {"conv": "x3"}, {"pieces": "3"}], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()) or "default")
+def test_boundary_with_dense_float32_depth(opts):
+    """_compute_local_delta_states_from_vo on simulator-style float32 depth frames (not float16-exact): per-pair method, batched
+    sibling (sensor-frame entry) against the reference's deltas."""
+    rec = load_golden("boundary_f32depth.npz")
+    assert int(rec["depth_fp16"]) == 0
+    t = make_trainer(rec)
+    for m in t.vo_model.values():
+        for k, v in opts.items():
+            m.set_option(k, v)
+    H, W = int(rec["height"]), int(rec["width"])
+    prevs, curs, acts = [], [], []
+    for (pi, ci, act, zb), want in zip(rec["steps"], rec["deltas"]):
+        prev = synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(pi), zero_border=int(zb), depth_fp16=False)
+        cur = synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(ci), zero_border=int(zb), depth_fp16=False)
+        deltas, std, extra = t._compute_local_delta_states_from_vo(prev, cur, int(act))
+        assert pair_rel_err(np.array(deltas)[None], want[None]).max() < TOL, (deltas, want)
+        prevs.append(prev), curs.append(cur), acts.append(int(act))
+    batch = t.compute_local_delta_states_batch(prevs, curs, acts)
+    assert pair_rel_err(batch, rec["deltas"]).max() < TOL
