@@ -780,8 +780,8 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.Wp = m->Wp;
     if (m->opt.stem_dbg == 9) {
       if (!m->mx_prof) {
-        HIPCHK(m, hipMalloc((void **)&m->mx_prof, 256));
-        HIPCHK(m, hipMemset(m->mx_prof, 0, 256));
+        HIPCHK(m, hipMalloc((void **)&m->mx_prof, 512));
+        HIPCHK(m, hipMemset(m->mx_prof, 0, 512));
       }
       a.prof = m->mx_prof;
     }
@@ -791,7 +791,15 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       const double in_bytes = (double)B * c.height * c.width * (m->raw_depth ? (c.n_rgb ? 6.0 : 0.0) + 8.0 + (c.n_tdv ? 8.0 : 0.0) : 4.0 * stem.cin);
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
               in_bytes + 4.0 * (M * stem.cout + (double)stem.cout * stem.cin * 49));
-      HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
+      // one persistent workgroup per CU with role-specialised waves (stem_ps_kernel) when the tiles fill the chip for a few
+      // rounds, the tile-per-workgroup kernel otherwise; bit-identical results (option stem_form: auto | persistent | tiles)
+      const bool ps = m->opt.stem_form != 2 && stem_ps_takes(a, pieces, ntn, false, m->num_cus) &&
+                      (m->opt.stem_form == 1 || true);
+      m->mx_prof_ps = ps;
+      if (ps)
+        HIPCHK(m, launch_stem_ps(a, m->num_cus, s));
+      else
+        HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     m->stem_slots_out = a.slots;
@@ -917,6 +925,7 @@ const OptDef kOptions[] = {
     {"stem", "PNVO_STEM", &PnvoOptions::stem, false, {{"auto", 0}, {"mx", 1}, {"dd", 2}, {"dense", 3}, {nullptr, 0}}},
     {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
     {"pieces", "PNVO_PIECES", &PnvoOptions::pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
+    {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"persistent", 1}, {"tiles", 2}, {nullptr, 0}}},
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
@@ -1031,6 +1040,7 @@ int pnvo_create(const pnvo_config *cfg, int device, pnvo_handle *out) {
   m->uid = next_uid.fetch_add(1);
   m->cfg = *cfg;
   m->device = device;
+  m->num_cus = prop.multiProcessorCount;
   if (m->cfg.flat_size <= 0) m->cfg.flat_size = 2048;
   if (m->cfg.n_acts <= 0) m->cfg.n_acts = 4;
   env_defaults(m);                 // the ONLY place the PNVO_* environment is read for this handle
@@ -1979,7 +1989,21 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->dd_sc);
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
-  if (m->mx_prof) {
+  if (m->mx_prof && m->mx_prof_ps) {
+    unsigned long long pr[64];
+    (void)hipMemcpy(pr, m->mx_prof, 512, hipMemcpyDeviceToHost);
+    for (int w = 0; w < 8; ++w) {
+      const double nt_ = (double)(pr[8 * w + 5] ? pr[8 * w + 5] : 1);
+      if (w < 4)
+        std::fprintf(stderr, "[pnvo] stem_ps M wave %d (cycles per tile): wait patch %.0f  k-loop %.0f  wait others %.0f  exchange writes %.0f  "
+                     "(%llu tiles)\n", w, pr[8 * w] / nt_, pr[8 * w + 1] / nt_, pr[8 * w + 2] / nt_, pr[8 * w + 3] / nt_, pr[8 * w + 5]);
+      else
+        std::fprintf(stderr, "[pnvo] stem_ps L wave %d (cycles per tile): epilogue %.0f  convert+store %.0f  wait M %.0f  issue loads %.0f  "
+                     "wait exchange %.0f  (%llu tiles)\n", w, pr[8 * w] / nt_, pr[8 * w + 1] / nt_, pr[8 * w + 2] / nt_, pr[8 * w + 3] / nt_,
+                     pr[8 * w + 4] / nt_, pr[8 * w + 5]);
+    }
+    (void)hipFree(m->mx_prof);
+  } else if (m->mx_prof) {
     unsigned long long pr[32];
     (void)hipMemcpy(pr, m->mx_prof, 256, hipMemcpyDeviceToHost);
     for (int w = 0; w < 4; ++w) {

@@ -95,7 +95,7 @@ struct StemMXArgs {
   int y_coff[4];              // per N-tile: first channel inside y / stats
   int y_cstride, stats_cstride;
   int B, H, W, Ho, Wo, slots, tiles_x, tiles_y;
-  unsigned long long *prof;   // [4 waves][8] phase cycle sums (PNVO_STEM_DBG=9) or nullptr
+  unsigned long long *prof;   // [8 waves][8] phase cycle sums (PNVO_STEM_DBG=9) or nullptr
   // pooled output (float32 results only): [B,Hp,Wp,y_cstride] order-preserving integer keys of max over the 3x3/2 window of
   // sgn(pool_gamma[c]) * x, pre-set to STEM_POOL_INIT; y is not written.  nullptr: the raw output goes to y
   int *pool;
@@ -116,6 +116,8 @@ size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);
 float pack_stem_mx_weight_h(const float *wk, int cout, const int *xslot, unsigned short *out);   // two float16 pieces -> oscale
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
+bool stem_ps_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs);   // persistent role-specialised form
+hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, hipStream_t s);
 hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                    const int *slot_new, const int *xslot, float *scale2, unsigned short *wpk2, hipStream_t s);
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,

@@ -34,6 +34,7 @@ struct Layer {
 struct PnvoOptions {
   int stem = 0;        // 0 auto (bf16-matrix-core stem when the model's modalities fit it, else one-hot-aware, else dense), 1 mx, 2 dd, 3 dense
   int conv = 0;        // 0 auto (conv_x3 for launches of >= 192 workgroups, fp32-MFMA kernels below), 1 x3 at any size, 2 fp32, 3 generic
+  int stem_form = 0;   // float16-piece stem: 0 auto (persistent role-specialised kernel when the tiles fill the chip), 1 persistent, 2 one tile per workgroup
   int pieces = 2;      // operand pieces of conv_x3 at inference: 2 float16 (three product terms) or 3 bf16 (six exact terms)
   int train_pieces = 2;  // the same choice for the TRAINING forward's convs (their backward-data convs keep three bf16 pieces:
                          //   gradients do not fit float16's range)
@@ -103,7 +104,9 @@ struct pnvo_model_s {
   int mx_xslot[4] = {-1, -1, -1, -1};        // K-slots of the float-modality channels
   std::vector<int> mx_slot_ref, mx_slot_new; // K-slot -> reference channel / position in the stem's tensor-major order (-1: none)
   float *mx_pages = nullptr;                 // device: 64 zeros (out-of-image reads)
-  unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx
+  unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx / stem_ps
+  bool mx_prof_ps = false;                   //   ... the last stem launch was the persistent form
+  int num_cus = 256;                         // compute units of the device (grid of the persistent kernels)
   bool in_train_forward = false;
   bool train_mx = false;                     // the attached training step rebuilds the mx stem operands every step
   PnvoOptions opt;

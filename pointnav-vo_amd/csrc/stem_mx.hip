@@ -616,6 +616,466 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
+
+// =====================================================================================================================
+// stem_ps_kernel — the PERSISTENT, ROLE-SPECIALISED form of the float32-grade stem (PIECES = 2, one N-tile of 32 channels).
+//
+// stem_mx_kernel runs its three phases one after the other in every workgroup (staging ~10.7 k cycles, two dependent memory round
+// trips; K loop ~13 k of which 7.8 k are MFMA issue; K-split exchange + pooling epilogue ~8.7 k), and two co-resident workgroups
+// overlap them only by chance: the matrix pipe sits at 0.45 busy (profiles/r3_stem_phases.txt).  Here ONE workgroup of eight waves
+// owns a CU for the whole launch and walks its tiles with the phases of consecutive tiles overlapped by construction:
+//
+//   waves 0-3 ("M", one per SIMD, the older half: they win the VALU arbitration)   K loop of tile i and nothing else: the same
+//       49-tap split, fragment order and accumulation order as stem_mx_kernel<2,1> — results are bit-identical — then 16 LDS
+//       writes of their partial sums into the patch buffer they just left;
+//   waves 4-7 ("L", one per SIMD, beside an M wave)   while the M waves multiply tile i: the epilogue of tile i-1 (fixed-order sum
+//       of the four K-split partials, power-of-two un-scale, GroupNorm partial sums, max-pool keys or raw stores), then the patch of
+//       tile i+1 — its global loads were issued a whole phase earlier, so no memory latency is exposed — converted to float16 pieces
+//       and written into the buffer the exchange has just vacated.
+//
+// LDS: two 64 KB buffers (patch of tile i | exchange of tile i-1 -> patch of tile i+1) + pooling scratch: 146 KB, one workgroup
+// per CU.  Two workgroup barriers per tile; the L waves synchronise among themselves through an LDS counter.
+namespace {
+constexpr int PS_THREADS = 512;
+constexpr int PS_BUF = XCHG_BYTES;                       // 65536 >= PATCH_BYTES
+constexpr int PS_PB_OFF = 2 * PS_BUF;                    // pooling scratch [8][16][33] floats
+constexpr int PS_RED_OFF = PS_PB_OFF + 8 * 16 * 33 * 4;  // [4 L waves][32][2] floats
+constexpr int PS_ETAB_OFF = PS_RED_OFF + 4 * 32 * 2 * 4; // RAW: bin edges (12 floats)
+constexpr int PS_CTR_OFF = PS_ETAB_OFF + 64;             // L-wave rendezvous counter
+constexpr int PS_LDS = PS_CTR_OFF + 64;
+static_assert(PS_BUF >= PATCH_BYTES, "patch must fit its buffer");
+static_assert(PS_LDS <= 160 * 1024, "LDS budget");
+
+// rendezvous of the four L waves (a monotonic LDS counter; the workgroup barrier belongs to the M/L hand-over)
+__device__ __forceinline__ void ps_lsync(unsigned *ctr, unsigned &epoch) {
+  epoch += 4u;
+  // LDS only: a workgroup-scope fence would also drain vmcnt, i.e. wait for the next patch's global loads in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch) < 0) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+}  // namespace
+
+template <bool POOL, bool RAW>
+__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_ps_kernel(const StemMXArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // tiles of this workgroup: the workgroups of one XCD (id % 8) walk neighbouring tiles at the same time, so halos meet in that L2
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  const int chunk = (ntiles + 7) >> 3;
+  const int per = (int)gridDim.x >> 3;                              // workgroups per XCD
+  const int t_first = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  const int t_end = min(((int)(blockIdx.x & 7) + 1) * chunk, ntiles);
+  if (t_first >= t_end) return;
+  const int nit = (t_end - t_first + per - 1) / per;
+  const bool prof = p.prof != nullptr;
+  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> unsigned long long { return prof ? __builtin_readcyclecounter() : 0ull; };
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned *>(lds + PS_CTR_OFF) = 0u;
+  if (RAW && threadIdx.x < 12) reinterpret_cast<float *>(lds + PS_ETAB_OFF)[threadIdx.x] = p.edges[threadIdx.x];
+  __syncthreads();
+
+  if (wave < 4) {
+    // ============================================================ M waves: the K loop (stem_mx_kernel's, PIECES = 2, NT = 1)
+    constexpr int NFT = 5;
+    const int rr = (lane & 31) >> 4, c = lane & 15, h = lane >> 5;
+    const unsigned baseA0 = (unsigned)(2 * rr * ROW + c * PITCH + h * 16);
+    const unsigned baseX0 = (unsigned)(2 * rr * ROW + c * PITCH + 64);
+    auto loadB = [&](int tap, u32x4 *b) {
+      const u32x4 *wt = reinterpret_cast<const u32x4 *>(p.wpk) + (long)tap * NFT * 64;
+#pragma unroll
+      for (int f = 0; f < NFT; ++f) b[f] = wt[f * 64 + lane];
+    };
+    auto tapof = [&](int i) { return i < 12 ? wave + 4 * i : (wave == 3 ? 48 : wave + 44); };
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      const unsigned buf = (unsigned)(it & 1) * PS_BUF;
+      const unsigned baseA = baseA0 + buf, baseX = baseX0 + buf;
+      u32x4 b0[NFT], b1[NFT], b2[NFT], a0[4], a1[4], ax[4];
+      loadB(tapof(0), b0);                                  // (the weights do not wait for the patch)
+      loadB(tapof(1), b1);
+      const unsigned long long t0 = now();
+      __syncthreads();                                      // patch(it) is in its buffer
+      const unsigned long long t1 = now();
+      f32x16 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      auto loadA0 = [&](int tap, u32x4 *a) {
+        const unsigned toff = TAPOFF.v[tap];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + toff + m * 4 * ROW);
+      };
+      auto loadA1 = [&](int tap, u32x4 *a, u32x4 *x) {
+        const unsigned toff = TAPOFF.v[tap];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          a[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + toff + m * 4 * ROW + 32);
+          x[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + toff + m * 4 * ROW);
+        }
+      };
+      auto mfmas_q = [&](int q, const u32x4 *aq, const u32x4 *b) {
+#pragma unroll
+        for (int pcs = 0; pcs < 2; ++pcs)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, b[pcs * 2 + q]),
+                                                            acc[m], 0, 0, 0);
+      };
+      auto mfmas_x = [&](const u32x4 *b) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ax[m]), __builtin_bit_cast(f16x8, b[4]), acc[m], 0, 0, 0);
+      };
+      auto step = [&](int i, const u32x4 *bcur, u32x4 *bnext2) {
+        loadA1(tapof(i), a1, ax);
+        loadB(tapof(i + 2), bnext2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas_q(0, a0, bcur);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA0(tapof(i + 1), a0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas_q(1, a1, bcur);
+        mfmas_x(bcur);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      loadA0(tapof(0), a0);
+#pragma unroll 1
+      for (int i = 0; i < 12; i += 3) {
+        step(i, b0, b2);
+        step(i + 1, b1, b0);
+        step(i + 2, b2, b1);
+      }
+      if (wave == 3) {
+        loadA1(48, a1, ax);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas_q(0, a0, b0);
+        mfmas_q(1, a1, b0);
+        mfmas_x(b0);
+      }
+      const unsigned long long t2 = now();
+      __syncthreads();                                      // every M wave has left the patch (and L the other buffer)
+      const unsigned long long t3 = now();
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + wave) * 4 + rq) * 64 + lane) * 16) =
+              f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+      if (prof) {
+        pc[0] += t1 - t0;                                   // wait for the patch
+        pc[1] += t2 - t1;                                   // K loop
+        pc[2] += t3 - t2;                                   // wait for the other M waves / the L waves
+        pc[3] += now() - t3;                                // exchange writes
+      }
+    }
+    __syncthreads();                                        // exchange of the last tile is complete
+  } else {
+    // ============================================================ L waves: epilogue of tile i-1, patch of tile i+1
+    const int lw = wave - 4;
+    const int ltid = (int)threadIdx.x - 256;
+    unsigned *ctr = reinterpret_cast<unsigned *>(lds + PS_CTR_OFF);
+    unsigned epoch = 0;
+    float *red = reinterpret_cast<float *>(lds + PS_RED_OFF);
+    float *pb = reinterpret_cast<float *>(lds + PS_PB_OFF);
+    float *etab = reinterpret_cast<float *>(lds + PS_ETAB_OFF);
+    // patch pixels of this thread: pixel index r * 256 + ltid (r = 3: the last nine pixels, L wave 0) — tile-independent
+    int ppy[4], ppx[4];
+    unsigned poff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pix = min(r * 256 + ltid, NPIX - 1);
+      ppy[r] = pix / PW;
+      ppx[r] = pix - ppy[r] * PW;
+      poff[r] = (unsigned)(ppy[r] * ROW + (ppx[r] & 1) * PAR + (ppx[r] >> 1) * PITCH);
+    }
+    const bool has3 = ltid < NPIX - 768;                    // (wave-uniform per lane group: lanes 0..8 of L wave 0)
+    const float *zp = p.zero_page;
+    const long fpix = (long)p.H * p.W;
+
+    // ---- registers of one patch in flight
+    f32x4 vdd[4][5], vr4[4];
+    f32x2 vr2[4], vd[4], vt[4];
+    unsigned rgbw[4][2];
+    float dv[4][2];
+    bool inb[4];
+    auto tile_coords = [&](int t, int &n, int &ty, int &tx) {
+      tx = t % p.tiles_x;
+      t /= p.tiles_x;
+      ty = t % p.tiles_y;
+      n = t / p.tiles_y;
+    };
+    auto stage_load = [&](int t) {
+      int n, ty, tx;
+      tile_coords(t, n, ty, tx);
+      const int hi_base = 2 * ty * TH - 3, wi_base = 2 * tx * TW - 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r == 3 && lw != 0) continue;
+        const int hi = hi_base + ppy[r], wi = wi_base + ppx[r];
+        const bool in = (r < 3 || has3) && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const int e = in ? hi * p.W + wi : 0;
+        inb[r] = in;
+        if (RAW) {
+          const unsigned char *zpb = reinterpret_cast<const unsigned char *>(zp);
+          const bool use_rgb = p.raw_rgb != nullptr;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const long gi = ((long)n * 2 + f) * fpix + e;
+            const long boff = 3 * gi - (gi > 0 ? 1 : 0);
+            const unsigned char *a_rgb = (in && use_rgb) ? p.raw_rgb + boff : zpb;
+            unsigned wv;
+            __builtin_memcpy(&wv, a_rgb, 4);
+            rgbw[r][f] = (in && use_rgb && gi > 0) ? (wv >> 8) : wv;
+            const float *a_d = in ? p.raw_depth + gi : zp;
+            dv[r][f] = *a_d;
+          }
+          const float *a_t = (in && p.src[3]) ? p.src[3] + ((long)n * fpix + e) * 2 : zp;
+          vt[r] = *reinterpret_cast<const f32x2 *>(a_t);
+        } else {
+          const long pe = (long)n * fpix + e;
+          const float *a_dd = (in && p.src[2]) ? p.src[2] + pe * 20 : zp;
+          const float *a_rgb = (in && p.src[0]) ? p.src[0] + pe * 6 : zp;
+          const float *a_d = (in && p.src[1]) ? p.src[1] + pe * 2 : zp;
+          const float *a_t = (in && p.src[3]) ? p.src[3] + pe * 2 : zp;
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) vdd[r][cc] = *reinterpret_cast<const f32x4 *>(a_dd + 4 * cc);
+          const f32x2 q0 = *reinterpret_cast<const f32x2 *>(a_rgb), q1 = *reinterpret_cast<const f32x2 *>(a_rgb + 2);
+          vr4[r] = f32x4{q0[0], q0[1], q1[0], q1[1]};
+          vr2[r] = *reinterpret_cast<const f32x2 *>(a_rgb + 4);
+          vd[r] = *reinterpret_cast<const f32x2 *>(a_d);
+          vt[r] = *reinterpret_cast<const f32x2 *>(a_t);
+        }
+      }
+    };
+    auto stage_store = [&](unsigned buf) {
+      unsigned lowbits = 0;
+      bool bad_depth = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r == 3 && lw != 0) continue;
+        if (r == 3 && !has3) continue;
+        unsigned w[16];
+        float d0, d1;
+        int bidx[2] = {0, 0};
+        bool bok[2] = {false, false};
+        if (RAW) {
+          const bool use_d = (p.raw_flags & 1) != 0;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const float d = dv[r][f];
+            int g = (int)(d * 10.0f);
+            g = min(max(g, 0), 9);
+            const float lo = etab[g], hi = etab[g + 1];
+            bidx[f] = g - (d < lo ? 1 : 0) + ((d >= hi && g < 9) ? 1 : 0);
+            bok[f] = d >= 0.f && d <= 1.f;
+            bad_depth = bad_depth || (inb[r] && !bok[f]);
+          }
+#pragma unroll
+          for (int cc = 0; cc < 10; ++cc) w[cc] = 0u;
+          const unsigned x0 = rgbw[r][0], x1 = rgbw[r][1];
+          const float pr = (float)(x0 & 0xffu), pg = (float)((x0 >> 8) & 0xffu), pbl = (float)((x0 >> 16) & 0xffu);
+          const float cr = (float)(x1 & 0xffu), cg = (float)((x1 >> 8) & 0xffu), cb = (float)((x1 >> 16) & 0xffu);
+          w[10] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
+          w[11] = pack_f16(pbl * 0.00390625f, cr * 0.00390625f);
+          w[12] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
+          d0 = use_d ? dv[r][0] : 0.f;
+          d1 = use_d ? dv[r][1] : 0.f;
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) {
+            w[2 * cc] = pack_f16(vdd[r][cc][0], vdd[r][cc][1]);
+            w[2 * cc + 1] = pack_f16(vdd[r][cc][2], vdd[r][cc][3]);
+            const float f0 = vdd[r][cc][0], f1 = vdd[r][cc][1], f2 = vdd[r][cc][2], f3 = vdd[r][cc][3];
+            lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
+            lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
+          }
+          w[10] = pack_f16(vr4[r][0] * 0.00390625f, vr4[r][1] * 0.00390625f);
+          w[11] = pack_f16(vr4[r][2] * 0.00390625f, vr4[r][3] * 0.00390625f);
+          w[12] = pack_f16(vr2[r][0] * 0.00390625f, vr2[r][1] * 0.00390625f);
+          {
+            const float f0 = vr4[r][0], f1 = vr4[r][1], f2 = vr4[r][2], f3 = vr4[r][3], f4 = vr2[r][0], f5 = vr2[r][1];
+            lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
+            lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
+            lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
+          }
+          d0 = vd[r][0];
+          d1 = vd[r][1];
+        }
+        w[13] = pack_f16(d0, d1);
+        w[14] = pack_f16(vt[r][0], vt[r][1]);
+        w[15] = inb[r] ? 0x3c003c00u : 0u;
+        unsigned char *dst = lds + buf + poff[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<u32x4 *>(dst + 16 * q) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        if (RAW && (p.raw_flags & 2) != 0 && inb[r]) {
+          if (bok[0]) *reinterpret_cast<unsigned short *>(dst + 2 * bidx[0]) = (unsigned short)0x3c00;
+          if (bok[1]) *reinterpret_cast<unsigned short *>(dst + 20 + 2 * bidx[1]) = (unsigned short)0x3c00;
+        }
+        const f16x2 hd = __builtin_bit_cast(f16x2, w[13]), ht = __builtin_bit_cast(f16x2, w[14]);
+        const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
+        const unsigned mt = pack_f16(vt[r][0] - (float)ht[0], vt[r][1] - (float)ht[1]);
+        *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{md, mt, 0u, 0u};
+      }
+      if (!RAW && (lowbits & 0x1fffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
+      if (RAW && bad_depth && p.raw_err != nullptr) *p.raw_err = 1;
+    };
+
+    // ---- epilogue of one tile: K-split sum in wave order, un-scale, GroupNorm partials, pooled keys / raw output
+    const float oscale = p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
+    const int rr16 = lane >> 5;
+    const int co = p.y_coff[0] + (lane & 31);
+    const float sgn = POOL ? (p.pool_gamma[co] < 0.f ? -1.f : 1.f) : 1.f;
+    auto epilogue = [&](int t, unsigned buf) {
+      int n, ty, tx;
+      tile_coords(t, n, ty, tx);
+      const int ho0 = ty * TH, wo0 = tx * TW;
+      f32x16 tot;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((lw * 4 + s4) * 4 + rq) * 64 + lane) * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? tq[e] : tot[4 * rq + e] + tq[e];
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[r] *= oscale;
+      float s1 = 0.f, s2 = 0.f;
+      const bool full = ho0 + TH <= p.Ho && wo0 + TW <= p.Wo;
+      if (POOL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16;
+          const int row = 2 * lw + (i >> 4), col = i & 15;
+          const bool ok = ho0 + row < p.Ho && wo0 + col < p.Wo;
+          const float v = ok ? tot[r] : 0.f;
+          pb[(row * 16 + col) * 33 + (lane & 31)] = ok ? sgn * tot[r] : -__builtin_inff();
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
+        }
+      } else if (full) {
+        const long rowpix = ((long)n * p.Ho + ho0 + 2 * lw) * p.Wo + wo0 + 4 * rr16;
+        float *y0 = reinterpret_cast<float *>(p.y[0]) + rowpix * p.y_cstride + co;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dpix = (r >> 3) * p.Wo + (r & 3) + 8 * ((r >> 2) & 1);
+          y0[(long)dpix * p.y_cstride] = tot[r];
+          s1 += tot[r];
+          s2 = __builtin_fmaf(tot[r], tot[r], s2);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16;
+          const int ho = ho0 + 2 * lw + (i >> 4), wo = wo0 + (i & 15);
+          const bool ok = ho < p.Ho && wo < p.Wo;
+          const float v = ok ? tot[r] : 0.f;
+          if (ok) reinterpret_cast<float *>(p.y[0])[(((long)n * p.Ho + ho) * p.Wo + wo) * p.y_cstride + co] = v;
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
+        }
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) {
+        red[(lw * 32 + lane) * 2] = s1;
+        red[(lw * 32 + lane) * 2 + 1] = s2;
+      }
+      ps_lsync(ctr, epoch);                                 // pb / red complete; every L wave has left the exchange buffer
+      if (POOL) {
+        const int ch = ltid & 31, pj = ltid >> 5;
+        const int Ib = ho0 >> 1, Jb = wo0 >> 1;
+        int *const pool0 = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0] + ch;
+        auto emit = [&](int I, int J, float mx, bool inside) {
+          if (I >= p.Hp || J >= p.Wp) return;
+          int key = __builtin_bit_cast(int, mx);
+          key = key >= 0 ? key : key ^ 0x7fffffff;
+          int *dst = pool0 + (I * p.Wp + J) * p.y_cstride;
+          if (inside)
+            *dst = key;
+          else
+            atomicMax(dst, key);
+        };
+        {
+          const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;
+          float cm[8];
+#pragma unroll
+          for (int lr = 0; lr < 8; ++lr)
+            cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
+          const bool colin = pj >= 1 || wo0 == 0;
+          emit(Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
+          emit(Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
+          emit(Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
+          emit(Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
+          emit(Ib + 4, Jb + pj, cm[7], false);
+        }
+        if (ltid < 160) {
+          const int pi = ltid >> 5;
+          float mx = -__builtin_inff();
+#pragma unroll
+          for (int dr = -1; dr <= 1; ++dr) {
+            const int lr = 2 * pi + dr;
+            if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
+          }
+          emit(Ib + pi, Jb + 8, mx, false);
+        }
+      }
+      if (ltid >= 224) {                                    // (the last 32 threads: they have no ninth pooled column to emit)
+        const int cch = ltid - 224;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          a1 += red[(w4 * 32 + cch) * 2];
+          a2 += red[(w4 * 32 + cch) * 2 + 1];
+        }
+        const int slot = ty * p.tiles_x + tx;
+        float *dst = p.stats[0] + (((long)n * p.slots + slot) * p.stats_cstride + p.y_coff[0] + cch) * 2;
+        dst[0] = a1;
+        dst[1] = a2;
+      }
+    };
+
+    // ---- prologue: patch of the first tile, loads of the second in flight
+    stage_load(t_first);
+    stage_store(0u);
+    if (nit > 1) stage_load(t_first + per);
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      const unsigned long long t0 = now();
+      if (it > 0) epilogue(t_first + (it - 1) * per, (unsigned)((it - 1) & 1) * PS_BUF);
+      const unsigned long long t1 = now();
+      if (it + 1 < nit) stage_store((unsigned)((it + 1) & 1) * PS_BUF);
+      const unsigned long long t2 = now();
+      __syncthreads();                                      // patch(it + 1) written; the M waves have left patch(it)
+      const unsigned long long t3 = now();
+      if (it + 2 < nit) stage_load(t_first + (it + 2) * per);
+      const unsigned long long t4 = now();
+      __syncthreads();                                      // exchange(it) written
+      if (prof) {
+        pc[0] += t1 - t0;                                   // epilogue of the previous tile
+        pc[1] += t2 - t1;                                   // convert + LDS writes of the next patch (incl. waiting for its loads)
+        pc[2] += t3 - t2;                                   // wait for the M waves
+        pc[3] += t4 - t3;                                   // issue of the loads of the patch after next
+        pc[4] += now() - t4;                                // wait for the exchange
+      }
+    }
+    epilogue(t_first + (nit - 1) * per, (unsigned)((nit - 1) & 1) * PS_BUF);
+  }
+  if (prof && lane == 0 && (blockIdx.x % 16) == 0) {
+    unsigned long long *q = p.prof + 8 * wave;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) atomicAdd(q + k, pc[k]);
+    atomicAdd(q + 5, (unsigned long long)nit);
+  }
+}
+
 int stem_mx_slots(int Ho, int Wo) { return ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW); }
 
 size_t stem_mx_packed_u16(int pieces, int ntiles) { return (size_t)49 * (pieces * 2 + (pieces >= 2 ? 1 : 0)) * ntiles * 64 * 8; }
@@ -840,6 +1300,39 @@ hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_n
   const int total = 49 * 7 * 64 * 8;
   hipLaunchKernelGGL(stem_mx_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cin, sc_new, sh_new,
                      slot_ref, slot_new, xslot, wpk3, total);
+  return hipGetLastError();
+}
+
+// Persistent form (stem_ps_kernel): float16 pieces, one N-tile, float32 output.  `wgs` = workgroups to launch (one per CU, a
+// multiple of 8).  Takes the launch when the tiles keep every workgroup busy for a few rounds.
+bool stem_ps_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs) {
+  const long ntiles = (long)a.B * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
+  return pieces == 2 && ntiles_n == 1 && !bf16_out && wgs >= 8 && ntiles >= 4L * wgs;
+}
+
+hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, hipStream_t s) {
+  StemMXArgs p = a;
+  p.tiles_x = (a.Wo + TW - 1) / TW;
+  p.tiles_y = (a.Ho + TH - 1) / TH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipSuccess;
+    auto set = [&](const void *f) {
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    };
+    set(reinterpret_cast<const void *>(stem_ps_kernel<true, true>));
+    set(reinterpret_cast<const void *>(stem_ps_kernel<true, false>));
+    set(reinterpret_cast<const void *>(stem_ps_kernel<false, true>));
+    set(reinterpret_cast<const void *>(stem_ps_kernel<false, false>));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const unsigned gx = (unsigned)(wgs & ~7);
+  const bool raw = a.raw_depth != nullptr, pool = a.pool != nullptr;
+  if (pool && raw) hipLaunchKernelGGL((stem_ps_kernel<true, true>), dim3(gx), dim3(PS_THREADS), PS_LDS, s, p);
+  else if (pool) hipLaunchKernelGGL((stem_ps_kernel<true, false>), dim3(gx), dim3(PS_THREADS), PS_LDS, s, p);
+  else if (raw) hipLaunchKernelGGL((stem_ps_kernel<false, true>), dim3(gx), dim3(PS_THREADS), PS_LDS, s, p);
+  else hipLaunchKernelGGL((stem_ps_kernel<false, false>), dim3(gx), dim3(PS_THREADS), PS_LDS, s, p);
   return hipGetLastError();
 }
 
