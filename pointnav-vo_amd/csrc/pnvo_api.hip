@@ -778,10 +778,11 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.pool_gamma = stem.gamma;
     a.Hp = m->Hp;
     a.Wp = m->Wp;
-    if (m->opt.stem_dbg == 9) {
+    a.dbg = m->opt.stem_dbg >= 16 ? m->opt.stem_dbg - 16 : 0;
+    if (m->opt.stem_dbg == 9 || m->opt.stem_dbg >= 16) {
       if (!m->mx_prof) {
-        HIPCHK(m, hipMalloc((void **)&m->mx_prof, 512));
-        HIPCHK(m, hipMemset(m->mx_prof, 0, 512));
+        HIPCHK(m, hipMalloc((void **)&m->mx_prof, 2048));
+        HIPCHK(m, hipMemset(m->mx_prof, 0, 2048));
       }
       a.prof = m->mx_prof;
     }
@@ -793,11 +794,12 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
               in_bytes + 4.0 * (M * stem.cout + (double)stem.cout * stem.cin * 49));
       // one persistent workgroup per CU with role-specialised waves (stem_ps_kernel) when the tiles fill the chip for a few
       // rounds, the tile-per-workgroup kernel otherwise; bit-identical results (option stem_form: auto | persistent | tiles)
-      const bool ps = m->opt.stem_form != 2 && stem_ps_takes(a, pieces, ntn, false, m->num_cus) &&
-                      (m->opt.stem_form == 1 || true);
+      // (auto = tiles: with the K loop's fetches spread between the MFMAs both forms sit at the same ~1.0 ms at 256 pairs — what bounds
+      //  them is the CU's vector-memory pipe, 245 KB of weight fragments + 93 KB of patch per 128-pixel tile)
+      const bool ps = m->opt.stem_form == 1 && stem_ps_takes(a, pieces, ntn, false, m->num_cus);
       m->mx_prof_ps = ps;
       if (ps)
-        HIPCHK(m, launch_stem_ps(a, m->num_cus, s));
+        HIPCHK(m, launch_stem_ps(a, m->num_cus, m->opt.stem_lwaves == 4 ? 4 : 8, s));
       else
         HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
@@ -925,6 +927,7 @@ const OptDef kOptions[] = {
     {"stem", "PNVO_STEM", &PnvoOptions::stem, false, {{"auto", 0}, {"mx", 1}, {"dd", 2}, {"dense", 3}, {nullptr, 0}}},
     {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
     {"pieces", "PNVO_PIECES", &PnvoOptions::pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
+    {"stem_lwaves", "PNVO_STEM_LWAVES", &PnvoOptions::stem_lwaves, true, {{nullptr, 0}}},
     {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"persistent", 1}, {"tiles", 2}, {nullptr, 0}}},
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1990,17 +1993,19 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
   if (m->mx_prof && m->mx_prof_ps) {
-    unsigned long long pr[64];
-    (void)hipMemcpy(pr, m->mx_prof, 512, hipMemcpyDeviceToHost);
-    for (int w = 0; w < 8; ++w) {
-      const double nt_ = (double)(pr[8 * w + 5] ? pr[8 * w + 5] : 1);
+    unsigned long long pr[256];
+    (void)hipMemcpy(pr, m->mx_prof, 2048, hipMemcpyDeviceToHost);
+    for (int w = 0; w < 12; ++w) {
+      const unsigned long long *q = pr + 16 * w;
+      if (q[5] == 0) continue;
+      const double nt_ = (double)q[5];
       if (w < 4)
         std::fprintf(stderr, "[pnvo] stem_ps M wave %d (cycles per tile): wait patch %.0f  k-loop %.0f  wait others %.0f  exchange writes %.0f  "
-                     "(%llu tiles)\n", w, pr[8 * w] / nt_, pr[8 * w + 1] / nt_, pr[8 * w + 2] / nt_, pr[8 * w + 3] / nt_, pr[8 * w + 5]);
+                     "(%llu tiles)\n", w, q[0] / nt_, q[1] / nt_, q[2] / nt_, q[3] / nt_, q[5]);
       else
-        std::fprintf(stderr, "[pnvo] stem_ps L wave %d (cycles per tile): epilogue %.0f  convert+store %.0f  wait M %.0f  issue loads %.0f  "
-                     "wait exchange %.0f  (%llu tiles)\n", w, pr[8 * w] / nt_, pr[8 * w + 1] / nt_, pr[8 * w + 2] / nt_, pr[8 * w + 3] / nt_,
-                     pr[8 * w + 4] / nt_, pr[8 * w + 5]);
+        std::fprintf(stderr, "[pnvo] stem_ps L wave %d (cycles per tile): epilogue %.0f [sum %.0f  scratch writes %.0f  rendezvous %.0f  pool+keys %.0f]  "
+                     "convert+store %.0f  issue loads %.0f  wait M %.0f  wait exchange %.0f\n", w, q[0] / nt_, q[8] / nt_, q[9] / nt_, q[10] / nt_,
+                     q[11] / nt_, q[1] / nt_, q[2] / nt_, q[3] / nt_, q[4] / nt_);
     }
     (void)hipFree(m->mx_prof);
   } else if (m->mx_prof) {

@@ -109,6 +109,9 @@ struct StemMXArgs {
   int raw_flags;                  // bit 0: the model has the depth modality, bit 1: discretised depth
   int *raw_err;                   // device flag: a depth outside [0, 1]
   float edges[12];                // bin edges e_0 .. e_10 of the one-hot depth (float32(i / 10))
+  // developer ablations of stem_ps_kernel (option stem_dbg = 16 + bits; WRONG RESULTS, timing only): 1 every staging load reads one
+  // address, 2 no epilogue, 4 no conversion / LDS writes of the patch, 8 no MFMAs, 16 no staging loads, 32 no exchange writes
+  int dbg;
 };
 constexpr int STEM_POOL_INIT = (int)0x807fffffu;   // key of -inf
 int stem_mx_slots(int Ho, int Wo);
@@ -117,7 +120,7 @@ void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot
 float pack_stem_mx_weight_h(const float *wk, int cout, const int *xslot, unsigned short *out);   // two float16 pieces -> oscale
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
 bool stem_ps_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs);   // persistent role-specialised form
-hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, hipStream_t s);
+hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, int l_waves, hipStream_t s);   // l_waves: 4 or 8 epilogue / staging waves
 hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                    const int *slot_new, const int *xslot, float *scale2, unsigned short *wpk2, hipStream_t s);
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
