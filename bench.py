@@ -173,6 +173,34 @@ def timed_steps(step, steps, sync_all, dev):
     return dt, out
 
 
+def multi_gpu_report(model, out_local, dt_local, steps, B, rank, world, dist, dev, backend):
+    """What makes an N > 1 line self-explaining: every rank's own step time (the value uses their MAX), and a proof that sharding
+    changed nothing — rank 0 re-generates every rank's shard (inputs depend only on the rank's seed), runs it alone, and compares with
+    what that rank computed: bit-identical by construction (fixed-order reductions, no data-path collective)."""
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt_local], dtype=torch.float64, device=cdev)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    per_rank_ms = [1e3 * float(x.item()) / steps for x in parts]
+    o = out_local.detach().to(cdev).contiguous()
+    outs = [torch.zeros_like(o) for _ in range(world)]
+    dist.all_gather(outs, o)
+    rep = {"per_rank_ms_per_step": per_rank_ms, "slowest_rank": int(np.argmax(per_rank_ms)),
+           "spread": (max(per_rank_ms) - min(per_rank_ms)) / max(per_rank_ms),
+           "collectives_in_the_timed_region": "none (independent pairs); barrier + MAX over ranks around it"}
+    if rank == 0:
+        same, worst = [], 0.0
+        with torch.no_grad():
+            for r in range(world):
+                mine = model(make_inputs(B, dev, r)).to(cdev)
+                same.append(bool(torch.equal(mine, outs[r])))
+                worst = max(worst, float((mine - outs[r]).abs().max()))
+        rep["shards_equal_single_gpu"] = all(same)
+        rep["shards_checked"] = world
+        rep["max_abs_diff_vs_single_gpu"] = worst
+    return rep
+
+
 def arithmetic_text(model):
     """What the measured forward multiplied with, read from the handle's options (not a fixed string)."""
     conv, stem, pieces = model.get_option("conv"), model.get_option("stem"), model.get_option("pieces")
@@ -361,7 +389,11 @@ def main():
         kt = model.timing_read()
         model.timing(False)
 
+    dt_local = dt
     dt = parallel.max_over_ranks(dt, dev)     # slowest rank
+    multi = None
+    if world > 1:
+        multi = multi_gpu_report(model, out, dt_local, args.steps, B, rank, world, dist, dev, args.backend)
 
     # ---- BASELINE configs[2] and configs[3] (per-GPU shape) next to the headline: 10 timed steps each under the same contract
     #      (tools/bench_configs.py), on the headline's own observation tensors; AFTER the headline's timed region, never in it
@@ -486,6 +518,8 @@ def main():
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
                                for k in kt), key=lambda k: -k["ms_per_step"])[:40],
         }
+        if multi is not None:
+            res["multi_gpu"] = multi
         if secondary is not None:
             res["secondary"] = secondary
         if raw_rec is not None:

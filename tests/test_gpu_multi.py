@@ -102,4 +102,12 @@ def test_bench_two_ranks_sharing_one_gpu(config):
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["global_batch"] == 32 and rec["value"] > 0
+    mg = rec["multi_gpu"]                                             # what makes an N > 1 line self-explaining
+    assert len(mg["per_rank_ms_per_step"]) == 2 and min(mg["per_rank_ms_per_step"]) > 0
+    assert abs(max(mg["per_rank_ms_per_step"]) - rec["ms_per_step"]) < 0.25 * rec["ms_per_step"] + 0.2   # the value is the slowest rank's
+    if config == "fwd_fp32":
+        assert mg["shards_equal_single_gpu"] is True and mg["shards_checked"] == 2 and mg["max_abs_diff_vs_single_gpu"] == 0.0
+    else:
+        assert mg["ms_per_step_bucketed"] > 0 and mg["ms_per_step_flat"] > 0 and mg["allreduce_alone_ms"] > 0
+        assert mg["allreduce_bytes"] == 4 * 3962305
 

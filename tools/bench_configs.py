@@ -157,6 +157,10 @@ def run_dual_bf16(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
         dist.destroy_process_group()
 
 
+def backend_is_nccl(args):
+    return getattr(args, "backend", "nccl") == "nccl"
+
+
 def run_train(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
     from pointnav_vo_amd.train import VOTrainStep
     B = args.batch or 128
@@ -191,7 +195,40 @@ def run_train(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
     sync_all()
     kt = model.timing_read()
     model.timing(False)
+    dt_local = dt
     dt = parallel.max_over_ranks(dt, dev)
+    multi = None
+    if world > 1 and dist is not None:
+        # N > 1: every rank's own step time, the OTHER gradient all-reduce schedule in the same run (A/B: buckets behind the backward
+        # vs one flat buffer after it), and the flat 15.85 MB all-reduce alone — their difference is what the overlap hides
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt_local], dtype=torch.float64, device=cdev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank_ms = [1e3 * float(x.item()) / args.steps for x in parts]
+        ts.bucketed = not ts.bucketed
+        for _ in range(2):
+            step()
+        dt_other, _ = bench.timed_steps(step, args.steps, sync_all, dev)
+        dt_other = parallel.max_over_ranks(dt_other, dev)
+        ts.bucketed = not ts.bucketed
+        flat = ts.grad.clone() if backend_is_nccl(args) else ts.grad.detach().cpu()
+        for _ in range(2):
+            dist.all_reduce(flat)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(flat)
+        sync_all()
+        ar_ms = parallel.max_over_ranks((time.perf_counter() - t0) / 10, dev) * 1e3
+        this, other = ("bucketed", "flat") if ts.bucketed else ("flat", "bucketed")
+        multi = {"per_rank_ms_per_step": per_rank_ms, "slowest_rank": int(np.argmax(per_rank_ms)),
+                 f"ms_per_step_{this}": 1e3 * dt / args.steps, f"ms_per_step_{other}": 1e3 * dt_other / args.steps,
+                 "allreduce_alone_ms": ar_ms, "allreduce_bytes": int(ts.grad.numel() * 4),
+                 "exposed_allreduce_ms_estimate": max(0.0, 1e3 * (dt if this == "bucketed" else dt_other) / args.steps
+                                                      - (1e3 * (dt if this == "flat" else dt_other) / args.steps - ar_ms)),
+                 "note": "flat = backward, then ONE all-reduce of the whole gradient; bucketed = three ranges reduced on a communication "
+                         "stream while the backward still runs; exposed estimate = bucketed step - (flat step - all-reduce alone)"}
     if rank == 0:
         value = world * B * args.steps / dt
         flops = 3 * 2.0 * ms.macs_per_pair(model.cfg)
@@ -231,6 +268,8 @@ def run_train(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
                                for k in kt), key=lambda k: -k["ms_per_step"])[:70],
         }
         res["config"]["gradient_allreduce"] = "bucketed behind the backward" if ts.bucketed else "one flat buffer after the backward"
+        if multi is not None:
+            res["multi_gpu"] = multi
         if not emit:
             return res
         print(json.dumps(res))
