@@ -198,6 +198,20 @@ int pnvo_build_obs_pairs(const uint8_t *rgb_frames, const float *depth_frames, i
                          const float *tdv_consts, int rows_around_center, void *tdv_work, float *rgb_pairs, float *depth_pairs,
                          float *dd_pairs, float *tdv_pairs, int32_t *err_flag, void *stream);
 
+/* Frame ring of the batched boundary call.  Consecutive simulator steps of an environment share a frame — this step's prev_obs IS the
+ * last step's cur_obs (rl/ppo/ppo_trainer.py:724-841 keeps `prev_obs = observations`) — so the caller uploads one frame per environment
+ * and step; the other half of every pair, and its top-down view, come from a per-environment device slot, which then takes the new frame.
+ *   up_rgb / up_depth / up_tdv   device: the m uploaded frames [m][H][W][3] uint8 / [m][H][W] float32 / their top-down views [m][H][W]
+ *                                 (pnvo_topdown_view on up_depth); up_rgb / up_tdv NULL for models without the modality
+ *   ring_rgb / ring_depth / ring_tdv   device: [slots][H][W][3] / [slots][H][W] / [slots][H][W], owned by the caller across calls
+ *   idx   device int32 [3][n]: for pair i the index into up_* of its cur frame | of its prev frame, or -1: take the prev frame from
+ *         ring slot idx[2][i] | the ring slot that records the cur frame, or -1: none (every slot at most once per call)
+ *   -> rgb_frames [n][2][H][W][3], depth_frames [n][2][H][W], tdv_pairs [n][H][W][2]: the inputs of pnvo_forward_raw, bit-identical to
+ *      staging both frames of every pair. */
+int pnvo_ring_assemble(const uint8_t *up_rgb, const float *up_depth, const float *up_tdv, uint8_t *ring_rgb, float *ring_depth,
+                       float *ring_tdv, const int32_t *idx, int n, int H, int W, uint8_t *rgb_frames, float *depth_frames, float *tdv_pairs,
+                       void *stream);
+
 /* Host helper of the same boundary: gathers n separately allocated host frames (each bytes_each long) into one (pinned)
  * staging buffer with `threads` copy threads — the per-frame numpy copies were what bounded the batched boundary call. */
 int pnvo_stage_frames(const void *const *src, int n, size_t bytes_each, void *dst, int threads);

@@ -90,6 +90,8 @@ _SIGNATURES = {
     "pnvo_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "pnvo_destroy": (C.c_int, [C.c_void_p]),
+    "pnvo_ring_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pnvo_last_error": (C.c_char_p, [C.c_void_p]),
     "pnvo_last_note": (C.c_char_p, [C.c_void_p]),
     "pnvo_set_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

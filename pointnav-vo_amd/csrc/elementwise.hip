@@ -11,6 +11,7 @@
 namespace pnvo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // single-rounding float32 primitives (HIP's __fmul_rn/__fadd_rn are header inlines that still carry the `contract`
 // fast-math flag and get fused into v_fma by the backend; these, defined under contract(off), do not)
@@ -691,6 +692,93 @@ hipError_t launch_frame_pairs(const unsigned char *rgb, const float *depth, int 
   a.bins = bins;
   for (int k = 0; k <= bins; ++k) a.ed.e[k] = (k == bins ? 1.0f : (float)((double)k / (double)(bins > 0 ? bins : 1)));
   hipLaunchKernelGGL(frame_pairs_kernel, dim3((unsigned)((a.npix + 255) / 256), (unsigned)n), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frame ring of the batched boundary call (pnvo_ring_assemble): consecutive steps of an environment share a frame — this step's
+// prev_obs is the last step's cur_obs (rl/ppo/ppo_trainer.py:724-841) — so a step uploads ONE frame per environment; the other
+// half of the pair (and its top-down view) comes from a per-environment device slot, which then takes the new frame.
+// Thread = one dword of the rgb frame (H*W*3/4) and one depth / top-down pixel; blockIdx.y = pair.
+struct RingArgs {
+  const unsigned char *up_rgb;   // [m][H][W][3] uploaded frames (nullptr: model without rgb)
+  const float *up_dep, *up_tdv;  // [m][H][W]; up_tdv nullptr: model without the top-down view
+  unsigned char *ring_rgb;       // [slots][H][W][3]
+  float *ring_dep, *ring_tdv;    // [slots][H][W]
+  const int *idx;                // [3][n]: up index of the cur frame | up index of the prev frame or -1 (take it from the ring) | ring slot or -1
+  unsigned char *pair_rgb;       // [n][2][H][W][3]
+  float *pair_dep, *pair_tdv;    // [n][2][H][W], [n][H][W][2]
+  int n;
+  long npix;
+};
+__global__ __launch_bounds__(256) void ring_assemble_kernel(const RingArgs a) {
+  const int i = blockIdx.y;
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cur = a.idx[i], prev = a.idx[a.n + i], slot = a.idx[2 * a.n + i];
+  const long fb = a.npix * 3;                                   // bytes of an rgb frame
+  if (a.up_rgb != nullptr) {
+    if ((fb & 3) == 0) {                                        // dword copies
+      if (g < (fb >> 2)) {
+        const unsigned *uc = reinterpret_cast<const unsigned *>(a.up_rgb + (long)cur * fb);
+        unsigned *rg = slot >= 0 ? reinterpret_cast<unsigned *>(a.ring_rgb + (long)slot * fb) : nullptr;
+        const unsigned pv = prev >= 0 ? reinterpret_cast<const unsigned *>(a.up_rgb + (long)prev * fb)[g] : rg[g];
+        const unsigned cv = uc[g];
+        unsigned *pr = reinterpret_cast<unsigned *>(a.pair_rgb + (long)i * 2 * fb);
+        pr[g] = pv;
+        pr[(fb >> 2) + g] = cv;
+        if (rg) rg[g] = cv;
+      }
+    } else {                                                    // odd frame sizes: three bytes of one pixel per thread
+      if (g < a.npix) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const long o = 3 * g + c;
+          unsigned char *rg = slot >= 0 ? a.ring_rgb + (long)slot * fb : nullptr;
+          const unsigned char pv = prev >= 0 ? a.up_rgb[(long)prev * fb + o] : rg[o];
+          const unsigned char cv = a.up_rgb[(long)cur * fb + o];
+          a.pair_rgb[(long)i * 2 * fb + o] = pv;
+          a.pair_rgb[(long)i * 2 * fb + fb + o] = cv;
+          if (rg) rg[o] = cv;
+        }
+      }
+    }
+  }
+  if (g < a.npix) {
+    float *rd = slot >= 0 ? a.ring_dep + (long)slot * a.npix : nullptr;
+    const float pd = prev >= 0 ? a.up_dep[(long)prev * a.npix + g] : rd[g];
+    const float cd = a.up_dep[(long)cur * a.npix + g];
+    a.pair_dep[(long)i * 2 * a.npix + g] = pd;
+    a.pair_dep[(long)i * 2 * a.npix + a.npix + g] = cd;
+    if (rd) rd[g] = cd;
+    if (a.up_tdv != nullptr) {
+      float *rt = slot >= 0 ? a.ring_tdv + (long)slot * a.npix : nullptr;
+      const float pt = prev >= 0 ? a.up_tdv[(long)prev * a.npix + g] : rt[g];
+      const float ct = a.up_tdv[(long)cur * a.npix + g];
+      *reinterpret_cast<f32x2 *>(a.pair_tdv + ((long)i * a.npix + g) * 2) = f32x2{pt, ct};
+      if (rt) rt[g] = ct;
+    }
+  }
+}
+
+hipError_t launch_ring_assemble(const unsigned char *up_rgb, const float *up_dep, const float *up_tdv, unsigned char *ring_rgb,
+                                float *ring_dep, float *ring_tdv, const int *idx, int n, int H, int W, unsigned char *pair_rgb,
+                                float *pair_dep, float *pair_tdv, hipStream_t s) {
+  RingArgs a;
+  a.up_rgb = up_rgb;
+  a.up_dep = up_dep;
+  a.up_tdv = up_tdv;
+  a.ring_rgb = ring_rgb;
+  a.ring_dep = ring_dep;
+  a.ring_tdv = ring_tdv;
+  a.idx = idx;
+  a.pair_rgb = pair_rgb;
+  a.pair_dep = pair_dep;
+  a.pair_tdv = pair_tdv;
+  a.n = n;
+  a.npix = (long)H * W;
+  const long work = a.npix;                                     // (>= the dwords of an rgb frame: 3/4 npix)
+  hipLaunchKernelGGL(ring_assemble_kernel, dim3((unsigned)((work + 255) / 256), (unsigned)n), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

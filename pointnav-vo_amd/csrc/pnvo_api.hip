@@ -1960,6 +1960,20 @@ int pnvo_build_obs_pairs(const uint8_t *rgb_frames, const float *depth_frames, i
   return PNVO_OK;
 }
 
+int pnvo_ring_assemble(const uint8_t *up_rgb, const float *up_depth, const float *up_tdv, uint8_t *ring_rgb, float *ring_depth,
+                       float *ring_tdv, const int32_t *idx, int n, int H, int W, uint8_t *rgb_frames, float *depth_frames, float *tdv_pairs,
+                       void *stream) {
+  if (!up_depth || !ring_depth || !idx || !depth_frames || n < 0 || H <= 0 || W <= 0) return fail(nullptr, PNVO_ERR_ARG, "bad argument");
+  if ((up_rgb != nullptr) != (rgb_frames != nullptr) || (up_rgb != nullptr) != (ring_rgb != nullptr))
+    return fail(nullptr, PNVO_ERR_ARG, "rgb buffers must be given together");
+  if ((up_tdv != nullptr) != (tdv_pairs != nullptr) || (up_tdv != nullptr) != (ring_tdv != nullptr))
+    return fail(nullptr, PNVO_ERR_ARG, "top-down buffers must be given together");
+  if (n == 0) return PNVO_OK;
+  HIPCHK(nullptr, launch_ring_assemble(up_rgb, up_depth, up_tdv, ring_rgb, ring_depth, ring_tdv, idx, n, H, W, rgb_frames, depth_frames,
+                                       tdv_pairs, (hipStream_t)stream));
+  return PNVO_OK;
+}
+
 int pnvo_destroy(pnvo_handle m) {
   if (!m) return PNVO_OK;
   (void)hipSetDevice(m->device);

@@ -243,6 +243,9 @@ hipError_t launch_dataset_pairs(const unsigned char *prev_rgb, const unsigned ch
                                 const unsigned short *cur_depth, const float *tdv_frames, const int *src, const int *swap,
                                 int N, int M, int H, int W, int bins, const float *edges, float *o_rgb, float *o_depth,
                                 float *o_dd, float *o_tdv, int *err_flag, hipStream_t s);
+hipError_t launch_ring_assemble(const unsigned char *up_rgb, const float *up_dep, const float *up_tdv, unsigned char *ring_rgb,
+                                float *ring_dep, float *ring_tdv, const int *idx, int n, int H, int W, unsigned char *pair_rgb,
+                                float *pair_dep, float *pair_tdv, hipStream_t s);
 hipError_t launch_frame_pairs(const unsigned char *rgb, const float *depth, int n, int H, int W, int bins, float *o_rgb,
                               float *o_depth, float *o_dd, int *err_flag, hipStream_t s);
 size_t topdown_workspace_bytes(int N, int H, int W);

@@ -263,9 +263,125 @@ class BaseRLTrainerWithVO:
         arr = (C.c_void_p * len(keep))(*[k.__array_interface__["data"][0] for k in keep])   # (.ctypes builds an object per frame)
         return arr, keep
 
-    def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts):
+    # ------------------------------------------------------------------------------------------------ frame ring (env_ids)
+    def reset_frame_ring(self, env_ids=None):
+        """Forget the recorded frames of the given environments (all of them by default)."""
+        src = getattr(self, "_ring_src", None)
+        if src is None:
+            return
+        if env_ids is None:
+            src.clear()
+        else:
+            for e in env_ids:
+                src.pop(e, None)
+
+    def _ring_buffers(self, slots, m, H, W, want_rgb, want_tdv):
+        """Device ring (one slot per environment: its last cur frame + top-down view) and the upload staging of m frames."""
+        dev = self.device
+        rg = getattr(self, "_ring", None)
+        shape = (H, W, want_rgb, want_tdv)
+        if rg is None or rg["shape"] != shape:
+            rg = dict(shape=shape, slots=0, cap=0, slot_of={})
+            self._ring = rg
+            self._ring_src = {}
+        if rg["slots"] < slots:
+            ns = max(slots, 2 * rg["slots"], 8)
+            new = dict(rgb=torch.empty((ns, H, W, 3), dtype=torch.uint8, device=dev) if want_rgb else None,
+                       dep=torch.empty((ns, H, W), dtype=torch.float32, device=dev),
+                       tdv=torch.empty((ns, H, W), dtype=torch.float32, device=dev) if want_tdv else None)
+            for k, t in new.items():
+                if t is not None and rg["slots"] > 0:
+                    t[: rg["slots"]].copy_(rg[k])
+            rg.update(new)
+            rg["slots"] = ns
+        if rg["cap"] < m:
+            cap = max(m, 2 * rg["cap"])
+            rg.update(cap=cap,
+                      h_rgb=torch.empty((cap, H, W, 3), dtype=torch.uint8).pin_memory() if want_rgb else None,
+                      h_dep=torch.empty((cap, H, W), dtype=torch.float32).pin_memory(),
+                      u_rgb=torch.empty((cap, H, W, 3), dtype=torch.uint8, device=dev) if want_rgb else None,
+                      u_dep=torch.empty((cap, H, W), dtype=torch.float32, device=dev),
+                      u_tdv=torch.empty((cap, H, W), dtype=torch.float32, device=dev) if want_tdv else None,
+                      h_idx=torch.empty((3 * cap,), dtype=torch.int32).pin_memory(),
+                      d_idx=torch.empty((3 * cap,), dtype=torch.int32, device=dev))
+            rg["h_idx_np"] = rg["h_idx"].numpy()              # (filled through numpy: a torch op per field costs more than the copy)
+        return rg
+
+    def _stage_pairs_through_ring(self, st, prev_obs_list, cur_obs_list, env_ids, H, W, want_rgb, want_tdv, gen):
+        """The frames of n pairs into st[d_rgb / d_dep / tdv] with ONE uploaded frame per pair wherever the pair's prev frame is the
+        frame its environment handed over as cur the call before (object identity of the numpy arrays: what `prev_obs = observations`
+        in the reference's loop gives; a reset, a new environment or a copied frame simply uploads both).  Bit-identical to staging
+        both frames: the ring holds the very bytes that were uploaded, and the top-down view is a function of the frame alone."""
+        n, dev = len(env_ids), self.device
+        assert len(set(env_ids)) == n, "env_ids must be distinct within a call"
+        src = getattr(self, "_ring_src", None)
+        if src is None or getattr(self, "_ring", None) is None or self._ring["shape"] != (H, W, want_rgb, want_tdv):
+            src = {}
+        hits = []
+        for pv, cv, e in zip(prev_obs_list, cur_obs_list, env_ids):
+            rec = src.get(e)
+            ok = (rec is not None and rec[0] is pv["depth"] and (not want_rgb or rec[1] is pv["rgb"])
+                  and pv["depth"] is not cv["depth"])
+            hits.append(ok)
+        miss = [i for i in range(n) if not hits[i]]
+        m = n + len(miss)
+        known = self._ring["slot_of"] if getattr(self, "_ring", None) is not None and self._ring["shape"] == (H, W, want_rgb, want_tdv) else {}
+        need_slots = len(known) + sum(1 for e in env_ids if e not in known)
+        rg = self._ring_buffers(need_slots, m, H, W, want_rgb, want_tdv)
+        src = self._ring_src
+        slot_of = rg["slot_of"]
+        for e in env_ids:
+            if e not in slot_of:
+                slot_of[e] = len(slot_of)
+        up = list(cur_obs_list) + [prev_obs_list[i] for i in miss]                 # frames to upload: every cur, the missed prevs
+        hx = rg["h_idx_np"]                                   # [3][n]: cur index | prev index or -1 (ring) | slot
+        hx[0:n] = np.arange(n, dtype=np.int32)
+        hx[n:2 * n] = -1
+        for k, i in enumerate(miss):
+            hx[n + i] = n + k
+        hx[2 * n:3 * n] = [slot_of[e] for e in env_ids]
+        rg["d_idx"][: 3 * n].copy_(rg["h_idx"][: 3 * n], non_blocking=True)      # (first on the stream: long landed when the assemble kernel runs)
+        p = lambda t, off=0: C.c_void_p(t[off:].data_ptr()) if t is not None else None
+        pd_all, keep_d = self._frame_ptrs([f["depth"] for f in up], np.float32, (H, W))
+        pr_all, keep_r = self._frame_ptrs([f["rgb"] for f in up], np.uint8, (H, W, 3)) if want_rgb else (None, None)
+        vp = C.sizeof(C.c_void_p)
+        nchunks = self.boundary_chunks or (1 if m < 24 else (2 if m < 64 else 4))
+        bounds = [(m * c // nchunks, m * (c + 1) // nchunks) for c in range(nchunks)]
+        main = torch.cuda.current_stream(dev)
+        if nchunks > 1 and getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+        copy = self._copy_stream if nchunks > 1 else main
+        if nchunks > 1:
+            copy.wait_stream(main)
+        for lo, hi in bounds:
+            k = hi - lo
+            threads = min(self.stage_threads, k)
+            pd_c = C.c_void_p(C.addressof(pd_all) + lo * vp)
+            with torch.cuda.stream(copy):
+                if want_rgb:
+                    pr_c = C.c_void_p(C.addressof(pr_all) + lo * vp)
+                    _lib.check(_lib.lib.pnvo_stage_frames2(pr_c, H * W * 3, p(rg["h_rgb"], lo), pd_c, H * W * 4, p(rg["h_dep"], lo), k, threads))
+                    rg["u_rgb"][lo:hi].copy_(rg["h_rgb"][lo:hi], non_blocking=True)
+                else:
+                    _lib.check(_lib.lib.pnvo_stage_frames(pd_c, k, H * W * 4, p(rg["h_dep"], lo), threads))
+                rg["u_dep"][lo:hi].copy_(rg["h_dep"][lo:hi], non_blocking=True)
+            if nchunks > 1:
+                main.wait_stream(copy)
+            if want_tdv:
+                gen.gen_top_down_view_batch(rg["u_dep"][lo:hi], out=rg["u_tdv"][lo:hi].unsqueeze(-1), out_channel=0)
+        _lib.check(_lib.lib.pnvo_ring_assemble(p(rg["u_rgb"]), p(rg["u_dep"]), p(rg["u_tdv"]), p(rg["rgb"]), p(rg["dep"]), p(rg["tdv"]),
+                                               p(rg["d_idx"]), int(n), int(H), int(W), p(st["d_rgb"]), p(st["d_dep"]), p(st["tdv"]),
+                                               _stream(dev)))
+        for cv, e in zip(cur_obs_list, env_ids):
+            src[e] = (cv["depth"], cv["rgb"] if want_rgb else None)
+        self._ring_stats = dict(pairs=n, uploaded_frames=m, ring_hits=n - len(miss))
+        return keep_d, keep_r
+
+    def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts, env_ids=None):
         """Batched sibling of _compute_local_delta_states_from_vo: lists of observation dicts and actions ->
-        float32 array [N,3].  The 2N raw frames are gathered into pinned staging by pnvo_stage_frames (parallel memcpy) and
+        float32 array [N,3].  env_ids (optional, one hashable id per pair, distinct within a call; mode 'det'): the call keeps each
+        environment's cur frame and its top-down view on the device and, when the next call's prev frame IS that frame (the
+        reference's loop: prev_obs = observations), uploads and pre-processes only the new frame — results are bit-identical.  The 2N raw frames are gathered into pinned staging by pnvo_stage_frames (parallel memcpy) and
         cross PCIe in 1-4 chunks on a copy stream; behind each chunk the two top-down views of its frames are built on the
         caller's stream.  Mode 'det': the frames then go STRAIGHT into the model (pnvo_forward_raw: pair concatenation, uint8 ->
         float and the one-hot depth of base_trainer_with_vo.py:172-269 happen in the stem's operand fetch; no observation-pair
@@ -297,8 +413,13 @@ class BaseRLTrainerWithVO:
             cur_obs_list = [cur_obs_list[i] for i in order]
             acts = [acts[i] for i in order]
             keys = [keys[i] for i in order]
+            if env_ids is not None:
+                env_ids = [env_ids[i] for i in order]
         else:
             order = None
+        use_ring = env_ids is not None and rm.mode == "det"
+        if env_ids is not None:
+            assert len(env_ids) == n
         # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, the
         # top-down views of chunk c-1 are built on the caller's stream (host staging, transfer and device work overlap).
         nchunks = self.boundary_chunks or (1 if n < 24 else (2 if n < 48 else 4))
@@ -308,14 +429,19 @@ class BaseRLTrainerWithVO:
             self._copy_stream = torch.cuda.Stream(dev)
         copy = self._copy_stream if nchunks > 1 else main
         pending = []
-        frames = [o for pc in zip(prev_obs_list, cur_obs_list) for o in pc]
-        # address tables over all 2N frames, once (frames are used in place when they are contiguous arrays of the right type)
-        pd_all, keep_d = self._frame_ptrs([f["depth"] for f in frames], np.float32, (H, W))
-        pr_all, keep_r = self._frame_ptrs([f["rgb"] for f in frames], np.uint8, (H, W, 3)) if want_rgb else (None, None)
+        if use_ring:
+            bounds = []                                   # the ring path stages (and chunks) on its own
+            with torch.cuda.device(dev), torch.no_grad():
+                keep_d, keep_r = self._stage_pairs_through_ring(st, prev_obs_list, cur_obs_list, env_ids, H, W, want_rgb, want_tdv, gen)
+        else:
+            frames = [o for pc in zip(prev_obs_list, cur_obs_list) for o in pc]
+            # address tables over all 2N frames, once (frames are used in place when they are contiguous arrays of the right type)
+            pd_all, keep_d = self._frame_ptrs([f["depth"] for f in frames], np.float32, (H, W))
+            pr_all, keep_r = self._frame_ptrs([f["rgb"] for f in frames], np.uint8, (H, W, 3)) if want_rgb else (None, None)
         vp = C.sizeof(C.c_void_p)
         with torch.cuda.device(dev), torch.no_grad():
             st["flag"].zero_()
-            if nchunks > 1:
+            if nchunks > 1 and not use_ring:
                 copy.wait_stream(main)
             for lo, hi in bounds:
                 m = hi - lo

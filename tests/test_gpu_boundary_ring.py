@@ -1,0 +1,99 @@
+"""GPU (-m gpu): the frame ring of the batched boundary call (compute_local_delta_states_batch(..., env_ids=...)).  Consecutive steps of
+an environment share a frame (this step's prev_obs is the last step's cur_obs, rl/ppo/ppo_trainer.py:724-841); with env_ids the call
+uploads and pre-processes one frame per pair instead of two.  Everything here is bit-exact against the same call without env_ids."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pair_rel_err
+from pointnav_vo_amd import synth
+from test_gpu_parity import make_trainer
+
+pytestmark = pytest.mark.gpu
+
+
+def frames(H, W, env, t, fp16=True):
+    return synth.make_raw_obs(H, W, seed=40 + env, index=t, zero_border=(env % 3), depth_fp16=fp16)
+
+
+def test_ring_is_bit_identical_to_uploading_both_frames():
+    rec = load_golden("boundary.npz")
+    H, W = int(rec["height"]), int(rec["width"])
+    ring, plain = make_trainer(rec), make_trainer(rec)
+    E, T = 6, 5
+    rng = np.random.default_rng(0)
+    seq = {e: [frames(H, W, e, t, fp16=(e % 2 == 0)) for t in range(T + 1)] for e in range(E)}
+    acts_all = rng.integers(1, 4, size=(T, E))
+    for t in range(T):
+        envs = list(range(E))
+        if t == 2:
+            envs = [4, 1, 5, 0]                                   # a subset, in another order
+        if t == 3:
+            rng.shuffle(envs)
+        prevs = [seq[e][t] for e in envs]
+        curs = [seq[e][t + 1] for e in envs]
+        expect_hits = 0 if t == 0 else len(envs)
+        if t == 3:                                                # an episode reset (a fresh observation) and a copied frame: both miss
+            prevs[0] = frames(H, W, 99, 7)
+            prevs[1] = {k: v.copy() for k, v in prevs[1].items()}
+            expect_hits -= 2
+        if t == 3:                                                # environments 2 and 3 sat out step 2: their recorded frame is step 1's
+            expect_hits -= sum(1 for i, e in enumerate(envs) if e in (2, 3) and i > 1)
+        acts = [int(acts_all[t, e]) for e in envs]
+        a = ring.compute_local_delta_states_batch(prevs, curs, acts, env_ids=envs)
+        b = plain.compute_local_delta_states_batch(prevs, curs, acts)
+        assert np.array_equal(a, b), (t, np.abs(a - b).max())
+        st = ring._ring_stats
+        assert st["pairs"] == len(envs) and st["uploaded_frames"] == 2 * len(envs) - st["ring_hits"]
+        assert st["ring_hits"] == expect_hits, (t, st, expect_hits)
+    # forgetting an environment makes its next pair upload both frames again; results do not change
+    ring.reset_frame_ring([0])
+    prevs, curs = [seq[e][T - 1] for e in range(E)], [seq[e][T] for e in range(E)]
+    a = ring.compute_local_delta_states_batch(prevs, curs, [1] * E, env_ids=list(range(E)))
+    b = plain.compute_local_delta_states_batch(prevs, curs, [1] * E)
+    assert np.array_equal(a, b)
+
+
+def test_ring_reproduces_the_reference_boundary_fixture():
+    """boundary.npz's four steps chain (cur of a step is the next step's prev): through the ring, one environment."""
+    rec = load_golden("boundary.npz")
+    t = make_trainer(rec)
+    H, W = int(rec["height"]), int(rec["width"])
+    cache = {}
+
+    def obs(i, zb):
+        return cache.setdefault((int(i), int(zb)), synth.make_raw_obs(H, W, seed=int(rec["obs_seed"]), index=int(i), zero_border=int(zb)))
+
+    hits = 0
+    for (pi, ci, act, zb), want in zip(rec["steps"], rec["deltas"]):
+        got = t.compute_local_delta_states_batch([obs(pi, zb)], [obs(ci, zb)], [int(act)], env_ids=["env0"])
+        assert pair_rel_err(got, want[None]).max() < 1e-4
+        hits += t._ring_stats["ring_hits"]
+    assert hits == 2          # steps 2 and 4 continue from the frame the step before left (step 3 changes the zero border: new objects)
+
+
+def test_ring_on_an_odd_resolution_without_rgb_alignment():
+    """45 x 37 frames: H * W * 3 is not a multiple of four bytes (the byte path of the assemble kernel)."""
+    from pointnav_vo_amd.trainer import AttrDict, BaseRLTrainerWithVO
+    from pointnav_vo_amd import model_spec as ms
+    H, W = 37, 45
+    cfg = AttrDict(VO=dict(VO_TYPE="REGRESS", OBS_TRANSFORM="none", VIS_SIZE_W=W, VIS_SIZE_H=H,
+                           REGRESS_MODEL=dict(name="vo_cnn_rgb_d_dd_top_down", visual_backbone="resnet18", hidden_size=512,
+                                              visual_type=["rgb", "depth", "discretized_depth", "top_down_view"], dropout_p=0.2,
+                                              discretize_depth="hard", discretized_depth_channels=10, regress_type="unified_act",
+                                              mode="det", rnd_mode_n=10, pretrained=False)),
+                   TASK_CONFIG=dict(SIMULATOR=dict(DEPTH_SENSOR=dict(MIN_DEPTH=0.1, MAX_DEPTH=10.0, HFOV=70))))
+    outs = []
+    for use_ring in (True, False):
+        t = BaseRLTrainerWithVO(cfg, torch.device("cuda", 0))
+        t._set_up_vo_obs_transformer()
+        t._setup_vo_model(cfg)
+        sd = synth.make_state_dict(ms.state_dict_spec(t.vo_model["all"].cfg), seed=3)
+        t.vo_model["all"].load_state_dict({n: torch.from_numpy(np.array(v)) for n, v in sd.items()})
+        seq = {e: [frames(H, W, e, k) for k in range(4)] for e in range(3)}
+        res = []
+        for k in range(3):
+            kw = dict(env_ids=[0, 1, 2]) if use_ring else {}
+            res.append(t.compute_local_delta_states_batch([seq[e][k] for e in range(3)], [seq[e][k + 1] for e in range(3)], [1, 2, 3], **kw))
+        outs.append(np.stack(res))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])

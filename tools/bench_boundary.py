@@ -49,6 +49,23 @@ for nb in (8, 64):
         t.compute_local_delta_states_batch(prev, cur, acts)
     dt = (time.perf_counter() - t0) / 10
     res[f"batch{nb}_boundary_pairs_per_s_pcie_inclusive"] = nb / dt
+# the same calls through the frame ring (env_ids): a rolling sequence per environment, so every call's prev frame IS the last call's
+# cur frame (the navigation loop's `prev_obs = observations`) and only the new frame crosses PCIe
+seq = [synth.make_raw_obs(H, W, seed=4, index=i) for i in range(64 + 40)]
+for nb in (1, 8, 64):
+    envs = list(range(nb))
+    step = lambda k: t.compute_local_delta_states_batch([seq[e + k] for e in envs], [seq[e + k + 1] for e in envs], [1] * nb, env_ids=envs)
+    for k in range(5):
+        step(k)
+    t0 = time.perf_counter()
+    for k in range(5, 35):
+        step(k)
+    dt = (time.perf_counter() - t0) / 30
+    assert t._ring_stats["ring_hits"] == nb, t._ring_stats
+    if nb == 1:
+        res["batch1_boundary_ring_ms"] = dt * 1e3
+    else:
+        res[f"batch{nb}_boundary_ring_pairs_per_s_pcie_inclusive"] = nb / dt
 m = t.vo_model["forward"].eval()
 o1 = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_obs_pairs(1, H, W, observation_space=cfg.VO.REGRESS_MODEL.visual_type, seed=2).items()}
 with torch.no_grad():

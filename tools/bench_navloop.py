@@ -84,6 +84,7 @@ def run(envs, steps, episode_steps=150.0, dev=None):
         prev_a = torch.zeros(E, 1, dtype=torch.long, device=dev)
         masks = torch.ones(E, 1, device=dev)
         prev_obs = [frames[e % 96] for e in range(E)]
+        env_ids = list(range(E)) if os.environ.get("PNVO_NAVLOOP_RING", "1") != "0" else None
 
         def step(s):
             nonlocal hid, prev_a, prev_obs
@@ -93,7 +94,7 @@ def run(envs, steps, episode_steps=150.0, dev=None):
             _, act, _, hid = pol.act(obs, hid, prev_a, masks, deterministic=False)
             acts = (act.view(-1).cpu().numpy() % 3 + 1).tolist()          # STOP never ends a synthetic episode here
             cur_obs = [frames[(e + s + 1) % 96] for e in range(E)]
-            deltas = t.compute_local_delta_states_batch(prev_obs, cur_obs, acts)
+            deltas = t.compute_local_delta_states_batch(prev_obs, cur_obs, acts, env_ids=env_ids)   # prev_obs IS last step's cur_obs: frame ring
             goals[:] = list(geometry.compute_goal_pos_batch(np.stack(goals), deltas)["cartesian"])
             prev_a = torch.as_tensor(acts, device=dev).view(E, 1)
             prev_obs = cur_obs
