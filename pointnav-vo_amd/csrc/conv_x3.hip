@@ -476,6 +476,379 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
   }
 }
 
+
+// =====================================================================================================================
+// conv_x3p_kernel — the PERSISTENT form of the float16-piece 3x3 stride-1 conv for the shallow stages (32 / 64 input channels:
+// the whole K dimension is one staged chunk, wave tiles (1,1) / (2,1)), input modes 0, 1 and 3.
+//
+// conv_x3_kernel's workgroup loads its patch, converts it, multiplies, stores, and exits; the next workgroup starts with a cold
+// memory round trip.  On the 48x86 and 24x43 maps the layers are HBM-bound in float32 activations (300 MB per conv at 256 pairs)
+// and ran at ~2.4 TB/s because every workgroup's loads come as one burst followed by ~20 k cycles without any.  Here a workgroup
+// walks tiles, and the NEXT tile's patch (and its sample's GroupNorm scale / shift) is fetched into registers right behind the
+// barrier that publishes the current patch: those loads are in flight during the whole K loop and epilogue of the current tile.
+// Same MFMA order, same statistics order as conv_x3_kernel: bit-identical outputs (tests/test_gpu_knobs.py).
+// BRES (32 -> 32 channels: layer1): the layer's whole B operand — 9 taps x 2 k-chunks x 2 pieces = 36 fragments, 144 registers — is
+// loaded ONCE per workgroup and stays in registers for every tile it walks.  Round 4 measured what bounds these layers: not the
+// patch loads (prefetching them changed nothing) but the CU's vector-memory pipe, ~20 B/clk, of which the weight fragments were two
+// thirds (4 waves x 36 KB per tile against 41 KB of patch + 32 KB of output).  Two waves per SIMD (256 registers), no patch prefetch.
+template <int MODE, int MW, int NW, bool BRES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BRES ? 2 : 3, BRES ? 2 : 3))) void conv_x3p_kernel(const ConvX3Args p) {
+  static_assert(MODE == 0 || MODE == 1 || MODE == 3, "the block-tail stager has no registers for a second patch");
+  static_assert(!BRES || NW == 1, "resident weights: one N-tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int KS = 3, PAD = 1, NP = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntiles = p.B * p.tiles_r * p.tiles_c;
+  const int chunk = (ntiles + 7) >> 3;
+  const int PR = p.PR, PC = p.PC, CK = p.CK;
+  const int pitch = CK * 2 + 16;
+  const int plane = PR * PC * pitch;
+  const int npix = p.TR * p.TC;
+  unsigned *qtab = reinterpret_cast<unsigned *>(lds + NP * plane);
+  unsigned *otab = qtab + p.MT * 32;
+  const int wn = p.wn;
+  const int wave_m = wave / wn;
+  const int wave_n = (wave & (wn - 1)) + (int)blockIdx.y * wn;
+  const int ntt = p.COUTP >> 5;
+  float in_mul = 1.f, in_div = 1.f;
+  const bool in_scaled = p.in_absmax != nullptr;
+  if (in_scaled) {
+    unsigned mb = p.in_absmax[(threadIdx.x & 63) * 16];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, d));
+    const int e = mb != 0u ? (int)((mb >> 23) & 0xffu) - 126 : 14;
+    in_mul = __builtin_bit_cast(float, (unsigned)(14 - e + 127) << 23);
+    in_div = __builtin_bit_cast(float, (unsigned)(e - 14 + 127) << 23);
+  }
+  const int G = CK >> 3;
+  const int cg = threadIdx.x & (G - 1), pl = threadIdx.x / G, PS = 256 / G;
+  const int nppix = PR * PC;
+  // this thread's (at most six) patch pixels: tile-independent
+  constexpr int NPX = 6;
+  int ppr[NPX], ppc[NPX];
+  unsigned poff[NPX];
+  bool pok[NPX];
+#pragma unroll
+  for (int k = 0; k < NPX; ++k) {
+    const int pix = pl + k * PS;
+    pok[k] = pix < nppix;
+    const int q = pok[k] ? pix : 0;
+    ppr[k] = q / PC;
+    ppc[k] = q - ppr[k] * PC;
+    poff[k] = (unsigned)((ppr[k] * PC + ppc[k]) * pitch + 16 * cg);
+  }
+  if ((int)threadIdx.x < p.MT * 32) {
+    const int q = min((int)threadIdx.x, npix - 1);
+    const int tr = q / p.TC, tc = q - tr * p.TC;
+    qtab[threadIdx.x] = (unsigned)((tr * PC + tc) * pitch);
+  }
+  struct Tile {
+    int n, tri, tci, r0, c0, hi0, wi0;
+    bool valid;
+  };
+  auto decode = [&](int vb) {
+    Tile t;
+    int bid = (vb & 7) * chunk + (vb >> 3);
+    t.valid = vb < 8 * chunk && bid < ntiles;
+    if (!t.valid) bid = 0;
+    t.tci = bid % p.tiles_c;
+    bid /= p.tiles_c;
+    t.tri = bid % p.tiles_r;
+    t.n = bid / p.tiles_r;
+    t.r0 = t.tri * p.TR;
+    t.c0 = t.tci * p.TC;
+    t.hi0 = t.r0 - PAD;
+    t.wi0 = t.c0 - PAD;
+    return t;
+  };
+  // ---- the patch of one tile in registers
+  f32x4 v[NPX][2], sc0, sc1, sh0, sh1;
+  bool inb[NPX];
+  auto fetch = [&](const Tile &t) {
+    const long img = ((long)t.n * p.H * p.W) * p.CIN + 8 * cg;
+    if (MODE >= 1) {
+      const float *ps = p.in_scale + (long)t.n * p.CIN + 8 * cg;
+      const float *pt = p.in_shift + (long)t.n * p.CIN + 8 * cg;
+      sc0 = *reinterpret_cast<const f32x4 *>(ps);
+      sc1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+      sh0 = *reinterpret_cast<const f32x4 *>(pt);
+      sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      const int hi = t.hi0 + ppr[k], wi = t.wi0 + ppc[k];
+      inb[k] = pok[k] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      v[k][0] = v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (inb[k]) {
+        const float *src = p.x + img + ((long)hi * p.W + wi) * p.CIN;
+        v[k][0] = *reinterpret_cast<const f32x4 *>(src);
+        v[k][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+      }
+    }
+  };
+  auto split_store = [&](const Tile &t) {
+    const long img = ((long)t.n * p.H * p.W) * p.CIN + 8 * cg;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      if (!pok[k]) continue;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[k][e >> 2][e & 3];
+        if (MODE == 1) {
+          const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
+          x = inb[k] ? fmaxf(__builtin_fmaf(x, sc[e & 3], sh[e & 3]), 0.f) : 0.f;
+        }
+        if (MODE == 3) {
+          const f32x4 &sc = e < 4 ? sc0 : sc1, &sh = e < 4 ? sh0 : sh1;
+          int key = __builtin_bit_cast(int, x);
+          key = key >= 0 ? key : key ^ 0x7fffffff;
+          x = inb[k] ? fmaxf(__builtin_fmaf(__builtin_bit_cast(float, key), __builtin_fabsf(sc[e & 3]), sh[e & 3]), 0.f) : 0.f;
+        }
+        f[e] = x;
+      }
+      if (MODE == 3) {                                                   // the tile owns the input pixels under its own outputs
+        const bool own = inb[k] && blockIdx.y == 0 && ppr[k] >= PAD && ppr[k] < PAD + p.TR && ppc[k] >= PAD && ppc[k] < PAD + p.TC;
+        if (own) {
+          float *dst = p.xout + img + ((long)(t.hi0 + ppr[k]) * p.W + t.wi0 + ppc[k]) * p.CIN;
+          *reinterpret_cast<f32x4 *>(dst) = f32x4{f[0], f[1], f[2], f[3]};
+          *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{f[4], f[5], f[6], f[7]};
+        }
+      }
+      if (in_scaled) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= in_mul;
+      }
+      u32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = f[2 * e], b = f[2 * e + 1];
+        const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+        o0[e] = __builtin_bit_cast(unsigned, h);
+        o1[e] = pack2h(a - (float)h[0], b - (float)h[1]);
+      }
+      *reinterpret_cast<u32x4 *>(lds + poff[k]) = o0;
+      *reinterpret_cast<u32x4 *>(lds + plane + poff[k]) = o1;
+    }
+  };
+
+  Tile cur = decode((int)blockIdx.x);
+  if (!cur.valid) return;
+  constexpr int RB = BRES ? 18 : 1;                                       // resident B: [step = tap * 2 + k-chunk][piece]
+  u32x4 bres[RB][NP];
+  if (BRES) {
+#pragma unroll
+    for (int st = 0; st < RB; ++st)
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc)
+        bres[st][pc] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.wpk) + (size_t)st * (NP * 1024u) + pc * 1024 + lane * 16);
+  }
+  fetch(cur);
+  for (int vb = (int)blockIdx.x;; vb += (int)gridDim.x) {
+    if ((int)threadIdx.x < p.MT * 32) {
+      const int q = min((int)threadIdx.x, npix - 1);
+      const int tr = q / p.TC, tc = q - tr * p.TC;
+      const bool ok = (int)threadIdx.x < npix && cur.r0 + tr < p.Ho && cur.c0 + tc < p.Wo;
+      otab[threadIdx.x] = (unsigned)((tr * p.Wo + tc) * p.COUTP) | (ok ? 0u : 0x80000000u);
+    }
+    split_store(cur);
+    __syncthreads();
+    const Tile nxt = decode(vb + (int)gridDim.x);
+    if (!BRES && nxt.valid) fetch(nxt);                                  // in flight during this tile's K loop and epilogue
+
+    // ---- compute (conv_x3_kernel's K loop, one staged chunk)
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    unsigned aoff[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = min(wave_m * MW + i, p.MT - 1);
+      aoff[i] = qtab[mt * 32 + (lane & 31)] + (unsigned)((lane >> 5) * 16);
+    }
+    const int kcc = CK >> 4;
+    const int nsteps = KS * KS * kcc;
+    const unsigned kstep = (unsigned)ntt * (NP * 1024u);
+    const char *wb_n = reinterpret_cast<const char *>(p.wpk);
+    unsigned toff_n = 0;
+    int kc_n = 0, kw_n = 0;
+    auto advance = [&]() {
+      ++kc_n;
+      toff_n += 32;
+      wb_n += kstep;
+      if (kc_n == kcc) {
+        kc_n = 0;
+        toff_n += (unsigned)(pitch - kcc * 32);
+        if (++kw_n == KS) {
+          kw_n = 0;
+          toff_n += (unsigned)((PC - KS) * pitch);
+        }
+      }
+    };
+    unsigned voff[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) voff[j] = (unsigned)min(wave_n * NW + j, ntt - 1) * (NP * 1024u) + (unsigned)lane * 16u;
+    auto loadA = [&](int i, u32x4 (*a)[MW]) {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) a[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + toff_n);
+    };
+    auto loadB = [&](u32x4 (*b)[NW]) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wb_n + (size_t)voff[j] + pc * 1024);
+    };
+    auto step = [&](u32x4 (*a)[MW], const u32x4 (*b)[NW]) {
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
+                                                               __builtin_bit_cast(f16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(i, a);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    u32x4 a[NP][MW], b0[NP][NW], b1[NP][NW];
+    if (BRES) {
+      // steps in conv_x3_kernel's order (tap-major, k-chunk inner); A offsets are compile-time: tap (kh, kw), chunk kc
+#pragma unroll
+      for (int i = 0; i < MW; ++i) loadA(i, a);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        const int nx = st + 1, ntap = nx >> 1, nkc = nx & 1;
+        toff_n = (unsigned)(((ntap / 3) * PC + (ntap % 3)) * pitch + nkc * 32);   // the NEXT step's A fragments (past the end: unused)
+        if (st == 17) toff_n = 0;
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+          constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
+                                                               __builtin_bit_cast(f16x8, bres[BRES ? st : 0][TB[t]]), acc[i][0], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          loadA(i, a);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      loadB(b0);
+#pragma unroll
+      for (int i = 0; i < MW; ++i) loadA(i, a);
+      advance();
+#pragma unroll 1
+      for (int s = 0; s < nsteps; s += 2) {
+        const bool more = s + 2 < nsteps;
+        loadB(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b0);
+        if (more) advance();
+        loadB(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b1);
+        if (more) advance();
+      }
+    }
+
+    // ---- epilogue (conv_x3_kernel's)
+    {
+      const float os = (p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale) * in_div;
+#pragma unroll
+      for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= os;
+    }
+    const int rr16 = lane >> 5;
+    const long ybase = (((long)cur.n * p.Ho + cur.r0) * p.Wo + cur.c0) * p.COUTP;
+    float t1[NW], t2[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = wave_m * MW + i;
+      if (mt >= p.MT) continue;
+      u32x4 ent[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
+      unsigned flags = 0;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) flags |= ent[g4][0] | ent[g4][1] | ent[g4][2] | ent[g4][3];
+      const bool whole = !__any((int)(flags >> 31));
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int nt = wave_n * NW + j;
+        if (nt >= ntt) continue;
+        const int co = nt * 32 + (lane & 31);
+        float s1 = 0.f, s2 = 0.f;
+        if (whole) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float x = acc[i][j][r];
+            (p.y + ybase + co)[ent[r >> 2][r & 3]] = x;
+            s1 += x;
+            s2 = __builtin_fmaf(x, x, s2);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned e = ent[r >> 2][r & 3];
+            const bool ok = (int)e >= 0;
+            const float x = ok ? acc[i][j][r] : 0.f;
+            if (ok) (p.y + ybase + co)[e] = x;
+            s1 += x;
+            s2 = __builtin_fmaf(x, x, s2);
+          }
+        }
+        t1[j] += s1 + __shfl_xor(s1, 32);
+        t2[j] += s2 + __shfl_xor(s2, 32);
+      }
+    }
+    if (p.stats != nullptr) {
+      const int rows = 4 / wn;
+      float *red = reinterpret_cast<float *>(lds);
+      if (rows > 1) {
+        __syncthreads();
+        if (lane < 32)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
+        __syncthreads();
+      }
+      if (wave_m == 0 && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const int nt = wave_n * NW + j;
+          if (nt >= ntt) continue;
+          float s1 = t1[j], s2 = t2[j];
+          for (int w = 1; w < rows; ++w) {
+            const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
+            s1 += o[0];
+            s2 += o[1];
+          }
+          float *dst = p.stats + (((long)cur.n * p.slots + cur.tri * p.tiles_c + cur.tci) * p.COUTP + nt * 32 + lane) * 2;
+          dst[0] = s1;
+          dst[1] = s2;
+        }
+      }
+    }
+    if (!nxt.valid) break;
+    if (BRES) fetch(nxt);
+    __syncthreads();                                                     // planes, tables and the reduction scratch are free again
+    cur = nxt;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 template <int KS, int STRIDE, int NP>
@@ -612,6 +985,28 @@ hipError_t launch_conv_x3(const ConvX3Args &a0, int ks, int stride, int mode, in
   const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
   const int ntt = a.COUTP / 32, per_wg = a.wn * nw;   // N-tiles one workgroup covers
   dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((ntt + per_wg - 1) / per_wg), 1u);
+  // persistent form (conv_x3p_kernel): float16 pieces, 3x3 stride 1, the whole K in one staged chunk, small wave tiles, no block
+  // tail in the stager, six patch pixels per thread at most, and enough tiles to walk
+  const int pwgs = a.persist_wgs;
+  // (measured at 256 pairs: with the weights resident the 32 -> 32 convs go 0.107 -> 0.085 ms; the prefetching form WITHOUT resident
+  //  weights — 64-channel stage — is 9 % slower than one tile per workgroup, and the pooled-key input mode, which also writes the
+  //  pooled activations, loses more from two workgroups per CU than it gains: both stay on conv_x3_kernel)
+  const bool bres = ntt == 1 && a.CIN == 32 && nw == 1 && (mode == 0 || mode == 1);   // the layer's weights stay in registers
+  if (a.np == 2 && ks == 3 && stride == 1 && bres && mw * nw <= 2 && a.CK == a.CIN && pwgs >= 8 &&
+      (long)a.PR * a.PC * (a.CK / 8) <= 6 * 256 && ntiles >= 2L * pwgs) {
+    dim3 pg((unsigned)(pwgs & ~7), grid.y, 1u);
+    if (bres) pg.x = (unsigned)(((pwgs / 3) * 2) & ~7);                 // two workgroups per CU (256 registers per lane)
+#define PNVO_X3P(MODE_, MW_, NW_)                                                                        \
+  if (mode == MODE_ && mw == MW_ && nw == NW_) {                                                         \
+    if (bres)                                                                                            \
+      hipLaunchKernelGGL((conv_x3p_kernel<MODE_, MW_, NW_, true>), pg, dim3(256), lds_bytes, s, a);     \
+    else                                                                                                 \
+      hipLaunchKernelGGL((conv_x3p_kernel<MODE_, MW_, NW_, false>), pg, dim3(256), lds_bytes, s, a);    \
+    return hipGetLastError();                                                                            \
+  }
+    PNVO_X3P(0, 1, 1) PNVO_X3P(1, 1, 1) PNVO_X3P(3, 1, 1) PNVO_X3P(0, 2, 1) PNVO_X3P(1, 2, 1) PNVO_X3P(3, 2, 1)
+#undef PNVO_X3P
+  }
   if (a.np == 2) {
     if (ks == 3 && stride == 1) return launch_ks<3, 1, 2>(a, mode, mw, nw, grid, lds_bytes, s);
     if (ks == 3 && stride == 2) return launch_ks<3, 2, 2>(a, mode, mw, nw, grid, lds_bytes, s);

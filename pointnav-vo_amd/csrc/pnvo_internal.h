@@ -147,6 +147,7 @@ struct ConvX3Args {
   int np;                            // operand pieces: 3 = bf16 (six exact product terms; 0 means 3), 2 = float16 (three terms)
   float oscale;                      // np == 2: inverse of the power-of-two scale folded into the packed weights
   const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
+  int persist_wgs;                   // > 0: eligible launches take conv_x3p_kernel with this many workgroups (3 per CU); 0: never
 };
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);

@@ -131,3 +131,26 @@ def test_training_knob_keeps_gradient_parity(env):
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
+
+def test_persistent_resident_weight_convs_are_bit_identical():
+    """conv_x3p_kernel (option x3_persist, default on: the 32 -> 32 convs of the first stage walk their tiles with the layer's whole
+    B operand resident in registers) uses conv_x3_kernel's MFMA and statistics order: the network output does not change by a bit,
+    at 16 and at 64 pairs of 341x192 (the launches it takes need >= 1024 tiles)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    for B in (16, 64):
+        obs = bench.make_inputs(B, dev, 1)
+        outs = []
+        for v in ("on", "off", "on"):
+            model.set_option("x3_persist", v)
+            with torch.no_grad():
+                outs.append(model(obs).clone())
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        fam = model.layer_kernel("visual_encoder.backbone.layer1.0.convs.3", B)[0]
+        assert fam in ("x2", "x3"), fam
