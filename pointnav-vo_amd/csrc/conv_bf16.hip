@@ -16,6 +16,7 @@
 // ahead.  Input channels beyond CK are processed in chunks with the accumulators kept in registers.
 // blockIdx.z selects one of up to two models (the geometric-invariance dual forward runs both in every launch).
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 #include "pnvo_internal.h"
@@ -38,7 +39,12 @@ __device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(fl
 __device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
-template <int KS, int STRIDE, int MODE, bool F32OUT, int MW, int NW>
+// BRES (round 4; 32 input channels: the first stage, the first conv of the second, its 1x1 downsample conv): the workgroup is
+// PERSISTENT — it walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... — and the B fragments of the wave's N-tile(s), 9 taps x 2
+// k-chunks = 18 fragments (72 registers), are loaded once and stay in registers.  What bounds these layers is the CU's vector-memory
+// pipe (~20 B/clk), and re-fetching the same 18 KB of weights for every tile, by each of the four waves, was most of its traffic
+// (conv_x3.hip conv_x3p_kernel: the float32-grade path's measurement).  Same MFMA order: bit-identical outputs.
+template <int KS, int STRIDE, int MODE, bool F32OUT, int MW, int NW, bool BRES = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
@@ -52,8 +58,22 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
 
   const int ntiles = p.B * p.tiles_r * p.tiles_c;
   const int chunk = (ntiles + 7) >> 3;
-  int bid = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);     // consecutive tiles of an XCD are neighbours
-  if (bid >= ntiles) return;
+  constexpr int RB = BRES ? KS * KS * 2 : 1;                             // resident B: [step = tap * 2 + k-chunk][N-tile of the wave]
+  u32x4 bres[RB][NW];
+  if (BRES) {
+    const int wn_ = p.wn, ntt_ = p.COUTP >> 5, kct_ = p.CIN >> 4;
+    const int wave_n_ = (wave & (wn_ - 1)) + (int)blockIdx.y * (8 / NW);
+#pragma unroll
+    for (int st = 0; st < RB; ++st)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int nt = min(wave_n_ * NW + j, ntt_ - 1);
+        bres[st][j] = wpk[(((st >> 1) * kct_ + (st & 1)) * ntt_ + nt) * 64 + lane];
+      }
+  }
+  for (int vb = (int)blockIdx.x;; vb += (int)gridDim.x) {                // (one pass unless BRES)
+  int bid = (vb & 7) * chunk + (vb >> 3);                               // consecutive tiles of an XCD are neighbours
+  if (vb >= 8 * chunk || bid >= ntiles) return;
   const int tci = bid % p.tiles_c;
   bid /= p.tiles_c;
   const int tri = bid % p.tiles_r;
@@ -235,6 +255,27 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
                                                               acc[i][j], 0, 0, 0);
     };
     u32x4 a0[MW], b0[NW], a1[MW], b1[NW];
+    if (BRES) {
+      // steps in the streaming loop's order (tap-major, two k-chunks inner); A of step st + 1 is fetched behind the MFMAs of step st
+      auto loadA = [&](int st, u32x4 *a) {
+        const int tap = st >> 1;
+        const unsigned toff = (unsigned)(((tap / KS) * PC + (tap % KS)) * pitch + (st & 1) * 32);
+#pragma unroll
+        for (int i = 0; i < MW; ++i) a[i] = *reinterpret_cast<const u32x4 *>(lds + aoff[i] + toff);
+      };
+      loadA(0, a0);
+#pragma unroll
+      for (int st = 0; st < RB; st += 2) {
+        loadA(st + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a0, bres[BRES ? st : 0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < RB) loadA(st + 2, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a1, bres[BRES ? st + 1 : 0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     loadAB(a0, b0);
     advance();                                                           // -> step 1
 #pragma unroll 1
@@ -250,6 +291,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
       mfmas(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
       if (more) advance();
+    }
     }
   }
 
@@ -318,6 +360,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         dst[1] = s2;
       }
     }
+  }
+  if (!BRES) return;
+  __syncthreads();                                                       // patch, tables and reduction scratch are free again
   }
 }
 
@@ -415,6 +460,29 @@ hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bo
                             int nmodels, hipStream_t s) {
   const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
   dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((a.COUTP + 255) / 256)   /* groups of 8 N-tiles */, (unsigned)nmodels);
+  // persistent workgroups with the weights resident in registers (BRES): 32 input channels in one staged chunk, one N-tile per wave
+  if (a.persist_wgs >= 8 && a.CIN == 32 && a.CK == 32 && nw == 1 && !f32out && ntiles >= 2L * a.persist_wgs) {
+    const int cus = a.persist_wgs / 3;
+    // as many workgroups as are RESIDENT at once (registers / LDS of the variant decide: 2-4 per CU): a persistent grid larger than
+    // that would run its surplus workgroups as a second, unbalanced round
+#define PNVO_CBP(KS_, ST_, MODE_, MW_)                                                                                  \
+  if (ks == KS_ && stride == ST_ && mode == MODE_ && mw == MW_) {                                                       \
+    auto kfn = conv_bf16_kernel<KS_, ST_, MODE_, false, MW_, 1, true>;                                                  \
+    int occ = 0;                                                                                                        \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds_bytes) != hipSuccess || occ < 1) occ = 1;      \
+    const int per_cu = std::max(1, occ / (int)(grid.y * grid.z));                                                       \
+    dim3 pg((unsigned)((per_cu * cus) & ~7), grid.y, grid.z);                                                           \
+    if (pg.x >= 8 && ntiles >= 2L * pg.x) {                                                                             \
+      hipLaunchKernelGGL(kfn, pg, dim3(256), lds_bytes, s, a);                                                          \
+      return hipGetLastError();                                                                                         \
+    }                                                                                                                   \
+  }
+    // (measured at 256 pairs x 2 models: the block-tail convs 0.240 -> 0.199 and 0.167 -> 0.146 ms, the 1x1 downsample conv 0.047 ->
+    //  0.039; the plain and GroupNorm-input convs LOSE — 0.11 -> 0.13 ms: their 60-register streaming form keeps five workgroups
+    //  per CU in flight, the 72 resident registers leave three — and stay on the streaming form)
+    PNVO_CBP(3, 1, 2, 2) PNVO_CBP(3, 1, 2, 4) PNVO_CBP(3, 2, 2, 2) PNVO_CBP(1, 2, 0, 2) PNVO_CBP(3, 2, 2, 1) PNVO_CBP(1, 2, 0, 1)
+#undef PNVO_CBP
+  }
   if (ks == 3 && stride == 1) return launch_ks<3, 1>(a, mode, f32out, mw, nw, grid, lds_bytes, s);
   if (ks == 3 && stride == 2) return launch_ks<3, 2>(a, mode, f32out, mw, nw, grid, lds_bytes, s);
   if (ks == 1 && stride == 2) return launch_ks<1, 2>(a, mode, f32out, mw, nw, grid, lds_bytes, s);

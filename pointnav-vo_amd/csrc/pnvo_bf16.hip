@@ -263,6 +263,7 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     const Layer &l = m->convs[li];
     ConvBArgs a = bs[0]->layers[li].plan;
     a.B = B;
+    a.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
     for (int z = 0; z < 2; ++z) {
       const int k = z < nm ? z : 0;
       a.x[z] = xin(k);

@@ -173,6 +173,7 @@ struct ConvBArgs {
   float *stats[2];                   // [B,slots,COUTP,2] GroupNorm partial sums
   int B, H, W, CIN, Ho, Wo, COUTP;
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_bf16_plan
+  int persist_wgs;                   // > 0: 32-input-channel layers run persistent with resident weights on this many workgroups
 };
 bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bool f32out, int mw, int nw, size_t lds_bytes,
