@@ -328,23 +328,27 @@ def test_float16_range_guard_follows_the_parameters_during_training():
     """The two-piece float16 operands need every conv input below 65504; the guard is an upper bound from the producers' GroupNorm
     parameters.  It used to be computed once, at load, from the host copy — and the training step changes gamma / beta on the device.
     Now pnvo_train_refresh re-computes the bounds on the device: a GroupNorm weight that grows past the float16 range (here: set from
-    outside, which also exercises the re-pack after an external edit) sends that layer to three bf16 pieces instead of to inf / NaN."""
+    outside, which also exercises the re-pack after an external edit) sends that layer to three bf16 pieces instead of to inf / NaN.
+    Two identical steps walk the same history, one on the default float16 pieces, one on three bf16 pieces everywhere (every
+    train-mode forward moves the running statistics, so only forwards with the same history compare)."""
     rec = load_golden("train_default_96x64_b3_f32.npz")
-    model, cfg, sd, obs, tobs = build(rec)
-    model.set_option("conv", "x3")                                   # the split kernels at this size
-    ts = VOTrainStep(model, lr=1e-6)
-    target = torch.from_numpy(rec["target"]).to("cuda:0")
-    out0, loss0 = ts.forward_backward(tobs, target=target)
-    assert torch.isfinite(out0).all()
-    gamma = dict(model.named_parameters())["visual_encoder.backbone.layer1.0.convs.1.weight"]   # GroupNorm behind the first 3x3 conv
-    with torch.no_grad():
-        gamma.data.fill_(5.0e3)                                      # bound = 5e3 * sqrt(2 * 16 * 24) + |beta| >> 65504
-    out1, loss1 = ts.forward_backward(tobs, target=target)
-    torch.cuda.synchronize()
-    assert torch.isfinite(out1).all() and torch.isfinite(loss1), (out1, loss1)
-    assert torch.isfinite(ts.grad).all()
-    # the same forward with three bf16 pieces everywhere: float32-grade agreement
-    model.set_option("train_pieces", "3")
-    out2, loss2 = ts.forward_backward(tobs, target=target)
-    torch.cuda.synchronize()
-    assert torch.allclose(out1, out2, rtol=2e-4, atol=2e-4), (out1, out2)
+    outs = {}
+    for pieces in ("2", "3"):
+        model, cfg, sd, obs, tobs = build(rec)
+        model.set_option("conv", "x3")                               # the split kernels at this size
+        model.set_option("train_pieces", pieces)
+        ts = VOTrainStep(model, lr=1e-6)
+        target = torch.from_numpy(rec["target"]).to("cuda:0")
+        out0, _ = ts.forward_backward(tobs, target=target)
+        assert torch.isfinite(out0).all()
+        gamma = dict(model.named_parameters())["visual_encoder.backbone.layer1.0.convs.1.weight"]   # GroupNorm behind the first 3x3 conv
+        with torch.no_grad():
+            gamma.data.fill_(5.0e3)                                  # bound = 5e3 * sqrt(2 * 16 * 24) + |beta| >> 65504
+        out1, loss1 = ts.forward_backward(tobs, target=target)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out1).all() and torch.isfinite(loss1), (pieces, out1, loss1)
+        assert torch.isfinite(ts.grad).all()
+        outs[pieces] = (out0.clone(), out1.clone())
+        del ts, model
+    assert torch.allclose(outs["2"][0], outs["3"][0], rtol=2e-4, atol=2e-4)
+    assert torch.allclose(outs["2"][1], outs["3"][1], rtol=2e-4, atol=2e-4), (outs["2"][1], outs["3"][1])
