@@ -90,12 +90,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
   // pixel inside the sample's output plane, bit 31 set when the pixel does not exist
   unsigned *qtab = reinterpret_cast<unsigned *>(lds + NP * plane);
   unsigned *otab = qtab + p.MT * 32;
-  if ((int)threadIdx.x < p.MT * 32) {
-    const int q = min((int)threadIdx.x, npix - 1);
+  for (int e = (int)threadIdx.x; e < p.MT * 32; e += 256) {               // (strip tiles: nine M-tiles = 288 entries)
+    const int q = min(e, npix - 1);
     const int tr = q / p.TC, tc = q - tr * p.TC;
-    qtab[threadIdx.x] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch);
-    const bool ok = (int)threadIdx.x < npix && r0 + tr < p.Ho && c0 + tc < p.Wo;
-    otab[threadIdx.x] = (unsigned)((tr * p.Wo + tc) * p.COUTP) | (ok ? 0u : 0x80000000u);
+    qtab[e] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch);
+    const bool ok = e < npix && r0 + tr < p.Ho && c0 + tc < p.Wo;
+    otab[e] = (unsigned)((tr * p.Wo + tc) * p.COUTP) | (ok ? 0u : 0x80000000u);
   }
 
   const int wn = p.wn;                                                   // wave grid: (4 / wn) x wn
@@ -860,6 +860,9 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
   }
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
   PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2) PNVO_X3(3, 1, 1) PNVO_X3(3, 2, 1) PNVO_X3(3, 2, 2) PNVO_X3(3, 3, 2)
+  if (KS == 3 && STRIDE == 1 && NP == 2) {                                                      // wide strips (conv_x3_plan)
+    PNVO_X3(0, 5, 1) PNVO_X3(1, 5, 1) PNVO_X3(2, 5, 1)
+  }
 #undef PNVO_X3
   return hipErrorInvalidValue;
 }
@@ -892,6 +895,18 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
     while (TR > 1 && (TR + 2) * (TC + 2) > 324) --TR;
     if (TR > a.Ho) TR = a.Ho;
     if (TR * TC <= 96) return false;                               // (small maps: not worth it)
+  } else if (a.strip && a.np == 2 && stride == 1 && ks == 3 && ntt == 4 && a.Wo >= 16 && a.Ho >= 8) {
+    // Round 4: what bounds these layers is the CU's vector-memory pipe, and most of its traffic is weight fragments — every workgroup
+    // streams the layer's whole B operand for ITS pixels.  Wide strips (up to 288 pixels = nine M-tiles: the 12 x 22 map whole, the
+    // 24 x 43 map in four) with the N-tiles split over blockIdx.y (two per workgroup, one per wave column, five M-tiles per wave)
+    // halve the weight bytes per pixel of the 8 x 22 tiles.  Measured at 256 pairs: the 128-channel stage 0.074 -> 0.067 ms per conv;
+    // the 64-channel stage (24 x 43 in four strips) 3 % SLOWER than its 8 x 16 tiles and left alone.
+    const int ncol = (a.Wo + 21) / 22;
+    TC = (a.Wo + ncol - 1) / ncol;
+    TR = 288 / TC;
+    if (TR > a.Ho) TR = a.Ho;
+    const int nrow = (a.Ho + TR - 1) / TR;
+    TR = (a.Ho + nrow - 1) / nrow;
   } else if (a.Wo >= 32) {
     TR = 8;
     TC = 16;
@@ -911,7 +926,14 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   a.PR = (TR - 1) * cs + ks;
   a.PC = (TC - 1) * cs + ks;
   // wave grid (4 / wn) x wn and accumulators per wave (accumulators + one A set + two B sets within 256 registers)
-  if (ntt == 1) {
+  const bool strip = a.strip && a.np == 2 && stride == 1 && ks == 3 && ntt == 4 && a.Wo >= 16 && a.Ho >= 8 && a.MT > 6;
+  if (strip) {
+    a.wn = 2;
+    *mw = (a.MT + 1) / 2;                                          // two wave rows
+    *nw = 1;
+    if (*mw > 5) return false;
+    if (*mw < 5) *mw = 5;                                          // (one instantiation)
+  } else if (ntt == 1) {
     a.wn = 1;
     *mw = 2;
     *nw = 1;

@@ -483,6 +483,7 @@ bool x3_two_pieces(pnvo_handle m, const Layer &l) {
 bool x3_args(pnvo_handle m, const Layer &l, int B, ConvX3Args &xa, int *mw, int *nw, size_t *ldsb) {
   std::memset(&xa, 0, sizeof(xa));
   xa.force = m->opt.conv == 1;
+    xa.strip = m->opt.x3_strip;
   xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
   xa.np = x3_two_pieces(m, l) ? 2 : 3;
   xa.B = B;
@@ -565,6 +566,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.force = m->opt.conv == 1;
+    xa.strip = m->opt.x3_strip;
     xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
     xa.B = B;
     xa.H = l.hin;
@@ -933,6 +935,7 @@ const OptDef kOptions[] = {
     {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"persistent", 1}, {"tiles", 2}, {nullptr, 0}}},
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_persist", "PNVO_X3_PERSIST", &PnvoOptions::x3_persist, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
     {"pool", "PNVO_POOL", &PnvoOptions::pool, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},

@@ -148,6 +148,7 @@ struct ConvX3Args {
   float oscale;                      // np == 2: inverse of the power-of-two scale folded into the packed weights
   const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
   int persist_wgs;                   // > 0: eligible launches take conv_x3p_kernel with this many workgroups (3 per CU); 0: never
+  int strip;                         // conv_x3_plan: wide strip tiles with the N-tiles split over blockIdx.y for 64 / 128 output channels
 };
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);

@@ -572,6 +572,7 @@ int run_dgrad(pnvo_handle m, TrainState *t, size_t li, int B, const float *draw,
     ConvX3Args xa;
     std::memset(&xa, 0, sizeof(xa));
     xa.force = m->opt.conv == 1;
+    xa.strip = m->opt.x3_strip;
     xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;   // (32 -> 32 backward-data convs: resident weights, conv_x3p_kernel)
     xa.B = B;
     xa.H = l.hout;
