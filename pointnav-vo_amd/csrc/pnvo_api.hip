@@ -800,9 +800,13 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       // rounds, the tile-per-workgroup kernel otherwise; bit-identical results (option stem_form: auto | persistent | tiles)
       // (auto = tiles: with the K loop's fetches spread between the MFMAs both forms sit at the same ~1.0 ms at 256 pairs — what bounds
       //  them is the CU's vector-memory pipe, 245 KB of weight fragments + 93 KB of patch per 128-pixel tile)
+      const bool rs = m->opt.stem_form == 3 && stem_rs_takes(a, pieces, ntn, false, m->num_cus);
       const bool ps = m->opt.stem_form == 1 && stem_ps_takes(a, pieces, ntn, false, m->num_cus);
-      m->mx_prof_ps = ps;
-      if (ps)
+      m->mx_prof_ps = ps || rs;
+      m->mx_prof_rs = rs;
+      if (rs)
+        HIPCHK(m, launch_stem_rs(a, m->num_cus, s));
+      else if (ps)
         HIPCHK(m, launch_stem_ps(a, m->num_cus, m->opt.stem_lwaves == 4 ? 4 : 8, s));
       else
         HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
@@ -932,7 +936,7 @@ const OptDef kOptions[] = {
     {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
     {"pieces", "PNVO_PIECES", &PnvoOptions::pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"stem_lwaves", "PNVO_STEM_LWAVES", &PnvoOptions::stem_lwaves, true, {{nullptr, 0}}},
-    {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"persistent", 1}, {"tiles", 2}, {nullptr, 0}}},
+    {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"persistent", 1}, {"tiles", 2}, {"resident", 3}, {nullptr, 0}}},
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_persist", "PNVO_X3_PERSIST", &PnvoOptions::x3_persist, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
@@ -2019,7 +2023,10 @@ int pnvo_destroy(pnvo_handle m) {
       const unsigned long long *q = pr + 16 * w;
       if (q[5] == 0) continue;
       const double nt_ = (double)q[5];
-      if (w < 4)
+      if (m->mx_prof_rs)
+        std::fprintf(stderr, "[pnvo] stem_rs wave %d (cycles per tile): k-loop with the next patch's staging %.0f  wait others %.0f  "
+                     "exchange + epilogue %.0f  (%llu tiles)\n", w, q[0] / nt_, q[1] / nt_, q[2] / nt_, q[5]);
+      else if (w < 4)
         std::fprintf(stderr, "[pnvo] stem_ps M wave %d (cycles per tile): wait patch %.0f  k-loop %.0f  wait others %.0f  exchange writes %.0f  "
                      "(%llu tiles)\n", w, q[0] / nt_, q[1] / nt_, q[2] / nt_, q[3] / nt_, q[5]);
       else

@@ -108,7 +108,7 @@ struct pnvo_model_s {
   std::vector<int> mx_slot_ref, mx_slot_new; // K-slot -> reference channel / position in the stem's tensor-major order (-1: none)
   float *mx_pages = nullptr;                 // device: 64 zeros (out-of-image reads)
   unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx / stem_ps
-  bool mx_prof_ps = false;                   //   ... the last stem launch was the persistent form
+  bool mx_prof_ps = false, mx_prof_rs = false;                   //   ... the last stem launch was the persistent form
   int num_cus = 256;                         // compute units of the device (grid of the persistent kernels)
   bool in_train_forward = false;
   bool train_mx = false;                     // the attached training step rebuilds the mx stem operands every step

@@ -1,0 +1,579 @@
+// stem_rs.hip — the float32-grade 7x7 stride-2 stem with its WEIGHTS RESIDENT IN REGISTERS (gfx950 only).
+//
+// Same operation, operand layout, tap split and summation order as stem_mx_kernel<2, 1, false, POOL, RAW> (stem_mx.hip: conv1 of
+// resnet.py:156-163 with the input assembly and whitening of vo_cnn.py:110-176 in front and, POOL, the max-pool of resnet.py:168
+// behind) — the results are bit-identical.  What changes is where the B operand lives.
+//
+// Round 4 measured that the tile-per-workgroup stem and its role-specialised persistent form are bound by the CU's vector-memory
+// pipe (~20 B/clk): every 128-pixel tile re-fetches all 245 KB of weight fragments next to 93 KB of patch, ~16 k cycles per tile
+// against 7.8 k cycles of MFMA issue.  245 KB is half of a CU's 512 KB register file.  Here ONE workgroup of FOUR waves owns a CU
+// for the whole launch, one wave per SIMD with the full 512-register budget, and each wave keeps the 60 fragments of its twelve
+// taps (240 registers) for all of its ~130 tiles; wave 3 streams the five fragments of tap 48 per tile.  What is left on the
+// vector-memory pipe is the patch.
+//
+// With one wave per SIMD nothing overlaps by itself, so the K loop is fully unrolled (it has to be: the resident fragments are
+// indexed statically) and the staging of the NEXT tile is cut into pieces placed in the tap regions of the CURRENT tile: loads of
+// piece j in tap j, its float16 conversion and LDS writes four taps (~2.5 k cycles) later, spread between the MFMAs by
+// sched_group_barrier.  No branches inside a tap region (a branch ends the scheduling region): absent lanes write to a trash slot.
+// After the K loop: K-split exchange through the patch buffer just consumed, GroupNorm partials, pooled keys — three workgroup
+// barriers per tile.
+//
+// LDS: two 64 KB buffers (patch of tile i / exchange of tile i | patch of tile i+1) + pooling scratch: 146 KB.
+#include <type_traits>
+
+#include "stem_tile.h"
+
+namespace pnvo {
+
+namespace {
+constexpr int RS_BUF = XCHG_BYTES;                          // 65536 >= PATCH_BYTES
+constexpr int RS_PB_OFF = 2 * RS_BUF;                       // pooling scratch [8][16][33] floats
+constexpr int RS_RED_OFF = RS_PB_OFF + 8 * 16 * 33 * 4;     // [4 waves][32][2] floats
+constexpr int RS_ETAB_OFF = RS_RED_OFF + 4 * 32 * 2 * 4;    // RAW: bin edges (12 floats)
+constexpr int RS_TRASH_OFF = RS_ETAB_OFF + 64;              // target of the writes of absent lanes
+constexpr int RS_LDS = RS_TRASH_OFF + 64;
+static_assert(RS_BUF >= PATCH_BYTES, "patch must fit its buffer");
+static_assert(RS_LDS <= 160 * 1024, "LDS budget");
+#define PNVO_INL __attribute__((always_inline))
+#ifndef PNVO_RS_NRES
+#define PNVO_RS_NRES 12
+#endif
+#ifndef PNVO_RS_LAGD
+#define PNVO_RS_LAGD 3
+#endif
+#ifndef PNVO_RS_LAGP
+#define PNVO_RS_LAGP 3
+#endif
+#ifndef PNVO_RS_NPIN
+#define PNVO_RS_NPIN 10
+#endif
+#ifndef PNVO_RS_ABL
+#define PNVO_RS_ABL 0   // developer: compile-time ablations for register-pressure studies (1 no granules, 2 no pixel rounds in the K loop)
+#endif
+}  // namespace
+
+template <bool POOL, bool RAW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void stem_rs_kernel(const StemMXArgs p) {
+  constexpr int NFT = 5;
+  constexpr int LAGP = PNVO_RS_LAGP, LAGD = PNVO_RS_LAGD;                         // taps between the loads of a staging piece (pixels / granules) and its LDS writes
+  constexpr int GROW = PW * 5;                              // 16-byte granules of one-hot depth per patch row (185)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *red = reinterpret_cast<float *>(lds + RS_RED_OFF);
+  float *pb = reinterpret_cast<float *>(lds + RS_PB_OFF);
+  float *etab = reinterpret_cast<float *>(lds + RS_ETAB_OFF);
+
+  // tiles of this workgroup: the workgroups of one XCD (id % 8) walk neighbouring tiles at the same time, so halos meet in that L2
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  const int chunk = (ntiles + 7) >> 3;
+  const int per = (int)gridDim.x >> 3;                      // workgroups per XCD
+  const int t_first = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  const int t_end = min(((int)(blockIdx.x & 7) + 1) * chunk, ntiles);
+  if (t_first >= t_end) return;
+  const int nit = (t_end - t_first + per - 1) / per;
+  const bool prof = p.prof != nullptr;
+  unsigned long long pc[4] = {0, 0, 0, 0};
+  auto now = [&]() PNVO_INL -> unsigned long long { return prof ? __builtin_readcyclecounter() : 0ull; };
+  if (RAW && tid < 12) etab[tid] = p.edges[tid];
+
+  // ---------------------------------------------------------------- staging: tile-independent lane geometry
+  // pixel rounds: patch pixel r * 256 + tid (three full rounds; the nine pixels of round 3 belong to wave 0)
+  unsigned pmeta[4];                                        // LDS offset | px << 16 | py << 22
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pix = min(r * 256 + tid, NPIX - 1);
+    const int py = pix / PW, px = pix - py * PW;
+    pmeta[r] = (unsigned)(py * ROW + (px & 1) * PAR + (px >> 1) * PITCH) | ((unsigned)px << 16) | ((unsigned)py << 22);
+  }
+  const bool haslast = tid < NPIX - 3 * 256;
+  // One-hot depth of the observation tensors: fetched by 16-BYTE GRANULE of a patch row (37 pixels x 80 B contiguous = 185
+  // granules; a wave-instruction covers 1 KiB of consecutive bytes, see stem_ps_kernel).  Wave w takes patch rows w, w + 4, ...,
+  // three 64-lane sub-rounds per row: the lane geometry is three registers (sub-round s: granule g = 64 s + lane -> pixel g / 5,
+  // chunk g % 5), the row is a compile-time constant.  Round q = 3 j + s is row w + 4 j (j = 5: row 20, wave 0 only).
+  unsigned gm[RAW ? 1 : 3];                                 // LDS offset inside the row | px << 16 | (granule exists) << 31
+  if (!RAW) {
+#pragma unroll
+    for (int sr = 0; sr < 3; ++sr) {
+      const int g = sr * 64 + lane;
+      const bool ex = g < GROW;
+      const int gg = ex ? g : 0;
+      const int px = gg / 5, c = gg - px * 5;
+      gm[sr] = (unsigned)((px & 1) * PAR + (px >> 1) * PITCH + c * 8) | ((unsigned)px << 16) | (ex ? 0x80000000u : 0u);
+    }
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const float *zp = p.zero_page;
+  const long fpix = (long)p.H * p.W;
+
+  // registers of the patch pieces in flight (nothing is computed on a loaded value before its store_* — a wave that touches it
+  // waits for the load, and there is no second wave on the SIMD to fill the gap)
+  f32x4 vr4[4], gdd[18];
+  f32x2 vr2[4], vd[4], vt[4];
+  unsigned rgbw[4][2];
+  float dv[4][2];
+  unsigned pflag[4];                                        // bit 0: inside the image, bit 1: not the first pixel of the sample
+  unsigned lowbits = 0, bad_depth = 0;
+  // Every staging load is a BUFFER load of the staged sample's tensors: out-of-image and absent lanes get an offset beyond the
+  // descriptor's range and read 0 (the zero padding after whitening), absent modalities a descriptor of zero records — no address
+  // selects on 64-bit pointers, which the compiler turns into branches (a branch ends the tap's scheduling region).
+  constexpr unsigned OOB = 0x80000000u;
+  int shi = 0, swi = 0;                                     // patch origin of the tile being staged (wave-uniform)
+  __amdgpu_buffer_rsrc_t r_rgb, r_d, r_dd, r_t;
+  auto rsrc = [&](const void *base, long off, long bytes) PNVO_INL {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base ? reinterpret_cast<const char *>(base) + off : reinterpret_cast<const char *>(zp)),
+                                             0, base ? (unsigned)bytes : 0u, 0x00020000);
+  };
+  auto set_stage_tile = [&](int t) PNVO_INL {
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const long sn = t / p.tiles_y;
+    shi = 2 * ty * TH - 3;
+    swi = 2 * tx * TW - 3;
+    if (RAW) {
+      r_rgb = rsrc(p.raw_rgb, sn * fpix * 6, fpix * 6);     // both frames of the sample: [2][H][W][3] uint8
+      r_d = rsrc(p.raw_depth, sn * fpix * 8, fpix * 8);     //                            [2][H][W] float32
+      r_dd = rsrc(nullptr, 0, 0);
+    } else {
+      r_rgb = rsrc(p.src[0], sn * fpix * 24, fpix * 24);
+      r_d = rsrc(p.src[1], sn * fpix * 8, fpix * 8);
+      r_dd = rsrc(p.src[2], sn * fpix * 80, fpix * 80);
+    }
+    r_t = rsrc(p.src[3], sn * fpix * 8, fpix * 8);
+  };
+  // (the packed lane geometry is read through an empty asm: the decode stays where it is used — hoisted out of the tile loop, as the
+  //  optimiser would, it costs three more live registers per staging piece)
+  auto opaque = [&](unsigned v) PNVO_INL {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  auto load_px = [&](int r, bool exists) PNVO_INL {
+    const unsigned pm = opaque(pmeta[r]);
+    const int hi = shi + (int)(pm >> 22), wi = swi + (int)((pm >> 16) & 0x3fu);
+    // (bitwise: a short-circuit && becomes an exec-mask region, which ends the scheduling region like a branch)
+    const bool in = (int)exists & (int)((unsigned)hi < (unsigned)p.H) & (int)((unsigned)wi < (unsigned)p.W);
+    const unsigned e = (unsigned)(hi * p.W + wi);
+    pflag[r] = (in ? 1u : 0u) | (e > 0u ? 2u : 0u);
+    if (RAW) {
+      // three bytes at 3 li as ONE unaligned dword that starts a byte early except at the sample's first pixel (never outside)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const unsigned li = (unsigned)f * (unsigned)fpix + e;
+        const unsigned boff = 3u * li - ((f > 0 || e > 0u) ? 1u : 0u);
+        rgbw[r][f] = __builtin_amdgcn_raw_buffer_load_b32(r_rgb, in ? boff : OOB, 0, 0);
+        dv[r][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_d, in ? li * 4u : OOB, 0, 0));
+      }
+      vt[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_t, in ? e * 8u : OOB, 0, 0));
+    } else {
+      const unsigned o24 = in ? e * 24u : OOB, o8 = in ? e * 8u : OOB;
+      const f32x2 q0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rgb, o24, 0, 0));
+      const f32x2 q1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rgb, o24 + 8u, 0, 0));
+      vr4[r] = f32x4{q0[0], q0[1], q1[0], q1[1]};
+      vr2[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rgb, o24 + 16u, 0, 0));
+      vd[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_d, o8, 0, 0));
+      vt[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_t, o8, 0, 0));
+    }
+  };
+  auto store_px = [&](int r, unsigned buf, bool exists) PNVO_INL {
+    unsigned w[16];
+    float d0, d1;
+    int bidx[2] = {0, 0};
+    unsigned bok[2] = {0u, 0u};
+    const bool in = (pflag[r] & 1u) != 0u;
+    if (RAW) {
+      const bool use_d = (p.raw_flags & 1) != 0;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float d = dv[r][f];
+        int g = (int)(d * 10.0f);
+        g = min(max(g, 0), 9);
+        const float lo = etab[g], hi = etab[g + 1];
+        bidx[f] = g - (d < lo ? 1 : 0) + (((d >= hi) & (g < 9)) ? 1 : 0);
+        bok[f] = ((d >= 0.f) & (d <= 1.f)) ? 1u : 0u;
+        bad_depth |= (pflag[r] & 1u) & (bok[f] ^ 1u);
+      }
+#pragma unroll
+      for (int cc = 0; cc < 10; ++cc) w[cc] = 0u;
+      const unsigned x0 = (pflag[r] & 2u) ? rgbw[r][0] >> 8 : rgbw[r][0], x1 = rgbw[r][1] >> 8;
+      const float pr = (float)(x0 & 0xffu), pg = (float)((x0 >> 8) & 0xffu), pbl = (float)((x0 >> 16) & 0xffu);
+      const float cr = (float)(x1 & 0xffu), cg = (float)((x1 >> 8) & 0xffu), cb = (float)((x1 >> 16) & 0xffu);
+      w[10] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
+      w[11] = pack_f16(pbl * 0.00390625f, cr * 0.00390625f);
+      w[12] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
+      d0 = use_d ? dv[r][0] : 0.f;
+      d1 = use_d ? dv[r][1] : 0.f;
+    } else {
+      w[10] = pack_f16(vr4[r][0] * 0.00390625f, vr4[r][1] * 0.00390625f);
+      w[11] = pack_f16(vr4[r][2] * 0.00390625f, vr4[r][3] * 0.00390625f);
+      w[12] = pack_f16(vr2[r][0] * 0.00390625f, vr2[r][1] * 0.00390625f);
+      {
+        const float f0 = vr4[r][0], f1 = vr4[r][1], f2 = vr4[r][2], f3 = vr4[r][3], f4 = vr2[r][0], f5 = vr2[r][1];
+        lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
+        lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
+        lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
+      }
+      d0 = vd[r][0];
+      d1 = vd[r][1];
+    }
+    w[13] = pack_f16(d0, d1);
+    w[14] = pack_f16(vt[r][0], vt[r][1]);
+    w[15] = in ? 0x3c003c00u : 0u;
+    const unsigned base = buf + (opaque(pmeta[r]) & 0xffffu);
+    constexpr unsigned TR = (unsigned)RS_TRASH_OFF;
+    if (RAW) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<u32x4 *>(lds + (exists ? base + 16u * q : TR)) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+      const bool dd = (p.raw_flags & 2) != 0 && in && exists;
+      *reinterpret_cast<unsigned short *>(lds + ((dd && bok[0]) ? base + 2u * (unsigned)bidx[0] : TR)) = (unsigned short)0x3c00;
+      *reinterpret_cast<unsigned short *>(lds + ((dd && bok[1]) ? base + 20u + 2u * (unsigned)bidx[1] : TR)) = (unsigned short)0x3c00;
+    } else {                                                 // K-slots 20..31 (rgb, depth, top-down view, indicator): bytes 40..63
+      *reinterpret_cast<u32x2 *>(lds + (exists ? base + 40u : TR)) = u32x2{w[10], w[11]};
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 48u : TR)) = u32x4{w[12], w[13], w[14], w[15]};
+    }
+    const f16x2 hd = __builtin_bit_cast(f16x2, w[13]), ht = __builtin_bit_cast(f16x2, w[14]);
+    const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
+    const unsigned mt = pack_f16(vt[r][0] - (float)ht[0], vt[r][1] - (float)ht[1]);
+    *reinterpret_cast<u32x4 *>(lds + (exists ? base + 64u : TR)) = u32x4{md, mt, 0u, 0u};
+  };
+  // Granules of the one-hot depth, patch row `row` (compile-time), sub-round sr.  Per tile and sub-round: the vector offset of the
+  // lane's granule in patch row 0 (or OOB for a column outside the image / a lane past the row's 185 granules) and its LDS address
+  // in row 0 (absent lanes: the 32 bytes of padding behind a patch row); a row adds a scalar to the first and an immediate to the
+  // second.  Rows outside the image are out of the descriptor's range by themselves (or land in a neighbouring row's columns that
+  // are forced out of range); OOB + a row offset stays out of range.
+  unsigned ddv[3], ddl[3];
+  auto set_dd_tile = [&](unsigned buf) PNVO_INL {
+    if (RAW) return;
+#pragma unroll
+    for (int sr = 0; sr < 3; ++sr) {
+      const unsigned g = opaque(gm[sr]);
+      const int wi = swi + (int)((g >> 16) & 0x3fu);
+      const bool ok = (int)((int)g < 0) & (int)((unsigned)wi < (unsigned)p.W);
+      // (everything in the vector offset: the range check does not see a scalar offset)
+      ddv[sr] = ok ? (unsigned)((shi * p.W + swi) * 80 + sr * 1024) + lane16 : OOB;
+      ddl[sr] = buf + ((int)g < 0 ? (g & 0xffffu) : (unsigned)(2 * PAR));
+    }
+  };
+  auto load_dd = [&](int slot, int row, int sr) PNVO_INL {
+    gdd[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dd, ddv[sr] + (unsigned)(row * p.W * 80), 0, 0));
+  };
+  auto store_dd = [&](int slot, int row, int sr) PNVO_INL {
+    const f32x4 v = gdd[slot];
+    lowbits |= __builtin_bit_cast(unsigned, v[0]) | __builtin_bit_cast(unsigned, v[1]);
+    lowbits |= __builtin_bit_cast(unsigned, v[2]) | __builtin_bit_cast(unsigned, v[3]);
+    *reinterpret_cast<u32x2 *>(lds + ddl[sr] + row * ROW) = u32x2{pack_f16(v[0], v[1]), pack_f16(v[2], v[3])};
+  };
+
+  // lane geometry of the A fragments and of the epilogue
+  const int arr = (lane & 31) >> 4, ac = lane & 15, ah = lane >> 5;
+  const unsigned baseA0 = (unsigned)(2 * arr * ROW + ac * PITCH + ah * 16);
+  const unsigned baseX0 = (unsigned)(2 * arr * ROW + ac * PITCH + 64);
+  const int rr16 = lane >> 5;
+  const float oscale = p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
+  const int co = p.y_coff[0] + (lane & 31);
+  const float sgn = POOL ? (p.pool_gamma[co] < 0.f ? -1.f : 1.f) : 1.f;
+
+  // Everything below is compiled once per wave of the workgroup (WV = 0..3): the wave's taps, patch rows and M-tile are then
+  // compile-time constants — every LDS address of the K loop is one register plus an immediate, no scalar arithmetic per tap.
+  auto body = [&](auto wv_c) PNVO_INL {
+    constexpr int WV = decltype(wv_c)::value;
+    constexpr int NROWS = WV == 0 ? 6 : 5;                  // patch rows WV, WV + 4, ... of the granule fetch
+    constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
+    constexpr int NT = WV == 3 ? 13 : 12;                   // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3)
+    auto tap_of = [](int i) constexpr { return i < 12 ? WV + 4 * i : 48; };
+    auto tap_off = [](int t) constexpr { return (t / 7) * ROW + ((t % 7) & 1) * PAR + ((t % 7) >> 1) * PITCH; };
+
+    // ---- prologue: the first patch, all at once
+    __syncthreads();                                        // (the edge table)
+    set_stage_tile(t_first);
+    set_dd_tile(0u);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) load_px(r, true);
+    if (WV == 0) load_px(3, haslast);
+#pragma unroll
+    for (int q = 0; q < RD; ++q) load_dd(q, WV + 4 * (q / 3), q % 3);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) store_px(r, 0u, true);
+    if (WV == 0) store_px(3, 0u, haslast);
+#pragma unroll
+    for (int q = 0; q < RD; ++q) store_dd(q, WV + 4 * (q / 3), q % 3);
+    __syncthreads();
+
+    // ---- the resident B operand (fetched AFTER the first patch is staged: the all-at-once prologue needs ~150 registers of its
+    // own).  The fifth fragment of a tap — w0 of the four float-valued channels against the remainders — has only its first 8
+    // bytes per lane non-zero by construction (pack_stem_mx_weight_h): two registers instead of four.
+    u32x4 bres[NT][4];
+    u32x2 bxr[NT];
+    {
+      const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wpk) + lane;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bres[i][f] = wp[(tap_of(i) * NFT + f) * 64];
+        bxr[i] = *reinterpret_cast<const u32x2 *>(wp + (tap_of(i) * NFT + 4) * 64);
+      }
+      // Register classes: a wave's 512 registers are 256 VGPRs + 256 AGPRs, and only matrix instructions, loads and stores reach
+      // the second half.  Pinned there, a fragment is read by its MFMAs in place; left to the allocator it is parked there and
+      // copied back (four v_accvgpr_read per fragment and tap, ~240 issue slots per tile).  Accumulators (64) + PNVO_RS_NPIN taps fit.
+#pragma unroll
+      for (int i = 0; i < (NT < PNVO_RS_NPIN ? NT : PNVO_RS_NPIN); ++i) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) asm volatile("" : "+a"(bres[i][f]));
+        asm volatile("" : "+a"(bxr[i]));
+      }
+    }
+
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      const unsigned buf = (unsigned)(it & 1) * RS_BUF, obuf = buf ^ (unsigned)RS_BUF;
+      const int t = t_first + it * per;
+      // the tile staged during this K loop: the next one (the last iteration re-stages its own tile into the idle buffer)
+      set_stage_tile(it + 1 < nit ? t + per : t);
+      set_dd_tile(obuf);
+      const unsigned long long t0 = now();
+
+      // ---------------------------------------------------------- K loop of tile it, staging of the next tile between its MFMAs
+      f32x16 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      // (opaque: hoisted out of the tile loop, the two buffers' bases would be separate live registers)
+      const unsigned baseA = opaque(baseA0 + buf), baseX = opaque(baseX0 + buf);
+      // A fragments: chunk 0 of a tap is fetched during the previous tap (two register sets in turn), chunk 1 and the remainders
+      // in the tap's first region, eight MFMAs before their first use — with one wave per SIMD an LDS read waited for right before
+      // its MFMA is ~100 idle cycles of the matrix pipe.
+      u32x4 a0[2][4], a1[4], ax[4];
+      auto tofs = [&](int i, int m) constexpr { return tap_off(tap_of(i)) + m * 4 * ROW; };
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a0[0][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(0, m));
+      // One tap = five scheduling regions of four MFMAs (one B fragment x the four M-tiles), each with its share of the other work
+      // in source order; inside a region every MFMA is followed by at most seven other instructions — about what its 32 cycles hide.
+      auto region_end = [&]() PNVO_INL {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mfma4 = [&](const u32x4 *aq, const u32x4 bq) PNVO_INL {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, bq), acc[m], 0, 0, 0);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const bool st = !(PNVO_RS_ABL & 2), sd = !RAW && !(PNVO_RS_ABL & 1);
+        // the MFMA order of stem_mx_kernel: chunk 0 x {w0, w1}, chunk 1 x {w0, w1}, remainders x w0; M-tiles innermost
+        // -- region 0: chunk 0 x w0 | this tap's chunk-1 and remainder fragments
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
+          ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
+        }
+        mfma4(a0[i & 1], bres[i][0]);
+        region_end();
+        // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
+        if (sd) {
+#pragma unroll
+          for (int q = 2 * i; q < 2 * i + 2; ++q)
+            if (q < RD) load_dd(q, WV + 4 * (q / 3), q % 3);
+        }
+        if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
+        if (st && WV == 0 && i == 8) load_px(3, haslast);
+        mfma4(a0[i & 1], bres[i][2]);
+        region_end();
+        // -- region 2: chunk 1 x w0 | the next tap's chunk-0 fragments
+        if (i + 1 < NT) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
+        }
+        mfma4(a1, bres[i][1]);
+        region_end();
+        // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
+        if (sd && i >= LAGD) {
+#pragma unroll
+          for (int q = 2 * (i - LAGD); q < 2 * (i - LAGD) + 2; ++q)
+            if (q < RD) store_dd(q, WV + 4 * (q / 3), q % 3);
+        }
+        mfma4(a1, bres[i][3]);
+        region_end();
+        // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
+        if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true);
+        if (st && WV == 0 && i == 11) store_px(3, obuf, haslast);
+        mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
+        region_end();
+      }
+      const unsigned long long t1 = now();
+      __syncthreads();                                      // every wave has left patch(it)
+      const unsigned long long t2 = now();
+
+      // ---------------------------------------------------------- K-split exchange through the buffer just consumed (fixed order)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
+              f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+      __syncthreads();                                      // exchange(it) complete; patch(it + 1) complete
+      f32x16 tot;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((WV * 4 + s4) * 4 + rq) * 64 + lane) * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? tq[e] : tot[4 * rq + e] + tq[e];
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[r] *= oscale;        // undo the weights' power-of-two scale (exact)
+
+      // ---------------------------------------------------------- epilogue of M-tile WV (rows 2 WV, 2 WV + 1 of the tile)
+      int n, ty, tx;
+      {
+        int tt = t;
+        tx = tt % p.tiles_x;
+        tt /= p.tiles_x;
+        ty = tt % p.tiles_y;
+        n = tt / p.tiles_y;
+      }
+      const int ho0 = ty * TH, wo0 = tx * TW;
+      const int rr16v = (int)opaque((unsigned)rr16), lc = (int)opaque((unsigned)(lane & 31));   // (no hoisted per-pixel addresses)
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16v;
+        const int row = 2 * WV + (i >> 4), col = i & 15;
+        const bool ok = (int)(ho0 + row < p.Ho) & (int)(wo0 + col < p.Wo);
+        const float v = ok ? tot[r] : 0.f;
+        if (POOL) {
+          pb[(row * 16 + col) * 33 + lc] = ok ? sgn * tot[r] : -__builtin_inff();
+        } else if (ok) {
+          reinterpret_cast<float *>(p.y[0])[(((long)n * p.Ho + ho0 + row) * p.Wo + wo0 + col) * p.y_cstride + co] = v;
+        }
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) {
+        red[(WV * 32 + lane) * 2] = s1;
+        red[(WV * 32 + lane) * 2 + 1] = s2;
+      }
+      __syncthreads();                                      // pooling scratch and partial sums complete
+      if (POOL) {
+        // MaxPool2d(3, 2, 1) on order-preserving integer keys of sgn(gamma) * x (see stem_mx_kernel): plain stores for windows
+        // inside the tile, integer atomic max for windows shared with a neighbour
+        const int ch = lc, pj = 2 * WV + rr16v;               // (= tid >> 5)
+        const int Ib = ho0 >> 1, Jb = wo0 >> 1;
+        int *const pool0 = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0] + ch;
+        auto emit = [&](int I, int J, float mx, bool inside) PNVO_INL {
+          if (I >= p.Hp || J >= p.Wp) return;
+          int key = __builtin_bit_cast(int, mx);
+          key = key >= 0 ? key : key ^ 0x7fffffff;
+          int *dst = pool0 + (I * p.Wp + J) * p.y_cstride;
+          if (inside)
+            *dst = key;
+          else
+            atomicMax(dst, key);
+        };
+        {
+          const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;
+          float cm[8];
+#pragma unroll
+          for (int lr = 0; lr < 8; ++lr)
+            cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
+          const bool colin = pj >= 1 || wo0 == 0;
+          emit(Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
+          emit(Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
+          emit(Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
+          emit(Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
+          emit(Ib + 4, Jb + pj, cm[7], false);
+        }
+        if (pj < 5) {                                       // ninth pooled column: tile column 15, always shared with the right tile
+          const int pi = pj;
+          float mx = -__builtin_inff();
+#pragma unroll
+          for (int dr = -1; dr <= 1; ++dr) {
+            const int lr = 2 * pi + dr;
+            if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
+          }
+          emit(Ib + pi, Jb + 8, mx, false);
+        }
+      }
+      if (WV == 3 && lane >= 32) {                          // GroupNorm partial sums of the tile, wave order (as stem_mx_kernel)
+        const int c = lc;
+        float a1s = 0.f, a2s = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          a1s += red[(w4 * 32 + c) * 2];
+          a2s += red[(w4 * 32 + c) * 2 + 1];
+        }
+        const int slot = ty * p.tiles_x + tx;
+        float *dst = p.stats[0] + (((long)n * p.slots + slot) * p.stats_cstride + p.y_coff[0] + c) * 2;
+        dst[0] = a1s;
+        dst[1] = a2s;
+      }
+      if (prof) {
+        pc[0] += t1 - t0;                                   // K loop (with the next patch's staging inside)
+        pc[1] += t2 - t1;                                   // wait for the other waves
+        pc[2] += now() - t2;                                // exchange + epilogue
+      }
+    }
+  };
+  switch (wave) {
+    case 0: body(std::integral_constant<int, 0>{}); break;
+    case 1: body(std::integral_constant<int, 1>{}); break;
+    case 2: body(std::integral_constant<int, 2>{}); break;
+    default: body(std::integral_constant<int, 3>{}); break;
+  }
+  if (!RAW && (lowbits & 0x1fffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
+  if (RAW && bad_depth != 0u && p.raw_err != nullptr) *p.raw_err = 1;
+  if (prof && lane == 0 && (blockIdx.x % 16) == 0) {
+    unsigned long long *q = p.prof + 16 * wave;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(q + k, pc[k]);
+    atomicAdd(q + 5, (unsigned long long)nit);
+  }
+}
+
+// Takes the launch when the tiles keep every workgroup busy for many rounds (the resident fragments cost ~one tile-time to load).
+bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs) {
+  const long ntiles = (long)a.B * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
+  return pieces == 2 && ntiles_n == 1 && !bf16_out && wgs >= 8 && ntiles >= 8L * wgs;
+}
+
+hipError_t launch_stem_rs(const StemMXArgs &a, int wgs, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipSuccess;
+    auto set = [&](const void *f) {
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+    };
+    set(reinterpret_cast<const void *>(stem_rs_kernel<true, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<true, false>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<false, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<false, false>));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  StemMXArgs p = a;
+  p.tiles_x = (a.Wo + TW - 1) / TW;
+  p.tiles_y = (a.Ho + TH - 1) / TH;
+  const unsigned gx = (unsigned)(wgs & ~7);
+  const bool raw = p.raw_depth != nullptr, pool = p.pool != nullptr;
+  if (pool && raw) hipLaunchKernelGGL((stem_rs_kernel<true, true>), dim3(gx), dim3(256), RS_LDS, s, p);
+  else if (pool) hipLaunchKernelGGL((stem_rs_kernel<true, false>), dim3(gx), dim3(256), RS_LDS, s, p);
+  else if (raw) hipLaunchKernelGGL((stem_rs_kernel<false, true>), dim3(gx), dim3(256), RS_LDS, s, p);
+  else hipLaunchKernelGGL((stem_rs_kernel<false, false>), dim3(gx), dim3(256), RS_LDS, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace pnvo
