@@ -35,6 +35,16 @@ constexpr int RS_LDS = RS_TRASH_OFF + 64;
 static_assert(RS_BUF >= PATCH_BYTES, "patch must fit its buffer");
 static_assert(RS_LDS <= 160 * 1024, "LDS budget");
 #define PNVO_INL __attribute__((always_inline))
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an unrolled loop whose index is a constant BEFORE the optimiser
+// runs (the tap loop holds every epilogue piece behind `if (tap == ...)`: as a #pragma unroll loop its body is over the unroller's
+// size limit until those conditions fold)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
 #ifndef PNVO_RS_NRES
 #define PNVO_RS_NRES 12
 #endif
@@ -120,6 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // selects on 64-bit pointers, which the compiler turns into branches (a branch ends the tap's scheduling region).
   constexpr unsigned OOB = 0x80000000u;
   int shi = 0, swi = 0;                                     // patch origin of the tile being staged (wave-uniform)
+  int st_n = 0, st_ty = 0, st_tx = 0;                       //   ... and its coordinates
   __amdgpu_buffer_rsrc_t r_rgb, r_d, r_dd, r_t;
   auto rsrc = [&](const void *base, long off, long bytes) PNVO_INL {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base ? reinterpret_cast<const char *>(base) + off : reinterpret_cast<const char *>(zp)),
@@ -132,6 +143,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long sn = t / p.tiles_y;
     shi = 2 * ty * TH - 3;
     swi = 2 * tx * TW - 3;
+    st_n = (int)sn;
+    st_ty = ty;
+    st_tx = tx;
     if (RAW) {
       r_rgb = rsrc(p.raw_rgb, sn * fpix * 6, fpix * 6);     // both frames of the sample: [2][H][W][3] uint8
       r_d = rsrc(p.raw_depth, sn * fpix * 8, fpix * 8);     //                            [2][H][W] float32
@@ -325,6 +339,174 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
 
+    // ---- the epilogue of a tile in pieces (POOL: they run between the MFMAs of the NEXT tile, see `epi` below): K-split sum in wave
+    // order, un-scale, GroupNorm partial sums, pooled keys.  e_*: the tile they work on; ebuf: the buffer its exchange is in.
+    int e_n = 0, e_ho0 = 0, e_wo0 = 0, e_slot = 0;
+    bool e_valid = false;
+    unsigned ebuf = 0u;
+    // Every piece that reads LDS is split into its reads and, one region later, the arithmetic on them: with one wave per SIMD a
+    // value used right behind its ds_read costs the read's whole latency.
+    f32x4 xq[4], tq4;
+    float s1 = 0.f, s2 = 0.f, cm[8], pl[6], rs9[3];
+    f32x2 rsv[4];
+    int rr16v = 0, lc = 0, colv = 0;
+    auto epi_begin = [&]() PNVO_INL {                       // per-tile lane values (opaque: no hoisted per-pixel addresses)
+      rr16v = (int)opaque((unsigned)rr16);
+      lc = (int)opaque((unsigned)(lane & 31));
+      colv = p.Wo - e_wo0 - 4 * rr16v;                      // columns of this lane's pixel group that exist
+      s1 = 0.f;
+      s2 = 0.f;
+    };
+    auto XAl = [&](int rq) PNVO_INL {                       // accumulator quad rq of M-tile WV: the four waves' partials
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        xq[s4] = *reinterpret_cast<const f32x4 *>(lds + ebuf + (((WV * 4 + s4) * 4 + rq) * 64 + lane) * 16);
+    };
+    auto XAs = [&]() PNVO_INL {                             //   ... summed in wave order, power-of-two scale undone (exact)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tq4[e] = (((xq[0][e] + xq[1][e]) + xq[2][e]) + xq[3][e]) * oscale;
+    };
+    auto XB = [&](int rq) PNVO_INL {                        // its four pixels: pooling scratch (sgn x, -inf outside) + partial sums
+      const bool rowok = e_ho0 + 2 * WV + (rq >> 1) < p.Ho;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int colc = e + 8 * (rq & 1);                  // pixel (row 2 WV + (rq >> 1), column colc + 4 rr16) of the tile
+        const bool ok = (int)rowok & (int)(colc < colv);
+        const float v = ok ? tq4[e] : 0.f;
+        pb[((2 * WV + (rq >> 1)) * 16 + colc + 4 * rr16v) * 33 + lc] = ok ? sgn * tq4[e] : -__builtin_inff();
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+    };
+    auto XC = [&]() PNVO_INL {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      // (both halves of the wave hold the sums now and write the same two words)
+      *reinterpret_cast<f32x2 *>(&red[(WV * 32 + lc) * 2]) = f32x2{s1, s2};
+    };
+    auto ebar = [&]() PNVO_INL {                            // workgroup barrier over LDS only (global loads stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // MaxPool2d(3, 2, 1) on order-preserving integer keys of sgn(gamma) * x (see stem_mx_kernel): lane = (pooled column pj, channel);
+    // every key goes out as an integer atomic max (exact, order-free), absent ones as the identity at a clamped address — no branch
+    auto PAl = [&](int j) PNVO_INL {                        // tile rows 2 j, 2 j + 1: the three columns of the lane's window
+      const int pj = 2 * WV + rr16v;
+      const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        pl[3 * d] = pb[((2 * j + d) * 16 + c0) * 33 + lc];
+        pl[3 * d + 1] = pb[((2 * j + d) * 16 + c1) * 33 + lc];
+        pl[3 * d + 2] = pb[((2 * j + d) * 16 + c1 + 1) * 33 + lc];
+      }
+    };
+    auto PAm = [&](int j) PNVO_INL {
+      cm[2 * j] = fmaxf(fmaxf(pl[0], pl[1]), pl[2]);
+      cm[2 * j + 1] = fmaxf(fmaxf(pl[3], pl[4]), pl[5]);
+    };
+    auto emit = [&](int I, int J, float mx, bool valid) PNVO_INL {
+      int key = __builtin_bit_cast(int, mx);
+      key = key >= 0 ? key : key ^ 0x7fffffff;
+      const bool ok = (int)valid & (int)e_valid & (int)(I < p.Hp) & (int)(J < p.Wp);
+      const int Ic = min(I, p.Hp - 1), Jc = min(J, p.Wp - 1);
+      int *base = p.pool + ((long)e_n * p.Hp + Ic) * p.Wp * p.y_cstride + p.y_coff[0];   // wave-uniform
+      atomicMax(base + (unsigned)(Jc * p.y_cstride + lc), ok ? key : STEM_POOL_INIT);
+    };
+    auto PE = [&](int k) PNVO_INL {                         // pooled row k of the 5 x 9 pooled pixels the tile touches
+      const int pj = 2 * WV + rr16v;
+      const float mx = k == 0 ? fmaxf(cm[0], cm[1]) : k == 4 ? cm[7] : fmaxf(fmaxf(cm[2 * k - 1], cm[2 * k]), cm[2 * k + 1]);
+      emit((e_ho0 >> 1) + k, (e_wo0 >> 1) + pj, mx, true);
+    };
+    auto P9l = [&]() PNVO_INL {                             // ninth pooled column (tile column 15): lanes with pj < 5 take pooled row pj
+      const int pi = 2 * WV + rr16v;
+#pragma unroll
+      for (int dr = -1; dr <= 1; ++dr) rs9[dr + 1] = pb[(min(max(2 * pi + dr, 0), 7) * 16 + 15) * 33 + lc];
+    };
+    auto P9e = [&]() PNVO_INL {
+      const int pi = 2 * WV + rr16v;
+      float mx = -__builtin_inff();
+#pragma unroll
+      for (int dr = -1; dr <= 1; ++dr) {
+        const int lr = 2 * pi + dr;
+        mx = fmaxf(mx, ((int)(lr >= 0) & (int)(lr < 8)) ? rs9[dr + 1] : -__builtin_inff());
+      }
+      emit((e_ho0 >> 1) + pi, (e_wo0 >> 1) + 8, mx, pi < 5);
+    };
+    auto PSl = [&]() PNVO_INL {                             // GroupNorm partial sums of the tile, wave order (as stem_mx_kernel)
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) rsv[w4] = *reinterpret_cast<const f32x2 *>(&red[(w4 * 32 + lc) * 2]);
+    };
+    auto PSs = [&]() PNVO_INL {
+      float a1s = 0.f, a2s = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        a1s += rsv[w4][0];
+        a2s += rsv[w4][1];
+      }
+      float *dst = p.stats[0] + (((long)e_n * p.slots + e_slot) * p.stats_cstride + p.y_coff[0]) * 2;   // wave-uniform
+      *reinterpret_cast<f32x2 *>(dst + 2 * lc) = f32x2{a1s, a2s};   // (both halves of the wave: the same two words)
+    };
+    // which piece runs in which region of the next tile's K loop (tap i, region rg: 0 and 2 carry only fragment reads of their
+    // own, 3 the granule stores, 4 the pixel stores of taps 3, 5, 7).  Taps 0-2: the exchange is read before the barrier behind
+    // tap 2 — from tap 3 on the stager overwrites that buffer.
+    auto epi = [&](int i, int rg) PNVO_INL {
+      if (!POOL) return;
+      const int k = 5 * i + rg;
+      if (k == 0) { epi_begin(); XAl(0); }
+      if (k == 2) { XAs(); XAl(1); }
+      if (k == 3) XB(0);
+      if (k == 4) { XAs(); XAl(2); }
+      if (k == 5) XB(1);
+      if (k == 7) { XAs(); XAl(3); }
+      if (k == 8) XB(2);
+      if (k == 9) XAs();
+      if (k == 10) XB(3);
+      if (k == 12) XC();
+      if (k == 15) PAl(0);
+      if (k == 17) { PAm(0); PAl(1); }
+      if (k == 20) { PAm(1); PAl(2); }
+      if (k == 22) { PAm(2); PAl(3); }
+      if (k == 24) PAm(3);
+      if (k == 25) PE(0);
+      if (k == 27) PE(1);
+      if (k == 30) PE(2);
+      if (k == 32) PE(3);
+      if (k == 35) { PE(4); P9l(); }
+      if (k == 37) P9e();
+      if (k == 40 && WV == 3) PSl();
+      if (k == 42 && WV == 3) PSs();
+    };
+    auto epi_serial = [&]() PNVO_INL {                      // the same pieces one after the other (after the last tile)
+      epi_begin();
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        XAl(rq);
+        XAs();
+        XB(rq);
+      }
+      XC();
+      ebar();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        PAl(j);
+        PAm(j);
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) PE(k);
+      P9l();
+      P9e();
+      if (WV == 3) {
+        PSl();
+        PSs();
+      }
+    };
+
+    int c_n = st_n, c_ty = st_ty, c_tx = st_tx;             // the current tile (staged by the prologue)
+    // (first tile: the pieces run on nothing — keys off, the partial sums land in this tile's own slot and are overwritten by its
+    //  real epilogue one iteration later)
+    e_n = c_n;
+    e_ho0 = c_ty * TH;
+    e_wo0 = c_tx * TW;
+    e_slot = c_ty * p.tiles_x + c_tx;
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
       const unsigned buf = (unsigned)(it & 1) * RS_BUF, obuf = buf ^ (unsigned)RS_BUF;
@@ -332,6 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // the tile staged during this K loop: the next one (the last iteration re-stages its own tile into the idle buffer)
       set_stage_tile(it + 1 < nit ? t + per : t);
       set_dd_tile(obuf);
+      ebuf = obuf;                                          // POOL: the previous tile's exchange (first tile: nothing valid, keys off)
       const unsigned long long t0 = now();
 
       // ---------------------------------------------------------- K loop of tile it, staging of the next tile between its MFMAs
@@ -356,8 +539,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int k = 0; k < 4; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -368,8 +551,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, bq), acc[m], 0, 0, 0);
       };
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
+      static_for<NT>([&](auto ic) PNVO_INL {
+        constexpr int i = decltype(ic)::value;
         const bool st = !(PNVO_RS_ABL & 2), sd = !RAW && !(PNVO_RS_ABL & 1);
         // the MFMA order of stem_mx_kernel: chunk 0 x {w0, w1}, chunk 1 x {w0, w1}, remainders x w0; M-tiles innermost
         // -- region 0: chunk 0 x w0 | this tap's chunk-1 and remainder fragments
@@ -378,6 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
           ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
         }
+        epi(i, 0);
         mfma4(a0[i & 1], bres[i][0]);
         region_end();
         // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
@@ -395,6 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
         }
+        epi(i, 2);
         mfma4(a1, bres[i][1]);
         region_end();
         // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
@@ -403,129 +588,147 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int q = 2 * (i - LAGD); q < 2 * (i - LAGD) + 2; ++q)
             if (q < RD) store_dd(q, WV + 4 * (q / 3), q % 3);
         }
+        epi(i, 3);
         mfma4(a1, bres[i][3]);
         region_end();
         // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
         if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true);
         if (st && WV == 0 && i == 11) store_px(3, obuf, haslast);
+        epi(i, 4);
         mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
         region_end();
-      }
+        if (POOL && i == 2) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
+      });
       const unsigned long long t1 = now();
       __syncthreads();                                      // every wave has left patch(it)
       const unsigned long long t2 = now();
-
+      const int n = c_n, ty = c_ty, tx = c_tx;
+      if (POOL) {
+        // K-split exchange through the buffer just consumed; the rest of this tile's epilogue rides in the next tile's K loop
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
+                f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+        __syncthreads();                                    // exchange(it) complete; patch(it + 1) complete
+        e_n = n;
+        e_ho0 = ty * TH;
+        e_wo0 = tx * TW;
+        e_slot = ty * p.tiles_x + tx;
+        e_valid = true;
+      } else {
       // ---------------------------------------------------------- K-split exchange through the buffer just consumed (fixed order)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
-              f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
-      __syncthreads();                                      // exchange(it) complete; patch(it + 1) complete
-      f32x16 tot;
+          for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
+                f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+        __syncthreads();                                      // exchange(it) complete; patch(it + 1) complete
+        f32x16 tot;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((WV * 4 + s4) * 4 + rq) * 64 + lane) * 16);
+          for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((WV * 4 + s4) * 4 + rq) * 64 + lane) * 16);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? tq[e] : tot[4 * rq + e] + tq[e];
-        }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tot[r] *= oscale;        // undo the weights' power-of-two scale (exact)
-
-      // ---------------------------------------------------------- epilogue of M-tile WV (rows 2 WV, 2 WV + 1 of the tile)
-      int n, ty, tx;
-      {
-        int tt = t;
-        tx = tt % p.tiles_x;
-        tt /= p.tiles_x;
-        ty = tt % p.tiles_y;
-        n = tt / p.tiles_y;
-      }
-      const int ho0 = ty * TH, wo0 = tx * TW;
-      const int rr16v = (int)opaque((unsigned)rr16), lc = (int)opaque((unsigned)(lane & 31));   // (no hoisted per-pixel addresses)
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16v;
-        const int row = 2 * WV + (i >> 4), col = i & 15;
-        const bool ok = (int)(ho0 + row < p.Ho) & (int)(wo0 + col < p.Wo);
-        const float v = ok ? tot[r] : 0.f;
-        if (POOL) {
-          pb[(row * 16 + col) * 33 + lc] = ok ? sgn * tot[r] : -__builtin_inff();
-        } else if (ok) {
-          reinterpret_cast<float *>(p.y[0])[(((long)n * p.Ho + ho0 + row) * p.Wo + wo0 + col) * p.y_cstride + co] = v;
-        }
-        s1 += v;
-        s2 = __builtin_fmaf(v, v, s2);
-      }
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32) {
-        red[(WV * 32 + lane) * 2] = s1;
-        red[(WV * 32 + lane) * 2 + 1] = s2;
-      }
-      __syncthreads();                                      // pooling scratch and partial sums complete
-      if (POOL) {
-        // MaxPool2d(3, 2, 1) on order-preserving integer keys of sgn(gamma) * x (see stem_mx_kernel): plain stores for windows
-        // inside the tile, integer atomic max for windows shared with a neighbour
-        const int ch = lc, pj = 2 * WV + rr16v;               // (= tid >> 5)
-        const int Ib = ho0 >> 1, Jb = wo0 >> 1;
-        int *const pool0 = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0] + ch;
-        auto emit = [&](int I, int J, float mx, bool inside) PNVO_INL {
-          if (I >= p.Hp || J >= p.Wp) return;
-          int key = __builtin_bit_cast(int, mx);
-          key = key >= 0 ? key : key ^ 0x7fffffff;
-          int *dst = pool0 + (I * p.Wp + J) * p.y_cstride;
-          if (inside)
-            *dst = key;
-          else
-            atomicMax(dst, key);
-        };
-        {
-          const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;
-          float cm[8];
-#pragma unroll
-          for (int lr = 0; lr < 8; ++lr)
-            cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
-          const bool colin = pj >= 1 || wo0 == 0;
-          emit(Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
-          emit(Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
-          emit(Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
-          emit(Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
-          emit(Ib + 4, Jb + pj, cm[7], false);
-        }
-        if (pj < 5) {                                       // ninth pooled column: tile column 15, always shared with the right tile
-          const int pi = pj;
-          float mx = -__builtin_inff();
-#pragma unroll
-          for (int dr = -1; dr <= 1; ++dr) {
-            const int lr = 2 * pi + dr;
-            if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
+            for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? tq[e] : tot[4 * rq + e] + tq[e];
           }
-          emit(Ib + pi, Jb + 8, mx, false);
-        }
-      }
-      if (WV == 3 && lane >= 32) {                          // GroupNorm partial sums of the tile, wave order (as stem_mx_kernel)
-        const int c = lc;
-        float a1s = 0.f, a2s = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) {
-          a1s += red[(w4 * 32 + c) * 2];
-          a2s += red[(w4 * 32 + c) * 2 + 1];
+        for (int r = 0; r < 16; ++r) tot[r] *= oscale;        // undo the weights' power-of-two scale (exact)
+
+        // ---------------------------------------------------------- epilogue of M-tile WV (rows 2 WV, 2 WV + 1 of the tile)
+        const int ho0 = ty * TH, wo0 = tx * TW;
+        const int rr16v = (int)opaque((unsigned)rr16), lc = (int)opaque((unsigned)(lane & 31));   // (no hoisted per-pixel addresses)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16v;
+          const int row = 2 * WV + (i >> 4), col = i & 15;
+          const bool ok = (int)(ho0 + row < p.Ho) & (int)(wo0 + col < p.Wo);
+          const float v = ok ? tot[r] : 0.f;
+          if (POOL) {
+            pb[(row * 16 + col) * 33 + lc] = ok ? sgn * tot[r] : -__builtin_inff();
+          } else if (ok) {
+            reinterpret_cast<float *>(p.y[0])[(((long)n * p.Ho + ho0 + row) * p.Wo + wo0 + col) * p.y_cstride + co] = v;
+          }
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
         }
-        const int slot = ty * p.tiles_x + tx;
-        float *dst = p.stats[0] + (((long)n * p.slots + slot) * p.stats_cstride + p.y_coff[0] + c) * 2;
-        dst[0] = a1s;
-        dst[1] = a2s;
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lane < 32) {
+          red[(WV * 32 + lane) * 2] = s1;
+          red[(WV * 32 + lane) * 2 + 1] = s2;
+        }
+        __syncthreads();                                      // pooling scratch and partial sums complete
+        if (POOL) {
+          // MaxPool2d(3, 2, 1) on order-preserving integer keys of sgn(gamma) * x (see stem_mx_kernel): plain stores for windows
+          // inside the tile, integer atomic max for windows shared with a neighbour
+          const int ch = lc, pj = 2 * WV + rr16v;               // (= tid >> 5)
+          const int Ib = ho0 >> 1, Jb = wo0 >> 1;
+          int *const pool0 = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0] + ch;
+          auto emit = [&](int I, int J, float mx, bool inside) PNVO_INL {
+            if (I >= p.Hp || J >= p.Wp) return;
+            int key = __builtin_bit_cast(int, mx);
+            key = key >= 0 ? key : key ^ 0x7fffffff;
+            int *dst = pool0 + (I * p.Wp + J) * p.y_cstride;
+            if (inside)
+              *dst = key;
+            else
+              atomicMax(dst, key);
+          };
+          {
+            const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;
+            float cm[8];
+#pragma unroll
+            for (int lr = 0; lr < 8; ++lr)
+              cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
+            const bool colin = pj >= 1 || wo0 == 0;
+            emit(Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
+            emit(Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
+            emit(Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
+            emit(Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
+            emit(Ib + 4, Jb + pj, cm[7], false);
+          }
+          if (pj < 5) {                                       // ninth pooled column: tile column 15, always shared with the right tile
+            const int pi = pj;
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int dr = -1; dr <= 1; ++dr) {
+              const int lr = 2 * pi + dr;
+              if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
+            }
+            emit(Ib + pi, Jb + 8, mx, false);
+          }
+        }
+        if (WV == 3 && lane >= 32) {                          // GroupNorm partial sums of the tile, wave order (as stem_mx_kernel)
+          const int c = lc;
+          float a1s = 0.f, a2s = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) {
+            a1s += red[(w4 * 32 + c) * 2];
+            a2s += red[(w4 * 32 + c) * 2 + 1];
+          }
+          const int slot = ty * p.tiles_x + tx;
+          float *dst = p.stats[0] + (((long)n * p.slots + slot) * p.stats_cstride + p.y_coff[0] + c) * 2;
+          dst[0] = a1s;
+          dst[1] = a2s;
+        }
       }
+      c_n = st_n;
+      c_ty = st_ty;
+      c_tx = st_tx;
       if (prof) {
-        pc[0] += t1 - t0;                                   // K loop (with the next patch's staging inside)
+        pc[0] += t1 - t0;                                   // K loop (with the next patch's staging and, POOL, the previous epilogue inside)
         pc[1] += t2 - t1;                                   // wait for the other waves
-        pc[2] += now() - t2;                                // exchange + epilogue
+        pc[2] += now() - t2;                                // exchange (+ the serial epilogue of the raw-output form)
       }
+    }
+    if (POOL) {
+      ebuf = (unsigned)((nit - 1) & 1) * RS_BUF;
+      epi_serial();
     }
   };
   switch (wave) {
