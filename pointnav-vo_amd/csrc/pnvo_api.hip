@@ -796,11 +796,13 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       const double in_bytes = (double)B * c.height * c.width * (m->raw_depth ? (c.n_rgb ? 6.0 : 0.0) + 8.0 + (c.n_tdv ? 8.0 : 0.0) : 4.0 * stem.cin);
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
               in_bytes + 4.0 * (M * stem.cout + (double)stem.cout * stem.cin * 49));
-      // one persistent workgroup per CU with role-specialised waves (stem_ps_kernel) when the tiles fill the chip for a few
-      // rounds, the tile-per-workgroup kernel otherwise; bit-identical results (option stem_form: auto | persistent | tiles)
-      // (auto = tiles: with the K loop's fetches spread between the MFMAs both forms sit at the same ~1.0 ms at 256 pairs — what bounds
-      //  them is the CU's vector-memory pipe, 245 KB of weight fragments + 93 KB of patch per 128-pixel tile)
-      const bool rs = m->opt.stem_form == 3 && stem_rs_takes(a, pieces, ntn, false, m->num_cus);
+      // Three forms of the float16-piece stem, bit-identical results (option stem_form: auto | resident | persistent | tiles):
+      //   resident (auto when every workgroup gets >= 8 tiles): one 4-wave workgroup per CU for the whole launch, the weights in its
+      //     registers, staging of the next tile and epilogue of the previous one between the MFMAs (stem_rs.hip) — 0.81 ms at 256 pairs;
+      //   tiles (auto otherwise): one tile per workgroup, two workgroups per CU — 0.99 ms, bound by the CU's vector-memory pipe
+      //     (245 KB of weight fragments + 93 KB of patch per 128-pixel tile);
+      //   persistent: the role-specialised 8 / 12-wave form (stem_ps_kernel), same speed as tiles.
+      const bool rs = (m->opt.stem_form == 3 || m->opt.stem_form == 0) && stem_rs_takes(a, pieces, ntn, false, m->num_cus);
       const bool ps = m->opt.stem_form == 1 && stem_ps_takes(a, pieces, ntn, false, m->num_cus);
       m->mx_prof_ps = ps || rs;
       m->mx_prof_rs = rs;

@@ -58,7 +58,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 #define PNVO_RS_NPIN 10
 #endif
 #ifndef PNVO_RS_ABL
-#define PNVO_RS_ABL 0   // developer: compile-time ablations for register-pressure studies (1 no granules, 2 no pixel rounds in the K loop)
+#define PNVO_RS_ABL 0   // developer: compile-time ablations for register-pressure studies (1 no granules, 2 no pixel rounds, 4 no epilogue pieces in the K loop)
 #endif
 }  // namespace
 
@@ -99,9 +99,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const bool haslast = tid < NPIX - 3 * 256;
   // One-hot depth of the observation tensors: fetched by 16-BYTE GRANULE of a patch row (37 pixels x 80 B contiguous = 185
-  // granules; a wave-instruction covers 1 KiB of consecutive bytes, see stem_ps_kernel).  Wave w takes patch rows w, w + 4, ...,
-  // three 64-lane sub-rounds per row: the lane geometry is three registers (sub-round s: granule g = 64 s + lane -> pixel g / 5,
-  // chunk g % 5), the row is a compile-time constant.  Round q = 3 j + s is row w + 4 j (j = 5: row 20, wave 0 only).
+  // granules; a wave-instruction covers 1 KiB of consecutive bytes, see stem_ps_kernel).  Waves 0..2 take patch rows w, w + 3,
+  // ... (seven each; wave 3 has a tap more instead), three 64-lane sub-rounds per row: the lane geometry is three registers
+  // (sub-round s: granule g = 64 s + lane -> pixel g / 5, chunk g % 5), the row is a compile-time constant.  Round q = 3 j + s is
+  // row w + 3 j; one row per tap.
   unsigned gm[RAW ? 1 : 3];                                 // LDS offset inside the row | px << 16 | (granule exists) << 31
   if (!RAW) {
 #pragma unroll
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // registers of the patch pieces in flight (nothing is computed on a loaded value before its store_* — a wave that touches it
   // waits for the load, and there is no second wave on the SIMD to fill the gap)
-  f32x4 vr4[4], gdd[18];
+  f32x4 vr4[4], gdd[21];
   f32x2 vr2[4], vd[4], vt[4];
   unsigned rgbw[4][2];
   float dv[4][2];
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // compile-time constants — every LDS address of the K loop is one register plus an immediate, no scalar arithmetic per tap.
   auto body = [&](auto wv_c) PNVO_INL {
     constexpr int WV = decltype(wv_c)::value;
-    constexpr int NROWS = WV == 0 ? 6 : 5;                  // patch rows WV, WV + 4, ... of the granule fetch
+    constexpr int NROWS = WV == 3 ? 0 : 7;                  // patch rows WV, WV + 3, ... of the granule fetch (wave 3 has a tap more)
     constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
     constexpr int NT = WV == 3 ? 13 : 12;                   // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3)
     auto tap_of = [](int i) constexpr { return i < 12 ? WV + 4 * i : 48; };
@@ -307,12 +308,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 3; ++r) load_px(r, true);
     if (WV == 0) load_px(3, haslast);
 #pragma unroll
-    for (int q = 0; q < RD; ++q) load_dd(q, WV + 4 * (q / 3), q % 3);
+    for (int q = 0; q < RD; ++q) load_dd(q, WV + 3 * (q / 3), q % 3);
 #pragma unroll
     for (int r = 0; r < 3; ++r) store_px(r, 0u, true);
     if (WV == 0) store_px(3, 0u, haslast);
 #pragma unroll
-    for (int q = 0; q < RD; ++q) store_dd(q, WV + 4 * (q / 3), q % 3);
+    for (int q = 0; q < RD; ++q) store_dd(q, WV + 3 * (q / 3), q % 3);
     __syncthreads();
 
     // ---- the resident B operand (fetched AFTER the first patch is staged: the all-at-once prologue needs ~150 registers of its
@@ -449,9 +450,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // own, 3 the granule stores, 4 the pixel stores of taps 3, 5, 7).  Taps 0-2: the exchange is read before the barrier behind
     // tap 2 — from tap 3 on the stager overwrites that buffer.
     auto epi = [&](int i, int rg) PNVO_INL {
-      if (!POOL) return;
+      if (!POOL || (PNVO_RS_ABL & 4)) return;
       const int k = 5 * i + rg;
-      if (k == 0) { epi_begin(); XAl(0); }
+      if (k == 0) epi_begin();
+      if ((PNVO_RS_ABL & 8) && k < 15) return;            // (ablation: no exchange sum / scratch pieces)
+      if ((PNVO_RS_ABL & 16) && k >= 15) return;          // (ablation: no pooling / key pieces)
+      if (k == 0) XAl(0);
       if (k == 2) { XAs(); XAl(1); }
       if (k == 3) XB(0);
       if (k == 4) { XAs(); XAl(2); }
@@ -472,8 +476,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (k == 32) PE(3);
       if (k == 35) { PE(4); P9l(); }
       if (k == 37) P9e();
-      if (k == 40 && WV == 3) PSl();
-      if (k == 42 && WV == 3) PSs();
+      if (k == 40 && WV == 1) PSl();
+      if (k == 42 && WV == 1) PSs();
     };
     auto epi_serial = [&]() PNVO_INL {                      // the same pieces one after the other (after the last tile)
       epi_begin();
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int k = 0; k < 5; ++k) PE(k);
       P9l();
       P9e();
-      if (WV == 3) {
+      if (WV == 1) {
         PSl();
         PSs();
       }
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
         if (sd) {
 #pragma unroll
-          for (int q = 2 * i; q < 2 * i + 2; ++q)
-            if (q < RD) load_dd(q, WV + 4 * (q / 3), q % 3);
+          for (int q = 3 * i; q < 3 * i + 3; ++q)
+            if (q < RD) load_dd(q, WV + 3 * (q / 3), q % 3);
         }
         if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
         if (st && WV == 0 && i == 8) load_px(3, haslast);
@@ -585,8 +589,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
         if (sd && i >= LAGD) {
 #pragma unroll
-          for (int q = 2 * (i - LAGD); q < 2 * (i - LAGD) + 2; ++q)
-            if (q < RD) store_dd(q, WV + 4 * (q / 3), q % 3);
+          for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
+            if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
         }
         epi(i, 3);
         mfma4(a1, bres[i][3]);
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         epi(i, 4);
         mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
         region_end();
-        if (POOL && i == 2) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
+        if (POOL && i == 2 && !(PNVO_RS_ABL & 32)) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
       });
       const unsigned long long t1 = now();
       __syncthreads();                                      // every wave has left patch(it)

@@ -64,3 +64,40 @@ def test_persistent_stem_on_an_odd_resolution():
     assert torch.equal(outs[("tiles", 4)], outs[("persistent", 4)])
     rel = (outs[("tiles", 4)] - outs[("persistent", 8)]).abs().max() / outs[("tiles", 4)].abs().max()
     assert rel < 5e-6, rel
+
+
+@pytest.mark.parametrize("B", [19, 64])
+@pytest.mark.parametrize("pool", ["fused", "separate"])
+def test_resident_weight_stem_equals_the_tile_kernel(B, pool):
+    """stem_rs_kernel (stem_form=resident, the default from 16 pairs of 341x192 on): one 4-wave workgroup per CU keeps the stem's
+    weights in registers for all of its tiles; same tap split, fragment order and K-split summation order as the tile kernel — not
+    one bit differs, on the observation-tensor entry, on the sensor-frame entry and with the max-pool as its own pass."""
+    model, _ = bench.build_model(DEV)
+    obs = bench.make_inputs(B, DEV, 0)
+    ref = run(model, obs, "tiles", 4, pool)
+    res = run(model, obs, "resident", 4, pool)
+    auto = run(model, obs, "auto", 4, pool)
+    assert torch.isfinite(ref[0]).all()
+    for k in range(3):
+        assert torch.equal(ref[k], res[k]), k
+        assert torch.equal(ref[k], auto[k]), k
+
+
+def test_resident_weight_stem_on_an_odd_resolution():
+    """45 x 37 (ragged tiles on both edges, patches that leave the image on every side), 700 pairs so that the kernel takes the launch."""
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(45, 37), hidden_size=512, backbone="resnet18", normalize_visual_inputs=True,
+        output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    obs = {k: torch.from_numpy(v).to(DEV) for k, v in
+           synth.make_obs_pairs(700, 37, 45, observation_space=bench.SPACE, dd_bins=10, seed=3).items()}
+    outs = {}
+    for form in ("tiles", "resident"):
+        m.set_option("stem_form", form)
+        with torch.no_grad():
+            outs[form] = m(obs).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs["tiles"]).all()
+    assert torch.equal(outs["tiles"], outs["resident"])
