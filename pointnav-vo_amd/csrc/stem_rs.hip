@@ -191,8 +191,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       vt[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_t, o8, 0, 0));
     }
   };
-  auto store_px = [&](int r, unsigned buf, bool exists) PNVO_INL {
-    unsigned w[16];
+  // part 1: the rgb K-slots (kept in registers), part 2: depth, top-down view, indicator, remainders and the LDS writes; 0: both
+  // (two halves of about twenty instructions: a whole pixel round overflows a scheduling region of four MFMAs)
+  unsigned wrgb[3] = {0u, 0u, 0u};
+  auto store_px = [&](int r, unsigned buf, bool exists, int part) PNVO_INL {
+    if (part != 2) {
+      if (RAW) {
+        const unsigned x0 = (pflag[r] & 2u) ? rgbw[r][0] >> 8 : rgbw[r][0], x1 = rgbw[r][1] >> 8;
+        const float pr = (float)(x0 & 0xffu), pg = (float)((x0 >> 8) & 0xffu), pbl = (float)((x0 >> 16) & 0xffu);
+        const float cr = (float)(x1 & 0xffu), cg = (float)((x1 >> 8) & 0xffu), cb = (float)((x1 >> 16) & 0xffu);
+        wrgb[0] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
+        wrgb[1] = pack_f16(pbl * 0.00390625f, cr * 0.00390625f);
+        wrgb[2] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
+      } else {
+        wrgb[0] = pack_f16(vr4[r][0] * 0.00390625f, vr4[r][1] * 0.00390625f);
+        wrgb[1] = pack_f16(vr4[r][2] * 0.00390625f, vr4[r][3] * 0.00390625f);
+        wrgb[2] = pack_f16(vr2[r][0] * 0.00390625f, vr2[r][1] * 0.00390625f);
+        const float f0 = vr4[r][0], f1 = vr4[r][1], f2 = vr4[r][2], f3 = vr4[r][3], f4 = vr2[r][0], f5 = vr2[r][1];
+        lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
+        lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
+        lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
+      }
+    }
+    if (part == 1) return;
     float d0, d1;
     int bidx[2] = {0, 0};
     unsigned bok[2] = {0u, 0u};
@@ -209,46 +230,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         bok[f] = ((d >= 0.f) & (d <= 1.f)) ? 1u : 0u;
         bad_depth |= (pflag[r] & 1u) & (bok[f] ^ 1u);
       }
-#pragma unroll
-      for (int cc = 0; cc < 10; ++cc) w[cc] = 0u;
-      const unsigned x0 = (pflag[r] & 2u) ? rgbw[r][0] >> 8 : rgbw[r][0], x1 = rgbw[r][1] >> 8;
-      const float pr = (float)(x0 & 0xffu), pg = (float)((x0 >> 8) & 0xffu), pbl = (float)((x0 >> 16) & 0xffu);
-      const float cr = (float)(x1 & 0xffu), cg = (float)((x1 >> 8) & 0xffu), cb = (float)((x1 >> 16) & 0xffu);
-      w[10] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
-      w[11] = pack_f16(pbl * 0.00390625f, cr * 0.00390625f);
-      w[12] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
       d0 = use_d ? dv[r][0] : 0.f;
       d1 = use_d ? dv[r][1] : 0.f;
     } else {
-      w[10] = pack_f16(vr4[r][0] * 0.00390625f, vr4[r][1] * 0.00390625f);
-      w[11] = pack_f16(vr4[r][2] * 0.00390625f, vr4[r][3] * 0.00390625f);
-      w[12] = pack_f16(vr2[r][0] * 0.00390625f, vr2[r][1] * 0.00390625f);
-      {
-        const float f0 = vr4[r][0], f1 = vr4[r][1], f2 = vr4[r][2], f3 = vr4[r][3], f4 = vr2[r][0], f5 = vr2[r][1];
-        lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
-        lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
-        lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
-      }
       d0 = vd[r][0];
       d1 = vd[r][1];
     }
-    w[13] = pack_f16(d0, d1);
-    w[14] = pack_f16(vt[r][0], vt[r][1]);
-    w[15] = in ? 0x3c003c00u : 0u;
+    const unsigned w13 = pack_f16(d0, d1), w14 = pack_f16(vt[r][0], vt[r][1]), w15 = in ? 0x3c003c00u : 0u;
     const unsigned base = buf + (opaque(pmeta[r]) & 0xffffu);
     constexpr unsigned TR = (unsigned)RS_TRASH_OFF;
     if (RAW) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<u32x4 *>(lds + (exists ? base + 16u * q : TR)) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base : TR)) = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 16u : TR)) = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 32u : TR)) = u32x4{0u, 0u, wrgb[0], wrgb[1]};
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 48u : TR)) = u32x4{wrgb[2], w13, w14, w15};
       const bool dd = (p.raw_flags & 2) != 0 && in && exists;
       *reinterpret_cast<unsigned short *>(lds + ((dd && bok[0]) ? base + 2u * (unsigned)bidx[0] : TR)) = (unsigned short)0x3c00;
       *reinterpret_cast<unsigned short *>(lds + ((dd && bok[1]) ? base + 20u + 2u * (unsigned)bidx[1] : TR)) = (unsigned short)0x3c00;
     } else {                                                 // K-slots 20..31 (rgb, depth, top-down view, indicator): bytes 40..63
-      *reinterpret_cast<u32x2 *>(lds + (exists ? base + 40u : TR)) = u32x2{w[10], w[11]};
-      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 48u : TR)) = u32x4{w[12], w[13], w[14], w[15]};
+      *reinterpret_cast<u32x2 *>(lds + (exists ? base + 40u : TR)) = u32x2{wrgb[0], wrgb[1]};
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 48u : TR)) = u32x4{wrgb[2], w13, w14, w15};
     }
-    const f16x2 hd = __builtin_bit_cast(f16x2, w[13]), ht = __builtin_bit_cast(f16x2, w[14]);
+    const f16x2 hd = __builtin_bit_cast(f16x2, w13), ht = __builtin_bit_cast(f16x2, w14);
     const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
     const unsigned mt = pack_f16(vt[r][0] - (float)ht[0], vt[r][1] - (float)ht[1]);
     *reinterpret_cast<u32x4 *>(lds + (exists ? base + 64u : TR)) = u32x4{md, mt, 0u, 0u};
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int q = 0; q < RD; ++q) load_dd(q, WV + 3 * (q / 3), q % 3);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) store_px(r, 0u, true);
-    if (WV == 0) store_px(3, 0u, haslast);
+    for (int r = 0; r < 3; ++r) store_px(r, 0u, true, 0);
+    if (WV == 0) store_px(3, 0u, haslast, 0);
 #pragma unroll
     for (int q = 0; q < RD; ++q) store_dd(q, WV + 3 * (q / 3), q % 3);
     __syncthreads();
@@ -404,18 +407,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       cm[2 * j] = fmaxf(fmaxf(pl[0], pl[1]), pl[2]);
       cm[2 * j + 1] = fmaxf(fmaxf(pl[3], pl[4]), pl[5]);
     };
-    auto emit = [&](int I, int J, float mx, bool valid) PNVO_INL {
+    // (per tile: the sample's key plane, the lane's column offset and validity; per key a row offset)
+    int *e_pool = p.pool;
+    unsigned e_joff = 0u, e_j9off = 0u;
+    bool e_jok = false, e_j9ok = false;
+    auto emit_begin = [&]() PNVO_INL {
+      const int pj = 2 * WV + rr16v, J = (e_wo0 >> 1) + pj, J9 = (e_wo0 >> 1) + 8;
+      e_pool = p.pool + (long)e_n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0];   // wave-uniform
+      e_joff = (unsigned)(min(J, p.Wp - 1) * p.y_cstride + lc);
+      e_j9off = (unsigned)(min(J9, p.Wp - 1) * p.y_cstride + lc);
+      e_jok = (int)e_valid & (int)(J < p.Wp);
+      e_j9ok = (int)e_valid & (int)(J9 < p.Wp) & (int)(pj < 5);
+    };
+    auto emit = [&](int I, unsigned joff, float mx, bool valid) PNVO_INL {
       int key = __builtin_bit_cast(int, mx);
       key = key >= 0 ? key : key ^ 0x7fffffff;
-      const bool ok = (int)valid & (int)e_valid & (int)(I < p.Hp) & (int)(J < p.Wp);
-      const int Ic = min(I, p.Hp - 1), Jc = min(J, p.Wp - 1);
-      int *base = p.pool + ((long)e_n * p.Hp + Ic) * p.Wp * p.y_cstride + p.y_coff[0];   // wave-uniform
-      atomicMax(base + (unsigned)(Jc * p.y_cstride + lc), ok ? key : STEM_POOL_INIT);
+      const bool ok = (int)valid & (int)(I < p.Hp);
+      atomicMax(e_pool + (long)(min(I, p.Hp - 1) * p.Wp * p.y_cstride) + joff, ok ? key : STEM_POOL_INIT);
     };
     auto PE = [&](int k) PNVO_INL {                         // pooled row k of the 5 x 9 pooled pixels the tile touches
-      const int pj = 2 * WV + rr16v;
       const float mx = k == 0 ? fmaxf(cm[0], cm[1]) : k == 4 ? cm[7] : fmaxf(fmaxf(cm[2 * k - 1], cm[2 * k]), cm[2 * k + 1]);
-      emit((e_ho0 >> 1) + k, (e_wo0 >> 1) + pj, mx, true);
+      emit((e_ho0 >> 1) + k, e_joff, mx, e_jok);
     };
     auto P9l = [&]() PNVO_INL {                             // ninth pooled column (tile column 15): lanes with pj < 5 take pooled row pj
       const int pi = 2 * WV + rr16v;
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int lr = 2 * pi + dr;
         mx = fmaxf(mx, ((int)(lr >= 0) & (int)(lr < 8)) ? rs9[dr + 1] : -__builtin_inff());
       }
-      emit((e_ho0 >> 1) + pi, (e_wo0 >> 1) + 8, mx, pi < 5);
+      emit((e_ho0 >> 1) + pi, e_j9off, mx, e_j9ok);
     };
     auto PSl = [&]() PNVO_INL {                             // GroupNorm partial sums of the tile, wave order (as stem_mx_kernel)
 #pragma unroll
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (k == 17) { PAm(0); PAl(1); }
       if (k == 20) { PAm(1); PAl(2); }
       if (k == 22) { PAm(2); PAl(3); }
-      if (k == 24) PAm(3);
+      if (k == 24) { PAm(3); emit_begin(); }
       if (k == 25) PE(0);
       if (k == 27) PE(1);
       if (k == 30) PE(2);
@@ -494,6 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         PAl(j);
         PAm(j);
       }
+      emit_begin();
 #pragma unroll
       for (int k = 0; k < 5; ++k) PE(k);
       P9l();
@@ -592,12 +605,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
             if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
         }
+        if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
         epi(i, 3);
         mfma4(a1, bres[i][3]);
         region_end();
         // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
-        if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true);
-        if (st && WV == 0 && i == 11) store_px(3, obuf, haslast);
+        if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
+        if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
         epi(i, 4);
         mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
         region_end();
