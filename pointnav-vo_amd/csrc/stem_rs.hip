@@ -535,11 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const unsigned long long t0 = now();
 
       // ---------------------------------------------------------- K loop of tile it, staging of the next tile between its MFMAs
-      f32x16 acc[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      f32x16 acc[4];                                        // (never zeroed: the first MFMA of a tile takes the constant 0 as its C operand)
       // (opaque: hoisted out of the tile loop, the two buffers' bases would be separate live registers)
       const unsigned baseA = opaque(baseA0 + buf), baseX = opaque(baseX0 + buf);
       // A fragments: chunk 0 of a tap is fetched during the previous tap (two register sets in turn), chunk 1 and the remainders
@@ -562,10 +558,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      auto mfma4 = [&](const u32x4 *aq, const u32x4 bq) PNVO_INL {
+      auto mfma4 = [&](const u32x4 *aq, const u32x4 bq, bool first = false) PNVO_INL {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, bq), acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, bq),
+                                                          first ? zero : acc[m], 0, 0, 0);
       };
       __builtin_amdgcn_sched_barrier(0);
       static_for<NT>([&](auto ic) PNVO_INL {
@@ -579,7 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
         }
         epi(i, 0);
-        mfma4(a0[i & 1], bres[i][0]);
+        mfma4(a0[i & 1], bres[i][0], i == 0);
         region_end();
         // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
         if (sd) {
