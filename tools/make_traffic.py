@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # rocprof kernel-name prefix -> the name bench.py gives that launch
-KERNELS = {"fwd_fp32": ("stem_mx_kernel<2, 1, false", "conv:visual_encoder.backbone.conv1.0"),
+KERNELS = {"fwd_fp32": ("stem_rs_kernel<true, false", "conv:visual_encoder.backbone.conv1.0"),
            "dual_bf16": ("stem_mx_kernel<1, 2, true", "bf16:stem")}
 
 

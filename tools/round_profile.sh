@@ -29,7 +29,7 @@ python tools/rocprof_summary.py $O/${tag}_trace_train/p_results.db > $O/${tag}_k
 rm -rf $O/${tag}_trace_train
 PNVO_WSM_PROF=1 python bench.py --config train --steps 10 --warmup 3 2>&1 >/dev/null | grep "pnvo\]" > $O/${tag}_wgrad_stem_phases.txt
 PNVO_X3_PROF=1 python bench.py --steps 1 --warmup 0 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] conv_x3" | sort -u -t: -k1,1 > $O/${tag}_conv_x3_phases.txt
-PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] stem_mx" > $O/${tag}_stem_phases.txt
+PNVO_STEM_FORM=tiles PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] stem_mx" > $O/${tag}_stem_phases.txt
 # the persistent role-specialised stem: phases per wave role, and its timing-only ablations (what bounds it)
 ( echo "# stem_ps_kernel (option stem_form=persistent, 8 L waves): cycles per tile and wave role; then ablations (WRONG results, timing only):"
   echo "# 17 = staging loads hit one address, 18 = no epilogue, 20 = no conversion / LDS writes, 24 = no MFMAs, 32 = no staging loads, 38 = K loop alone"
@@ -40,7 +40,11 @@ for l in sys.stdin:
         j = json.loads(l); print('stem ms per launch', round([k for k in j['kernels'] if 'conv1.0' in k['name']][0]['ms_per_step'], 4))
     elif 'pnvo]' in l and ('M wave 0' in l or 'L wave 4' in l or 'L wave 9' in l): print(l.rstrip())
 "; done ) > $O/${tag}_stem_ps_phases.txt 2>&1
-python tools/ab_option.py stem_form tiles persistent > $O/${tag}_ab_stem_form.txt 2>/dev/null
+# the resident-weight stem (the default): cycles per tile of its three sections, per wave
+( echo "# stem_rs_kernel (stem_form=resident, the default at 256 pairs): cycles per tile (s_memtime), option stem_dbg=9"
+  bash tools/stem_rs_prof.sh ) > $O/${tag}_stem_rs_phases.txt 2>&1
+python tools/ab_option.py stem_form tiles resident > $O/${tag}_ab_stem_form.txt 2>/dev/null
+python tools/ab_option.py stem_form tiles persistent >> $O/${tag}_ab_stem_form.txt 2>/dev/null
 python tools/ab_option.py x3_persist off on > $O/${tag}_ab_x3_persist.txt 2>/dev/null
 python tools/ab_dual.py x3_persist off on > $O/${tag}_ab_dual_persist.txt 2>/dev/null
 python tools/bench_boundary.py > $O/${tag}_bench_boundary.json 2>/dev/null
