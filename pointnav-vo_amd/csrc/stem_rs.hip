@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int WV = decltype(wv_c)::value;
     constexpr int NROWS = WV == 3 ? 0 : 7;                  // patch rows WV, WV + 3, ... of the granule fetch (wave 3 has a tap more)
     constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
+    constexpr int NTL = 1;                                  // N-tiles (32 output channels each)
     constexpr int NT = WV == 3 ? 13 : 12;                   // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3)
     auto tap_of = [](int i) constexpr { return i < 12 ? WV + 4 * i : 48; };
     auto tap_off = [](int t) constexpr { return (t / 7) * ROW + ((t % 7) & 1) * PAR + ((t % 7) >> 1) * PITCH; };
@@ -458,12 +459,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float *dst = p.stats[0] + (((long)e_n * p.slots + e_slot) * p.stats_cstride + p.y_coff[0]) * 2;   // wave-uniform
       *reinterpret_cast<f32x2 *>(dst + 2 * lc) = f32x2{a1s, a2s};   // (both halves of the wave: the same two words)
     };
+    // ---- raw-output form (!POOL): the K-split sum is taken in the serial section behind the K loop (the exchange buffer is free
+    // again before the next K loop starts); the pieces store the pixels — buffer stores, an out-of-range offset for pixels outside
+    // the output — and add up the GroupNorm partial sums.
+    constexpr int ESZ = 4;                                  // bytes per output element
+    f32x16 totv[NTL];
+    float es1[NTL], es2[NTL];
+    __amdgpu_buffer_rsrc_t r_y[NTL];
+    unsigned e_yoff = 0u;                                   // pixel (row 2 WV, column 4 rr16) of the tile, channel lc: byte offset in the sample
+    auto out_begin = [&]() PNVO_INL {
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) {
+        const long plane = (long)p.Ho * p.Wo * p.y_cstride * ESZ;
+        r_y[nt] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.y[nt]) + (long)e_n * plane + (long)p.y_coff[nt] * ESZ, 0,
+                                                    (unsigned)plane, 0x00020000);
+        es1[nt] = 0.f;
+        es2[nt] = 0.f;
+      }
+      e_yoff = (unsigned)((((e_ho0 + 2 * WV) * p.Wo + e_wo0 + 4 * rr16v) * p.y_cstride + lc) * ESZ);
+    };
+    auto XS = [&](int nt, int rq) PNVO_INL {                // accumulator quad rq: four pixels of row 2 WV + (rq >> 1)
+      const bool rowok = (int)e_valid & (int)(e_ho0 + 2 * WV + (rq >> 1) < p.Ho);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int colc = e + 8 * (rq & 1);
+        const bool ok = (int)rowok & (int)(colc < colv);
+        const float v = ok ? totv[nt][4 * rq + e] : 0.f;
+        const unsigned off = e_yoff + (unsigned)(((rq >> 1) * p.Wo + colc) * p.y_cstride * ESZ);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_y[nt], ok ? off : OOB, 0, 0);
+        es1[nt] += v;
+        es2[nt] = __builtin_fmaf(v, v, es2[nt]);
+      }
+    };
+    auto XCn = [&](int nt) PNVO_INL {
+      const float a = es1[nt] + __shfl_xor(es1[nt], 32), b = es2[nt] + __shfl_xor(es2[nt], 32);
+      *reinterpret_cast<f32x2 *>(&red[((WV * NTL + nt) * 32 + lc) * 2]) = f32x2{a, b};   // (both halves of the wave: the same words)
+    };
+    f32x2 rsn[NTL][4];
+    auto PSnl = [&](int nt) PNVO_INL {
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) rsn[nt][w4] = *reinterpret_cast<const f32x2 *>(&red[((w4 * NTL + nt) * 32 + lc) * 2]);
+    };
+    auto PSns = [&](int nt) PNVO_INL {
+      float a1s = 0.f, a2s = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        a1s += rsn[nt][w4][0];
+        a2s += rsn[nt][w4][1];
+      }
+      float *dst = p.stats[nt] + (((long)e_n * p.slots + e_slot) * p.stats_cstride + p.y_coff[nt]) * 2;   // wave-uniform
+      *reinterpret_cast<f32x2 *>(dst + 2 * lc) = f32x2{a1s, a2s};
+    };
     // which piece runs in which region of the next tile's K loop (tap i, region rg: 0 and 2 carry only fragment reads of their
     // own, 3 the granule stores, 4 the pixel stores of taps 3, 5, 7).  Taps 0-2: the exchange is read before the barrier behind
     // tap 2 — from tap 3 on the stager overwrites that buffer.
     auto epi = [&](int i, int rg) PNVO_INL {
-      if (!POOL || (PNVO_RS_ABL & 4)) return;
+      if (PNVO_RS_ABL & 4) return;
       const int k = 5 * i + rg;
+      if (!POOL) {
+        if (k == 0) { epi_begin(); out_begin(); }
+        if (k == 2) XS(0, 0);
+        if (k == 3) XS(0, 1);
+        if (k == 4) XS(0, 2);
+        if (k == 5) XS(0, 3);
+        if (k == 7) XCn(0);
+        if (k == 15 && WV == 1) PSnl(0);
+        if (k == 17 && WV == 1) PSns(0);
+        return;
+      }
       if (k == 0) epi_begin();
       if ((PNVO_RS_ABL & 8) && k < 15) return;            // (ablation: no exchange sum / scratch pieces)
       if ((PNVO_RS_ABL & 16) && k >= 15) return;          // (ablation: no pooling / key pieces)
@@ -493,6 +556,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto epi_serial = [&]() PNVO_INL {                      // the same pieces one after the other (after the last tile)
       epi_begin();
+      if (!POOL) {
+        out_begin();
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) XS(nt, rq);
+          XCn(nt);
+        }
+        ebar();
+        if (WV == 1) {
+#pragma unroll
+          for (int nt = 0; nt < NTL; ++nt) {
+            PSnl(nt);
+            PSns(nt);
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         XAl(rq);
@@ -613,7 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         epi(i, 4);
         mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
         region_end();
-        if (POOL && i == 2 && !(PNVO_RS_ABL & 32)) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
+        if (i == 2 && !(PNVO_RS_ABL & 32)) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
       });
       const unsigned long long t1 = now();
       __syncthreads();                                      // every wave has left patch(it)
@@ -634,104 +715,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         e_slot = ty * p.tiles_x + tx;
         e_valid = true;
       } else {
-      // ---------------------------------------------------------- K-split exchange through the buffer just consumed (fixed order)
+        // raw-output form: exchange and K-split sum here (fixed order), stores and partial sums ride in the next tile's K loop
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int nt = 0; nt < NTL; ++nt) {
+          if (nt > 0) __syncthreads();                      // the previous N-tile's partials have been read
 #pragma unroll
-          for (int rq = 0; rq < 4; ++rq)
-            *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
-                f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
-        __syncthreads();                                      // exchange(it) complete; patch(it + 1) complete
-        f32x16 tot;
+          for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+            for (int rq = 0; rq < 4; ++rq)
+              *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
+                  f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+          __syncthreads();                                  // exchange(it) complete; patch(it + 1) complete
 #pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((WV * 4 + s4) * 4 + rq) * 64 + lane) * 16);
+          for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tot[4 * rq + e] = s4 == 0 ? tq[e] : tot[4 * rq + e] + tq[e];
-          }
+            for (int rq = 0; rq < 4; ++rq) {
+              const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((WV * 4 + s4) * 4 + rq) * 64 + lane) * 16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot[r] *= oscale;        // undo the weights' power-of-two scale (exact)
-
-        // ---------------------------------------------------------- epilogue of M-tile WV (rows 2 WV, 2 WV + 1 of the tile)
-        const int ho0 = ty * TH, wo0 = tx * TW;
-        const int rr16v = (int)opaque((unsigned)rr16), lc = (int)opaque((unsigned)(lane & 31));   // (no hoisted per-pixel addresses)
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * rr16v;
-          const int row = 2 * WV + (i >> 4), col = i & 15;
-          const bool ok = (int)(ho0 + row < p.Ho) & (int)(wo0 + col < p.Wo);
-          const float v = ok ? tot[r] : 0.f;
-          if (POOL) {
-            pb[(row * 16 + col) * 33 + lc] = ok ? sgn * tot[r] : -__builtin_inff();
-          } else if (ok) {
-            reinterpret_cast<float *>(p.y[0])[(((long)n * p.Ho + ho0 + row) * p.Wo + wo0 + col) * p.y_cstride + co] = v;
-          }
-          s1 += v;
-          s2 = __builtin_fmaf(v, v, s2);
-        }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lane < 32) {
-          red[(WV * 32 + lane) * 2] = s1;
-          red[(WV * 32 + lane) * 2 + 1] = s2;
-        }
-        __syncthreads();                                      // pooling scratch and partial sums complete
-        if (POOL) {
-          // MaxPool2d(3, 2, 1) on order-preserving integer keys of sgn(gamma) * x (see stem_mx_kernel): plain stores for windows
-          // inside the tile, integer atomic max for windows shared with a neighbour
-          const int ch = lc, pj = 2 * WV + rr16v;               // (= tid >> 5)
-          const int Ib = ho0 >> 1, Jb = wo0 >> 1;
-          int *const pool0 = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0] + ch;
-          auto emit = [&](int I, int J, float mx, bool inside) PNVO_INL {
-            if (I >= p.Hp || J >= p.Wp) return;
-            int key = __builtin_bit_cast(int, mx);
-            key = key >= 0 ? key : key ^ 0x7fffffff;
-            int *dst = pool0 + (I * p.Wp + J) * p.y_cstride;
-            if (inside)
-              *dst = key;
-            else
-              atomicMax(dst, key);
-          };
-          {
-            const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;
-            float cm[8];
-#pragma unroll
-            for (int lr = 0; lr < 8; ++lr)
-              cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
-            const bool colin = pj >= 1 || wo0 == 0;
-            emit(Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
-            emit(Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
-            emit(Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
-            emit(Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
-            emit(Ib + 4, Jb + pj, cm[7], false);
-          }
-          if (pj < 5) {                                       // ninth pooled column: tile column 15, always shared with the right tile
-            const int pi = pj;
-            float mx = -__builtin_inff();
-#pragma unroll
-            for (int dr = -1; dr <= 1; ++dr) {
-              const int lr = 2 * pi + dr;
-              if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
+              for (int e = 0; e < 4; ++e) totv[nt][4 * rq + e] = s4 == 0 ? tq[e] : totv[nt][4 * rq + e] + tq[e];
             }
-            emit(Ib + pi, Jb + 8, mx, false);
-          }
-        }
-        if (WV == 3 && lane >= 32) {                          // GroupNorm partial sums of the tile, wave order (as stem_mx_kernel)
-          const int c = lc;
-          float a1s = 0.f, a2s = 0.f;
 #pragma unroll
-          for (int w4 = 0; w4 < 4; ++w4) {
-            a1s += red[(w4 * 32 + c) * 2];
-            a2s += red[(w4 * 32 + c) * 2 + 1];
-          }
-          const int slot = ty * p.tiles_x + tx;
-          float *dst = p.stats[0] + (((long)n * p.slots + slot) * p.stats_cstride + p.y_coff[0] + c) * 2;
-          dst[0] = a1s;
-          dst[1] = a2s;
+          for (int r = 0; r < 16; ++r) totv[nt][r] *= oscale;   // undo the weights' power-of-two scale (exact)
         }
+        e_n = n;
+        e_ho0 = ty * TH;
+        e_wo0 = tx * TW;
+        e_slot = ty * p.tiles_x + tx;
+        e_valid = true;
       }
       c_n = st_n;
       c_ty = st_ty;
@@ -742,10 +752,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         pc[2] += now() - t2;                                // exchange (+ the serial epilogue of the raw-output form)
       }
     }
-    if (POOL) {
-      ebuf = (unsigned)((nit - 1) & 1) * RS_BUF;
-      epi_serial();
-    }
+    ebuf = (unsigned)((nit - 1) & 1) * RS_BUF;
+    epi_serial();
   };
   switch (wave) {
     case 0: body(std::integral_constant<int, 0>{}); break;
