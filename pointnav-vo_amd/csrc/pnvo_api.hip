@@ -807,7 +807,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       m->mx_prof_ps = ps || rs;
       m->mx_prof_rs = rs;
       if (rs)
-        HIPCHK(m, launch_stem_rs(a, m->num_cus, s));
+        HIPCHK(m, launch_stem_rs(a, pieces, m->num_cus, s));
       else if (ps)
         HIPCHK(m, launch_stem_ps(a, m->num_cus, m->opt.stem_lwaves == 4 ? 4 : 8, s));
       else

@@ -28,8 +28,8 @@ namespace pnvo {
 namespace {
 constexpr int RS_BUF = XCHG_BYTES;                          // 65536 >= PATCH_BYTES
 constexpr int RS_PB_OFF = 2 * RS_BUF;                       // pooling scratch [8][16][33] floats
-constexpr int RS_RED_OFF = RS_PB_OFF + 8 * 16 * 33 * 4;     // [4 waves][32][2] floats
-constexpr int RS_ETAB_OFF = RS_RED_OFF + 4 * 32 * 2 * 4;    // RAW: bin edges (12 floats)
+constexpr int RS_RED_OFF = RS_PB_OFF + 8 * 16 * 33 * 4;     // [4 waves][N-tiles <= 2][32][2] floats
+constexpr int RS_ETAB_OFF = RS_RED_OFF + 4 * 2 * 32 * 2 * 4;   // RAW: bin edges (12 floats)
 constexpr int RS_TRASH_OFF = RS_ETAB_OFF + 64;              // target of the writes of absent lanes
 constexpr int RS_LDS = RS_TRASH_OFF + 64;
 static_assert(RS_BUF >= PATCH_BYTES, "patch must fit its buffer");
@@ -62,9 +62,15 @@ __device__ __forceinline__ void static_for(F &&f) {
 #endif
 }  // namespace
 
-template <bool POOL, bool RAW>
+// PIECES = 2: float32-grade results from two float16 weight pieces, one N-tile of 32 channels, float32 output (pooled keys or raw).
+// PIECES = 1: the bf16 dual stem (stem_mx_kernel<1, 2, true>): one bf16 weight piece, TWO N-tiles (two models' 32 channels), bf16
+//             raw output; 192 fragment registers + 128 accumulator registers per wave, four regions of four MFMAs per tap.
+template <int PIECES, bool POOL, bool RAW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void stem_rs_kernel(const StemMXArgs p) {
-  constexpr int NFT = 5;
+  static_assert(PIECES == 2 || (PIECES == 1 && !POOL), "float16 pieces, or the bf16 dual stem with raw output");
+  constexpr bool H = PIECES == 2;                           // float16 pieces (else bf16)
+  constexpr int NTL = H ? 1 : 2;                            // N-tiles (32 output channels each)
+  constexpr int NFT = H ? 5 : 4;                            // B fragments per tap
   constexpr int LAGP = PNVO_RS_LAGP, LAGD = PNVO_RS_LAGD;                         // taps between the loads of a staging piece (pixels / granules) and its LDS writes
   constexpr int GROW = PW * 5;                              // 16-byte granules of one-hot depth per patch row (185)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -194,19 +200,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // part 1: the rgb K-slots (kept in registers), part 2: depth, top-down view, indicator, remainders and the LDS writes; 0: both
   // (two halves of about twenty instructions: a whole pixel round overflows a scheduling region of four MFMAs)
   unsigned wrgb[3] = {0u, 0u, 0u};
+  constexpr float RGBS = H ? 0.00390625f : 1.f;             // float16: rgb * 2^-8 here, 2^8 in the packed weights (exact)
+  constexpr unsigned ONE2 = H ? 0x3c003c00u : 0x3f803f80u;  // 1.0 twice in float16 / bf16 (the indicator's two slots)
+  constexpr unsigned short ONE1 = H ? 0x3c00 : 0x3f80;
   auto store_px = [&](int r, unsigned buf, bool exists, int part) PNVO_INL {
     if (part != 2) {
       if (RAW) {
         const unsigned x0 = (pflag[r] & 2u) ? rgbw[r][0] >> 8 : rgbw[r][0], x1 = rgbw[r][1] >> 8;
         const float pr = (float)(x0 & 0xffu), pg = (float)((x0 >> 8) & 0xffu), pbl = (float)((x0 >> 16) & 0xffu);
         const float cr = (float)(x1 & 0xffu), cg = (float)((x1 >> 8) & 0xffu), cb = (float)((x1 >> 16) & 0xffu);
-        wrgb[0] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
-        wrgb[1] = pack_f16(pbl * 0.00390625f, cr * 0.00390625f);
-        wrgb[2] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
+        wrgb[0] = pack_pair<H>(pr * RGBS, pg * RGBS);
+        wrgb[1] = pack_pair<H>(pbl * RGBS, cr * RGBS);
+        wrgb[2] = pack_pair<H>(cg * RGBS, cb * RGBS);
       } else {
-        wrgb[0] = pack_f16(vr4[r][0] * 0.00390625f, vr4[r][1] * 0.00390625f);
-        wrgb[1] = pack_f16(vr4[r][2] * 0.00390625f, vr4[r][3] * 0.00390625f);
-        wrgb[2] = pack_f16(vr2[r][0] * 0.00390625f, vr2[r][1] * 0.00390625f);
+        wrgb[0] = pack_pair<H>(vr4[r][0] * RGBS, vr4[r][1] * RGBS);
+        wrgb[1] = pack_pair<H>(vr4[r][2] * RGBS, vr4[r][3] * RGBS);
+        wrgb[2] = pack_pair<H>(vr2[r][0] * RGBS, vr2[r][1] * RGBS);
         const float f0 = vr4[r][0], f1 = vr4[r][1], f2 = vr4[r][2], f3 = vr4[r][3], f4 = vr2[r][0], f5 = vr2[r][1];
         lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
         lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       d0 = vd[r][0];
       d1 = vd[r][1];
     }
-    const unsigned w13 = pack_f16(d0, d1), w14 = pack_f16(vt[r][0], vt[r][1]), w15 = in ? 0x3c003c00u : 0u;
+    const unsigned w13 = pack_pair<H>(d0, d1), w14 = pack_pair<H>(vt[r][0], vt[r][1]), w15 = in ? ONE2 : 0u;
     const unsigned base = buf + (opaque(pmeta[r]) & 0xffffu);
     constexpr unsigned TR = (unsigned)RS_TRASH_OFF;
     if (RAW) {
@@ -245,16 +254,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<u32x4 *>(lds + (exists ? base + 32u : TR)) = u32x4{0u, 0u, wrgb[0], wrgb[1]};
       *reinterpret_cast<u32x4 *>(lds + (exists ? base + 48u : TR)) = u32x4{wrgb[2], w13, w14, w15};
       const bool dd = (p.raw_flags & 2) != 0 && in && exists;
-      *reinterpret_cast<unsigned short *>(lds + ((dd && bok[0]) ? base + 2u * (unsigned)bidx[0] : TR)) = (unsigned short)0x3c00;
-      *reinterpret_cast<unsigned short *>(lds + ((dd && bok[1]) ? base + 20u + 2u * (unsigned)bidx[1] : TR)) = (unsigned short)0x3c00;
+      *reinterpret_cast<unsigned short *>(lds + ((dd && bok[0]) ? base + 2u * (unsigned)bidx[0] : TR)) = ONE1;
+      *reinterpret_cast<unsigned short *>(lds + ((dd && bok[1]) ? base + 20u + 2u * (unsigned)bidx[1] : TR)) = ONE1;
     } else {                                                 // K-slots 20..31 (rgb, depth, top-down view, indicator): bytes 40..63
       *reinterpret_cast<u32x2 *>(lds + (exists ? base + 40u : TR)) = u32x2{wrgb[0], wrgb[1]};
       *reinterpret_cast<u32x4 *>(lds + (exists ? base + 48u : TR)) = u32x4{wrgb[2], w13, w14, w15};
     }
-    const f16x2 hd = __builtin_bit_cast(f16x2, w13), ht = __builtin_bit_cast(f16x2, w14);
-    const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
-    const unsigned mt = pack_f16(vt[r][0] - (float)ht[0], vt[r][1] - (float)ht[1]);
-    *reinterpret_cast<u32x4 *>(lds + (exists ? base + 64u : TR)) = u32x4{md, mt, 0u, 0u};
+    if (H) {                                                 // float-valued channels: x = x0 + x1 to 22 bits
+      const f16x2 hd = __builtin_bit_cast(f16x2, w13), ht = __builtin_bit_cast(f16x2, w14);
+      const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
+      const unsigned mt = pack_f16(vt[r][0] - (float)ht[0], vt[r][1] - (float)ht[1]);
+      *reinterpret_cast<u32x4 *>(lds + (exists ? base + 64u : TR)) = u32x4{md, mt, 0u, 0u};
+    }
   };
   // Granules of the one-hot depth, patch row `row` (compile-time), sub-round sr.  Per tile and sub-round: the vector offset of the
   // lane's granule in patch row 0 (or OOB for a column outside the image / a lane past the row's 185 granules) and its LDS address
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const f32x4 v = gdd[slot];
     lowbits |= __builtin_bit_cast(unsigned, v[0]) | __builtin_bit_cast(unsigned, v[1]);
     lowbits |= __builtin_bit_cast(unsigned, v[2]) | __builtin_bit_cast(unsigned, v[3]);
-    *reinterpret_cast<u32x2 *>(lds + ddl[sr] + row * ROW) = u32x2{pack_f16(v[0], v[1]), pack_f16(v[2], v[3])};
+    *reinterpret_cast<u32x2 *>(lds + ddl[sr] + row * ROW) = u32x2{pack_pair<H>(v[0], v[1]), pack_pair<H>(v[2], v[3])};
   };
 
   // lane geometry of the A fragments and of the epilogue
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned baseA0 = (unsigned)(2 * arr * ROW + ac * PITCH + ah * 16);
   const unsigned baseX0 = (unsigned)(2 * arr * ROW + ac * PITCH + 64);
   const int rr16 = lane >> 5;
-  const float oscale = p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
+  const float oscale = !H ? 1.f : p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
   const int co = p.y_coff[0] + (lane & 31);
   const float sgn = POOL ? (p.pool_gamma[co] < 0.f ? -1.f : 1.f) : 1.f;
 
@@ -299,7 +310,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int WV = decltype(wv_c)::value;
     constexpr int NROWS = WV == 3 ? 0 : 7;                  // patch rows WV, WV + 3, ... of the granule fetch (wave 3 has a tap more)
     constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
-    constexpr int NTL = 1;                                  // N-tiles (32 output channels each)
     constexpr int NT = WV == 3 ? 13 : 12;                   // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3)
     auto tap_of = [](int i) constexpr { return i < 12 ? WV + 4 * i : 48; };
     auto tap_off = [](int t) constexpr { return (t / 7) * ROW + ((t % 7) & 1) * PAR + ((t % 7) >> 1) * PITCH; };
@@ -323,24 +333,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- the resident B operand (fetched AFTER the first patch is staged: the all-at-once prologue needs ~150 registers of its
     // own).  The fifth fragment of a tap — w0 of the four float-valued channels against the remainders — has only its first 8
     // bytes per lane non-zero by construction (pack_stem_mx_weight_h): two registers instead of four.
-    u32x4 bres[NT][4];
-    u32x2 bxr[NT];
+    u32x4 bres[NT][4];                                      // float16: (w0, w1) x (chunk 0, 1); bf16: (chunk 0, 1) x (N-tile 0, 1)
+    u32x2 bxr[H ? NT : 1];
     {
       const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wpk) + lane;
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) bres[i][f] = wp[(tap_of(i) * NFT + f) * 64];
-        bxr[i] = *reinterpret_cast<const u32x2 *>(wp + (tap_of(i) * NFT + 4) * 64);
+        if (H) bxr[i] = *reinterpret_cast<const u32x2 *>(wp + (tap_of(i) * NFT + 4) * 64);
       }
       // Register classes: a wave's 512 registers are 256 VGPRs + 256 AGPRs, and only matrix instructions, loads and stores reach
       // the second half.  Pinned there, a fragment is read by its MFMAs in place; left to the allocator it is parked there and
       // copied back (four v_accvgpr_read per fragment and tap, ~240 issue slots per tile).  Accumulators (64) + PNVO_RS_NPIN taps fit.
+      constexpr int NPIN = H ? PNVO_RS_NPIN : 7;              // (bf16 dual stem: 128 accumulator registers leave room for seven taps)
 #pragma unroll
-      for (int i = 0; i < (NT < PNVO_RS_NPIN ? NT : PNVO_RS_NPIN); ++i) {
+      for (int i = 0; i < (NT < NPIN ? NT : NPIN); ++i) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) asm volatile("" : "+a"(bres[i][f]));
-        asm volatile("" : "+a"(bxr[i]));
+        if (H) asm volatile("" : "+a"(bxr[i]));
       }
     }
 
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- raw-output form (!POOL): the K-split sum is taken in the serial section behind the K loop (the exchange buffer is free
     // again before the next K loop starts); the pieces store the pixels — buffer stores, an out-of-range offset for pixels outside
     // the output — and add up the GroupNorm partial sums.
-    constexpr int ESZ = 4;                                  // bytes per output element
+    constexpr int ESZ = H ? 4 : 2;                          // bytes per output element (float32 / bf16)
     f32x16 totv[NTL];
     float es1[NTL], es2[NTL];
     __amdgpu_buffer_rsrc_t r_y[NTL];
@@ -486,7 +497,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool ok = (int)rowok & (int)(colc < colv);
         const float v = ok ? totv[nt][4 * rq + e] : 0.f;
         const unsigned off = e_yoff + (unsigned)(((rq >> 1) * p.Wo + colc) * p.y_cstride * ESZ);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_y[nt], ok ? off : OOB, 0, 0);
+        if (H)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_y[nt], ok ? off : OOB, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), r_y[nt], ok ? off : OOB, 0, 0);
         es1[nt] += v;
         es2[nt] = __builtin_fmaf(v, v, es2[nt]);
       }
@@ -516,6 +530,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto epi = [&](int i, int rg) PNVO_INL {
       if (PNVO_RS_ABL & 4) return;
       const int k = 5 * i + rg;
+      if (!H) {                                             // four regions per tap: k = 4 i + rg (rg 1 carries the loads)
+        const int k4 = 4 * i + rg;
+        if (k4 == 0) { epi_begin(); out_begin(); }
+        if (k4 == 2) XS(0, 0);
+        if (k4 == 3) XS(0, 1);
+        if (k4 == 4) XS(0, 2);
+        if (k4 == 6) XS(0, 3);
+        if (k4 == 7) XS(1, 0);
+        if (k4 == 8) XS(1, 1);
+        if (k4 == 10) XS(1, 2);
+        if (k4 == 11) XS(1, 3);
+        if (k4 == 12) { XCn(0); XCn(1); }
+        if (k4 == 16 && WV == 1) PSnl(0);
+        if (k4 == 16 && WV == 2) PSnl(1);
+        if (k4 == 18 && WV == 1) PSns(0);
+        if (k4 == 18 && WV == 2) PSns(1);
+        return;
+      }
       if (!POOL) {
         if (k == 0) { epi_begin(); out_begin(); }
         if (k == 2) XS(0, 0);
@@ -566,11 +598,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         ebar();
         if (WV == 1) {
-#pragma unroll
-          for (int nt = 0; nt < NTL; ++nt) {
-            PSnl(nt);
-            PSns(nt);
-          }
+          PSnl(0);
+          PSns(0);
+        }
+        if (NTL > 1 && WV == 2) {
+          PSnl(NTL - 1);
+          PSns(NTL - 1);
         }
         return;
       }
@@ -616,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const unsigned long long t0 = now();
 
       // ---------------------------------------------------------- K loop of tile it, staging of the next tile between its MFMAs
-      f32x16 acc[4];                                        // (never zeroed: the first MFMA of a tile takes the constant 0 as its C operand)
+      f32x16 acc[NTL][4];                                   // (never zeroed: the first MFMA of a tile takes the constant 0 as its C operand)
       // (opaque: hoisted out of the tile loop, the two buffers' bases would be separate live registers)
       const unsigned baseA = opaque(baseA0 + buf), baseX = opaque(baseX0 + buf);
       // A fragments: chunk 0 of a tap is fetched during the previous tap (two register sets in turn), chunk 1 and the remainders
@@ -639,62 +672,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      auto mfma4 = [&](const u32x4 *aq, const u32x4 bq, bool first = false) PNVO_INL {
+      auto mfma4 = [&](const u32x4 *aq, const u32x4 bq, bool first = false, int nt = 0) PNVO_INL {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, bq),
-                                                          first ? zero : acc[m], 0, 0, 0);
+          acc[nt][m] = H ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, bq),
+                                                                  first ? zero : acc[nt][m], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m]), __builtin_bit_cast(bf16x8, bq),
+                                                                   first ? zero : acc[nt][m], 0, 0, 0);
       };
       __builtin_amdgcn_sched_barrier(0);
       static_for<NT>([&](auto ic) PNVO_INL {
         constexpr int i = decltype(ic)::value;
         const bool st = !(PNVO_RS_ABL & 2), sd = !RAW && !(PNVO_RS_ABL & 1);
-        // the MFMA order of stem_mx_kernel: chunk 0 x {w0, w1}, chunk 1 x {w0, w1}, remainders x w0; M-tiles innermost
-        // -- region 0: chunk 0 x w0 | this tap's chunk-1 and remainder fragments
+        if (H) {
+          // the MFMA order of stem_mx_kernel: chunk 0 x {w0, w1}, chunk 1 x {w0, w1}, remainders x w0; M-tiles innermost
+          // -- region 0: chunk 0 x w0 | this tap's chunk-1 and remainder fragments
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
-          ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
-        }
-        epi(i, 0);
-        mfma4(a0[i & 1], bres[i][0], i == 0);
-        region_end();
-        // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
-        if (sd) {
+          for (int m = 0; m < 4; ++m) {
+            a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
+            ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
+          }
+          epi(i, 0);
+          mfma4(a0[i & 1], bres[i][0], i == 0);
+          region_end();
+          // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
+          if (sd) {
 #pragma unroll
-          for (int q = 3 * i; q < 3 * i + 3; ++q)
-            if (q < RD) load_dd(q, WV + 3 * (q / 3), q % 3);
-        }
-        if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
-        if (st && WV == 0 && i == 8) load_px(3, haslast);
-        mfma4(a0[i & 1], bres[i][2]);
-        region_end();
-        // -- region 2: chunk 1 x w0 | the next tap's chunk-0 fragments
-        if (i + 1 < NT) {
+            for (int q = 3 * i; q < 3 * i + 3; ++q)
+              if (q < RD) load_dd(q, WV + 3 * (q / 3), q % 3);
+          }
+          if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
+          if (st && WV == 0 && i == 8) load_px(3, haslast);
+          mfma4(a0[i & 1], bres[i][2]);
+          region_end();
+          // -- region 2: chunk 1 x w0 | the next tap's chunk-0 fragments
+          if (i + 1 < NT) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
-        }
-        epi(i, 2);
-        mfma4(a1, bres[i][1]);
-        region_end();
-        // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
-        if (sd && i >= LAGD) {
+            for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
+          }
+          epi(i, 2);
+          mfma4(a1, bres[i][1]);
+          region_end();
+          // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
+          if (sd && i >= LAGD) {
 #pragma unroll
-          for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
-            if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
+            for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
+              if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
+          }
+          if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
+          epi(i, 3);
+          mfma4(a1, bres[i][3]);
+          region_end();
+          // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
+          if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
+          if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
+          epi(i, 4);
+          mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
+          region_end();
+        } else {
+          // bf16 dual stem — the MFMA order of stem_mx_kernel<1, 2>: chunk 0 x {N-tile 0, 1}, chunk 1 x {N-tile 0, 1}; M-tiles innermost
+          // -- region 0: chunk 0, N-tile 0 | this tap's chunk-1 fragments
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
+          epi(i, 0);
+          mfma4(a0[i & 1], bres[i][0], i == 0, 0);
+          region_end();
+          // -- region 1: chunk 0, N-tile 1 | loads of the next patch
+          if (sd) {
+#pragma unroll
+            for (int q = 3 * i; q < 3 * i + 3; ++q)
+              if (q < RD) load_dd(q, WV + 3 * (q / 3), q % 3);
+          }
+          if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
+          if (st && WV == 0 && i == 8) load_px(3, haslast);
+          mfma4(a0[i & 1], bres[i][1], i == 0, 1);
+          region_end();
+          // -- region 2: chunk 1, N-tile 0 | the next tap's chunk-0 fragments, second half of a pixel round's store
+          if (i + 1 < NT) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
+          }
+          if (st && i >= LAGP + 1 && (i - LAGP - 1) % 2 == 0 && i - LAGP - 1 < 6) store_px((i - LAGP - 1) / 2, obuf, true, 2);
+          if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
+          epi(i, 2);
+          mfma4(a1, bres[i][2], false, 0);
+          region_end();
+          // -- region 3: chunk 1, N-tile 1 | granule stores, first half of a pixel round's store
+          if (sd && i >= LAGD) {
+#pragma unroll
+            for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
+              if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
+          }
+          if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
+          epi(i, 3);
+          mfma4(a1, bres[i][3], false, 1);
+          region_end();
         }
-        if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
-        epi(i, 3);
-        mfma4(a1, bres[i][3]);
-        region_end();
-        // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
-        if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
-        if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
-        epi(i, 4);
-        mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
-        region_end();
-        if (i == 2 && !(PNVO_RS_ABL & 32)) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
+        if (i == (H ? 2 : 3) && !(PNVO_RS_ABL & 32)) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
       });
       const unsigned long long t1 = now();
       __syncthreads();                                      // every wave has left patch(it)
@@ -707,7 +782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq)
             *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
-                f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+                f32x4{acc[0][m][4 * rq], acc[0][m][4 * rq + 1], acc[0][m][4 * rq + 2], acc[0][m][4 * rq + 3]};
         __syncthreads();                                    // exchange(it) complete; patch(it + 1) complete
         e_n = n;
         e_ho0 = ty * TH;
@@ -724,7 +799,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
               *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + WV) * 4 + rq) * 64 + lane) * 16) =
-                  f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
+                  f32x4{acc[nt][m][4 * rq], acc[nt][m][4 * rq + 1], acc[nt][m][4 * rq + 2], acc[nt][m][4 * rq + 3]};
           __syncthreads();                                  // exchange(it) complete; patch(it + 1) complete
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4)
@@ -734,8 +809,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
               for (int e = 0; e < 4; ++e) totv[nt][4 * rq + e] = s4 == 0 ? tq[e] : totv[nt][4 * rq + e] + tq[e];
             }
+          if (H) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) totv[nt][r] *= oscale;   // undo the weights' power-of-two scale (exact)
+            for (int r = 0; r < 16; ++r) totv[nt][r] *= oscale;   // undo the weights' power-of-two scale (exact)
+          }
         }
         e_n = n;
         e_ho0 = ty * TH;
@@ -761,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     case 2: body(std::integral_constant<int, 2>{}); break;
     default: body(std::integral_constant<int, 3>{}); break;
   }
-  if (!RAW && (lowbits & 0x1fffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
+  if (H && !RAW && (lowbits & 0x1fffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
   if (RAW && bad_depth != 0u && p.raw_err != nullptr) *p.raw_err = 1;
   if (prof && lane == 0 && (blockIdx.x % 16) == 0) {
     unsigned long long *q = p.prof + 16 * wave;
@@ -771,23 +848,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
-// Takes the launch when the tiles keep every workgroup busy for many rounds (the resident fragments cost ~one tile-time to load).
+// Takes the launch when the tiles keep every workgroup busy for many rounds (the resident fragments cost ~one tile-time to load):
+// the float16-piece stem with one N-tile and float32 output, or the bf16 dual stem (one piece, two N-tiles, bf16 raw output).
 bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs) {
   const long ntiles = (long)a.B * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
-  return pieces == 2 && ntiles_n == 1 && !bf16_out && wgs >= 8 && ntiles >= 8L * wgs;
+  const bool f16 = pieces == 2 && ntiles_n == 1 && !bf16_out, dual = pieces == 1 && ntiles_n == 2 && bf16_out && a.pool == nullptr;
+  return (f16 || dual) && wgs >= 8 && ntiles >= 8L * wgs;
 }
 
-hipError_t launch_stem_rs(const StemMXArgs &a, int wgs, hipStream_t s) {
+hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, int wgs, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipSuccess;
     auto set = [&](const void *f) {
       if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     };
-    set(reinterpret_cast<const void *>(stem_rs_kernel<true, true>));
-    set(reinterpret_cast<const void *>(stem_rs_kernel<true, false>));
-    set(reinterpret_cast<const void *>(stem_rs_kernel<false, true>));
-    set(reinterpret_cast<const void *>(stem_rs_kernel<false, false>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, true, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, true, false>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, false, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, false, false>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<1, false, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<1, false, false>));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -796,10 +877,13 @@ hipError_t launch_stem_rs(const StemMXArgs &a, int wgs, hipStream_t s) {
   p.tiles_y = (a.Ho + TH - 1) / TH;
   const unsigned gx = (unsigned)(wgs & ~7);
   const bool raw = p.raw_depth != nullptr, pool = p.pool != nullptr;
-  if (pool && raw) hipLaunchKernelGGL((stem_rs_kernel<true, true>), dim3(gx), dim3(256), RS_LDS, s, p);
-  else if (pool) hipLaunchKernelGGL((stem_rs_kernel<true, false>), dim3(gx), dim3(256), RS_LDS, s, p);
-  else if (raw) hipLaunchKernelGGL((stem_rs_kernel<false, true>), dim3(gx), dim3(256), RS_LDS, s, p);
-  else hipLaunchKernelGGL((stem_rs_kernel<false, false>), dim3(gx), dim3(256), RS_LDS, s, p);
+  if (pieces == 1) {
+    if (raw) hipLaunchKernelGGL((stem_rs_kernel<1, false, true>), dim3(gx), dim3(256), RS_LDS, s, p);
+    else hipLaunchKernelGGL((stem_rs_kernel<1, false, false>), dim3(gx), dim3(256), RS_LDS, s, p);
+  } else if (pool && raw) hipLaunchKernelGGL((stem_rs_kernel<2, true, true>), dim3(gx), dim3(256), RS_LDS, s, p);
+  else if (pool) hipLaunchKernelGGL((stem_rs_kernel<2, true, false>), dim3(gx), dim3(256), RS_LDS, s, p);
+  else if (raw) hipLaunchKernelGGL((stem_rs_kernel<2, false, true>), dim3(gx), dim3(256), RS_LDS, s, p);
+  else hipLaunchKernelGGL((stem_rs_kernel<2, false, false>), dim3(gx), dim3(256), RS_LDS, s, p);
   return hipGetLastError();
 }
 

@@ -101,3 +101,27 @@ def test_resident_weight_stem_on_an_odd_resolution():
     torch.cuda.synchronize()
     assert torch.isfinite(outs["tiles"]).all()
     assert torch.equal(outs["tiles"], outs["resident"])
+
+
+def test_resident_weight_dual_bf16_stem_equals_the_tile_kernel():
+    """configs[2]: the bf16 dual stem (one weight piece, two models' 32 channels) with its 196 KB of fragments resident in registers
+    (stem_rs_kernel<1, ...>) against stem_mx_kernel<1, 2, true>: both models' outputs bit-identical, observation-tensor and
+    sensor-frame entry."""
+    from pointnav_vo_amd import vo_cnn as V
+    ma, _ = bench.build_model(DEV, seed=0)
+    mb, _ = bench.build_model(DEV, seed=1)
+    for m in (ma, mb):
+        m.set_precision("bfloat16")
+    obs = bench.make_inputs(32, DEV, 0)
+    outs = {}
+    for form in ("tiles", "resident", "auto"):
+        for m in (ma, mb):
+            m.set_option("stem_form", form)
+        with torch.no_grad():
+            oa, ob = V.dual_forward(ma, mb, obs)
+        torch.cuda.synchronize()
+        outs[form] = (oa.clone(), ob.clone())
+    assert torch.isfinite(outs["tiles"][0]).all() and torch.isfinite(outs["tiles"][1]).all()
+    for form in ("resident", "auto"):
+        assert torch.equal(outs["tiles"][0], outs[form][0]) and torch.equal(outs["tiles"][1], outs[form][1]), form
+    assert not torch.equal(outs["tiles"][0], outs["tiles"][1])     # (two different models)
