@@ -54,6 +54,18 @@ __device__ __forceinline__ void static_for(F &&f) {
 #ifndef PNVO_RS_LAGP
 #define PNVO_RS_LAGP 3
 #endif
+#ifndef PNVO_RS_GDS
+#define PNVO_RS_GDS 2   // per MFMA of a region: at most this many LDS reads, ...
+#endif
+#ifndef PNVO_RS_GVM
+#define PNVO_RS_GVM 1   // ... vector-memory instructions ...
+#endif
+#ifndef PNVO_RS_GVA
+#define PNVO_RS_GVA 4   // ... and VALU instructions (plus one LDS write)
+#endif
+#ifndef PNVO_RS_A1AHEAD
+#define PNVO_RS_A1AHEAD 0
+#endif
 #ifndef PNVO_RS_NPIN
 #define PNVO_RS_NPIN 10
 #endif
@@ -71,6 +83,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr bool H = PIECES == 2;                           // float16 pieces (else bf16)
   constexpr int NTL = H ? 1 : 2;                            // N-tiles (32 output channels each)
   constexpr int NFT = H ? 5 : 4;                            // B fragments per tap
+  constexpr bool A1AHEAD = H && PNVO_RS_A1AHEAD;            // chunk-1 fragments fetched a tap ahead too
   constexpr int LAGP = PNVO_RS_LAGP, LAGD = PNVO_RS_LAGD;                         // taps between the loads of a staging piece (pixels / granules) and its LDS writes
   constexpr int GROW = PW * 5;                              // 16-byte granules of one-hot depth per patch row (185)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -655,19 +668,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // A fragments: chunk 0 of a tap is fetched during the previous tap (two register sets in turn), chunk 1 and the remainders
       // in the tap's first region, eight MFMAs before their first use — with one wave per SIMD an LDS read waited for right before
       // its MFMA is ~100 idle cycles of the matrix pipe.
-      u32x4 a0[2][4], a1[4], ax[4];
+      u32x4 a0[2][4], a1s[2][4], ax[4];
       auto tofs = [&](int i, int m) constexpr { return tap_off(tap_of(i)) + m * 4 * ROW; };
 #pragma unroll
-      for (int m = 0; m < 4; ++m) a0[0][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(0, m));
+      for (int m = 0; m < 4; ++m) {
+        a0[0][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(0, m));
+        if (A1AHEAD) a1s[0][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(0, m) + 32);
+      }
       // One tap = five scheduling regions of four MFMAs (one B fragment x the four M-tiles), each with its share of the other work
       // in source order; inside a region every MFMA is followed by at most seven other instructions — about what its 32 cycles hide.
       auto region_end = [&]() PNVO_INL {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, PNVO_RS_GDS, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, PNVO_RS_GVM, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, PNVO_RS_GVA, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // -- region 0: chunk 0 x w0 | this tap's chunk-1 and remainder fragments
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
+            if (!A1AHEAD) a1s[i & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
             ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
           }
           epi(i, 0);
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
           }
           epi(i, 2);
-          mfma4(a1, bres[i][1]);
+          mfma4(a1s[i & 1], bres[i][1]);
           region_end();
           // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
           if (sd && i >= LAGD) {
@@ -721,8 +737,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
           }
           if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
+          if (A1AHEAD && i + 1 < NT) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a1s[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m) + 32);
+          }
           epi(i, 3);
-          mfma4(a1, bres[i][3]);
+          mfma4(a1s[i & 1], bres[i][3]);
           region_end();
           // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
           if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
@@ -734,7 +754,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // bf16 dual stem — the MFMA order of stem_mx_kernel<1, 2>: chunk 0 x {N-tile 0, 1}, chunk 1 x {N-tile 0, 1}; M-tiles innermost
           // -- region 0: chunk 0, N-tile 0 | this tap's chunk-1 fragments
 #pragma unroll
-          for (int m = 0; m < 4; ++m) a1[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
+          for (int m = 0; m < 4; ++m) a1s[i & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
           epi(i, 0);
           mfma4(a0[i & 1], bres[i][0], i == 0, 0);
           region_end();
@@ -756,7 +776,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (st && i >= LAGP + 1 && (i - LAGP - 1) % 2 == 0 && i - LAGP - 1 < 6) store_px((i - LAGP - 1) / 2, obuf, true, 2);
           if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
           epi(i, 2);
-          mfma4(a1, bres[i][2], false, 0);
+          mfma4(a1s[i & 1], bres[i][2], false, 0);
           region_end();
           // -- region 3: chunk 1, N-tile 1 | granule stores, first half of a pixel round's store
           if (sd && i >= LAGD) {
@@ -766,7 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
           if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
           epi(i, 3);
-          mfma4(a1, bres[i][3], false, 1);
+          mfma4(a1s[i & 1], bres[i][3], false, 1);
           region_end();
         }
         if (i == (H ? 2 : 3) && !(PNVO_RS_ABL & 32)) ebar();                          // scratch + partial sums of the previous tile complete; its exchange is read
