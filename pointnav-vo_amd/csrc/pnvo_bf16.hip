@@ -228,9 +228,9 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       if (m->opt.bf16_stem3 == 1 && nm == 1) {                 // experiment: exact three-piece stem in front of the bf16 stages
         a.wpk = m->mx_wpk3;
         HIPCHK(m, launch_stem_mx(a, 3, 1, true, s));
-      } else if ((m->opt.stem_form == 0 || m->opt.stem_form == 3) && stem_rs_takes(a, 1, nm, true, m->num_cus)) {
+      } else if ((m->opt.stem_form == 0 || m->opt.stem_form == 3 || m->opt.stem_form == 4) && stem_rs_takes(a, 1, nm, true, m->num_cus)) {
         // two models: the dual stem with its 196 KB of weight fragments resident in registers (stem_rs.hip), bit-identical
-        HIPCHK(m, launch_stem_rs(a, 1, m->num_cus, s));
+        HIPCHK(m, launch_stem_rs(a, 1, false, m->num_cus, s));
       } else {
         HIPCHK(m, launch_stem_mx(a, 1, nm, true, s));
       }

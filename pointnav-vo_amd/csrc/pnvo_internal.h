@@ -122,7 +122,7 @@ hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf
 bool stem_ps_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs);   // persistent role-specialised form
 hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, int l_waves, hipStream_t s);   // l_waves: 4 or 8 epilogue / staging waves
 bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs);   // persistent, weights resident in registers
-hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, int wgs, hipStream_t s);                      //   (stem_rs.hip)
+hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, bool fast, int wgs, hipStream_t s);   // fast: see stem_rs.hip (FAST)                      //   (stem_rs.hip)
 hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
                                    const int *slot_new, const int *xslot, float *scale2, unsigned short *wpk2, hipStream_t s);
 hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,

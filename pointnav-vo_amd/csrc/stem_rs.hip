@@ -77,9 +77,16 @@ __device__ __forceinline__ void static_for(F &&f) {
 // PIECES = 2: float32-grade results from two float16 weight pieces, one N-tile of 32 channels, float32 output (pooled keys or raw).
 // PIECES = 1: the bf16 dual stem (stem_mx_kernel<1, 2, true>): one bf16 weight piece, TWO N-tiles (two models' 32 channels), bf16
 //             raw output; 192 fragment registers + 128 accumulator registers per wave, four regions of four MFMAs per tap.
-template <int PIECES, bool POOL, bool RAW>
+// FAST (float16 pieces only): two changes of the SUMMATION ORDER, so the results are float32-grade equal to the tile kernel's instead of
+//   bit-identical (still deterministic):
+//   - the remainder MFMAs (w0 of the four float-valued channels x the inputs' low float16 halves: 4 of their 16 K-slots used) of FOUR
+//     consecutive taps of a wave share ONE K = 16 chunk — A gathered from the four taps' remainders (two 8-byte LDS reads per lane),
+//     B built once per launch: 12 instead of 48 such MFMAs per wave and tile, 8 instead of 16 fragment reads per four taps;
+//   - tap 48, which the tile kernel gives to wave 3 for all four M-tiles, is split by M-tile: wave w multiplies it for M-tile w
+//     (five MFMAs): every wave issues 209 MFMAs per tile instead of 240 / 240 / 240 / 260.
+template <int PIECES, bool POOL, bool RAW, bool FAST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void stem_rs_kernel(const StemMXArgs p) {
-  static_assert(PIECES == 2 || (PIECES == 1 && !POOL), "float16 pieces, or the bf16 dual stem with raw output");
+  static_assert(PIECES == 2 || (PIECES == 1 && !POOL && !FAST), "float16 pieces, or the bf16 dual stem with raw output");
   constexpr bool H = PIECES == 2;                           // float16 pieces (else bf16)
   constexpr int NTL = H ? 1 : 2;                            // N-tiles (32 output channels each)
   constexpr int NFT = H ? 5 : 4;                            // B fragments per tap
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int WV = decltype(wv_c)::value;
     constexpr int NROWS = WV == 3 ? 0 : 7;                  // patch rows WV, WV + 3, ... of the granule fetch (wave 3 has a tap more)
     constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
-    constexpr int NT = WV == 3 ? 13 : 12;                   // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3)
+    constexpr int NT = (WV == 3 && !FAST) ? 13 : 12;        // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3; FAST: by M-tile)
     auto tap_of = [](int i) constexpr { return i < 12 ? WV + 4 * i : 48; };
     auto tap_off = [](int t) constexpr { return (t / 7) * ROW + ((t % 7) & 1) * PAR + ((t % 7) >> 1) * PITCH; };
 
@@ -347,14 +354,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // own).  The fifth fragment of a tap — w0 of the four float-valued channels against the remainders — has only its first 8
     // bytes per lane non-zero by construction (pack_stem_mx_weight_h): two registers instead of four.
     u32x4 bres[NT][4];                                      // float16: (w0, w1) x (chunk 0, 1); bf16: (chunk 0, 1) x (N-tile 0, 1)
-    u32x2 bxr[H ? NT : 1];
+    u32x2 bxr[(H && !FAST) ? NT : 1];
+    u32x4 bxs[FAST ? 3 : 1], b48[FAST ? 4 : 1];             // FAST: remainder fragments of taps 4 g .. 4 g + 3; tap 48's fragments
+    u32x2 b48x = {0u, 0u};
     {
       const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wpk) + lane;
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) bres[i][f] = wp[(tap_of(i) * NFT + f) * 64];
-        if (H) bxr[i] = *reinterpret_cast<const u32x2 *>(wp + (tap_of(i) * NFT + 4) * 64);
+        if (H && !FAST) bxr[i] = *reinterpret_cast<const u32x2 *>(wp + (tap_of(i) * NFT + 4) * 64);
+      }
+      if (FAST) {
+        // K-slots 0-3 / 4-7 of the shared chunk (lanes 0-31) = the remainder weights of taps 4 g / 4 g + 1, slots 8-11 / 12-15 (lanes
+        // 32-63) = taps 4 g + 2 / 4 g + 3: the first 8 bytes of those taps' fifth fragment at lane (n = lane & 31)
+        const u32x4 *wq = reinterpret_cast<const u32x4 *>(p.wpk) + (lane & 31);
+        const bool kh1 = lane >= 32;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const u32x2 lo = *reinterpret_cast<const u32x2 *>(wq + ((kh1 ? tap_of(4 * g + 2) : tap_of(4 * g)) * NFT + 4) * 64);
+          const u32x2 hi = *reinterpret_cast<const u32x2 *>(wq + ((kh1 ? tap_of(4 * g + 3) : tap_of(4 * g + 1)) * NFT + 4) * 64);
+          bxs[g] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) b48[f] = wp[(48 * NFT + f) * 64];
+        b48x = *reinterpret_cast<const u32x2 *>(wp + (48 * NFT + 4) * 64);
       }
       // Register classes: a wave's 512 registers are 256 VGPRs + 256 AGPRs, and only matrix instructions, loads and stores reach
       // the second half.  Pinned there, a fragment is read by its MFMAs in place; left to the allocator it is parked there and
@@ -364,7 +388,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < (NT < NPIN ? NT : NPIN); ++i) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) asm volatile("" : "+a"(bres[i][f]));
-        if (H) asm volatile("" : "+a"(bxr[i]));
+        if (H && !FAST) asm volatile("" : "+a"(bxr[i]));
+      }
+      if (FAST) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) asm volatile("" : "+a"(bxs[g]));
       }
     }
 
@@ -669,6 +697,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // in the tap's first region, eight MFMAs before their first use — with one wave per SIMD an LDS read waited for right before
       // its MFMA is ~100 idle cycles of the matrix pipe.
       u32x4 a0[2][4], a1s[2][4], ax[4];
+      u32x4 t48[3];                                         // FAST: tap 48's fragments of M-tile WV
+      const bool xkh = lane >= 32;
       auto tofs = [&](int i, int m) constexpr { return tap_off(tap_of(i)) + m * 4 * ROW; };
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -707,7 +737,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             if (!A1AHEAD) a1s[i & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
-            ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
+            if (!FAST) ax[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + tofs(i, m));
+          }
+          if (FAST && i > 0 && (i - 1) % 4 != 3) {            // (the previous tap had no fifth region: its pieces ride here)
+            epi(i - 1, 4);
+            if (st && i - 1 >= LAGP && (i - 1 - LAGP) % 2 == 0 && i - 1 - LAGP < 6) store_px((i - 1 - LAGP) / 2, obuf, true, 2);
           }
           epi(i, 0);
           mfma4(a0[i & 1], bres[i][0], i == 0);
@@ -727,6 +761,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int m = 0; m < 4; ++m) a0[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m));
           }
+          if (FAST && i % 4 == 3) {
+            // the shared remainder chunk of taps i - 3 .. i: lanes 0-31 read the remainders of taps i - 3 | i - 2, lanes 32-63 of i - 1 | i
+            const unsigned xa = baseX + (unsigned)(xkh ? tofs(i - 1, 0) : tofs(i - 3, 0)), xb = baseX + (unsigned)(xkh ? tofs(i, 0) : tofs(i - 2, 0));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const u32x2 lo = *reinterpret_cast<const u32x2 *>(lds + xa + m * 4 * ROW), hi = *reinterpret_cast<const u32x2 *>(lds + xb + m * 4 * ROW);
+              ax[m] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+          }
+          if (FAST && i == 11) {                              // tap 48, M-tile WV
+            t48[0] = *reinterpret_cast<const u32x4 *>(lds + baseA + tap_off(48) + WV * 4 * ROW);
+            t48[1] = *reinterpret_cast<const u32x4 *>(lds + baseA + tap_off(48) + WV * 4 * ROW + 32);
+            t48[2] = *reinterpret_cast<const u32x4 *>(lds + baseX + tap_off(48) + WV * 4 * ROW);
+          }
           epi(i, 2);
           mfma4(a1s[i & 1], bres[i][1]);
           region_end();
@@ -745,11 +793,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           mfma4(a1s[i & 1], bres[i][3]);
           region_end();
           // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
-          if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
-          if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
-          epi(i, 4);
-          mfma4(ax, u32x4{bxr[i][0], bxr[i][1], 0u, 0u});
-          region_end();
+          //    (FAST: only behind every fourth tap, for the four of them)
+          if (!FAST || i % 4 == 3) {
+            if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
+            if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
+            epi(i, 4);
+            mfma4(ax, FAST ? bxs[FAST ? i / 4 : 0] : u32x4{bxr[FAST ? 0 : i][0], bxr[FAST ? 0 : i][1], 0u, 0u});
+            region_end();
+          }
+          if (FAST && i == 11) {
+            // tap 48 for M-tile WV: five MFMAs in the tile kernel's order (chunk 0 x {w0, w1}, chunk 1 x {w0, w1}, remainders x w0)
+            const u32x4 bq5[5] = {b48[0], b48[2], b48[1], b48[3], u32x4{b48x[0], b48x[1], 0u, 0u}};
+#pragma unroll
+            for (int g5 = 0; g5 < 5; ++g5)
+              acc[0][WV] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, t48[g5 < 2 ? 0 : g5 < 4 ? 1 : 2]),
+                                                                  __builtin_bit_cast(f16x8, bq5[g5]), acc[0][WV], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else {
           // bf16 dual stem — the MFMA order of stem_mx_kernel<1, 2>: chunk 0 x {N-tile 0, 1}, chunk 1 x {N-tile 0, 1}; M-tiles innermost
           // -- region 0: chunk 0, N-tile 0 | this tap's chunk-1 fragments
@@ -876,7 +936,7 @@ bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out,
   return (f16 || dual) && wgs >= 8 && ntiles >= 8L * wgs;
 }
 
-hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, int wgs, hipStream_t s) {
+hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, bool fast, int wgs, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipSuccess;
@@ -887,6 +947,10 @@ hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, int wgs, hipStream_t 
     set(reinterpret_cast<const void *>(stem_rs_kernel<2, true, false>));
     set(reinterpret_cast<const void *>(stem_rs_kernel<2, false, true>));
     set(reinterpret_cast<const void *>(stem_rs_kernel<2, false, false>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, true, true, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, true, false, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, false, true, true>));
+    set(reinterpret_cast<const void *>(stem_rs_kernel<2, false, false, true>));
     set(reinterpret_cast<const void *>(stem_rs_kernel<1, false, true>));
     set(reinterpret_cast<const void *>(stem_rs_kernel<1, false, false>));
     if (e != hipSuccess) return e;
@@ -895,15 +959,24 @@ hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, int wgs, hipStream_t 
   StemMXArgs p = a;
   p.tiles_x = (a.Wo + TW - 1) / TW;
   p.tiles_y = (a.Ho + TH - 1) / TH;
-  const unsigned gx = (unsigned)(wgs & ~7);
+  const dim3 g((unsigned)(wgs & ~7)), b(256);
   const bool raw = p.raw_depth != nullptr, pool = p.pool != nullptr;
+#define PNVO_RS_LAUNCH(...) hipLaunchKernelGGL((stem_rs_kernel<__VA_ARGS__>), g, b, RS_LDS, s, p)
   if (pieces == 1) {
-    if (raw) hipLaunchKernelGGL((stem_rs_kernel<1, false, true>), dim3(gx), dim3(256), RS_LDS, s, p);
-    else hipLaunchKernelGGL((stem_rs_kernel<1, false, false>), dim3(gx), dim3(256), RS_LDS, s, p);
-  } else if (pool && raw) hipLaunchKernelGGL((stem_rs_kernel<2, true, true>), dim3(gx), dim3(256), RS_LDS, s, p);
-  else if (pool) hipLaunchKernelGGL((stem_rs_kernel<2, true, false>), dim3(gx), dim3(256), RS_LDS, s, p);
-  else if (raw) hipLaunchKernelGGL((stem_rs_kernel<2, false, true>), dim3(gx), dim3(256), RS_LDS, s, p);
-  else hipLaunchKernelGGL((stem_rs_kernel<2, false, false>), dim3(gx), dim3(256), RS_LDS, s, p);
+    if (raw) PNVO_RS_LAUNCH(1, false, true);
+    else PNVO_RS_LAUNCH(1, false, false);
+  } else if (fast) {
+    if (pool && raw) PNVO_RS_LAUNCH(2, true, true, true);
+    else if (pool) PNVO_RS_LAUNCH(2, true, false, true);
+    else if (raw) PNVO_RS_LAUNCH(2, false, true, true);
+    else PNVO_RS_LAUNCH(2, false, false, true);
+  } else {
+    if (pool && raw) PNVO_RS_LAUNCH(2, true, true);
+    else if (pool) PNVO_RS_LAUNCH(2, true, false);
+    else if (raw) PNVO_RS_LAUNCH(2, false, true);
+    else PNVO_RS_LAUNCH(2, false, false);
+  }
+#undef PNVO_RS_LAUNCH
   return hipGetLastError();
 }
 

@@ -78,9 +78,10 @@ def test_resident_weight_stem_equals_the_tile_kernel(B, pool):
     res = run(model, obs, "resident", 4, pool)
     auto = run(model, obs, "auto", 4, pool)
     assert torch.isfinite(ref[0]).all()
+    fast = run(model, obs, "fast", 4, pool)
     for k in range(3):
         assert torch.equal(ref[k], res[k]), k
-        assert torch.equal(ref[k], auto[k]), k
+        assert torch.equal(fast[k], auto[k]), k                       # (auto = fast from 16 pairs on: float32-grade, see below)
 
 
 def test_resident_weight_stem_on_an_odd_resolution():
@@ -125,3 +126,18 @@ def test_resident_weight_dual_bf16_stem_equals_the_tile_kernel():
     for form in ("resident", "auto"):
         assert torch.equal(outs["tiles"][0], outs[form][0]) and torch.equal(outs["tiles"][1], outs[form][1]), form
     assert not torch.equal(outs["tiles"][0], outs["tiles"][1])     # (two different models)
+
+
+@pytest.mark.parametrize("pool", ["fused", "separate"])
+def test_fast_resident_stem_is_float32_grade_equal_and_reproducible(pool):
+    """stem_form=fast: the resident-weight stem with the remainder MFMAs of four taps sharing one K chunk and tap 48 split over the
+    waves by M-tile — another summation order, so float32-grade agreement with the tile kernel (2e-6 of the output's largest
+    magnitude; measured ~3e-7), run-to-run reproducible, and the sensor-frame entry identical to the observation-tensor entry."""
+    model, _ = bench.build_model(DEV)
+    obs = bench.make_inputs(64, DEV, 0)
+    ref = run(model, obs, "tiles", 4, pool)
+    fast = run(model, obs, "fast", 4, pool)
+    assert torch.isfinite(fast[0]).all()
+    assert torch.equal(fast[0], fast[1]) and torch.equal(fast[0], fast[2])
+    rel = (ref[0] - fast[0]).abs().max() / ref[0].abs().max()
+    assert 0 < rel < 2e-6, rel

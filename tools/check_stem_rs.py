@@ -17,7 +17,7 @@ for B in (19, 64, 256):
     rgb_f, dep_f = bench.frames_of(obs)
     for opts in ({}, {"pool": "separate"}):
         outs = {}
-        for form in ("tiles", "resident"):
+        for form in ("tiles", "resident", "fast"):
             model.set_option("stem_form", form)
             model.set_option("pool", opts.get("pool", "fused"))
             with torch.no_grad():
@@ -39,7 +39,7 @@ if "--odd" in sys.argv:
     m2 = m2.to(dev).eval()
     o2 = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_obs_pairs(700, 37, 45, observation_space=bench.SPACE, dd_bins=10, seed=3).items()}
     res = {}
-    for form in ("tiles", "resident"):
+    for form in ("tiles", "resident", "fast"):
         m2.set_option("stem_form", form)
         with torch.no_grad():
             res[form] = m2(o2).clone()
@@ -48,7 +48,7 @@ if "--odd" in sys.argv:
     ok = ok and bool(torch.equal(res["tiles"], res["resident"]))
 obs = bench.make_inputs(256, dev, 0)
 rgb_f, dep_f = bench.frames_of(obs)
-for form in ("tiles", "resident"):
+for form in ("tiles", "resident", "fast"):
     model.set_option("stem_form", form)
     model.set_option("pool", "fused")
     for raw in (False, True):

@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # rocprof kernel-name prefix -> the name bench.py gives that launch
-KERNELS = {"fwd_fp32": ("stem_rs_kernel<true, false", "conv:visual_encoder.backbone.conv1.0"),
-           "dual_bf16": ("stem_mx_kernel<1, 2, true", "bf16:stem")}
+KERNELS = {"fwd_fp32": ("stem_rs_kernel<2, true, false", "conv:visual_encoder.backbone.conv1.0"),
+           "dual_bf16": ("stem_rs_kernel<1, false, false", "bf16:stem")}
 
 
 def avg_counter(db, prefix, counter):

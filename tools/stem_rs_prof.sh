@@ -1,5 +1,5 @@
 # phase cycles of stem_rs_kernel (option stem_form=resident, PNVO_STEM_DBG=9) at 256 pairs, tensor entry
-PNVO_STEM_FORM=resident PNVO_STEM_DBG=9 timeout 200 python bench.py --steps 6 --warmup 2 --no-preheat --no-cpu-baseline --no-secondary 2>&1 | python -c "
+PNVO_STEM_FORM=${FORM:-resident} PNVO_STEM_DBG=9 timeout 200 python bench.py --steps 6 --warmup 2 --no-preheat --no-cpu-baseline --no-secondary 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
