@@ -163,6 +163,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base ? reinterpret_cast<const char *>(base) + off : reinterpret_cast<const char *>(zp)),
                                              0, base ? (unsigned)bytes : 0u, 0x00020000);
   };
+  // coordinates of the tile `per` tiles further on, without dividing again (the walk's stride is fixed: one carry per digit)
+  const int per_n = per / (p.tiles_x * p.tiles_y), per_r = per % (p.tiles_x * p.tiles_y), per_y = per_r / p.tiles_x, per_x = per_r % p.tiles_x;
+  auto set_stage_coords = [&](int sn_i, int ty, int tx) PNVO_INL {
+    const long sn = sn_i;
+    shi = 2 * ty * TH - 3;
+    swi = 2 * tx * TW - 3;
+    st_n = sn_i;
+    st_ty = ty;
+    st_tx = tx;
+    if (RAW) {
+      r_rgb = rsrc(p.raw_rgb, sn * fpix * 6, fpix * 6);     // both frames of the sample: [2][H][W][3] uint8
+      r_d = rsrc(p.raw_depth, sn * fpix * 8, fpix * 8);     //                            [2][H][W] float32
+      r_dd = rsrc(nullptr, 0, 0);
+    } else {
+      r_rgb = rsrc(p.src[0], sn * fpix * 24, fpix * 24);
+      r_d = rsrc(p.src[1], sn * fpix * 8, fpix * 8);
+      r_dd = rsrc(p.src[2], sn * fpix * 80, fpix * 80);
+    }
+    r_t = rsrc(p.src[3], sn * fpix * 8, fpix * 8);
+  };
+  auto stage_next_tile = [&](bool advance) PNVO_INL {       // advance = false: the same tile again (last iteration)
+    int tx = st_tx + (advance ? per_x : 0);
+    const int cx = tx >= p.tiles_x ? 1 : 0;
+    tx -= cx * p.tiles_x;
+    int ty = st_ty + (advance ? per_y + cx : 0);
+    const int cy = ty >= p.tiles_y ? 1 : 0;
+    ty -= cy * p.tiles_y;
+    set_stage_coords(st_n + (advance ? per_n + cy : 0), ty, tx);
+  };
   auto set_stage_tile = [&](int t) PNVO_INL {
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
@@ -328,7 +357,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // compile-time constants — every LDS address of the K loop is one register plus an immediate, no scalar arithmetic per tap.
   auto body = [&](auto wv_c) PNVO_INL {
     constexpr int WV = decltype(wv_c)::value;
-    constexpr int NROWS = WV == 3 ? 0 : 7;                  // patch rows WV, WV + 3, ... of the granule fetch (wave 3 has a tap more)
+    // patch rows of the granule fetch: wave 3 has a tap more -> rows WV, WV + 3, ... on waves 0..2; FAST (equal MFMA counts): rows WV,
+    // WV + 4, ... on all four, the twenty-first row on wave 1 (wave 0 has the nine left-over pixels)
+    constexpr int NROWS = FAST ? (WV == 1 ? 6 : 5) : WV == 3 ? 0 : 7;
+    auto dd_row = [](int j) constexpr { return FAST ? (j < 5 ? WV + 4 * j : 20) : WV + 3 * j; };
     constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
     constexpr int NT = (WV == 3 && !FAST) ? 13 : 12;        // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3; FAST: by M-tile)
     auto tap_of = [](int i) constexpr { return i < 12 ? WV + 4 * i : 48; };
@@ -342,12 +374,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 3; ++r) load_px(r, true);
     if (WV == 0) load_px(3, haslast);
 #pragma unroll
-    for (int q = 0; q < RD; ++q) load_dd(q, WV + 3 * (q / 3), q % 3);
+    for (int q = 0; q < RD; ++q) load_dd(q, dd_row(q / 3), q % 3);
 #pragma unroll
     for (int r = 0; r < 3; ++r) store_px(r, 0u, true, 0);
     if (WV == 0) store_px(3, 0u, haslast, 0);
 #pragma unroll
-    for (int q = 0; q < RD; ++q) store_dd(q, WV + 3 * (q / 3), q % 3);
+    for (int q = 0; q < RD; ++q) store_dd(q, dd_row(q / 3), q % 3);
     __syncthreads();
 
     // ---- the resident B operand (fetched AFTER the first patch is staged: the all-at-once prologue needs ~150 registers of its
@@ -682,9 +714,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
       const unsigned buf = (unsigned)(it & 1) * RS_BUF, obuf = buf ^ (unsigned)RS_BUF;
-      const int t = t_first + it * per;
       // the tile staged during this K loop: the next one (the last iteration re-stages its own tile into the idle buffer)
-      set_stage_tile(it + 1 < nit ? t + per : t);
+      stage_next_tile(it + 1 < nit);
       set_dd_tile(obuf);
       ebuf = obuf;                                          // POOL: the previous tile's exchange (first tile: nothing valid, keys off)
       const unsigned long long t0 = now();
@@ -750,7 +781,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (sd) {
 #pragma unroll
             for (int q = 3 * i; q < 3 * i + 3; ++q)
-              if (q < RD) load_dd(q, WV + 3 * (q / 3), q % 3);
+              if (q < RD) load_dd(q, dd_row(q / 3), q % 3);
           }
           if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
           if (st && WV == 0 && i == 8) load_px(3, haslast);
@@ -782,7 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (sd && i >= LAGD) {
 #pragma unroll
             for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
-              if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
+              if (q < RD) store_dd(q, dd_row(q / 3), q % 3);
           }
           if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
           if (A1AHEAD && i + 1 < NT) {
@@ -822,7 +853,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (sd) {
 #pragma unroll
             for (int q = 3 * i; q < 3 * i + 3; ++q)
-              if (q < RD) load_dd(q, WV + 3 * (q / 3), q % 3);
+              if (q < RD) load_dd(q, dd_row(q / 3), q % 3);
           }
           if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
           if (st && WV == 0 && i == 8) load_px(3, haslast);
@@ -842,7 +873,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (sd && i >= LAGD) {
 #pragma unroll
             for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
-              if (q < RD) store_dd(q, WV + 3 * (q / 3), q % 3);
+              if (q < RD) store_dd(q, dd_row(q / 3), q % 3);
           }
           if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
           epi(i, 3);
