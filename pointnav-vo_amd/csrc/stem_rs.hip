@@ -66,6 +66,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 #ifndef PNVO_RS_A1AHEAD
 #define PNVO_RS_A1AHEAD 0
 #endif
+#ifndef PNVO_RS_MERGE
+#define PNVO_RS_MERGE 1   // bit 0: regions 0+1 and 2+3 of a tap are scheduled together (K loop -4 %); bits 1, 2: larger unions (slower)
+#endif
 #ifndef PNVO_RS_NPIN
 #define PNVO_RS_NPIN 10
 #endif
@@ -736,9 +739,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         a0[0][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(0, m));
         if (A1AHEAD) a1s[0][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(0, m) + 32);
       }
-      // One tap = five scheduling regions of four MFMAs (one B fragment x the four M-tiles), each with its share of the other work
-      // in source order; inside a region every MFMA is followed by at most seven other instructions — about what its 32 cycles hide.
-      auto region_end = [&]() PNVO_INL {
+      // One tap = five groups of four MFMAs (one B fragment x the four M-tiles), each with its share of the other work in source
+      // order; groups 0+1 and 2+3 form one scheduling region each (measured: a region per group 10.1 k cycles per tile, pairs 9.7 k,
+      // the whole tap 10.7 k); inside a region every MFMA is followed by at most eight other instructions.
+      auto region_end = [&](bool hard = true) PNVO_INL {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           __builtin_amdgcn_sched_group_barrier(0x002, PNVO_RS_GVA, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (hard) __builtin_amdgcn_sched_barrier(0);
       };
       auto mfma4 = [&](const u32x4 *aq, const u32x4 bq, bool first = false, int nt = 0) PNVO_INL {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
           epi(i, 0);
           mfma4(a0[i & 1], bres[i][0], i == 0);
-          region_end();
+          region_end(!(PNVO_RS_MERGE & 1));
           // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
           if (sd) {
 #pragma unroll
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
           if (st && WV == 0 && i == 8) load_px(3, haslast);
           mfma4(a0[i & 1], bres[i][2]);
-          region_end();
+          region_end(!(PNVO_RS_MERGE & 2));
           // -- region 2: chunk 1 x w0 | the next tap's chunk-0 fragments
           if (i + 1 < NT) {
 #pragma unroll
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
           epi(i, 2);
           mfma4(a1s[i & 1], bres[i][1]);
-          region_end();
+          region_end(!(PNVO_RS_MERGE & 1));
           // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
           if (sd && i >= LAGD) {
 #pragma unroll
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
           epi(i, 3);
           mfma4(a1s[i & 1], bres[i][3]);
-          region_end();
+          region_end(!(PNVO_RS_MERGE & 4));
           // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
           //    (FAST: only behind every fourth tap, for the four of them)
           if (!FAST || i % 4 == 3) {
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int m = 0; m < 4; ++m) a1s[i & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i, m) + 32);
           epi(i, 0);
           mfma4(a0[i & 1], bres[i][0], i == 0, 0);
-          region_end();
+          region_end(!(PNVO_RS_MERGE & 1));
           // -- region 1: chunk 0, N-tile 1 | loads of the next patch
           if (sd) {
 #pragma unroll
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
           epi(i, 2);
           mfma4(a1s[i & 1], bres[i][2], false, 0);
-          region_end();
+          region_end(!(PNVO_RS_MERGE & 1));
           // -- region 3: chunk 1, N-tile 1 | granule stores, first half of a pixel round's store
           if (sd && i >= LAGD) {
 #pragma unroll
