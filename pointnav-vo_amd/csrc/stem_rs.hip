@@ -363,6 +363,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // patch rows of the granule fetch: wave 3 has a tap more -> rows WV, WV + 3, ... on waves 0..2; FAST (equal MFMA counts): rows WV,
     // WV + 4, ... on all four, the twenty-first row on wave 1 (wave 0 has the nine left-over pixels)
     constexpr int NROWS = FAST ? (WV == 1 ? 6 : 5) : WV == 3 ? 0 : 7;
+    // staging placement: granule rounds per tap (loads from tap 0 on, stores LAGD taps later), taps of the three pixel rounds' loads
+    // (stores LAGP taps later).  FAST spreads both over the whole K loop: two rounds per tap, pixel rounds at taps 1, 4, 7.
+    constexpr int DPT = FAST ? 2 : 3, PX0 = FAST ? 1 : 0, PXS = FAST ? 3 : 2;
+    auto px_store_tap = [](int i) constexpr { return i >= LAGP + PX0 && (i - LAGP - PX0) % PXS == 0 && (i - LAGP - PX0) / PXS < 3; };
     auto dd_row = [](int j) constexpr { return FAST ? (j < 5 ? WV + 4 * j : 20) : WV + 3 * j; };
     constexpr int RD = RAW ? 0 : 3 * NROWS;                 // granule rounds of this wave
     constexpr int NT = (WV == 3 && !FAST) ? 13 : 12;        // taps: WV, WV + 4, ..., WV + 44 (+ tap 48 on wave 3; FAST: by M-tile)
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
           if (FAST && i > 0 && (i - 1) % 4 != 3) {            // (the previous tap had no fifth region: its pieces ride here)
             epi(i - 1, 4);
-            if (st && i - 1 >= LAGP && (i - 1 - LAGP) % 2 == 0 && i - 1 - LAGP < 6) store_px((i - 1 - LAGP) / 2, obuf, true, 2);
+            if (st && px_store_tap(i - 1)) store_px((i - 1 - LAGP - PX0) / PXS, obuf, true, 2);
           }
           epi(i, 0);
           mfma4(a0[i & 1], bres[i][0], i == 0);
@@ -784,10 +788,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // -- region 1: chunk 0 x w1 | loads of the next patch: two granule rounds, a pixel round on taps 0, 2, 4
           if (sd) {
 #pragma unroll
-            for (int q = 3 * i; q < 3 * i + 3; ++q)
+            for (int q = DPT * i; q < DPT * i + DPT; ++q)
               if (q < RD) load_dd(q, dd_row(q / 3), q % 3);
           }
-          if (st && i % 2 == 0 && i < 6) load_px(i / 2, true);
+          if (st && i >= PX0 && (i - PX0) % PXS == 0 && (i - PX0) / PXS < 3) load_px((i - PX0) / PXS, true);
           if (st && WV == 0 && i == 8) load_px(3, haslast);
           mfma4(a0[i & 1], bres[i][2]);
           region_end(!(PNVO_RS_MERGE & 2));
@@ -816,10 +820,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // -- region 3: chunk 1 x w1 | conversion + LDS writes of the granule rounds loaded LAGD taps ago
           if (sd && i >= LAGD) {
 #pragma unroll
-            for (int q = 3 * (i - LAGD); q < 3 * (i - LAGD) + 3; ++q)
+            for (int q = DPT * (i - LAGD); q < DPT * (i - LAGD) + DPT; ++q)
               if (q < RD) store_dd(q, dd_row(q / 3), q % 3);
           }
-          if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 1);
+          if (st && px_store_tap(i)) store_px((i - LAGP - PX0) / PXS, obuf, true, 1);
           if (A1AHEAD && i + 1 < NT) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) a1s[(i + 1) & 1][m] = *reinterpret_cast<const u32x4 *>(lds + baseA + tofs(i + 1, m) + 32);
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           // -- region 4: remainders x w0 | conversion + LDS writes of the pixel round loaded LAGP taps ago
           //    (FAST: only behind every fourth tap, for the four of them)
           if (!FAST || i % 4 == 3) {
-            if (st && i >= LAGP && (i - LAGP) % 2 == 0 && i - LAGP < 6) store_px((i - LAGP) / 2, obuf, true, 2);
+            if (st && px_store_tap(i)) store_px((i - LAGP - PX0) / PXS, obuf, true, 2);
             if (st && WV == 0 && i == 11) store_px(3, obuf, haslast, 0);
             epi(i, 4);
             mfma4(ax, FAST ? bxs[FAST ? i / 4 : 0] : u32x4{bxr[FAST ? 0 : i][0], bxr[FAST ? 0 : i][1], 0u, 0u});
