@@ -244,13 +244,16 @@ def strict_variant(model, obs, ref, chk, opts, B, world, sync_all, dev, note):
             model.set_option(k, v.split(" ")[0])
 
 
-def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2"):
+def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2", form="auto"):
     """Work the stem kernels EXECUTE (not the algorithmic 30-channel conv): matrix-core FLOPs per launch against the
     peak of the pipe they run on."""
     ho, wo = (H + 1) // 2, (W + 1) // 2
     px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128              # pixels of the 8x16 tiles, padding included
-    if sel in ("auto", "mx") and pieces == "2":   # stem_mx.hip, float16 pieces: 5 x v_mfma_f32_32x32x16_f16 per tap and 32-pixel
-        flops = px / 32 * 49 * 5 * (2.0 * 32 * 32 * 16)       #   tile (2 weight pieces x 2 K-chunks + 1 chunk of float-modality remainders)
+    if sel in ("auto", "mx") and pieces == "2":   # stem_mx.hip / stem_rs.hip, float16 pieces: 5 x v_mfma_f32_32x32x16_f16 per tap and
+        per_tile = 4 * 49 * 5                                 #   32-pixel tile (2 weight pieces x 2 K-chunks + 1 chunk of remainders)
+        if form in ("auto", "fast") and B * (-(-ho // 8)) * (-(-wo // 16)) >= 8 * 256:
+            per_tile = 4 * (12 * 16 + 3 * 4 + 5)              # stem_rs FAST: the remainder MFMAs of four taps share a chunk: 836, not 980
+        flops = px / 128 * per_tile * (2.0 * 32 * 32 * 16)
         peak, pipe = PEAK_BF16_TFLOPS, "float16 MFMA (two float16 weight pieces, inputs exact in float16 -> float32-grade results)"
     elif sel in ("auto", "mx"):        # stem_mx.hip: 7 x v_mfma_f32_32x32x16_bf16 per tap and 32-pixel tile (3 weight pieces x 2
         flops = px / 32 * 49 * 7 * (2.0 * 32 * 32 * 16)       #   K-chunks + 1 chunk of float-modality remainders)
@@ -481,7 +484,7 @@ def main():
         total_kernel_ms = sum(k["total_ms"] for k in kt)
         is_stem = dom["name"].endswith("conv1.0")
         if is_stem:
-            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"), model.get_option("pieces"))
+            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"), model.get_option("pieces"), model.get_option("stem_form"))
         else:
             fam, ex = model.layer_kernel(dom["name"][len("conv:"):], B)
             if fam in ("x3", "x2"):                  # six bf16 / three float16 MFMA terms per float32 product, tile padding included
