@@ -41,9 +41,13 @@ for l in sys.stdin:
     elif 'pnvo]' in l and ('M wave 0' in l or 'L wave 4' in l or 'L wave 9' in l): print(l.rstrip())
 "; done ) > $O/${tag}_stem_ps_phases.txt 2>&1
 # the resident-weight stem (the default): cycles per tile of its three sections, per wave
-( echo "# stem_rs_kernel (stem_form=resident, the default at 256 pairs): cycles per tile (s_memtime), option stem_dbg=9"
-  bash tools/stem_rs_prof.sh ) > $O/${tag}_stem_rs_phases.txt 2>&1
-python tools/ab_option.py stem_form tiles resident > $O/${tag}_ab_stem_form.txt 2>/dev/null
+( echo "# stem_rs_kernel at 256 pairs: cycles per tile (s_memtime) of its three sections per wave, option stem_dbg=9"
+  echo "# -- stem_form=fast (the default: 209 MFMAs per wave and tile)"
+  FORM=fast bash tools/stem_rs_prof.sh
+  echo "# -- stem_form=resident (the tile kernel's summation order: 240 / 240 / 240 / 260 MFMAs)"
+  FORM=resident bash tools/stem_rs_prof.sh ) > $O/${tag}_stem_rs_phases.txt 2>&1
+python tools/ab_option.py stem_form tiles fast > $O/${tag}_ab_stem_form.txt 2>/dev/null
+python tools/ab_option.py stem_form tiles resident >> $O/${tag}_ab_stem_form.txt 2>/dev/null
 python tools/ab_option.py stem_form tiles persistent >> $O/${tag}_ab_stem_form.txt 2>/dev/null
 python tools/ab_option.py x3_persist off on > $O/${tag}_ab_x3_persist.txt 2>/dev/null
 python tools/ab_dual.py x3_persist off on > $O/${tag}_ab_dual_persist.txt 2>/dev/null
