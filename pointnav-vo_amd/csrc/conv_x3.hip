@@ -462,6 +462,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
         float *dst = p.stats + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
         dst[0] = s1;
         dst[1] = s2;
+        if (p.gn_scale != nullptr) {                                     // the sample's only slot: finalise here (no launch)
+          const int c = nt * 32 + lane;
+          gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma[c], p.gn_beta[c], p.gn_scale + (long)n * p.COUTP + c,
+                           p.gn_shift + (long)n * p.COUTP + c);
+        }
       }
     }
   }

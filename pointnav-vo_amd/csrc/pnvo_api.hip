@@ -631,10 +631,25 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         xa.res_shift = tail->res_shift;
         xa.xout = tail->out;
       }
+      // one tile per sample (the 12 x 22 and 6 x 11 maps): the workgroup that sums a sample's channels also turns the sums into the
+      // GroupNorm scale / shift — the same fp64 arithmetic as gn_finalize_kernel, bit for bit, one launch less (option gn_fuse)
+      const int cpg = l.groups > 0 ? l.cout / l.groups : 0;
+      const bool fuse = m->opt.gn_fuse && xa.slots == 1 && mu_out == nullptr && l.cout == l.coutp && cpg >= 1 && cpg <= 32 &&
+                        32 % cpg == 0 && l.cout % cpg == 0 && !(xa.persist_wgs > 0 && l.cin == 32 && l.coutp == 32);
+      if (fuse) {
+        xa.gn_gamma = l.gamma;
+        xa.gn_beta = l.beta;
+        xa.gn_scale = ss[0];
+        xa.gn_shift = ss[1];
+        xa.gn_cpg = cpg;
+        xa.gn_eps = 1e-5f;
+        xa.gn_P = P;
+      }
       {
         Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes + (tail ? 8.0 * B * l.hin * l.win * l.cin : 0.0));
         HIPCHK(m, launch_conv_x3(xa, l.k, l.stride, tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0), mw, nw, ldsb, s));
       }
+      if (fuse) return PNVO_OK;
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
                                    xa.slots, mu_out, rstd_out));
@@ -944,6 +959,7 @@ const OptDef kOptions[] = {
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_persist", "PNVO_X3_PERSIST", &PnvoOptions::x3_persist, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
     {"pool", "PNVO_POOL", &PnvoOptions::pool, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},

@@ -151,7 +151,35 @@ struct ConvX3Args {
   const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
   int persist_wgs;                   // > 0: eligible launches take conv_x3p_kernel with this many workgroups (3 per CU); 0: never
   int strip;                         // conv_x3_plan: wide strip tiles with the N-tiles split over blockIdx.y for 64 / 128 output channels
+  // GroupNorm finalisation inside the conv (slots == 1: the workgroup that wrote a sample's only partial sums holds the complete sums
+  // of its channels): scale / shift [B,COUTP] as gn_finalize_kernel would write them, bit for bit; nullptr: the separate launch
+  const float *gn_gamma, *gn_beta;
+  float *gn_scale, *gn_shift;
+  int gn_cpg;                        // channels per group (divides 32)
+  float gn_eps;
+  long gn_P;                         // pixels per sample
 };
+#if defined(__HIPCC__)
+// One lane = one channel of a sample, lanes of a group adjacent and aligned: GroupNorm scale / shift from the channel's complete
+// sums (s1, s2), in gn_finalize_kernel's arithmetic — fp64, the butterfly over the group's lanes in its order (the wider offsets
+// of that kernel's 64-lane butterfly add exact zeros), no a*b+c contraction (elementwise.hip is compiled without it).
+__device__ __forceinline__ void gn_finalize_lane(float s1, float s2, int cpg, long P, float eps, float gamma, float beta, float *scale, float *shift) {
+#pragma clang fp contract(off)
+  double d1 = (double)s1, d2 = (double)s2;
+  for (int o = cpg >> 1; o >= 1; o >>= 1) {
+    d1 += __shfl_xor(d1, o);
+    d2 += __shfl_xor(d2, o);
+  }
+  const double cnt = (double)P * cpg;
+  const double mu = d1 / cnt;
+  double var = d2 / cnt - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = rstd * (double)gamma;
+  *scale = (float)sc;
+  *shift = (float)((double)beta - mu * sc);
+}
+#endif
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
 hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,

@@ -41,6 +41,7 @@ struct PnvoOptions {
                          //   gradients do not fit float16's range)
   int x3_persist = 1;  // shallow-stage 3x3 convs on the persistent form of conv_x3 (next tile's patch fetched during the K loop)
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
+  int gn_fuse = 1;     // conv_x3 launches with one tile per sample finalise their GroupNorm themselves (bit-identical, one launch less)
   int x3_s2 = 1;       // stride-2 convs on conv_x3
   int tail = 1;        // BasicBlock tails fused into the next conv's stager (0: residual_kernel)
   int pool = 1;        // max-pool fused into the stem's epilogue (0: gn_relu_maxpool_kernel)

@@ -177,3 +177,24 @@ def test_strip_tiles_of_the_128_channel_stage_agree_with_square_tiles():
         assert np.array_equal(outs[0], outs[2])          # same plan, same bits
         err = np.linalg.norm(outs[0] - outs[1], axis=1) / np.maximum(np.linalg.norm(outs[1], axis=1), 1e-2)
         assert err.max() < 2e-5, err.max()
+
+
+def test_in_kernel_groupnorm_finalisation_is_bit_identical():
+    """Option gn_fuse (default on): conv_x3 launches with one tile per sample (the 12x22 and 6x11 maps) turn their channel sums into
+    the GroupNorm scale / shift themselves, in gn_finalize_kernel's fp64 arithmetic and butterfly order: the network output does
+    not change by a bit, at 16, 64 and 256 pairs."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    for B in (16, 64, 256):
+        obs = bench.make_inputs(B, dev, 1)
+        outs = []
+        for v in ("on", "off", "on"):
+            model.set_option("gn_fuse", v)
+            with torch.no_grad():
+                outs.append(model(obs).clone())
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
