@@ -141,3 +141,40 @@ def test_fast_resident_stem_is_float32_grade_equal_and_reproducible(pool):
     assert torch.equal(fast[0], fast[1]) and torch.equal(fast[0], fast[2])
     rel = (ref[0] - fast[0]).abs().max() / ref[0].abs().max()
     assert 0 < rel < 2e-6, rel
+
+
+VARIANTS = [("vo_cnn", "rgb,depth", 0), ("vo_cnn_rgb", "rgb", 0), ("vo_cnn_rgb_d_dd", "rgb,depth,discretized_depth", 10),
+            ("vo_cnn_d_dd_top_down", "depth,discretized_depth,top_down_view", 10)]
+
+
+@pytest.mark.parametrize("name,space,bins", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_resident_stems_on_models_without_some_modalities(name, space, bins):
+    """Registry variants whose stems lack rgb, depth, the one-hot depth or the top-down view (absent tensors are descriptors of zero
+    records in stem_rs_kernel): 600 pairs at 64 x 48 so that the resident kernel takes the launch; `resident` bit-identical to the tile
+    kernel, `fast` float32-grade equal, and the tile kernel itself within 2e-5 of the fp64 oracle on the first pairs."""
+    from oracle import oracle
+    W, H, B = 64, 48, 600
+    kw = dict(observation_space=space.split(","), observation_size=(W, H), hidden_size=512, backbone="resnet18",
+              normalize_visual_inputs=True, output_dim=3, dropout_p=0.2)
+    if bins:
+        kw["discretized_depth_channels"] = bins
+    model = baseline_registry.get_vo_model(name)(**kw)
+    sd = synth.make_state_dict(ms.state_dict_spec(model.cfg), seed=5)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    obs = synth.make_obs_pairs(B, H, W, observation_space=space.split(","), dd_bins=bins or 10, seed=9)
+    tobs = {k: torch.from_numpy(v).to(DEV) for k, v in obs.items()}
+    outs = {}
+    for form in ("tiles", "resident", "fast"):
+        model.set_option("stem_form", form)
+        with torch.no_grad():
+            outs[form] = model(tobs).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs["tiles"]).all()
+    assert torch.equal(outs["tiles"], outs["resident"])
+    rel = (outs["tiles"] - outs["fast"]).abs().max() / outs["tiles"].abs().max()
+    assert rel < 2e-6, rel
+    ref = oracle.forward(sd, {k: v[:3] for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    got = outs["fast"][:3].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
