@@ -178,3 +178,31 @@ def test_resident_stems_on_models_without_some_modalities(name, space, bins):
     got = outs["fast"][:3].double().cpu().numpy()
     err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
     assert err.max() < 2e-5, err
+
+
+@pytest.mark.parametrize("kind", ["fractional rgb", "soft depth code"])
+def test_resident_stem_detects_input_outside_its_contract(kind):
+    """The contract check (rgb uint8-valued, one-hot depth: exact in float16) lives in the resident kernel's stager too: 32 pairs at
+    341 x 192 take stem_rs_kernel; one fractional rgb value / one soft depth code in the LAST pair makes the call re-run on the dense
+    stem and return what the dense stem returns (vo_cnn.py:110-176 takes any float tensor)."""
+    model, _ = bench.build_model(DEV)
+    obs = bench.make_inputs(32, DEV, 0)
+    bad = dict(obs)
+    if kind == "fractional rgb":
+        bad["rgb"] = obs["rgb"].clone()
+        bad["rgb"][31, 150, 300, 4] = 17.3
+    else:
+        bad["discretized_depth"] = obs["discretized_depth"].clone()
+        bad["discretized_depth"][31, 100, 7, :] = 0.1
+    with torch.no_grad():
+        clean = model(obs).clone()
+        assert model.get_option("stem") == "auto"
+        out = model(bad).clone()                              # the offending call itself
+        assert model.get_option("stem") == "dense (fallback)" and "dense" in model.last_note()
+        model.set_option("stem", "dense")
+        ref = model(bad).clone()
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(out[:31], ref[:31]) and not torch.equal(out[31], clean[31])
+    rel = (out[:31] - clean[:31]).abs().max() / clean.abs().max()
+    assert rel < 5e-6, rel                                    # the untouched pairs: dense stem vs split stem, float32-grade
