@@ -464,8 +464,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
         dst[1] = s2;
         if (p.gn_scale != nullptr) {                                     // the sample's only slot: finalise here (no launch)
           const int c = nt * 32 + lane;
+          const bool first = p.gn_mu != nullptr && c % p.gn_cpg == 0;
+          const long gi = (long)n * (p.COUTP / p.gn_cpg) + c / p.gn_cpg;
           gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma[c], p.gn_beta[c], p.gn_scale + (long)n * p.COUTP + c,
-                           p.gn_shift + (long)n * p.COUTP + c);
+                           p.gn_shift + (long)n * p.COUTP + c, first ? p.gn_mu + gi : nullptr, first ? p.gn_rstd + gi : nullptr);
         }
       }
     }

@@ -634,13 +634,15 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       // one tile per sample (the 12 x 22 and 6 x 11 maps): the workgroup that sums a sample's channels also turns the sums into the
       // GroupNorm scale / shift — the same fp64 arithmetic as gn_finalize_kernel, bit for bit, one launch less (option gn_fuse)
       const int cpg = l.groups > 0 ? l.cout / l.groups : 0;
-      const bool fuse = m->opt.gn_fuse && xa.slots == 1 && mu_out == nullptr && l.cout == l.coutp && cpg >= 1 && cpg <= 32 &&
+      const bool fuse = m->opt.gn_fuse && xa.slots == 1 && l.cout == l.coutp && cpg >= 1 && cpg <= 32 &&
                         32 % cpg == 0 && l.cout % cpg == 0 && !(xa.persist_wgs > 0 && l.cin == 32 && l.coutp == 32);
       if (fuse) {
         xa.gn_gamma = l.gamma;
         xa.gn_beta = l.beta;
         xa.gn_scale = ss[0];
         xa.gn_shift = ss[1];
+        xa.gn_mu = mu_out;
+        xa.gn_rstd = rstd_out;
         xa.gn_cpg = cpg;
         xa.gn_eps = 1e-5f;
         xa.gn_P = P;

@@ -155,6 +155,7 @@ struct ConvX3Args {
   // of its channels): scale / shift [B,COUTP] as gn_finalize_kernel would write them, bit for bit; nullptr: the separate launch
   const float *gn_gamma, *gn_beta;
   float *gn_scale, *gn_shift;
+  float *gn_mu, *gn_rstd;            // [B,groups] mean / reciprocal standard deviation for the backward pass, or nullptr
   int gn_cpg;                        // channels per group (divides 32)
   float gn_eps;
   long gn_P;                         // pixels per sample
@@ -163,7 +164,8 @@ struct ConvX3Args {
 // One lane = one channel of a sample, lanes of a group adjacent and aligned: GroupNorm scale / shift from the channel's complete
 // sums (s1, s2), in gn_finalize_kernel's arithmetic — fp64, the butterfly over the group's lanes in its order (the wider offsets
 // of that kernel's 64-lane butterfly add exact zeros), no a*b+c contraction (elementwise.hip is compiled without it).
-__device__ __forceinline__ void gn_finalize_lane(float s1, float s2, int cpg, long P, float eps, float gamma, float beta, float *scale, float *shift) {
+__device__ __forceinline__ void gn_finalize_lane(float s1, float s2, int cpg, long P, float eps, float gamma, float beta, float *scale, float *shift,
+                                                 float *mu_out = nullptr, float *rstd_out = nullptr) {
 #pragma clang fp contract(off)
   double d1 = (double)s1, d2 = (double)s2;
   for (int o = cpg >> 1; o >= 1; o >>= 1) {
@@ -175,6 +177,10 @@ __device__ __forceinline__ void gn_finalize_lane(float s1, float s2, int cpg, lo
   double var = d2 / cnt - mu * mu;
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (mu_out != nullptr) {                                   // (the group's first lane, as thread 0 of gn_finalize_kernel's block)
+    *mu_out = (float)mu;
+    *rstd_out = (float)rstd;
+  }
   const double sc = rstd * (double)gamma;
   *scale = (float)sc;
   *shift = (float)((double)beta - mu * sc);

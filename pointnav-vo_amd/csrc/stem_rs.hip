@@ -1,24 +1,34 @@
-// stem_rs.hip — the float32-grade 7x7 stride-2 stem with its WEIGHTS RESIDENT IN REGISTERS (gfx950 only).
+// stem_rs.hip — the 7x7 stride-2 stem on the 16-bit matrix cores with its WEIGHTS RESIDENT IN REGISTERS (gfx950 only).
 //
-// Same operation, operand layout, tap split and summation order as stem_mx_kernel<2, 1, false, POOL, RAW> (stem_mx.hip: conv1 of
-// resnet.py:156-163 with the input assembly and whitening of vo_cnn.py:110-176 in front and, POOL, the max-pool of resnet.py:168
-// behind) — the results are bit-identical.  What changes is where the B operand lives.
+// The operation, operand layout and tap split of stem_mx_kernel (stem_mx.hip: conv1 of resnet.py:156-163 with the input assembly and
+// whitening of vo_cnn.py:110-176 in front and, POOL, the max-pool of resnet.py:168 behind).  What changes is where the B operand
+// lives.  Three uses:
+//   stem_rs_kernel<2, POOL, RAW, FAST>   float32-grade results from two float16 weight pieces (the inference stem; !POOL: the raw-output
+//                                        stem of pool=separate and of the training forward).  FAST = false: stem_mx_kernel's summation
+//                                        order, bit-identical results; FAST = true (default): 15 % fewer MFMAs, see the kernel.
+//   stem_rs_kernel<1, false, RAW>        the bf16 dual stem (two models' 32 channels: stem_mx_kernel<1, 2, true>), bit-identical.
 //
 // Round 4 measured that the tile-per-workgroup stem and its role-specialised persistent form are bound by the CU's vector-memory
-// pipe (~20 B/clk): every 128-pixel tile re-fetches all 245 KB of weight fragments next to 93 KB of patch, ~16 k cycles per tile
-// against 7.8 k cycles of MFMA issue.  245 KB is half of a CU's 512 KB register file.  Here ONE workgroup of FOUR waves owns a CU
-// for the whole launch, one wave per SIMD with the full 512-register budget, and each wave keeps the 60 fragments of its twelve
-// taps (240 registers) for all of its ~130 tiles; wave 3 streams the five fragments of tap 48 per tile.  What is left on the
+// pipe: every 128-pixel tile re-fetches all 245 KB of weight fragments next to 93 KB of patch, ~16 k cycles per tile against 7.8 k
+// cycles of MFMA issue.  245 KB is half of a CU's 512 KB register file.  Here ONE workgroup of FOUR waves owns a CU for the whole
+// launch, one wave per SIMD with the full 512-register budget (256 VGPRs + 256 AGPRs), and each wave keeps the fragments of its
+// twelve or thirteen taps — pinned to AGPRs, where the MFMAs read them in place — for all of its ~130 tiles.  What is left on the
 // vector-memory pipe is the patch.
 //
-// With one wave per SIMD nothing overlaps by itself, so the K loop is fully unrolled (it has to be: the resident fragments are
-// indexed statically) and the staging of the NEXT tile is cut into pieces placed in the tap regions of the CURRENT tile: loads of
-// piece j in tap j, its float16 conversion and LDS writes four taps (~2.5 k cycles) later, spread between the MFMAs by
-// sched_group_barrier.  No branches inside a tap region (a branch ends the scheduling region): absent lanes write to a trash slot.
-// After the K loop: K-split exchange through the patch buffer just consumed, GroupNorm partials, pooled keys — three workgroup
-// barriers per tile.
+// With one wave per SIMD nothing overlaps by itself, and the wave issues in order.  Measured in this kernel: about 3.6 instruction
+// slots hide behind one 32x32x16 MFMA; beyond that every instruction costs its ~4 cycles.  So:
+//   - the body is compiled once per wave (a switch over the wave index): taps, patch rows and M-tile are constants, every LDS address
+//     of the K loop is one register plus an immediate;
+//   - the K loop is fully unrolled (it has to be: the resident fragments are indexed statically) in groups of four MFMAs — one B
+//     fragment x the four M-tiles — each with its share of the other work in source order: fragment reads, the loads of the NEXT
+//     tile's patch (buffer loads: an out-of-range offset for absent lanes instead of an address select, which the compiler turns into
+//     a branch — and a branch, or a short-circuit &&, ends the scheduling region), their conversion and LDS writes three taps later,
+//     and the epilogue of the PREVIOUS tile cut into pieces that read LDS in one group and compute in the next;
+//   - per tile three workgroup barriers around the K-split exchange (through the patch buffer just consumed) and one over LDS only
+//     inside the K loop (the previous tile's partial sums / pooling scratch).
 //
-// LDS: two 64 KB buffers (patch of tile i / exchange of tile i | patch of tile i+1) + pooling scratch: 146 KB.
+// LDS: two 64 KB buffers (patch of tile i, then exchange of tile i | patch of tile i+1) + pooling scratch + partial sums: 147 KB.
+// Evidence: profiles/r4_stem_rs_phases.txt (cycles per tile), profiles/r4_stem_rs_ablations.txt (what each part costs).
 #include <type_traits>
 
 #include "stem_tile.h"
@@ -45,32 +55,30 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for<N, I + 1>(f);
   }
 }
-#ifndef PNVO_RS_NRES
-#define PNVO_RS_NRES 12
-#endif
+// compile-time tunables (each one measured, profiles/r4_stem_rs_ablations.txt; the defaults are what ships)
 #ifndef PNVO_RS_LAGD
-#define PNVO_RS_LAGD 3
+#define PNVO_RS_LAGD 3   // taps between the load of a one-hot-depth granule round and its conversion + LDS write (2..5: no difference)
 #endif
 #ifndef PNVO_RS_LAGP
-#define PNVO_RS_LAGP 3
+#define PNVO_RS_LAGP 3   // the same for the pixel rounds
 #endif
 #ifndef PNVO_RS_GDS
-#define PNVO_RS_GDS 2   // per MFMA of a region: at most this many LDS reads, ...
+#define PNVO_RS_GDS 2    // scheduling pattern per MFMA of a region: at most this many LDS reads, ...
 #endif
 #ifndef PNVO_RS_GVM
-#define PNVO_RS_GVM 1   // ... vector-memory instructions ...
+#define PNVO_RS_GVM 1    // ... vector-memory instructions ...
 #endif
 #ifndef PNVO_RS_GVA
-#define PNVO_RS_GVA 4   // ... and VALU instructions (plus one LDS write)
+#define PNVO_RS_GVA 4    // ... and VALU instructions (plus one LDS write); 3..8: no difference
 #endif
 #ifndef PNVO_RS_A1AHEAD
-#define PNVO_RS_A1AHEAD 0
+#define PNVO_RS_A1AHEAD 0   // chunk-1 fragments fetched a whole tap ahead as well (no difference: not LDS latency)
 #endif
 #ifndef PNVO_RS_MERGE
-#define PNVO_RS_MERGE 1   // bit 0: regions 0+1 and 2+3 of a tap are scheduled together (K loop -4 %); bits 1, 2: larger unions (slower)
+#define PNVO_RS_MERGE 1  // bit 0: groups 0+1 and 2+3 of a tap are one scheduling region (K loop -4 %); bits 1, 2: larger unions (slower)
 #endif
 #ifndef PNVO_RS_NPIN
-#define PNVO_RS_NPIN 10
+#define PNVO_RS_NPIN 10  // taps whose fragments are pinned to AGPRs (8..13: no difference once most are)
 #endif
 #ifndef PNVO_RS_ABL
 #define PNVO_RS_ABL 0   // developer: compile-time ablations for register-pressure studies (1 no granules, 2 no pixel rounds, 4 no epilogue pieces in the K loop)
