@@ -251,7 +251,7 @@ def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2", form="auto
     px = B * (-(-ho // 8)) * (-(-wo // 16)) * 128              # pixels of the 8x16 tiles, padding included
     if sel in ("auto", "mx") and pieces == "2":   # stem_mx.hip / stem_rs.hip, float16 pieces: 5 x v_mfma_f32_32x32x16_f16 per tap and
         per_tile = 4 * 49 * 5                                 #   32-pixel tile (2 weight pieces x 2 K-chunks + 1 chunk of remainders)
-        if form in ("auto", "fast") and B * (-(-ho // 8)) * (-(-wo // 16)) >= 8 * 256:
+        if form in ("auto", "fast") and B * (-(-ho // 8)) * (-(-wo // 16)) >= 4 * 256:
             per_tile = 4 * (12 * 16 + 3 * 4 + 5)              # stem_rs FAST: the remainder MFMAs of four taps share a chunk: 836, not 980
         flops = px / 128 * per_tile * (2.0 * 32 * 32 * 16)
         peak, pipe = PEAK_BF16_TFLOPS, "float16 MFMA (two float16 weight pieces, inputs exact in float16 -> float32-grade results)"

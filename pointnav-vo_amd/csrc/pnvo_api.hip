@@ -814,7 +814,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
               in_bytes + 4.0 * (M * stem.cout + (double)stem.cout * stem.cin * 49));
       // Forms of the float16-piece stem (option stem_form: auto | fast | resident | persistent | tiles):
-      //   fast (auto when every workgroup gets >= 8 tiles): one 4-wave workgroup per CU for the whole launch, the weights in its
+      //   fast (auto when every workgroup gets >= 4 tiles): one 4-wave workgroup per CU for the whole launch, the weights in its
       //     registers, staging of the next tile and epilogue of the previous one between the MFMAs (stem_rs.hip), the remainder MFMAs
       //     of four taps in one K chunk and tap 48 split over the waves — 0.78 ms at 256 pairs, float32-grade equal to the others;
       //   resident: the same kernel in the tile kernel's summation order — 0.81 ms, bit-identical to tiles;

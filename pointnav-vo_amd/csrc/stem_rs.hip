@@ -77,6 +77,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 #ifndef PNVO_RS_MERGE
 #define PNVO_RS_MERGE 1  // bit 0: groups 0+1 and 2+3 of a tap are one scheduling region (K loop -4 %); bits 1, 2: larger unions (slower)
 #endif
+#ifndef PNVO_RS_MIN_TILES
+#define PNVO_RS_MIN_TILES 4   // tiles per workgroup from which the resident kernel takes the launch (8 pairs of 341x192; measured break-even ~6)
+#endif
 #ifndef PNVO_RS_NPIN
 #define PNVO_RS_NPIN 10  // taps whose fragments are pinned to AGPRs (8..13: no difference once most are)
 #endif
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs) {
   const long ntiles = (long)a.B * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
   const bool f16 = pieces == 2 && ntiles_n == 1 && !bf16_out, dual = pieces == 1 && ntiles_n == 2 && bf16_out && a.pool == nullptr;
-  return (f16 || dual) && wgs >= 8 && ntiles >= 8L * wgs;
+  return (f16 || dual) && wgs >= 8 && ntiles >= PNVO_RS_MIN_TILES * (long)wgs;
 }
 
 hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, bool fast, int wgs, hipStream_t s) {

@@ -69,7 +69,7 @@ def test_persistent_stem_on_an_odd_resolution():
 @pytest.mark.parametrize("B", [19, 64])
 @pytest.mark.parametrize("pool", ["fused", "separate"])
 def test_resident_weight_stem_equals_the_tile_kernel(B, pool):
-    """stem_rs_kernel (stem_form=resident, the default from 16 pairs of 341x192 on): one 4-wave workgroup per CU keeps the stem's
+    """stem_rs_kernel (stem_form=resident, the default from 8 pairs of 341x192 on): one 4-wave workgroup per CU keeps the stem's
     weights in registers for all of its tiles; same tap split, fragment order and K-split summation order as the tile kernel — not
     one bit differs, on the observation-tensor entry, on the sensor-frame entry and with the max-pool as its own pass."""
     model, _ = bench.build_model(DEV)
@@ -81,7 +81,7 @@ def test_resident_weight_stem_equals_the_tile_kernel(B, pool):
     fast = run(model, obs, "fast", 4, pool)
     for k in range(3):
         assert torch.equal(ref[k], res[k]), k
-        assert torch.equal(fast[k], auto[k]), k                       # (auto = fast from 16 pairs on: float32-grade, see below)
+        assert torch.equal(fast[k], auto[k]), k                       # (auto = fast from 8 pairs on: float32-grade, see below)
 
 
 def test_resident_weight_stem_on_an_odd_resolution():
