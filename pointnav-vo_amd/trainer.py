@@ -346,6 +346,7 @@ class BaseRLTrainerWithVO:
         pr_all, keep_r = self._frame_ptrs([f["rgb"] for f in up], np.uint8, (H, W, 3)) if want_rgb else (None, None)
         vp = C.sizeof(C.c_void_p)
         nchunks = self.boundary_chunks or (1 if m < 24 else (2 if m < 64 else 4))
+        nchunks = max(1, min(int(nchunks), m))           # (a chunk holds at least one frame)
         bounds = [(m * c // nchunks, m * (c + 1) // nchunks) for c in range(nchunks)]
         main = torch.cuda.current_stream(dev)
         if nchunks > 1 and getattr(self, "_copy_stream", None) is None:
@@ -423,6 +424,7 @@ class BaseRLTrainerWithVO:
         # Large batches travel as 2-4 chunks: while chunk c is gathered on the host and crosses PCIe on a copy stream, the
         # top-down views of chunk c-1 are built on the caller's stream (host staging, transfer and device work overlap).
         nchunks = self.boundary_chunks or (1 if n < 24 else (2 if n < 48 else 4))
+        nchunks = max(1, min(int(nchunks), n))           # (a chunk holds at least one pair)
         bounds = [(n * c // nchunks, n * (c + 1) // nchunks) for c in range(nchunks)]
         main = torch.cuda.current_stream(dev)
         if nchunks > 1 and getattr(self, "_copy_stream", None) is None:
