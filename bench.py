@@ -309,6 +309,42 @@ def slim_secondary(name, full):
     return out
 
 
+def self_launch(n, port=0):
+    """Re-exec this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on 127.0.0.1 (one process
+    per GPU); rank 0 of the children prints the JSON line on the inherited stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    argv, skip = [], False
+    for a in sys.argv[1:]:                                   # the children get this command line minus --master-port
+        if skip or a.startswith("--master-port="):
+            skip = False
+        elif a == "--master-port":
+            skip = True
+        else:
+            argv.append(a)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.exit(rc)
+    return rc
+
+
+def process_group_record(dist, world):
+    """What the driver needs to see N ranks: the process group's own size and backend (`nccl` IS RCCL on ROCm)."""
+    if dist is None or not dist.is_initialized():
+        return {"world_size": 1, "backend": None}
+    be = dist.get_backend()
+    return {"world_size": dist.get_world_size(), "backend": be, "is_rccl": be == "nccl", "launched_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,7 +366,13 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="--config train: ONE flat gradient all-reduce after the backward instead of buckets behind it (A/B)")
     ap.add_argument("--no-preheat", action="store_true")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = a free one)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (the reference's launch.py:9-32 shells out to
+        # torch.distributed.launch the same way); the ranks re-enter this file with RANK / WORLD_SIZE set
+        return self_launch(args.gpus, args.master_port)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
@@ -510,10 +552,14 @@ def main():
             "model_tflops": value * flops_pair / 1e12,
             "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
-            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "pipe": pipe,
-                         "definition": "EXECUTED matrix-core FLOPs per launch / HIP-event launch duration / peak of that pipe",
-                         "algorithmic_tflops": alg, "algorithmic_frac": alg / PEAK_FP32_TFLOPS,
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s",
+                         "frac": alg / peak, "pipe": pipe,
+                         "definition": "SURVEY 8(d): ALGORITHMIC FLOPs of the layer per launch (2 x MACs of the 30-channel fp32 conv x pairs) "
+                                       "/ HIP-event launch duration / dense peak of the pipe the kernel runs on",
+                         "executed_tflops": ach, "executed_frac": ach / peak,
+                         "executed_note": "matrix-core FLOPs the kernel issues (operand splitting: 2-3 MFMA terms per float32 product, "
+                                          "K and tile padding) / the same duration / the same peak",
+                         "frac_of_fp32_pipe_peak": alg / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_note": traffic_note,
                          "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
@@ -521,6 +567,7 @@ def main():
                                 "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
                                for k in kt), key=lambda k: -k["ms_per_step"])[:40],
         }
+        res["rccl_ranks"] = process_group_record(dist, world)
         if multi is not None:
             res["multi_gpu"] = multi
         if secondary is not None:
@@ -575,7 +622,7 @@ def dry_run(args, rank, world, dist):
         print(json.dumps({"metric": "dry-run (no GPU work)", "value": world * B * args.steps / dt, "unit": "frame-pairs/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
-                          "data": "none", "preheat_steps": pre[1],
+                          "data": "none", "preheat_steps": pre[1], "rccl_ranks": process_group_record(dist, world),
                           "config": {"workload": "dry run of the N-rank control flow", "backend": args.backend,
                                      "shard_counts": counts}}))
     if dist is not None:

@@ -221,3 +221,26 @@ def test_bench_multi_rank_control_flow_runs_under_gloo():
     # the pre-heat loop is left by all ranks together (its steps may contain collectives): rank 1's stub settles two steps
     # later than rank 0's, and the run did not hang
     assert rec["preheat_steps"] >= 6
+
+
+def test_bench_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the round-4 driver called it; the reference's launch.py:9-32 starts its
+    own ranks the same way): bench.py re-enters itself under torch.distributed.run; still ONE JSON line, and the record
+    shows the process group's own world size."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--dry-run"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == {"world_size": 2, "backend": "gloo", "is_rccl": False,
+                                                        "launched_by": "torch.distributed.run"}
+    # a failing rank is not swallowed: the launcher's exit code comes back
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--backend", "gloo",
+                        "--dry-run", "--config", "nonsense"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0

@@ -85,6 +85,24 @@ def test_bench_headline_with_its_secondary_runs_as_two_ranks_sharing_one_gpu():
     assert sec["train"]["gradient_allreduce"].startswith("bucketed")
 
 
+def test_bench_plain_invocation_self_launches_two_ranks_on_the_real_kernels():
+    """`python bench.py --gpus 2 ...` with no launcher in front (the round-4 driver's command shape): bench.py starts its own
+    two ranks; here both share cuda:0 over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--shared-gpu", "--no-cpu-baseline", "--no-secondary", "--batch", "16"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"]["world_size"] == 2 and rec["config"]["global_batch"] == 32
+    assert rec["multi_gpu"]["shards_equal_single_gpu"] is True
+    rf = rec["roofline"]                                   # SURVEY 8(d): the fraction is the ALGORITHMIC one; executed work beside it
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["executed_frac"] >= rf["frac"]
+
+
 @pytest.mark.parametrize("config", ["fwd_fp32", "train"])
 def test_bench_two_ranks_sharing_one_gpu(config):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run), both ranks on cuda:0 over gloo: the real timed

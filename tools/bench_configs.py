@@ -258,9 +258,10 @@ def run_train(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
             "ms_per_step_events": per_step, "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
             "loss_first_last": [lv[0], lv[-1]], "tflops_3x_fwd": value * flops / 1e12,
             "frac_fp32_peak_3x_fwd": value * flops / 1e12 / (bench.PEAK_FP32_TFLOPS * world),
-            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "pipe": pipe, "definition": "EXECUTED matrix-core FLOPs per launch / HIP-event launch duration / peak of that pipe",
-                         "algorithmic_tflops": alg, "traffic": None, "launch_ms": launch_ms},
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
+                         "pipe": pipe, "definition": "SURVEY 8(d): ALGORITHMIC FLOPs of the layer's weight gradient per launch / HIP-event "
+                                                     "launch duration / dense peak of the pipe the kernel runs on",
+                         "executed_tflops": ach, "executed_frac": ach / peak, "traffic": None, "launch_ms": launch_ms},
             "ms_by_kernel_class": agg,
             "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps, "launches": k["launches"] // args.steps,
                                 "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
@@ -268,6 +269,7 @@ def run_train(args, rank, world, dist, dev, sync_all, obs=None, emit=True):
                                for k in kt), key=lambda k: -k["ms_per_step"])[:70],
         }
         res["config"]["gradient_allreduce"] = "bucketed behind the backward" if ts.bucketed else "one flat buffer after the backward"
+        res["rccl_ranks"] = bench.process_group_record(dist, world)
         if multi is not None:
             res["multi_gpu"] = multi
         if not emit:
