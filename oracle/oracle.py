@@ -285,3 +285,27 @@ def topdown_view(depth, consts, rows_around_center=50, blur_in=None, return_aux=
         blur = blur_out[: max(hc, 0) * max(wc, 0)].reshape(max(hc, 0), max(wc, 0)) if rc == 0 else None
         return out[..., None], dict(bbox=bbox, blur=blur, cnt=cnt, empty=bool(rc))
     return out[..., None]
+
+
+# ----------------------------------------------------------------------------- baseline form: one pair per host thread
+def forward_pairs_parallel(sd, obs, *, ngroups, threads=None, dtype=np.float32, indices=None):
+    """The same forward, parallelised over PAIRS instead of inside each layer (frame pairs are independent; per-sample
+    GroupNorm): `threads` host threads, each running whole single-pair forwards with an OpenMP team of one, so a pair's
+    working set (7.9 MB of input, 2.1 MB of stem output, ...) stays in that core's caches.  ctypes releases the GIL inside
+    the C calls.  Results equal `forward` (same per-element summation order).  bench.py's cpu_baseline leg.
+    `indices`: the pairs of `obs` to run, repeats allowed (a long timed sample over a small set of distinct pairs)."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = int(threads or usable_cores())
+    idx = list(range(next(iter(obs.values())).shape[0])) if indices is None else [int(i) for i in indices]
+    n = len(idx)
+    sdc = {k: np.ascontiguousarray(np.asarray(v)) for k, v in sd.items()}
+
+    def init():
+        set_threads(1)                                   # omp nthreads-var is per host thread: a team of one in THIS thread
+
+    def one(i):
+        return forward(sdc, {k: v[i:i + 1] for k, v in obs.items()}, ngroups=ngroups, dtype=dtype)
+
+    with ThreadPoolExecutor(max_workers=min(threads, n), initializer=init) as ex:
+        outs = list(ex.map(one, idx))
+    return np.concatenate(outs, axis=0)
