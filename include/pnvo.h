@@ -406,17 +406,20 @@ int pnvo_forward_features(pnvo_handle h, const float *rgb, const float *depth, c
 /* The fused stems exploit the reference's own observation contract: rgb holds integers 0..255 (uint8 frames cast to float,
  * base_trainer_with_vo.py:196-207) and the discretised depth is one-hot per frame (what _discretize_depth_func produces and
  * asserts, :163).  The reference MODEL, however, accepts any float tensor (vo_cnn.py:110-176), so a drop-in must too:
- *   option input_fallback = on (default): a forward whose stem met a value outside the contract is RE-RUN inside the same
- *     pnvo_forward / pnvo_forward_features / pnvo_train_forward call on the dense fp32 stem — the caller gets the correct
- *     result from that call — and the handle stays on the dense stem from then on (pnvo_last_note holds a one-line note,
- *     pnvo_get_option(h, "stem") reports "dense (fallback)"; pnvo_set_option(h, "stem", ...) lifts it).  Cost for contract
- *     inputs: the call waits (hipEventSynchronize) for the stem kernel of THIS forward before it returns — the first of its ~55
- *     launches, so on an idle stream the wait is over before the enqueue is; on a stream with a backlog (several action models
- *     enqueued back to back, 'rnd' mode, a training step whose gradient all-reduce should run ahead of the host) the host
- *     blocks until the earlier work and this stem have run.  Such callers switch the option off and poll pnvo_check_inputs.
- *   option input_fallback = off, or a forward issued while the stream is being captured into a hipGraph: no wait; the stem
- *     raises a host-visible flag instead and pnvo_check_inputs (definitive after the caller synchronised the stream) as well
- *     as every later forward on the handle return PNVO_ERR_INPUT until the weights are re-loaded. */
+ *   option input_fallback = on (default): pnvo_forward / pnvo_forward_features stay ASYNCHRONOUS — no host wait.  Behind the fused
+ *     stem the call enqueues the float32 stem once more, PREDICATED ON THE DEVICE on the flag the fused stem raises when a value
+ *     breaks the contract (stem_lds_kernel<.., PAIRED> + pool_keys_from_raw_kernel: both return at once while the flag is down,
+ *     ~2 x 3 us of GPU time for contract inputs), so the forward that met such a value repairs itself and delivers the correct
+ *     result.  The host reads the (host-mapped) flag at its next entry, without waiting: from then on the handle launches the
+ *     float32 stem directly (pnvo_last_note holds a one-line note, pnvo_get_option(h, "stem") reports "dense (fallback)";
+ *     pnvo_set_option(h, "stem", ...) lifts it — the one call that waits for the device, to lower the flag safely).  Works inside a
+ *     hipGraph capture too (the repair is captured with the forward).  pnvo_train_forward keeps a host-side decision: its
+ *     backward must know which stem ran, so it waits (hipEventSynchronize) for its stem kernel — the first of its launches —
+ *     and re-runs on the dense stem when the flag is up; the same holds for models the float32 LDS stem does not serve
+ *     (stem outputs other than 32 / 64 channels).
+ *   option input_fallback = off: no repair launches and no wait; the stem raises the flag and pnvo_check_inputs (definitive after
+ *     the caller synchronised the stream) as well as every later forward on the handle return PNVO_ERR_INPUT until the weights
+ *     are re-loaded. */
 int pnvo_check_inputs(pnvo_handle h);
 
 /* Which kernel family a conv of the residual stages / the compression conv (state_dict prefix, e.g.

@@ -243,6 +243,57 @@ hipError_t launch_gn_relu_maxpool(const float *x, const float *scale, const floa
   return hipGetLastError();
 }
 
+// The pooled stem output in the form the fused stems write it (stem_mx.hip POOL: order-preserving integer keys of the 3x3/2 window
+// maximum of sgn(gamma) * x, decoded by conv_x3 MODE 3), rebuilt from a RAW stem output: the second half of the device-side
+// input-contract repair (pnvo_api.hip).  Every key is a plain store, so whatever the contract-breaking launch left is replaced.
+// Predicated like stem_lds_kernel<.., PAIRED>: a no-op while *only_if == 0 (only_if == nullptr: always).
+__global__ __launch_bounds__(256) void pool_keys_from_raw_kernel(const float *x, const float *gamma, int B, int H, int W, int C, int Ho,
+                                                               int Wo, int *keys, const int *only_if) {
+  if (only_if != nullptr && *reinterpret_cast<const volatile int *>(only_if) == 0) return;
+  const int Q = C >> 2;
+  const long total = (long)B * Ho * Wo * Q;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const int q = (int)(g % Q);
+    long r = g / Q;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + 4 * q);
+    f32x4 m = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = 2 * ho - 1 + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = 2 * wo - 1 + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + hi) * W + wi) * C + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m[t] = fmaxf(m[t], gm[t] < 0.f ? -v[t] : v[t]);
+      }
+    }
+    int k[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int b = __builtin_bit_cast(int, m[t]);
+      k[t] = b >= 0 ? b : b ^ 0x7fffffff;
+    }
+    *reinterpret_cast<int4 *>(keys + 4 * g) = int4{k[0], k[1], k[2], k[3]};
+  }
+}
+
+hipError_t launch_pool_keys_from_raw(const float *x, const float *gamma, int B, int H, int W, int C, int *keys, const int *only_if,
+                                     hipStream_t s) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(pool_keys_from_raw_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, x, gamma, B, H, W, C,
+                     Ho, Wo, keys, only_if);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // BasicBlock tail (resnet.py:47-55): y = relu(GN2(conv2) + residual), residual = x or GN_d(conv1x1(x)).
 __global__ __launch_bounds__(256) void residual_kernel(const float *a, const float *sa, const float *ta, const float *b,

@@ -729,21 +729,82 @@ void pnvo_stem_raw_args(pnvo_handle m, StemMXArgs &a) {
   a.src[0] = a.src[1] = a.src[2] = nullptr;
 }
 
+// The float32-MFMA stem (stem_lds.hip) serves this model: the kernel the input-contract repair runs.
+static bool stem_lds_serves(pnvo_handle m) {
+  const Layer &stem = m->convs[0];
+  return (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
+}
+
+// Inference forwards decide on the DEVICE whether the stem is redone on float32 operands (pnvo_stem_repair); the training forward
+// keeps the host-side event (its backward has to know, too).
+static bool stem_repairs_on_device(pnvo_handle m) {
+  return m->opt.input_fallback && m->dd_flag != nullptr && !m->in_train_forward && stem_lds_serves(m);
+}
+
+// The stem's place in the forward is the 16-bit-matrix-core stems' (8 x 16-tile slots, pooled keys, raw entry).  Once the input
+// fallback engaged (dense_sticky) that place is kept and the float32 stem stands in (stem_lds_kernel<.., PAIRED>) wherever it
+// serves the model; elsewhere, and in the training forward, the handle leaves the mx path as before.
 bool pnvo_stem_on_mx(pnvo_handle m) {
-  return m->mx_ok && !m->dense_sticky && (!m->in_train_forward || m->train_mx) && m->opt.stem <= 1;
+  if (m->dense_sticky && (m->in_train_forward || !stem_lds_serves(m))) return false;
+  return m->mx_ok && (!m->in_train_forward || m->train_mx) && m->opt.stem <= 1;
+}
+
+// The float32 stem in the place of an 8 x 16-tile stem: raw output + that stem's GroupNorm slot layout (+ pooled keys).  `only_if`
+// (device-readable flag) makes both launches no-ops while it is zero.
+static int pnvo_stem_standin(pnvo_handle m, int B, const float *const *src, float *y, int slots, int *pool_keys, const int *only_if,
+                             hipStream_t s) {
+  const pnvo_config &c = m->cfg;
+  const Layer &stem = m->convs[0];
+  const int nsrc[4] = {c.n_rgb, c.n_depth, c.n_dd, c.n_tdv};
+  StemArgs a;
+  std::memset(&a, 0, sizeof(a));
+  for (int j = 0; j < m->CPL / 8; ++j)
+    for (int hh = 0; hh < 2; ++hh)
+      for (int q = 0; q < 2; ++q) {
+        const int nc = 8 * j + 4 * hh + 2 * q;
+        const int tn = nc < m->CP ? m->stem_tensor_of_new[nc] : -1;
+        a.pieces[j][hh][q].base = tn >= 0 ? src[tn] : nullptr;
+        a.pieces[j][hh][q].nch = tn >= 0 ? nsrc[tn] : 0;
+        a.pieces[j][hh][q].choff = tn >= 0 ? m->stem_ch_of_new[nc] : 0;
+      }
+  a.sc = m->stem_sc;
+  a.sh = m->stem_sh;
+  a.wpk = m->stem_wpk16;
+  a.zero_page = m->zero_page;
+  a.y = y;
+  a.stats = m->stats;
+  a.B = B;
+  a.H = c.height;
+  a.W = c.width;
+  a.Ho = m->Hs;
+  a.Wo = m->Ws;
+  a.CPL = m->CPL;
+  a.slots = slots;
+  a.paired = 1;
+  a.only_if = only_if;
+  {
+    const double M = (double)B * m->Hs * m->Ws;
+    Timed t(m, s, only_if ? "stem_repair" : "conv:" + stem.name, only_if ? 0.0 : 2.0 * M * stem.cout * stem.cin * 49,
+            only_if ? 0.0 : 4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
+    HIPCHK(m, launch_stem_lds(a, stem.coutp, s));
+  }
+  if (pool_keys != nullptr) {
+    Timed t(m, s, only_if ? "stem_repair" : "pool_keys", 0.0, only_if ? 0.0 : 4.0 * B * ((double)m->Hs * m->Ws + (double)m->Hp * m->Wp) * stem.coutp);
+    HIPCHK(m, launch_pool_keys_from_raw(y, stem.gamma, B, m->Hs, m->Ws, stem.coutp, pool_keys, only_if, s));
+  }
+  return PNVO_OK;
 }
 
 // An event behind a contract-checking stem launch (see pnvo_input_fallback); nothing while a stream capture is under way
 // (an event recorded into a graph cannot be waited for: such forwards keep the deferred check of pnvo_check_inputs).
 // Does the stem kernel pnvo_run_stem would launch leave per-tile statistics ([B][slots][CP][2]) in m->stats?
 bool stem_writes_slots(pnvo_handle m) {
-  const Layer &stem = m->convs[0];
-  const bool lds_stem = (m->CPL <= 32) && (stem.coutp == 32 || stem.coutp == 64) && stem.cout == stem.coutp;
-  return pnvo_stem_on_mx(m) || (m->dd_ok && m->opt.stem != 3 && !m->dense_sticky) || lds_stem;
+  return pnvo_stem_on_mx(m) || (m->dd_ok && m->opt.stem != 3 && !m->dense_sticky) || stem_lds_serves(m);
 }
 
 int pnvo_mark_stem(pnvo_handle m, hipStream_t s) {
   if (!m->opt.input_fallback || m->dense_sticky || !m->dd_flag) return PNVO_OK;
+  if (stem_repairs_on_device(m)) return PNVO_OK;    // decided on the device: pnvo_stem_standin(.., only_if = the flag) follows the stem
   if (m->raw_depth != nullptr) return PNVO_OK;      // sensor frames: uint8 rgb, one-hot derived in the stager — inside the contract by construction
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return PNVO_OK;
@@ -808,7 +869,10 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       a.prof = m->mx_prof;
     }
     const double M = (double)B * m->Hs * m->Ws;
-    {
+    if (m->dense_sticky) {
+      // the input fallback engaged: the float32 stem stands in (same place in the forward, same slot layout, pooled keys)
+      if ((rc = pnvo_stem_standin(m, B, src, y, a.slots, pool_keys, nullptr, s)) != PNVO_OK) return rc;
+    } else {
       // algorithmic bytes: the observation tensors (or, RAW: 6 B of rgb + 8 B of depth + 8 B of top-down view per pixel) once
       const double in_bytes = (double)B * c.height * c.width * (m->raw_depth ? (c.n_rgb ? 6.0 : 0.0) + 8.0 + (c.n_tdv ? 8.0 : 0.0) : 4.0 * stem.cin);
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
@@ -832,12 +896,28 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       else
         HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
+    // a value outside the observation contract (the flag the stager raised): redone on float32 operands, decided on the DEVICE —
+    // two launches that return at once while the flag is down; the host never waits (it reads the flag at its next entry and
+    // moves the handle to the stand-in for good: pnvo_check_inputs)
+    if (!m->dense_sticky && m->raw_depth == nullptr && stem_repairs_on_device(m) &&
+        (rc = pnvo_stem_standin(m, B, src, y, a.slots, pool_keys, m->dd_flag, s)) != PNVO_OK)
+      return rc;
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     m->stem_slots_out = a.slots;
     if (!m->stem_skip_finalize) {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
                                    stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
+    }
+  } else if (m->dd_ok && m->opt.stem != 3 && m->dense_sticky && !m->in_train_forward && stem_lds_serves(m)) {
+    // the input fallback engaged on the one-hot-aware stem: the float32 stem stands in, in that stem's slot layout
+    const int slots = stem_dd_slots(m->Hs, m->Ws);
+    if ((rc = pnvo_stem_standin(m, B, src, y, slots, nullptr, nullptr, s)) != PNVO_OK) return rc;
+    m->stem_slots_out = slots;
+    if (!m->stem_skip_finalize) {
+      Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      HIPCHK(m, launch_gn_finalize(m->stats, B, slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
+                                   stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, slots, mu_out, rstd_out));
     }
   } else if (m->dd_ok && m->opt.stem != 3 && !m->dense_sticky) {
     // one-hot-aware stem (in training its operands are rebuilt on the device every step: refresh_stem_dd)
@@ -882,6 +962,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
               4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
       HIPCHK(m, launch_stem_dd(a, s));
     }
+    if (stem_repairs_on_device(m) && (rc = pnvo_stem_standin(m, B, src, y, a.slots, nullptr, m->dd_flag, s)) != PNVO_OK) return rc;
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     m->stem_slots_out = a.slots;
     if (!m->stem_skip_finalize) {
@@ -1052,7 +1133,10 @@ const char *pnvo_version(void) { return "pnvo 0.2 (gfx950: fp32 + bf16 MFMA)"; }
 
 const char *pnvo_last_error(pnvo_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
-const char *pnvo_last_note(pnvo_handle h) { return h ? h->note.c_str() : ""; }
+const char *pnvo_last_note(pnvo_handle h) {
+  if (h && h->loaded && h->opt.input_fallback) (void)pnvo_check_inputs(h);     // a raised input-contract flag (host-mapped, no wait) is noted here at the latest
+  return h ? h->note.c_str() : "";
+}
 
 int pnvo_create(const pnvo_config *cfg, int device, pnvo_handle *out) {
   if (!cfg || !out) return fail(nullptr, PNVO_ERR_ARG, "null argument");
@@ -1353,7 +1437,15 @@ int pnvo_set_option(pnvo_handle h, const char *key, const char *value) {
   if (h->opt.*(d->field) == v && !lift) return PNVO_OK;
   h->opt.*(d->field) = v;
   pnvo_drop_graphs(h);                       // captured launches encode the kernel selection
-  if (lift) h->dense_sticky = false;
+  if (lift) {
+    // repairs of forwards still in flight read the flag on the device: wait for them before it is lowered (a rare, explicit call)
+    if (h->dd_flag && *(volatile int *)h->dd_flag != 0) {
+      HIPCHK(h, hipSetDevice(h->device));
+      HIPCHK(h, hipDeviceSynchronize());
+      *(volatile int *)h->dd_flag = 0;
+    }
+    h->dense_sticky = false;
+  }
   return PNVO_OK;
 }
 
@@ -1368,6 +1460,7 @@ int pnvo_get_option(pnvo_handle h, const char *key, char *buf, size_t cap) {
       word = c->word;
       break;
     }
+  if (d->field == &PnvoOptions::stem && h->loaded && h->opt.input_fallback) (void)pnvo_check_inputs(h);   // see pnvo_last_note
   if (d->field == &PnvoOptions::stem && h->dense_sticky) word = "dense (fallback)";
   std::snprintf(buf, cap, "%s", word.c_str());
   return PNVO_OK;
@@ -1405,12 +1498,26 @@ int pnvo_forward_dual(pnvo_handle ha, pnvo_handle hb, const float *rgb, const fl
 
 int pnvo_check_inputs(pnvo_handle m) {
   if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
-  if (m->dd_flag && *(volatile int *)m->dd_flag != 0)
+  if (m->dd_flag && *(volatile int *)m->dd_flag != 0) {
+    if (m->opt.input_fallback && !m->in_train_forward && stem_lds_serves(m)) {
+      // The flag is host-mapped: read without waiting for anything.  The forward that raised it repaired itself on the device
+      // (pnvo_stem_standin behind its stem); from here on this handle launches the float32 stand-in directly.  The flag stays up
+      // — repairs of forwards still in flight read it — until pnvo_set_option(h, "stem", ..) lifts the fallback.
+      if (!m->dense_sticky) {
+        m->dense_sticky = true;
+        m->fallback_count += 1;
+        pnvo_drop_graphs(m);
+        m->note = "note: observation values outside the fused stems' contract (fractional rgb or depth codes that are not one-hot) — "
+                  "the forward redid its stem on float32 operands (decided on the device) and this handle stays on the dense float32 stem";
+      }
+      return PNVO_OK;
+    }
     return fail(m, PNVO_ERR_INPUT,
                 "an earlier forward met observation values outside the reference's contract — a discretised-depth pixel "
                 "that is not one-hot (base_trainer_with_vo.py:163) or an rgb value that is not an integer 0..255 — so its "
-                "outputs are invalid (this handle runs with input_fallback=off, or the forward was stream-captured).  Feed "
+                "outputs are invalid (this handle runs with input_fallback=off).  Feed "
                 "contract inputs, keep option input_fallback on, or select the dense stem: pnvo_set_option(h, \"stem\", \"dense\")");
+  }
   return PNVO_OK;
 }
 

@@ -55,6 +55,8 @@ struct StemArgs {
   float *stats;               // [B,slots,COUT,2]
   int B, H, W, Ho, Wo, CPL, slots, tiles_x, tiles_y;
   int dbg, lds_pad;           // experiment knobs (PNVO_STEM_DBG="<flags>,<lds_pad_bytes>"): 1 skip staging, 2 skip epilogue
+  int paired;                 // 1: stand in for an 8 x 16-tile stem — slots = ceil(Ho/8) * ceil(Wo/16), partials of a tile pair summed
+  const int *only_if;         // paired: predicate read on the DEVICE (nullptr: always run) — the launch is a no-op while *only_if == 0
 };
 int stem_tiles_x(int Wo);
 int stem_tiles_y(int Ho);
@@ -263,6 +265,10 @@ hipError_t launch_assemble(const AssembleArgs &a, hipStream_t s);
 // relu(gn(x)) then MaxPool 3x3 s2 p1.
 hipError_t launch_gn_relu_maxpool(const float *x, const float *scale, const float *shift, int B, int H, int W,
                                   int C, float *out, hipStream_t s);
+
+// Pooled order-preserving keys (the fused stems' POOL output) from a raw stem output; a no-op while *only_if == 0 (device-side).
+hipError_t launch_pool_keys_from_raw(const float *x, const float *gamma, int B, int H, int W, int C, int *keys, const int *only_if,
+                                     hipStream_t s);
 
 // y = relu(a*sa+ta + r)  with r = b (plain) or b*sb+tb.  a,b,y: [B,P,C].
 hipError_t launch_residual(const float *a, const float *sa, const float *ta, const float *b, const float *sb,

@@ -35,8 +35,14 @@ __device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t r, unsigned voff,
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int NT16, int CPL>   // Cout / 16; channels per pixel in LDS (16 or 32)
+// PAIRED (the device-side input-contract repair and the handle's fallback stem, pnvo_api.hip pnvo_run_stem): the launch stands in
+// for a stem on the 16-bit matrix cores (stem_mx.hip / stem_rs.hip / stem_dd.hip) — same raw output, GroupNorm partials in THEIR
+// slot layout (one slot per 8 x 16 tile = two vertically adjacent tiles of this kernel, summed upper + lower), and PREDICATED:
+// with `only_if` set the whole launch returns at once unless *only_if != 0 (the flag those stems raise when a value breaks the
+// observation contract), so the decision to redo the stem on float32 operands is taken on the device, not by a waiting host.
+template <int NT16, int CPL, bool PAIRED = false>   // Cout / 16; channels per pixel in LDS (16 or 32)
 __global__ __launch_bounds__(NTHREADS, 4) void stem_lds_kernel(const StemArgs p) {
+  if (PAIRED && p.only_if != nullptr && *reinterpret_cast<const volatile int *>(p.only_if) == 0) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int G = CPL >> 2;         // 16-byte slots per pixel (4 or 8)
   constexpr int J16 = CPL >> 4;       // 16-channel K groups per tap (1 or 2)
@@ -58,12 +64,17 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_lds_kernel(const StemArgs p)
   const f32x4 wsc = *reinterpret_cast<const f32x4 *>(p.sc + 4 * sg);
   const f32x4 wsh = *reinterpret_cast<const f32x4 *>(p.sh + 4 * sg);
 
-  const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  constexpr int NSUB = PAIRED ? 2 : 1;
+  const int ntiles = p.B * p.tiles_x * p.tiles_y;     // PAIRED: tiles_y counts 8-row tile pairs
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float pair_s1 = 0.f, pair_s2 = 0.f;               // PAIRED: the upper tile's partials (threads < COUT)
+#pragma unroll 1
+    for (int sub = 0; sub < NSUB; ++sub) {
     int bid = tile;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
+    const int ty_slot = bid % p.tiles_y;
+    const int ty = NSUB * ty_slot + sub;
     const int n = bid / p.tiles_y;
     const int ho0 = ty * TH, wo0 = tx * TW;
     const int hi_base = 2 * ho0 - 3, wi_base = 2 * wo0 - 3;
@@ -202,12 +213,18 @@ __global__ __launch_bounds__(NTHREADS, 4) void stem_lds_kernel(const StemArgs p)
         s1 += red[(w * COUT + c) * 2];
         s2 += red[(w * COUT + c) * 2 + 1];
       }
-      const int slot = ty * p.tiles_x + tx;
-      float *dst = p.stats + (((long)n * p.slots + slot) * COUT + c) * 2;
-      dst[0] = s1;
-      dst[1] = s2;
+      if (PAIRED && sub == 0) {
+        pair_s1 = s1;
+        pair_s2 = s2;
+      } else {
+        const int slot = ty_slot * p.tiles_x + tx;
+        float *dst = p.stats + (((long)n * p.slots + slot) * COUT + c) * 2;
+        dst[0] = PAIRED ? pair_s1 + s1 : s1;
+        dst[1] = PAIRED ? pair_s2 + s2 : s2;
+      }
     }
     __syncthreads();   // xch/red alias the patch: the next tile's staging must not start before they are consumed
+    }  // sub-tile
   }  // tile loop
 }
 
@@ -218,13 +235,27 @@ size_t stem_lds_bytes(int CPL) { return (size_t)PH * PW * CPL * 4; }
 hipError_t launch_stem_lds(const StemArgs &a, int cout, hipStream_t s) {
   StemArgs p = a;
   p.tiles_x = stem_tiles_x(a.Wo);
-  p.tiles_y = stem_tiles_y(a.Ho);
+  p.tiles_y = a.paired ? (a.Ho + 2 * TH - 1) / (2 * TH) : stem_tiles_y(a.Ho);
   const size_t lds = stem_lds_bytes(a.CPL);
   if ((a.CPL != 16 && a.CPL != 32) || lds < (size_t)(4 * (cout / 16) * 64 * 4 + 4 * cout * 2) * 4) return hipErrorInvalidValue;
   const long ntiles = (long)a.B * p.tiles_x * p.tiles_y;
   const long resident = (long)(160 * 1024 / (lds + (size_t)a.lds_pad)) * 256;   // workgroups the chip holds at once
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
   const size_t dyn = lds + (size_t)a.lds_pad;
+  if (a.paired) {                              // stand-in for the 8 x 16-tile stems (their slot layout), optionally predicated
+    if (p.slots != p.tiles_x * p.tiles_y) return hipErrorInvalidValue;
+    if (cout == 32 && a.CPL == 32)
+      hipLaunchKernelGGL((stem_lds_kernel<2, 32, true>), grid, dim3(NTHREADS), dyn, s, p);
+    else if (cout == 32 && a.CPL == 16)
+      hipLaunchKernelGGL((stem_lds_kernel<2, 16, true>), grid, dim3(NTHREADS), dyn, s, p);
+    else if (cout == 64 && a.CPL == 32)
+      hipLaunchKernelGGL((stem_lds_kernel<4, 32, true>), grid, dim3(NTHREADS), dyn, s, p);
+    else if (cout == 64 && a.CPL == 16)
+      hipLaunchKernelGGL((stem_lds_kernel<4, 16, true>), grid, dim3(NTHREADS), dyn, s, p);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (cout == 32 && a.CPL == 32)
     hipLaunchKernelGGL((stem_lds_kernel<2, 32>), grid, dim3(NTHREADS), dyn, s, p);
   else if (cout == 32 && a.CPL == 16)

@@ -197,12 +197,15 @@ def test_resident_stem_detects_input_outside_its_contract(kind):
     with torch.no_grad():
         clean = model(obs).clone()
         assert model.get_option("stem") == "auto"
-        out = model(bad).clone()                              # the offending call itself
-        assert model.get_option("stem") == "dense (fallback)" and "dense" in model.last_note()
+        out = model(bad).clone()                              # the offending call itself: its stem redone on the device
+        torch.cuda.synchronize()                              # (the host learns of it at its next entry, once the stem has run)
+        assert model.get_option("stem") == "dense (fallback)" and "float32 stem" in model.last_note()
+        again = model(bad).clone()                            # the stand-in launched directly: the same kernel, the same bits
         model.set_option("stem", "dense")
-        ref = model(bad).clone()
+        ref = model(bad).clone()                              # the classic dense path (4 x 16-tile GroupNorm slots, separate max-pool)
         torch.cuda.synchronize()
-    assert torch.equal(out, ref)
-    assert torch.equal(out[:31], ref[:31]) and not torch.equal(out[31], clean[31])
+    assert torch.equal(out, again)
+    assert float((out - ref).abs().max() / ref.abs().max()) < 5e-6      # float32-grade: only the statistics' slot partition differs
+    assert not torch.equal(out[31], clean[31])
     rel = (out[:31] - clean[:31]).abs().max() / clean.abs().max()
     assert rel < 5e-6, rel                                    # the untouched pairs: dense stem vs split stem, float32-grade
