@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void pool_keys_from_raw_kernel(const float *x,
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
     const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + 4 * q);
-    f32x4 m = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float m0 = -__builtin_inff(), m1 = m0, m2 = m0, m3 = m0;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hi = 2 * ho - 1 + kh;
@@ -270,18 +270,33 @@ __global__ __launch_bounds__(256) void pool_keys_from_raw_kernel(const float *x,
         const int wi = 2 * wo - 1 + kw;
         if ((unsigned)wi >= (unsigned)W) continue;
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((long)n * H + hi) * W + wi) * C + 4 * q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) m[t] = fmaxf(m[t], gm[t] < 0.f ? -v[t] : v[t]);
+        m0 = fmaxf(m0, gm.x < 0.f ? -v.x : v.x);
+        m1 = fmaxf(m1, gm.y < 0.f ? -v.y : v.y);
+        m2 = fmaxf(m2, gm.z < 0.f ? -v.z : v.z);
+        m3 = fmaxf(m3, gm.w < 0.f ? -v.w : v.w);
       }
     }
-    int k[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int b = __builtin_bit_cast(int, m[t]);
-      k[t] = b >= 0 ? b : b ^ 0x7fffffff;
-    }
-    *reinterpret_cast<int4 *>(keys + 4 * g) = int4{k[0], k[1], k[2], k[3]};
+    auto key_of = [](float f) {
+      const int b = __builtin_bit_cast(int, f);
+      return b >= 0 ? b : b ^ 0x7fffffff;
+    };
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 kv;
+    kv.x = key_of(m0);
+    kv.y = key_of(m1);
+    kv.z = key_of(m2);
+    kv.w = key_of(m3);
+    *reinterpret_cast<i32x4 *>(keys + 4 * g) = kv;
   }
+}
+
+__global__ void flag_publish_kernel(const int *dev_flag, int *host_flag) {
+  if (threadIdx.x == 0 && *reinterpret_cast<const volatile int *>(dev_flag) != 0) *reinterpret_cast<volatile int *>(host_flag) = 1;
+}
+
+hipError_t launch_flag_publish(const int *dev_flag, int *host_flag, hipStream_t s) {
+  hipLaunchKernelGGL(flag_publish_kernel, dim3(1), dim3(64), 0, s, dev_flag, host_flag);
+  return hipGetLastError();
 }
 
 hipError_t launch_pool_keys_from_raw(const float *x, const float *gamma, int B, int H, int W, int C, int *keys, const int *only_if,

@@ -782,6 +782,7 @@ static int pnvo_stem_standin(pnvo_handle m, int B, const float *const *src, floa
   a.slots = slots;
   a.paired = 1;
   a.only_if = only_if;
+  a.publish = only_if ? m->dd_flag : nullptr;     // a raised flag reaches the host-mapped copy from this launch
   {
     const double M = (double)B * m->Hs * m->Ws;
     Timed t(m, s, only_if ? "stem_repair" : "conv:" + stem.name, only_if ? 0.0 : 2.0 * M * stem.cout * stem.cin * 49,
@@ -803,9 +804,10 @@ bool stem_writes_slots(pnvo_handle m) {
 }
 
 int pnvo_mark_stem(pnvo_handle m, hipStream_t s) {
-  if (!m->opt.input_fallback || m->dense_sticky || !m->dd_flag) return PNVO_OK;
+  if (!m->dd_flag || m->dense_sticky || m->raw_depth != nullptr) return PNVO_OK;   // sensor frames: inside the contract by construction
   if (stem_repairs_on_device(m)) return PNVO_OK;    // decided on the device: pnvo_stem_standin(.., only_if = the flag) follows the stem
-  if (m->raw_depth != nullptr) return PNVO_OK;      // sensor frames: uint8 rgb, one-hot derived in the stager — inside the contract by construction
+  HIPCHK(m, launch_flag_publish(m->dd_flag_dev, m->dd_flag, s));   // the host-side decisions below / pnvo_check_inputs read the host copy
+  if (!m->opt.input_fallback) return PNVO_OK;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return PNVO_OK;
   if (!m->stem_ev) HIPCHK(m, hipEventCreateWithFlags(&m->stem_ev, hipEventDisableTiming));
@@ -841,7 +843,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.oscale = m->mx_oscale;
     // (after a device-side re-pack the scale lives on the device; a later pnvo_load_weights re-packs on the host with its own)
     a.oscale_ptr = m->mx_wpk2_dev ? m->mx_scale2_dev + 1 : nullptr;
-    a.bad_input = m->dd_flag;
+    a.bad_input = m->dd_flag_dev;
     const int ntn = stem.cout / 32;
     for (int g = 0; g < ntn; ++g) {
       a.y[g] = y;
@@ -900,7 +902,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     // two launches that return at once while the flag is down; the host never waits (it reads the flag at its next entry and
     // moves the handle to the stand-in for good: pnvo_check_inputs)
     if (!m->dense_sticky && m->raw_depth == nullptr && stem_repairs_on_device(m) &&
-        (rc = pnvo_stem_standin(m, B, src, y, a.slots, pool_keys, m->dd_flag, s)) != PNVO_OK)
+        (rc = pnvo_stem_standin(m, B, src, y, a.slots, pool_keys, m->dd_flag_dev, s)) != PNVO_OK)
       return rc;
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     m->stem_slots_out = a.slots;
@@ -938,7 +940,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.table = m->dd_table;
     a.dd = src[2];
     a.zero_page = m->zero_page;
-    a.bad_onehot = m->dd_flag;
+    a.bad_onehot = m->dd_flag_dev;
     a.y = y;
     a.stats = m->stats;
     a.B = B;
@@ -962,7 +964,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
               4.0 * ((double)B * c.height * c.width * stem.cin + M * stem.cout + (double)stem.cout * stem.cin * 49));
       HIPCHK(m, launch_stem_dd(a, s));
     }
-    if (stem_repairs_on_device(m) && (rc = pnvo_stem_standin(m, B, src, y, a.slots, nullptr, m->dd_flag, s)) != PNVO_OK) return rc;
+    if (stem_repairs_on_device(m) && (rc = pnvo_stem_standin(m, B, src, y, a.slots, nullptr, m->dd_flag_dev, s)) != PNVO_OK) return rc;
     if ((rc = pnvo_mark_stem(m, s)) != PNVO_OK) return rc;
     m->stem_slots_out = a.slots;
     if (!m->stem_skip_finalize) {
@@ -1111,6 +1113,7 @@ int pnvo_input_fallback(pnvo_handle m, hipStream_t s, bool *rerun) {
   HIPCHK(m, hipEventSynchronize(m->stem_ev));
   if (!m->dd_flag || *(volatile int *)m->dd_flag == 0) return PNVO_OK;
   *(volatile int *)m->dd_flag = 0;
+  HIPCHK(m, hipMemsetAsync(m->dd_flag_dev, 0, sizeof(int), s));
   m->dense_sticky = true;
   m->fallback_count += 1;
   pnvo_drop_graphs(m);
@@ -1294,7 +1297,9 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
         if ((rc = upload(h, h->dd_sc, sc16.data(), 12)) != PNVO_OK) return rc;
         if ((rc = upload(h, h->dd_sh, sh16.data(), 12)) != PNVO_OK) return rc;
         if (!h->dd_flag) HIPCHK(h, hipHostMalloc((void **)&h->dd_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+        if (!h->dd_flag_dev) HIPCHK(h, hipMalloc((void **)&h->dd_flag_dev, sizeof(int)));
         *(volatile int *)h->dd_flag = 0;
+        HIPCHK(h, hipMemset(h->dd_flag_dev, 0, sizeof(int)));
         h->dd_bins = bins;
         h->dd_ok = true;
       }
@@ -1369,7 +1374,9 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
         if ((rc = upload(h, h->mx_pages, pages.data(), pages.size())) != PNVO_OK) return rc;
       }
       if (!h->dd_flag) HIPCHK(h, hipHostMalloc((void **)&h->dd_flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+      if (!h->dd_flag_dev) HIPCHK(h, hipMalloc((void **)&h->dd_flag_dev, sizeof(int)));
       *(volatile int *)h->dd_flag = 0;
+      HIPCHK(h, hipMemset(h->dd_flag_dev, 0, sizeof(int)));
       h->mx_ok = true;
     }
   }
@@ -1443,6 +1450,7 @@ int pnvo_set_option(pnvo_handle h, const char *key, const char *value) {
       HIPCHK(h, hipSetDevice(h->device));
       HIPCHK(h, hipDeviceSynchronize());
       *(volatile int *)h->dd_flag = 0;
+      HIPCHK(h, hipMemset(h->dd_flag_dev, 0, sizeof(int)));
     }
     h->dense_sticky = false;
   }
@@ -2145,6 +2153,7 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->dd_sc);
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
+  if (m->dd_flag_dev) (void)hipFree(m->dd_flag_dev);
   if (m->mx_prof && m->mx_prof_ps) {
     unsigned long long pr[256];
     (void)hipMemcpy(pr, m->mx_prof, 2048, hipMemcpyDeviceToHost);

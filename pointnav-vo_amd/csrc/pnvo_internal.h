@@ -57,6 +57,7 @@ struct StemArgs {
   int dbg, lds_pad;           // experiment knobs (PNVO_STEM_DBG="<flags>,<lds_pad_bytes>"): 1 skip staging, 2 skip epilogue
   int paired;                 // 1: stand in for an 8 x 16-tile stem — slots = ceil(Ho/8) * ceil(Wo/16), partials of a tile pair summed
   const int *only_if;         // paired: predicate read on the DEVICE (nullptr: always run) — the launch is a no-op while *only_if == 0
+  int *publish;               // paired + only_if: host-mapped copy of the flag, set by this launch when the flag is up
 };
 int stem_tiles_x(int Wo);
 int stem_tiles_y(int Ho);
@@ -265,6 +266,9 @@ hipError_t launch_assemble(const AssembleArgs &a, hipStream_t s);
 // relu(gn(x)) then MaxPool 3x3 s2 p1.
 hipError_t launch_gn_relu_maxpool(const float *x, const float *scale, const float *shift, int B, int H, int W,
                                   int C, float *out, hipStream_t s);
+
+// *host_flag = 1 if *dev_flag != 0 (one lane): the input-contract flag for the handle's host-side decisions.
+hipError_t launch_flag_publish(const int *dev_flag, int *host_flag, hipStream_t s);
 
 // Pooled order-preserving keys (the fused stems' POOL output) from a raw stem output; a no-op while *only_if == 0 (device-side).
 hipError_t launch_pool_keys_from_raw(const float *x, const float *gamma, int B, int H, int W, int C, int *keys, const int *only_if,

@@ -93,7 +93,9 @@ struct pnvo_model_s {
   int dd_bins = 0;
   std::vector<int> dd_dense_tensor, dd_dense_ch;   // dense channel d -> (observation tensor, channel), -1 = indicator/pad
   float *dd_wpk = nullptr, *dd_table = nullptr, *dd_sc = nullptr, *dd_sh = nullptr;
-  int *dd_flag = nullptr;            // host-mapped: set when a depth pixel was not one-hot
+  int *dd_flag = nullptr;            // host-mapped copy of dd_flag_dev (published by the kernel behind the stem): what the HOST reads
+  int *dd_flag_dev = nullptr;        // device memory: raised by a fused stem whose stager met a value outside the observation contract;
+                                     // read by the predicated repair launches (a host-mapped flag costs every wave a PCIe round trip)
   unsigned long long *dd_prof = nullptr;   // PNVO_STEM_DBG=9: {staging, K loop, epilogue} cycles, tiles
 
   // stem on the bf16 matrix cores (stem_mx.hip): exact three-piece bf16 weights -> float32 results (inference default)

@@ -42,7 +42,10 @@ __device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t r, unsigned voff,
 // observation contract), so the decision to redo the stem on float32 operands is taken on the device, not by a waiting host.
 template <int NT16, int CPL, bool PAIRED = false>   // Cout / 16; channels per pixel in LDS (16 or 32)
 __global__ __launch_bounds__(NTHREADS, 4) void stem_lds_kernel(const StemArgs p) {
-  if (PAIRED && p.only_if != nullptr && *reinterpret_cast<const volatile int *>(p.only_if) == 0) return;
+  if (PAIRED && p.only_if != nullptr) {
+    if (*reinterpret_cast<const volatile int *>(p.only_if) == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.publish != nullptr) *reinterpret_cast<volatile int *>(p.publish) = 1;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int G = CPL >> 2;         // 16-byte slots per pixel (4 or 8)
   constexpr int J16 = CPL >> 4;       // 16-channel K groups per tap (1 or 2)
