@@ -265,15 +265,31 @@ class BaseRLTrainerWithVO:
 
     # ------------------------------------------------------------------------------------------------ frame ring (env_ids)
     def reset_frame_ring(self, env_ids=None):
-        """Forget the recorded frames of the given environments (all of them by default)."""
+        """Forget the recorded frames of the given environments (all of them by default) and give their device slots back: a caller
+        that mints fresh environment ids (one per episode, say) and resets the finished ones keeps the ring at its working size."""
         src = getattr(self, "_ring_src", None)
         if src is None:
             return
-        if env_ids is None:
-            src.clear()
-        else:
-            for e in env_ids:
-                src.pop(e, None)
+        rg = getattr(self, "_ring", None)
+        ids = list(src.keys() if env_ids is None else env_ids)
+        if rg is not None and env_ids is None:
+            ids = list(set(ids) | set(rg["slot_of"].keys()))
+        for e in ids:
+            src.pop(e, None)
+            if rg is not None and e in rg["slot_of"]:
+                rg["free"].append(rg["slot_of"].pop(e))
+
+    @staticmethod
+    def _frame_fingerprint(depth, rgb):
+        """A strided sample of a frame's bytes (~1 KB): what the ring compares on an identity hit, so that an observation buffer
+        REFILLED IN PLACE (shared-memory vector environments, preallocated buffers, np.copyto) is recognised as a new frame — a
+        new observation differs in nearly every sampled pixel — and uploaded, instead of being served from the ring."""
+        d = np.asarray(depth).reshape(-1)
+        fp = d[:: max(1, d.size // 251)].tobytes()
+        if rgb is not None:
+            r = np.asarray(rgb).reshape(-1)
+            fp += r[:: max(1, r.size // 509)].tobytes()
+        return fp
 
     def _ring_buffers(self, slots, m, H, W, want_rgb, want_tdv):
         """Device ring (one slot per environment: its last cur frame + top-down view) and the upload staging of m frames."""
@@ -281,7 +297,7 @@ class BaseRLTrainerWithVO:
         rg = getattr(self, "_ring", None)
         shape = (H, W, want_rgb, want_tdv)
         if rg is None or rg["shape"] != shape:
-            rg = dict(shape=shape, slots=0, cap=0, slot_of={})
+            rg = dict(shape=shape, slots=0, cap=0, slot_of={}, free=[])
             self._ring = rg
             self._ring_src = {}
         if rg["slots"] < slots:
@@ -311,7 +327,10 @@ class BaseRLTrainerWithVO:
         """The frames of n pairs into st[d_rgb / d_dep / tdv] with ONE uploaded frame per pair wherever the pair's prev frame is the
         frame its environment handed over as cur the call before (object identity of the numpy arrays: what `prev_obs = observations`
         in the reference's loop gives; a reset, a new environment or a copied frame simply uploads both).  Bit-identical to staging
-        both frames: the ring holds the very bytes that were uploaded, and the top-down view is a function of the frame alone."""
+        both frames: the ring holds the very bytes that were uploaded, and the top-down view is a function of the frame alone.
+        CONTRACT: a recorded frame is not modified between the call that handed it over as cur and the call that hands it over as
+        prev.  Guard: identity alone would also match a buffer refilled in place, so a hit additionally needs the frame's strided
+        fingerprint (_frame_fingerprint, taken when it was recorded) to be unchanged; otherwise both frames are uploaded."""
         n, dev = len(env_ids), self.device
         assert len(set(env_ids)) == n, "env_ids must be distinct within a call"
         src = getattr(self, "_ring_src", None)
@@ -321,18 +340,21 @@ class BaseRLTrainerWithVO:
         for pv, cv, e in zip(prev_obs_list, cur_obs_list, env_ids):
             rec = src.get(e)
             ok = (rec is not None and rec[0] is pv["depth"] and (not want_rgb or rec[1] is pv["rgb"])
-                  and pv["depth"] is not cv["depth"])
+                  and pv["depth"] is not cv["depth"]
+                  and rec[2] == self._frame_fingerprint(pv["depth"], pv["rgb"] if want_rgb else None))
             hits.append(ok)
         miss = [i for i in range(n) if not hits[i]]
         m = n + len(miss)
-        known = self._ring["slot_of"] if getattr(self, "_ring", None) is not None and self._ring["shape"] == (H, W, want_rgb, want_tdv) else {}
-        need_slots = len(known) + sum(1 for e in env_ids if e not in known)
+        same = getattr(self, "_ring", None) is not None and self._ring["shape"] == (H, W, want_rgb, want_tdv)
+        known = self._ring["slot_of"] if same else {}
+        nfree = len(self._ring["free"]) if same else 0
+        need_slots = len(known) + nfree + max(0, sum(1 for e in env_ids if e not in known) - nfree)
         rg = self._ring_buffers(need_slots, m, H, W, want_rgb, want_tdv)
         src = self._ring_src
         slot_of = rg["slot_of"]
         for e in env_ids:
-            if e not in slot_of:
-                slot_of[e] = len(slot_of)
+            if e not in slot_of:                                      # a slot given back by reset_frame_ring first, a new one otherwise
+                slot_of[e] = rg["free"].pop() if rg["free"] else len(slot_of) + len(rg["free"])
         up = list(cur_obs_list) + [prev_obs_list[i] for i in miss]                 # frames to upload: every cur, the missed prevs
         hx = rg["h_idx_np"]                                   # [3][n]: cur index | prev index or -1 (ring) | slot
         hx[0:n] = np.arange(n, dtype=np.int32)
@@ -374,7 +396,7 @@ class BaseRLTrainerWithVO:
                                                p(rg["d_idx"]), int(n), int(H), int(W), p(st["d_rgb"]), p(st["d_dep"]), p(st["tdv"]),
                                                _stream(dev)))
         for cv, e in zip(cur_obs_list, env_ids):
-            src[e] = (cv["depth"], cv["rgb"] if want_rgb else None)
+            src[e] = (cv["depth"], cv["rgb"] if want_rgb else None, self._frame_fingerprint(cv["depth"], cv["rgb"] if want_rgb else None))
         self._ring_stats = dict(pairs=n, uploaded_frames=m, ring_hits=n - len(miss))
         return keep_d, keep_r
 

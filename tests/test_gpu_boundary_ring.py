@@ -97,3 +97,59 @@ def test_ring_on_an_odd_resolution_without_rgb_alignment():
             res.append(t.compute_local_delta_states_batch([seq[e][k] for e in range(3)], [seq[e][k + 1] for e in range(3)], [1, 2, 3], **kw))
         outs.append(np.stack(res))
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+def test_ring_detects_a_frame_refilled_in_place():
+    """Shared-memory vector environments and preallocated observation buffers hand over the SAME numpy arrays every step, refilled in
+    place: object identity still matches, the bytes do not.  The ring's fingerprint guard must treat such a prev frame as new (upload
+    both frames) — results stay bit-identical to the call without env_ids, and nothing stale is served."""
+    rec = load_golden("boundary.npz")
+    H, W = int(rec["height"]), int(rec["width"])
+    ring, plain = make_trainer(rec), make_trainer(rec)
+    E, T = 3, 4
+    seq = {e: [frames(H, W, e, t) for t in range(T + 2)] for e in range(E)}
+    buf_prev = [{k: v.copy() for k, v in seq[e][0].items()} for e in range(E)]       # two preallocated buffers per environment
+    buf_cur = [{k: v.copy() for k, v in seq[e][1].items()} for e in range(E)]
+    for t in range(T):
+        for e in range(E):                                         # the "simulator" refills the buffers in place
+            for k in buf_prev[e]:
+                np.copyto(buf_prev[e][k], seq[e][t][k])
+                np.copyto(buf_cur[e][k], seq[e][t + 1][k])
+        # the same objects every step, and this step's prev buffer is NOT last step's cur buffer object ... (identity misses)
+        a = ring.compute_local_delta_states_batch(buf_prev, buf_cur, [1 + (t + e) % 3 for e in range(E)], env_ids=list(range(E)))
+        b = plain.compute_local_delta_states_batch(buf_prev, buf_cur, [1 + (t + e) % 3 for e in range(E)])
+        assert np.array_equal(a, b), t
+    # ... and the hard case: the caller swaps the two buffers each step (prev IS the object recorded as cur) but the simulator has
+    # meanwhile overwritten it with a different frame: identity hits, the fingerprint does not
+    ring.reset_frame_ring()
+    a0 = ring.compute_local_delta_states_batch(buf_prev, buf_cur, [1] * E, env_ids=list(range(E)))
+    for e in range(E):
+        for k in buf_cur[e]:
+            np.copyto(buf_cur[e][k], seq[e][T + 1][k])             # recorded cur buffers refilled in place with another frame
+    a = ring.compute_local_delta_states_batch(buf_cur, buf_prev, [2] * E, env_ids=list(range(E)))
+    b = plain.compute_local_delta_states_batch(buf_cur, buf_prev, [2] * E)
+    assert ring._ring_stats["ring_hits"] == 0
+    assert np.array_equal(a, b) and a0.shape == a.shape
+    # an untouched recorded frame still hits
+    c = ring.compute_local_delta_states_batch(buf_prev, buf_cur, [3] * E, env_ids=list(range(E)))
+    assert ring._ring_stats["ring_hits"] == E
+    assert np.array_equal(c, plain.compute_local_delta_states_batch(buf_prev, buf_cur, [3] * E))
+
+
+def test_ring_slots_are_reused_after_a_reset():
+    """Fresh environment ids per episode: reset_frame_ring gives the slots back, the device ring does not grow."""
+    rec = load_golden("boundary.npz")
+    H, W = int(rec["height"]), int(rec["width"])
+    ring, plain = make_trainer(rec), make_trainer(rec)
+    for episode in range(12):
+        ids = [f"ep{episode}-env{e}" for e in range(4)]
+        f0 = [frames(H, W, e, episode) for e in range(4)]
+        f1 = [frames(H, W, e, episode + 1) for e in range(4)]
+        f2 = [frames(H, W, e, episode + 2) for e in range(4)]
+        ring.compute_local_delta_states_batch(f0, f1, [1] * 4, env_ids=ids)
+        a = ring.compute_local_delta_states_batch(f1, f2, [2] * 4, env_ids=ids)
+        assert ring._ring_stats["ring_hits"] == 4
+        assert np.array_equal(a, plain.compute_local_delta_states_batch(f1, f2, [2] * 4))
+        ring.reset_frame_ring(ids)
+    assert ring._ring["slots"] == 8 and len(ring._ring["slot_of"]) == 0 and len(ring._ring["free"]) == 4
+    assert len(ring._ring_src) == 0
