@@ -868,7 +868,7 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
   PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2) PNVO_X3(3, 1, 1) PNVO_X3(3, 2, 1) PNVO_X3(3, 2, 2) PNVO_X3(3, 3, 2)
   if (KS == 3 && STRIDE == 1 && NP == 2) {                                                      // wide strips (conv_x3_plan)
-    PNVO_X3(0, 5, 1) PNVO_X3(1, 5, 1) PNVO_X3(2, 5, 1)
+    PNVO_X3(0, 5, 1) PNVO_X3(1, 5, 1) PNVO_X3(2, 5, 1) PNVO_X3(3, 5, 1)   // (mode 3 on a strip plan: a 128-channel first block)
   }
 #undef PNVO_X3
   return hipErrorInvalidValue;
@@ -1027,13 +1027,10 @@ hipError_t launch_conv_x3(const ConvX3Args &a0, int ks, int stride, int mode, in
     if (bres) pg.x = (unsigned)(((pwgs / 3) * 2) & ~7);                 // two workgroups per CU (256 registers per lane)
 #define PNVO_X3P(MODE_, MW_, NW_)                                                                        \
   if (mode == MODE_ && mw == MW_ && nw == NW_) {                                                         \
-    if (bres)                                                                                            \
-      hipLaunchKernelGGL((conv_x3p_kernel<MODE_, MW_, NW_, true>), pg, dim3(256), lds_bytes, s, a);     \
-    else                                                                                                 \
-      hipLaunchKernelGGL((conv_x3p_kernel<MODE_, MW_, NW_, false>), pg, dim3(256), lds_bytes, s, a);    \
+    hipLaunchKernelGGL((conv_x3p_kernel<MODE_, MW_, NW_, true>), pg, dim3(256), lds_bytes, s, a);       \
     return hipGetLastError();                                                                            \
   }
-    PNVO_X3P(0, 1, 1) PNVO_X3P(1, 1, 1) PNVO_X3P(3, 1, 1) PNVO_X3P(0, 2, 1) PNVO_X3P(1, 2, 1) PNVO_X3P(3, 2, 1)
+    PNVO_X3P(0, 1, 1) PNVO_X3P(1, 1, 1) PNVO_X3P(0, 2, 1) PNVO_X3P(1, 2, 1)     // (bres only: resident weights, plain / GN-input modes)
 #undef PNVO_X3P
   }
   if (a.np == 2) {

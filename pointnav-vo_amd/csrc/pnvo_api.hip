@@ -879,22 +879,18 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       const double in_bytes = (double)B * c.height * c.width * (m->raw_depth ? (c.n_rgb ? 6.0 : 0.0) + 8.0 + (c.n_tdv ? 8.0 : 0.0) : 4.0 * stem.cin);
       Timed t(m, s, "conv:" + stem.name, 2.0 * M * stem.cout * stem.cin * 49,
               in_bytes + 4.0 * (M * stem.cout + (double)stem.cout * stem.cin * 49));
-      // Forms of the float16-piece stem (option stem_form: auto | fast | resident | persistent | tiles):
+      // Forms of the float16-piece stem (option stem_form: auto | fast | resident | tiles):
       //   fast (auto when every workgroup gets >= 4 tiles): one 4-wave workgroup per CU for the whole launch, the weights in its
       //     registers, staging of the next tile and epilogue of the previous one between the MFMAs (stem_rs.hip), the remainder MFMAs
       //     of four taps in one K chunk and tap 48 split over the waves — 0.78 ms at 256 pairs, float32-grade equal to the others;
       //   resident: the same kernel in the tile kernel's summation order — 0.81 ms, bit-identical to tiles;
       //   tiles (auto otherwise): one tile per workgroup, two workgroups per CU — 0.99 ms, bound by the CU's vector-memory pipe
       //     (245 KB of weight fragments + 93 KB of patch per 128-pixel tile);
-      //   persistent: the role-specialised 8 / 12-wave form (stem_ps_kernel), same speed as tiles, bit-identical with stem_lwaves = 4.
+      //   (round 4's role-specialised persistent form — stem_ps_kernel, as fast as tiles — was retired in round 5: HISTORY.md.)
       const bool rs = (m->opt.stem_form == 3 || m->opt.stem_form == 4 || m->opt.stem_form == 0) && stem_rs_takes(a, pieces, ntn, false, m->num_cus);
-      const bool ps = m->opt.stem_form == 1 && stem_ps_takes(a, pieces, ntn, false, m->num_cus);
-      m->mx_prof_ps = ps || rs;
       m->mx_prof_rs = rs;
       if (rs)
         HIPCHK(m, launch_stem_rs(a, pieces, m->opt.stem_form == 4 || m->opt.stem_form == 0, m->num_cus, s));
-      else if (ps)
-        HIPCHK(m, launch_stem_ps(a, m->num_cus, m->opt.stem_lwaves == 4 ? 4 : 8, s));
       else
         HIPCHK(m, launch_stem_mx(a, pieces, ntn, false, s));
     }
@@ -1039,8 +1035,7 @@ const OptDef kOptions[] = {
     {"stem", "PNVO_STEM", &PnvoOptions::stem, false, {{"auto", 0}, {"mx", 1}, {"dd", 2}, {"dense", 3}, {nullptr, 0}}},
     {"conv", "PNVO_CONV", &PnvoOptions::conv, false, {{"auto", 0}, {"x3", 1}, {"fp32", 2}, {"generic", 3}, {nullptr, 0}}},
     {"pieces", "PNVO_PIECES", &PnvoOptions::pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
-    {"stem_lwaves", "PNVO_STEM_LWAVES", &PnvoOptions::stem_lwaves, true, {{nullptr, 0}}},
-    {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"persistent", 1}, {"tiles", 2}, {"resident", 3}, {"fast", 4}, {nullptr, 0}}},
+    {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"tiles", 2}, {"resident", 3}, {"fast", 4}, {nullptr, 0}}},
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_persist", "PNVO_X3_PERSIST", &PnvoOptions::x3_persist, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
@@ -2154,23 +2149,15 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->dd_sh);
   if (m->dd_flag) (void)hipHostFree(m->dd_flag);
   if (m->dd_flag_dev) (void)hipFree(m->dd_flag_dev);
-  if (m->mx_prof && m->mx_prof_ps) {
+  if (m->mx_prof && m->mx_prof_rs) {
     unsigned long long pr[256];
     (void)hipMemcpy(pr, m->mx_prof, 2048, hipMemcpyDeviceToHost);
     for (int w = 0; w < 12; ++w) {
       const unsigned long long *q = pr + 16 * w;
       if (q[5] == 0) continue;
       const double nt_ = (double)q[5];
-      if (m->mx_prof_rs)
-        std::fprintf(stderr, "[pnvo] stem_rs wave %d (cycles per tile): k-loop with the next patch's staging %.0f  wait others %.0f  "
-                     "exchange + epilogue %.0f  (%llu tiles)\n", w, q[0] / nt_, q[1] / nt_, q[2] / nt_, q[5]);
-      else if (w < 4)
-        std::fprintf(stderr, "[pnvo] stem_ps M wave %d (cycles per tile): wait patch %.0f  k-loop %.0f  wait others %.0f  exchange writes %.0f  "
-                     "(%llu tiles)\n", w, q[0] / nt_, q[1] / nt_, q[2] / nt_, q[3] / nt_, q[5]);
-      else
-        std::fprintf(stderr, "[pnvo] stem_ps L wave %d (cycles per tile): epilogue %.0f [sum %.0f  scratch writes %.0f  rendezvous %.0f  pool+keys %.0f]  "
-                     "convert+store %.0f  issue loads %.0f  wait M %.0f  wait exchange %.0f\n", w, q[0] / nt_, q[8] / nt_, q[9] / nt_, q[10] / nt_,
-                     q[11] / nt_, q[1] / nt_, q[2] / nt_, q[3] / nt_, q[4] / nt_);
+      std::fprintf(stderr, "[pnvo] stem_rs wave %d (cycles per tile): k-loop with the next patch's staging %.0f  wait others %.0f  "
+                   "exchange + epilogue %.0f  (%llu tiles)\n", w, q[0] / nt_, q[1] / nt_, q[2] / nt_, q[5]);
     }
     (void)hipFree(m->mx_prof);
   } else if (m->mx_prof) {

@@ -1,5 +1,6 @@
 // pnvo_internal.h — declarations shared by the HIP translation units of libpnvo.so (gfx950 only).
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -112,8 +113,7 @@ struct StemMXArgs {
   int raw_flags;                  // bit 0: the model has the depth modality, bit 1: discretised depth
   int *raw_err;                   // device flag: a depth outside [0, 1]
   float edges[12];                // bin edges e_0 .. e_10 of the one-hot depth (float32(i / 10))
-  // developer ablations of stem_ps_kernel (option stem_dbg = 16 + bits; WRONG RESULTS, timing only): 1 every staging load reads one
-  // address, 2 no epilogue, 4 no conversion / LDS writes of the patch, 8 no MFMAs, 16 no staging loads, 32 no exchange writes
+  // developer ablations of stem_rs_kernel (option stem_dbg = 16 + bits; WRONG RESULTS, timing only)
   int dbg;
 };
 constexpr int STEM_POOL_INIT = (int)0x807fffffu;   // key of -inf
@@ -122,8 +122,6 @@ size_t stem_mx_packed_u16(int pieces, int ntiles);
 void pack_stem_mx_weight(const float *wk, int cout, int pieces, const int *xslot, unsigned short *out);
 float pack_stem_mx_weight_h(const float *wk, int cout, const int *xslot, unsigned short *out);   // two float16 pieces -> oscale
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s);
-bool stem_ps_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs);   // persistent role-specialised form
-hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, int l_waves, hipStream_t s);   // l_waves: 4 or 8 epilogue / staging waves
 bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs);   // persistent, weights resident in registers
 hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, bool fast, int wgs, hipStream_t s);   // fast: see stem_rs.hip (FAST)                      //   (stem_rs.hip)
 hipError_t launch_stem_mx_repack_h(const float *w_oihw, int cin, const float *sc_new, const float *sh_new, const int *slot_ref,
@@ -269,6 +267,18 @@ hipError_t launch_gn_relu_maxpool(const float *x, const float *scale, const floa
 
 // *host_flag = 1 if *dev_flag != 0 (one lane): the input-contract flag for the handle's host-side decisions.
 hipError_t launch_flag_publish(const int *dev_flag, int *host_flag, hipStream_t s);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: true exactly once per (device, `seen` mask) — the caller then sets the
+// attributes of its kernels for that device.  Serialised by `mu` (two handles on two GPUs may launch from two threads).
+inline bool pnvo_first_launch_on_device(std::mutex &mu, unsigned long long &seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  const unsigned long long bit = 1ull << (dev & 63);
+  std::lock_guard<std::mutex> lk(mu);
+  if (seen & bit) return false;
+  seen |= bit;
+  return true;
+}
 
 // Pooled order-preserving keys (the fused stems' POOL output) from a raw stem output; a no-op while *only_if == 0 (device-side).
 hipError_t launch_pool_keys_from_raw(const float *x, const float *gamma, int B, int H, int W, int C, int *keys, const int *only_if,

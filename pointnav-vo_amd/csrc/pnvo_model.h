@@ -34,8 +34,7 @@ struct Layer {
 struct PnvoOptions {
   int stem = 0;        // 0 auto (bf16-matrix-core stem when the model's modalities fit it, else one-hot-aware, else dense), 1 mx, 2 dd, 3 dense
   int conv = 0;        // 0 auto (conv_x3 for launches of >= 192 workgroups, fp32-MFMA kernels below), 1 x3 at any size, 2 fp32, 3 generic
-  int stem_lwaves = 8; // persistent stem: epilogue / staging waves beside the four multiplying waves (4 or 8)
-  int stem_form = 0;   // float16-piece stem: 0 auto (fast resident weights when every workgroup gets >= 4 tiles, else one tile per workgroup), 1 persistent role-specialised kernel (stem_ps_kernel), 2 one tile per workgroup, 3 resident weights in the tile kernel's summation order (stem_rs_kernel), 4 fast (its own order)
+  int stem_form = 0;   // float16-piece stem: 0 auto (fast resident weights when every workgroup gets >= 4 tiles, else one tile per workgroup), 2 one tile per workgroup, 3 resident weights in the tile kernel's summation order (stem_rs_kernel), 4 fast (its own order)
   int pieces = 2;      // operand pieces of conv_x3 at inference: 2 float16 (three product terms) or 3 bf16 (six exact terms)
   int train_pieces = 2;  // the same choice for the TRAINING forward's convs (their backward-data convs keep three bf16 pieces:
                          //   gradients do not fit float16's range)
@@ -111,7 +110,7 @@ struct pnvo_model_s {
   std::vector<int> mx_slot_ref, mx_slot_new; // K-slot -> reference channel / position in the stem's tensor-major order (-1: none)
   float *mx_pages = nullptr;                 // device: 64 zeros (out-of-image reads)
   unsigned long long *mx_prof = nullptr;     // PNVO_STEM_DBG=9: per-wave phase cycle sums of stem_mx / stem_ps
-  bool mx_prof_ps = false, mx_prof_rs = false;                   //   ... the last stem launch was the persistent form
+  bool mx_prof_rs = false;                   //   ... the last stem launch was the resident-weight form
   int num_cus = 256;                         // compute units of the device (grid of the persistent kernels)
   bool in_train_forward = false;
   bool train_mx = false;                     // the attached training step rebuilds the mx stem operands every step

@@ -94,7 +94,9 @@ struct TrainState {
   // forward chains them into in_bound without a synchronisation (a value may lag one optimiser step: a step moves gamma by <= lr)
   struct GnbSeg { long goff, boff; int c; float rootn; };
   GnbSeg *gnb_seg = nullptr;            // device [convs]
-  float *gnb_host = nullptr;            // host-mapped [convs]; < 0: not computed yet
+  float *gnb_host = nullptr;            // host-mapped [3][convs]: the bounds of the last three refreshes (ring); < 0: not computed yet
+  hipEvent_t gnb_ev[3] = {nullptr, nullptr, nullptr};   // behind the gn_bound_kernel of each ring entry
+  long gnb_refreshes = 0;               // refreshes issued so far: entry (r % 3) holds refresh r
   int gnb_n = 0;
 };
 
@@ -709,6 +711,8 @@ void pnvo_train_free(pnvo_handle m) {
   if (t->embed_err) (void)hipHostFree(t->embed_err);
   dfree(t->gnb_seg);
   if (t->gnb_host) (void)hipHostFree(t->gnb_host);
+  for (hipEvent_t &e : t->gnb_ev)
+    if (e) (void)hipEventDestroy(e);
   m->train_mx = false;
   delete t;
   m->train = nullptr;
@@ -806,7 +810,10 @@ extern "C++" const float *pnvo_train_weight_ptr(pnvo_handle m, const std::string
 
 __global__ __launch_bounds__(64) void gn_bound_kernel(const float *params, const TrainState::GnbSeg *seg, float *out) {
   const TrainState::GnbSeg sg = seg[blockIdx.x];
-  if (sg.c <= 0) return;
+  if (sg.c <= 0) {                       // no GroupNorm (or parameters not found) behind this conv: "no bound", never "not computed yet"
+    if (threadIdx.x == 0) __hip_atomic_store(out + blockIdx.x, 3.0e38f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   float mx = 0.f;
   for (int c = threadIdx.x; c < sg.c; c += 64) mx = fmaxf(mx, fabsf(params[sg.goff + c]) * sg.rootn + fabsf(params[sg.boff + c]));
 #pragma unroll
@@ -814,14 +821,20 @@ __global__ __launch_bounds__(64) void gn_bound_kernel(const float *params, const
   if (threadIdx.x == 0) __hip_atomic_store(out + blockIdx.x, fminf(mx, 3.0e38f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Layer::in_bound from the bounds the device last reported (no-op until every conv has one)
+// Layer::in_bound from the bounds of the parameters TWO refreshes back (a fixed lag, so the float16-piece / three-piece choice
+// per layer is the same run to run and rank to rank however far the host runs ahead of the stream): the ring entry is waited for
+// through its event — the kernel behind it ran two optimiser steps ago, so the wait is over before it starts unless the host is
+// more than two whole steps ahead.  Until two refreshes exist the load-time bounds stay.
 static void chain_tracked_bounds(pnvo_handle m, TrainState *t) {
-  if (!t->gnb_host || m->bottleneck) return;
+  if (!t->gnb_host || m->bottleneck || t->gnb_refreshes < 2) return;
+  const int e = (int)((t->gnb_refreshes - 2) % 3);
+  if (t->gnb_ev[e] == nullptr || hipEventSynchronize(t->gnb_ev[e]) != hipSuccess) return;
+  const float *tab = t->gnb_host + (size_t)e * t->gnb_n;
   for (int i = 0; i < t->gnb_n; ++i)
-    if (m->convs[i].gn.size() && !(*(volatile float *)(t->gnb_host + i) >= 0.f)) return;
+    if (!(*(volatile const float *)(tab + i) >= 0.f)) return;
   pnvo_chain_in_bounds(m, [&](const Layer &l) {
     const long i = &l - m->convs.data();
-    return i >= 0 && i < t->gnb_n ? *(volatile float *)(t->gnb_host + i) : 3.0e38f;
+    return i >= 0 && i < t->gnb_n ? *(volatile const float *)(tab + i) : 3.0e38f;
   });
 }
 
@@ -878,11 +891,18 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
       int rc0 = dmalloc(m, (void **)&t->gnb_seg, seg.size() * sizeof(TrainState::GnbSeg));
       if (rc0 != PNVO_OK) return rc0;
       HIPCHK(m, hipMemcpy(t->gnb_seg, seg.data(), seg.size() * sizeof(TrainState::GnbSeg), hipMemcpyHostToDevice));
-      HIPCHK(m, hipHostMalloc((void **)&t->gnb_host, seg.size() * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
-      for (int i = 0; i < t->gnb_n; ++i) t->gnb_host[i] = -1.f;
+      HIPCHK(m, hipHostMalloc((void **)&t->gnb_host, 3 * seg.size() * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+      for (int i = 0; i < 3 * t->gnb_n; ++i) t->gnb_host[i] = -1.f;
+      for (hipEvent_t &e : t->gnb_ev) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    hipLaunchKernelGGL(gn_bound_kernel, dim3((unsigned)t->gnb_n), dim3(64), 0, (hipStream_t)stream, t->params, t->gnb_seg, t->gnb_host);
+    const int e = (int)(t->gnb_refreshes % 3);
+    hipLaunchKernelGGL(gn_bound_kernel, dim3((unsigned)t->gnb_n), dim3(64), 0, (hipStream_t)stream, t->params, t->gnb_seg,
+                       t->gnb_host + (size_t)e * t->gnb_n);
     HIPCHK(m, hipGetLastError());
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusNone)
+      HIPCHK(m, hipEventRecord(t->gnb_ev[e], (hipStream_t)stream));
+    t->gnb_refreshes += 1;
   }
   if (m->cfg.act_embed) {      // eval-mode bias rows bias[a][o] = b1[o] + W1[o][flat:] . emb[a]  (pnvo_load_weights does this on the host)
     const pnvo_config &c = m->cfg;

@@ -608,584 +608,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 
-// =====================================================================================================================
-// stem_ps_kernel — the PERSISTENT, ROLE-SPECIALISED form of the float32-grade stem (PIECES = 2, one N-tile of 32 channels).
-//
-// stem_mx_kernel runs its three phases one after the other in every workgroup (staging ~10.7 k cycles, two dependent memory round
-// trips; K loop ~13 k of which 7.8 k are MFMA issue; K-split exchange + pooling epilogue ~8.7 k), and two co-resident workgroups
-// overlap them only by chance: the matrix pipe sits at 0.45 busy (profiles/r3_stem_phases.txt).  Here ONE workgroup of eight waves
-// owns a CU for the whole launch and walks its tiles with the phases of consecutive tiles overlapped by construction:
-//
-//   waves 0-3 ("M", one per SIMD, the older half: they win the VALU arbitration)   K loop of tile i and nothing else: the same
-//       49-tap split, fragment order and accumulation order as stem_mx_kernel<2,1> — results are bit-identical — then 16 LDS
-//       writes of their partial sums into the patch buffer they just left;
-//   waves 4-7 ("L", one per SIMD, beside an M wave)   while the M waves multiply tile i: the epilogue of tile i-1 (fixed-order sum
-//       of the four K-split partials, power-of-two un-scale, GroupNorm partial sums, max-pool keys or raw stores), then the patch of
-//       tile i+1 — its global loads were issued a whole phase earlier, so no memory latency is exposed — converted to float16 pieces
-//       and written into the buffer the exchange has just vacated.
-//
-// LDS: two 64 KB buffers (patch of tile i | exchange of tile i-1 -> patch of tile i+1) + pooling scratch: 146 KB, one workgroup
-// per CU.  Two workgroup barriers per tile; the L waves synchronise among themselves through an LDS counter.
-namespace {
-#ifndef PNVO_PS_SCHED
-#define PNVO_PS_SCHED 1
-#endif
-constexpr int PS_SCHED = PNVO_PS_SCHED;                  // 1: fetches spread between the MFMAs by sched_group_barrier; 0: in bursts
-constexpr int PS_BUF = XCHG_BYTES;                       // 65536 >= PATCH_BYTES
-constexpr int PS_PB_OFF = 2 * PS_BUF;                    // pooling scratch [8][16][33] floats
-constexpr int PS_RED_OFF = PS_PB_OFF + 8 * 16 * 33 * 4;  // [8 L waves][32][2] floats
-constexpr int PS_ETAB_OFF = PS_RED_OFF + 8 * 32 * 2 * 4; // RAW: bin edges (12 floats)
-constexpr int PS_CTR_OFF = PS_ETAB_OFF + 64;             // L-wave rendezvous counter
-constexpr int PS_LDS = PS_CTR_OFF + 64;
-static_assert(PS_BUF >= PATCH_BYTES, "patch must fit its buffer");
-static_assert(PS_LDS <= 160 * 1024, "LDS budget");
-
-// rendezvous of the four L waves (a monotonic LDS counter; the workgroup barrier belongs to the M/L hand-over)
-template <int NL>
-__device__ __forceinline__ void ps_lsync(unsigned *ctr, unsigned &epoch) {
-  epoch += (unsigned)NL;
-  // LDS only: a workgroup-scope fence would also drain vmcnt, i.e. wait for the next patch's global loads in flight
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch) < 0) __builtin_amdgcn_s_sleep(1);
-  asm volatile("" ::: "memory");
-}
-}  // namespace
-
-template <bool POOL, bool RAW, int NL>
-__global__ __launch_bounds__(256 + 64 * NL) __attribute__((amdgpu_waves_per_eu(NL == 8 ? 3 : 2, NL == 8 ? 3 : 2))) void stem_ps_kernel(const StemMXArgs p) {
-  constexpr int LT = 64 * NL;                               // L threads
-  constexpr int R = (NPIX + LT - 1) / LT;                   // patch pixels per L thread (the last round is partial)
-  constexpr int LASTN = NPIX - (R - 1) * LT;                // pixels of the last round
-  constexpr int HPW = 8 / NL;                               // half M-tiles (one output row of 16 pixels) per L wave
-  constexpr bool B3 = NL == 4;                              // weight fragments fetched two taps ahead (three register sets) or one
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-  // tiles of this workgroup: the workgroups of one XCD (id % 8) walk neighbouring tiles at the same time, so halos meet in that L2
-  const int ntiles = p.B * p.tiles_x * p.tiles_y;
-  const int chunk = (ntiles + 7) >> 3;
-  const int per = (int)gridDim.x >> 3;                              // workgroups per XCD
-  const int t_first = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-  const int t_end = min(((int)(blockIdx.x & 7) + 1) * chunk, ntiles);
-  if (t_first >= t_end) return;
-  const int nit = (t_end - t_first + per - 1) / per;
-  const bool prof = p.prof != nullptr;
-  unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, ep[4] = {0, 0, 0, 0};
-  auto now = [&]() -> unsigned long long { return prof ? __builtin_readcyclecounter() : 0ull; };
-  if (threadIdx.x == 0) *reinterpret_cast<unsigned *>(lds + PS_CTR_OFF) = 0u;
-  if (RAW && threadIdx.x < 12) reinterpret_cast<float *>(lds + PS_ETAB_OFF)[threadIdx.x] = p.edges[threadIdx.x];
-  __syncthreads();
-
-  if (wave < 4) {
-    // ============================================================ M waves: the K loop (stem_mx_kernel's, PIECES = 2, NT = 1)
-    constexpr int NFT = 5;
-    if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);
-    const int rr = (lane & 31) >> 4, c = lane & 15, h = lane >> 5;
-    const unsigned baseA0 = (unsigned)(2 * rr * ROW + c * PITCH + h * 16);
-    const unsigned baseX0 = (unsigned)(2 * rr * ROW + c * PITCH + 64);
-    auto loadB = [&](int tap, u32x4 *b) {
-      const u32x4 *wt = reinterpret_cast<const u32x4 *>(p.wpk) + (long)tap * NFT * 64;
-#pragma unroll
-      for (int f = 0; f < NFT; ++f) b[f] = wt[f * 64 + lane];
-    };
-    auto tapof = [&](int i) { return i < 12 ? wave + 4 * i : (wave == 3 ? 48 : wave + 44); };
-#pragma unroll 1
-    for (int it = 0; it < nit; ++it) {
-      const unsigned buf = (unsigned)(it & 1) * PS_BUF;
-      const unsigned baseA = baseA0 + buf, baseX = baseX0 + buf;
-      u32x4 b0[NFT], b1[NFT], b2[B3 ? NFT : 1], a0[4], a1[4], ax[4];
-      loadB(tapof(0), b0);                                  // (the weights do not wait for the patch)
-      if (B3) loadB(tapof(1), b1);
-      const unsigned long long t0 = now();
-      __syncthreads();                                      // patch(it) is in its buffer
-      const unsigned long long t1 = now();
-      f32x16 acc[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-      auto loadA0 = [&](int tap, u32x4 *a) {
-        const unsigned toff = tap_lds_offset(tap);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + toff + m * 4 * ROW);
-      };
-      auto loadA1 = [&](int tap, u32x4 *a, u32x4 *x) {
-        const unsigned toff = tap_lds_offset(tap);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          a[m] = *reinterpret_cast<const u32x4 *>(lds + baseA + toff + m * 4 * ROW + 32);
-          x[m] = *reinterpret_cast<const u32x4 *>(lds + baseX + toff + m * 4 * ROW);
-        }
-      };
-      auto mfmas_q = [&](int q, const u32x4 *aq, const u32x4 *b) {
-#pragma unroll
-        for (int pcs = 0; pcs < 2; ++pcs)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[m]), __builtin_bit_cast(f16x8, b[pcs * 2 + q]),
-                                                            acc[m], 0, 0, 0);
-      };
-      auto mfmas_x = [&](const u32x4 *b) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ax[m]), __builtin_bit_cast(f16x8, b[4]), acc[m], 0, 0, 0);
-      };
-      // (same MFMA order as stem_mx_kernel in either form: the sums are bit-identical)
-      auto step = [&](int i, const u32x4 *bcur, u32x4 *bnext, int ahead) {
-        if (PS_SCHED == 0) {
-          loadA1(tapof(i), a1, ax);
-          loadB(tapof(i + ahead), bnext);
-          __builtin_amdgcn_sched_barrier(0);
-          mfmas_q(0, a0, bcur);
-          __builtin_amdgcn_sched_barrier(0);
-          loadA0(tapof(i + 1), a0);
-          __builtin_amdgcn_sched_barrier(0);
-          mfmas_q(1, a1, bcur);
-          mfmas_x(bcur);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          // one scheduling region per tap, the fetches spread between the MFMAs (an issue slot is ~4 cycles, an MFMA 32: a burst of
-          // 25 fetch / address instructions in front of the MFMAs drains the matrix pipe; <= 5 per gap are free)
-          __builtin_amdgcn_sched_barrier(0);
-          loadA1(tapof(i), a1, ax);
-          loadB(tapof(i + ahead), bnext);
-          mfmas_q(0, a0, bcur);
-          u32x4 a0n[4];
-          loadA0(tapof(i + 1), a0n);
-          mfmas_q(1, a1, bcur);
-          mfmas_x(bcur);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) a0[m] = a0n[m];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {                       // MFMA 0-3: the eight A1 / AX fragment reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          }
-#pragma unroll
-          for (int k = 0; k < 5; ++k) {                       // MFMA 4-8: the five weight-fragment loads of a later tap
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMA 9-11
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {                       // MFMA 12-15: the next tap's A0 fragments
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA 16-19
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if (!(p.dbg & 8)) {
-        loadA0(tapof(0), a0);
-        if (B3) {
-#pragma unroll 1
-          for (int i = 0; i < 12; i += 3) {
-            step(i, b0, b2, 2);
-            step(i + 1, b1, b0, 2);
-            step(i + 2, b2, b1, 2);
-          }
-        } else {
-#pragma unroll 1
-          for (int i = 0; i < 12; i += 2) {
-            step(i, b0, b1, 1);
-            step(i + 1, b1, b0, 1);
-          }
-        }
-        if (wave == 3) {
-          loadA1(48, a1, ax);
-          __builtin_amdgcn_sched_barrier(0);
-          mfmas_q(0, a0, b0);
-          mfmas_q(1, a1, b0);
-          mfmas_x(b0);
-        }
-      }
-      const unsigned long long t2 = now();
-      __syncthreads();                                      // every M wave has left the patch (and L the other buffer)
-      const unsigned long long t3 = now();
-      if (!(p.dbg & 32))
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq)
-            *reinterpret_cast<f32x4 *>(lds + buf + (((m * 4 + wave) * 4 + rq) * 64 + lane) * 16) =
-                f32x4{acc[m][4 * rq], acc[m][4 * rq + 1], acc[m][4 * rq + 2], acc[m][4 * rq + 3]};
-      if (prof) {
-        pc[0] += t1 - t0;                                   // wait for the patch
-        pc[1] += t2 - t1;                                   // K loop
-        pc[2] += t3 - t2;                                   // wait for the other M waves / the L waves
-        pc[3] += now() - t3;                                // exchange writes
-      }
-    }
-    __syncthreads();                                        // exchange of the last tile is complete
-  } else {
-    // ============================================================ L waves: epilogue of tile i-1, patch of tile i+1
-    const int lw = wave - 4;
-    const int ltid = (int)threadIdx.x - 256;
-    if (p.dbg & 64) __builtin_amdgcn_s_setprio(3);
-    unsigned *ctr = reinterpret_cast<unsigned *>(lds + PS_CTR_OFF);
-    unsigned epoch = 0;
-    float *red = reinterpret_cast<float *>(lds + PS_RED_OFF);
-    float *pb = reinterpret_cast<float *>(lds + PS_PB_OFF);
-    float *etab = reinterpret_cast<float *>(lds + PS_ETAB_OFF);
-    // patch pixels of this thread: pixel index r * LT + ltid (the last round is partial) — tile-independent
-    int ppy[R], ppx[R];
-    unsigned poff[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int pix = min(r * LT + ltid, NPIX - 1);
-      ppy[r] = pix / PW;
-      ppx[r] = pix - ppy[r] * PW;
-      poff[r] = (unsigned)(ppy[r] * ROW + (ppx[r] & 1) * PAR + (ppx[r] >> 1) * PITCH);
-    }
-    const bool haslast = ltid < LASTN;
-    const bool wavelast = lw * 64 < LASTN;                  // wave-uniform: some lane of this wave has a pixel in the last round
-    const float *zp = p.zero_page;
-    const long fpix = (long)p.H * p.W;
-    // Observation tensors (!RAW): the one-hot depth (80 of the 120 bytes of a pixel) is fetched by 16-BYTE GRANULE, not by pixel:
-    // lane = consecutive 16 bytes of a patch row (37 pixels x 80 B contiguous), so a wave-instruction covers 1 KiB = 8 cache lines
-    // instead of 64 lanes x 16 B at an 80-byte stride = 40 lines — the vector-memory pipe, which the M waves' weight loads share, was
-    // what the pixel-mapped fetch saturated (round 4: K loop 14.7 k cycles per tile with these loads in flight, 10.4 k without).
-    // Granule q = k * LT + ltid -> (patch row, pixel, 4-channel chunk c): tile-independent; a granule lands in LDS as 8 bytes
-    // (4 float16) at its pixel's K-slots 4c .. 4c + 3.  Buffer loads: rows outside the image are out of range of the image's
-    // descriptor and read 0, columns outside are forced out of range; interior tiles skip even that.
-    constexpr int GROW = PW * 5;                            // granules per patch row (185)
-    constexpr int NG = PH * GROW;                           // 3885
-    constexpr int RD = (NG + LT - 1) / LT;                  // dd granules per L thread
-    unsigned ddmeta[RD];                                    // LDS offset (16 bits) | px << 16 | row << 22 | c << 27 | (granule exists) << 31
-#pragma unroll
-    for (int k = 0; k < RD; ++k) {
-      const int q = k * LT + ltid;
-      const bool ex = q < NG;
-      const int qq = ex ? q : 0;
-      const int row = qq / GROW, g = qq - row * GROW, px = g / 5, c = g - px * 5;
-      ddmeta[k] = (unsigned)(row * ROW + (px & 1) * PAR + (px >> 1) * PITCH + c * 8) | ((unsigned)px << 16) | ((unsigned)row << 22) |
-                  ((unsigned)c << 27) | (ex ? 0x80000000u : 0u);
-    }
-    // byte offset of a granule from the patch origin inside the image's dd tensor
-    auto ddoff_of = [&](unsigned m) { return (((m >> 22) & 0x1fu) * (unsigned)p.W + ((m >> 16) & 0x3fu)) * 80u + ((m >> 27) & 7u) * 16u; };
-
-    // ---- registers of one patch in flight
-    f32x4 vr4[R];
-    f32x4 gdd[RAW ? 1 : RD];
-    f32x2 vr2[R], vd[R], vt[R];
-    unsigned rgbw[R][2];
-    float dv[R][2];
-    bool inb[R];
-    auto tile_coords = [&](int t, int &n, int &ty, int &tx) {
-      tx = t % p.tiles_x;
-      t /= p.tiles_x;
-      ty = t % p.tiles_y;
-      n = t / p.tiles_y;
-    };
-    // pacing of the patch loads: a burst of them queues in front of the M waves' weight-fragment loads (see the header)
-    const int pace_n = (p.dbg >> 9) & 7;
-    auto pace = [&]() {
-      if (pace_n == 1) __builtin_amdgcn_s_sleep(1);
-      else if (pace_n == 2) __builtin_amdgcn_s_sleep(2);
-      else if (pace_n == 3) __builtin_amdgcn_s_sleep(3);
-      else if (pace_n == 4) __builtin_amdgcn_s_sleep(4);
-      else if (pace_n == 5) __builtin_amdgcn_s_sleep(6);
-      else if (pace_n == 6) __builtin_amdgcn_s_sleep(8);
-    };
-    auto stage_load = [&](int t) {
-      int n, ty, tx;
-      tile_coords(t, n, ty, tx);
-      const int hi_base = 2 * ty * TH - 3, wi_base = 2 * tx * TW - 3;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (r == R - 1 && !wavelast) continue;
-        const int hi = hi_base + ppy[r], wi = wi_base + ppx[r];
-        bool in = (r < R - 1 || haslast) && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        if (p.dbg & 1) in = false;
-        const int e = in ? hi * p.W + wi : 0;
-        inb[r] = in;
-        if (RAW) {
-          const unsigned char *zpb = reinterpret_cast<const unsigned char *>(zp);
-          const bool use_rgb = p.raw_rgb != nullptr;
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const long gi = ((long)n * 2 + f) * fpix + e;
-            const long boff = 3 * gi - (gi > 0 ? 1 : 0);
-            const unsigned char *a_rgb = (in && use_rgb) ? p.raw_rgb + boff : zpb;
-            unsigned wv;
-            __builtin_memcpy(&wv, a_rgb, 4);
-            rgbw[r][f] = (in && use_rgb && gi > 0) ? (wv >> 8) : wv;
-            const float *a_d = in ? p.raw_depth + gi : zp;
-            dv[r][f] = *a_d;
-          }
-          const float *a_t = (in && p.src[3]) ? p.src[3] + ((long)n * fpix + e) * 2 : zp;
-          vt[r] = *reinterpret_cast<const f32x2 *>(a_t);
-        } else {
-          const long pe = (long)n * fpix + e;
-          const float *a_rgb = (in && p.src[0]) ? p.src[0] + pe * 6 : zp;
-          const float *a_d = (in && p.src[1]) ? p.src[1] + pe * 2 : zp;
-          const float *a_t = (in && p.src[3]) ? p.src[3] + pe * 2 : zp;
-          const f32x2 q0 = *reinterpret_cast<const f32x2 *>(a_rgb), q1 = *reinterpret_cast<const f32x2 *>(a_rgb + 2);
-          vr4[r] = f32x4{q0[0], q0[1], q1[0], q1[1]};
-          vr2[r] = *reinterpret_cast<const f32x2 *>(a_rgb + 4);
-          vd[r] = *reinterpret_cast<const f32x2 *>(a_d);
-          vt[r] = *reinterpret_cast<const f32x2 *>(a_t);
-        }
-        if (p.dbg & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pace();
-        pace();
-      }
-      if (!RAW) {
-        const __amdgpu_buffer_rsrc_t rdd = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(p.src[2] ? p.src[2] + (long)n * fpix * 20 : zp), 0, p.src[2] ? (unsigned)(fpix * 80) : 0u, 0x00020000);
-        const int tb = (hi_base * p.W + wi_base) * 80;            // byte offset of the patch origin (negative on the top / left edge)
-        const bool interior = hi_base >= 0 && hi_base + PH <= p.H && wi_base >= 0 && wi_base + PW <= p.W && !(p.dbg & 1);
-        if (interior) {
-#pragma unroll
-          for (int k = 0; k < RD; ++k) {
-            gdd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdd, ddoff_of(ddmeta[k]), tb, 0));
-            if ((p.dbg & 256) && (k & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (ablation: throttled issue)
-            pace();
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < RD; ++k) {
-            const int wi = wi_base + (int)((ddmeta[k] >> 16) & 0x3fu);
-            const bool colok = wi >= 0 && wi < p.W && !(p.dbg & 1);
-            const unsigned off = colok ? ddoff_of(ddmeta[k]) + (unsigned)tb : 0xfffffff0u;     // (rows outside the image: out of range by themselves)
-            gdd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdd, off, 0, 0));
-            pace();
-          }
-        }
-      }
-    };
-    auto stage_store = [&](unsigned buf) {
-      unsigned lowbits = 0;
-      bool bad_depth = false;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (r == R - 1 && !wavelast) continue;
-        if (r == R - 1 && !haslast) continue;
-        unsigned w[16];
-        float d0, d1;
-        int bidx[2] = {0, 0};
-        bool bok[2] = {false, false};
-        if (RAW) {
-          const bool use_d = (p.raw_flags & 1) != 0;
-#pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const float d = dv[r][f];
-            int g = (int)(d * 10.0f);
-            g = min(max(g, 0), 9);
-            const float lo = etab[g], hi = etab[g + 1];
-            bidx[f] = g - (d < lo ? 1 : 0) + ((d >= hi && g < 9) ? 1 : 0);
-            bok[f] = d >= 0.f && d <= 1.f;
-            bad_depth = bad_depth || (inb[r] && !bok[f]);
-          }
-#pragma unroll
-          for (int cc = 0; cc < 10; ++cc) w[cc] = 0u;
-          const unsigned x0 = rgbw[r][0], x1 = rgbw[r][1];
-          const float pr = (float)(x0 & 0xffu), pg = (float)((x0 >> 8) & 0xffu), pbl = (float)((x0 >> 16) & 0xffu);
-          const float cr = (float)(x1 & 0xffu), cg = (float)((x1 >> 8) & 0xffu), cb = (float)((x1 >> 16) & 0xffu);
-          w[10] = pack_f16(pr * 0.00390625f, pg * 0.00390625f);
-          w[11] = pack_f16(pbl * 0.00390625f, cr * 0.00390625f);
-          w[12] = pack_f16(cg * 0.00390625f, cb * 0.00390625f);
-          d0 = use_d ? dv[r][0] : 0.f;
-          d1 = use_d ? dv[r][1] : 0.f;
-        } else {
-          w[10] = pack_f16(vr4[r][0] * 0.00390625f, vr4[r][1] * 0.00390625f);
-          w[11] = pack_f16(vr4[r][2] * 0.00390625f, vr4[r][3] * 0.00390625f);
-          w[12] = pack_f16(vr2[r][0] * 0.00390625f, vr2[r][1] * 0.00390625f);
-          {
-            const float f0 = vr4[r][0], f1 = vr4[r][1], f2 = vr4[r][2], f3 = vr4[r][3], f4 = vr2[r][0], f5 = vr2[r][1];
-            lowbits |= __builtin_bit_cast(unsigned, f0) | __builtin_bit_cast(unsigned, f1);
-            lowbits |= __builtin_bit_cast(unsigned, f2) | __builtin_bit_cast(unsigned, f3);
-            lowbits |= __builtin_bit_cast(unsigned, f4) | __builtin_bit_cast(unsigned, f5);
-          }
-          d0 = vd[r][0];
-          d1 = vd[r][1];
-        }
-        w[13] = pack_f16(d0, d1);
-        w[14] = pack_f16(vt[r][0], vt[r][1]);
-        w[15] = inb[r] ? 0x3c003c00u : 0u;
-        unsigned char *dst = lds + buf + poff[r];
-        if (RAW) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<u32x4 *>(dst + 16 * q) = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-        } else {                                               // K-slots 20..31 (rgb, depth, top-down view, indicator): bytes 40..63
-          *reinterpret_cast<u32x2 *>(dst + 40) = u32x2{w[10], w[11]};
-          *reinterpret_cast<u32x4 *>(dst + 48) = u32x4{w[12], w[13], w[14], w[15]};
-        }
-        if (RAW && (p.raw_flags & 2) != 0 && inb[r]) {
-          if (bok[0]) *reinterpret_cast<unsigned short *>(dst + 2 * bidx[0]) = (unsigned short)0x3c00;
-          if (bok[1]) *reinterpret_cast<unsigned short *>(dst + 20 + 2 * bidx[1]) = (unsigned short)0x3c00;
-        }
-        const f16x2 hd = __builtin_bit_cast(f16x2, w[13]), ht = __builtin_bit_cast(f16x2, w[14]);
-        const unsigned md = pack_f16(d0 - (float)hd[0], d1 - (float)hd[1]);
-        const unsigned mt = pack_f16(vt[r][0] - (float)ht[0], vt[r][1] - (float)ht[1]);
-        *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{md, mt, 0u, 0u};
-      }
-      if (!RAW) {                                              // the one-hot depth, granule by granule: K-slots 4c .. 4c + 3 of its pixel
-#pragma unroll
-        for (int k = 0; k < RD; ++k) {
-          const f32x4 v = gdd[k];
-          lowbits |= __builtin_bit_cast(unsigned, v[0]) | __builtin_bit_cast(unsigned, v[1]);
-          lowbits |= __builtin_bit_cast(unsigned, v[2]) | __builtin_bit_cast(unsigned, v[3]);
-          if (k < RD - 1 || (int)ddmeta[k] < 0)
-            *reinterpret_cast<u32x2 *>(lds + buf + (ddmeta[k] & 0xffffu)) = u32x2{pack_f16(v[0], v[1]), pack_f16(v[2], v[3])};
-        }
-      }
-      if (!RAW && (lowbits & 0x1fffu) != 0 && p.bad_input != nullptr) *p.bad_input = 1;
-      if (RAW && bad_depth && p.raw_err != nullptr) *p.raw_err = 1;
-    };
-
-    // ---- epilogue of one tile: K-split sum in wave order, un-scale, GroupNorm partials, pooled keys / raw output.
-    //      An L wave owns HPW output rows of 16 pixels (half M-tiles): M-tile mt, accumulator quads rq0 .. rq0 + 2 HPW - 1
-    const float oscale = p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale;
-    const int rr16 = lane >> 5;
-    const int co = p.y_coff[0] + (lane & 31);
-    const float sgn = POOL ? (p.pool_gamma[co] < 0.f ? -1.f : 1.f) : 1.f;
-    const int mt = (lw * HPW) >> 1, rq0 = ((lw * HPW) & 1) * 2;
-    auto epilogue = [&](int t, unsigned buf) {
-      int n, ty, tx;
-      tile_coords(t, n, ty, tx);
-      const int ho0 = ty * TH, wo0 = tx * TW;
-      const unsigned long long e0 = now();
-      float tot[8 * HPW];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int q = 0; q < 2 * HPW; ++q) {
-          const f32x4 tq = *reinterpret_cast<const f32x4 *>(lds + buf + (((mt * 4 + s4) * 4 + rq0 + q) * 64 + lane) * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tot[4 * q + e] = s4 == 0 ? tq[e] : tot[4 * q + e] + tq[e];
-        }
-#pragma unroll
-      for (int r = 0; r < 8 * HPW; ++r) tot[r] *= oscale;
-      if (prof) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long e1 = now();
-      float s1 = 0.f, s2 = 0.f;
-      // pixel of tot[r] inside the 8 x 16 tile: i = e + 8 rq + 4 rr16 in the 32-pixel M-tile (row i >> 4, column i & 15)
-#pragma unroll
-      for (int r = 0; r < 8 * HPW; ++r) {
-        const int i = (r & 3) + 8 * (rq0 + (r >> 2)) + 4 * rr16;
-        const int row = 2 * mt + (i >> 4), col = i & 15;
-        const bool ok = ho0 + row < p.Ho && wo0 + col < p.Wo;
-        const float v = ok ? tot[r] : 0.f;
-        if (POOL) {
-          pb[(row * 16 + col) * 33 + (lane & 31)] = ok ? sgn * tot[r] : -__builtin_inff();
-        } else if (ok) {
-          reinterpret_cast<float *>(p.y[0])[(((long)n * p.Ho + ho0 + row) * p.Wo + wo0 + col) * p.y_cstride + co] = v;
-        }
-        s1 += v;
-        s2 = __builtin_fmaf(v, v, s2);
-      }
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32) {
-        red[(lw * 32 + lane) * 2] = s1;
-        red[(lw * 32 + lane) * 2 + 1] = s2;
-      }
-      const unsigned long long e2 = now();
-      ps_lsync<NL>(ctr, epoch);                             // pb / red complete; every L wave has left the exchange buffer
-      const unsigned long long e3 = now();
-      const int Ib = ho0 >> 1, Jb = wo0 >> 1;
-      auto emit = [&](int ch, int I, int J, float mx, bool inside) {
-        if (I >= p.Hp || J >= p.Wp) return;
-        int key = __builtin_bit_cast(int, mx);
-        key = key >= 0 ? key : key ^ 0x7fffffff;
-        int *dst = p.pool + (long)n * p.Hp * p.Wp * p.y_cstride + p.y_coff[0] + ch + (I * p.Wp + J) * p.y_cstride;
-        if (inside)
-          *dst = key;
-        else
-          atomicMax(dst, key);
-      };
-      if (POOL && ltid < 256) {
-        const int ch = ltid & 31, pj = ltid >> 5;
-        const int c0 = pj > 0 ? 2 * pj - 1 : 0, c1 = 2 * pj, c2 = 2 * pj + 1;
-        float cm[8];
-#pragma unroll
-        for (int lr = 0; lr < 8; ++lr)
-          cm[lr] = fmaxf(fmaxf(pb[(lr * 16 + c0) * 33 + ch], pb[(lr * 16 + c1) * 33 + ch]), pb[(lr * 16 + c2) * 33 + ch]);
-        const bool colin = pj >= 1 || wo0 == 0;
-        emit(ch, Ib + 0, Jb + pj, fmaxf(cm[0], cm[1]), colin && ho0 == 0);
-        emit(ch, Ib + 1, Jb + pj, fmaxf(fmaxf(cm[1], cm[2]), cm[3]), colin);
-        emit(ch, Ib + 2, Jb + pj, fmaxf(fmaxf(cm[3], cm[4]), cm[5]), colin);
-        emit(ch, Ib + 3, Jb + pj, fmaxf(fmaxf(cm[5], cm[6]), cm[7]), colin);
-        emit(ch, Ib + 4, Jb + pj, cm[7], false);
-      }
-      // ninth pooled column (tile column 15, always shared with the right tile) and the GroupNorm partials: with eight L waves the
-      // second half of the threads takes them, with four the first 160 / the last 32 do after the main part
-      constexpr int T9 = NL == 8 ? 256 : 0, TS = NL == 8 ? 416 : 224;
-      if (POOL && ltid >= T9 && ltid < T9 + 160) {
-        const int ch = ltid & 31, pi = (ltid - T9) >> 5;
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int dr = -1; dr <= 1; ++dr) {
-          const int lr = 2 * pi + dr;
-          if (lr >= 0 && lr < 8) mx = fmaxf(mx, pb[(lr * 16 + 15) * 33 + ch]);
-        }
-        emit(ch, Ib + pi, Jb + 8, mx, false);
-      }
-      if (ltid >= TS && ltid < TS + 32) {
-        const int cch = ltid - TS;
-        float a1 = 0.f, a2 = 0.f;
-        // (four-wave order: partials of M-tile 0..3; eight waves: the two rows of an M-tile are added first — the same values in the
-        //  same order as stem_mx_kernel only for NL = 4; the GroupNorm statistics of NL = 8 differ in the last bit)
-#pragma unroll
-        for (int w4 = 0; w4 < NL; ++w4) {
-          a1 += red[(w4 * 32 + cch) * 2];
-          a2 += red[(w4 * 32 + cch) * 2 + 1];
-        }
-        const int slot = ty * p.tiles_x + tx;
-        float *dst = p.stats[0] + (((long)n * p.slots + slot) * p.stats_cstride + p.y_coff[0] + cch) * 2;
-        dst[0] = a1;
-        dst[1] = a2;
-      }
-      if (prof) {
-        ep[0] += e1 - e0;
-        ep[1] += e2 - e1;
-        ep[2] += e3 - e2;
-        ep[3] += now() - e3;
-      }
-    };
-
-    // ---- prologue: patch of the first tile, loads of the second in flight
-    stage_load(t_first);
-    stage_store(0u);
-    if (nit > 1) stage_load(t_first + per);
-    __syncthreads();
-#pragma unroll 1
-    for (int it = 0; it < nit; ++it) {
-      const unsigned long long t0 = now();
-      if (it > 0 && !(p.dbg & 2)) epilogue(t_first + (it - 1) * per, (unsigned)((it - 1) & 1) * PS_BUF);
-      const unsigned long long t1 = now();
-      if (it + 1 < nit && !(p.dbg & 4)) stage_store((unsigned)((it + 1) & 1) * PS_BUF);
-      const unsigned long long t2 = now();
-      if (it + 2 < nit && !(p.dbg & 16)) stage_load(t_first + (it + 2) * per);
-      const unsigned long long t3 = now();
-      __syncthreads();                                      // patch(it + 1) written; the M waves have left patch(it)
-      const unsigned long long t4 = now();
-      __syncthreads();                                      // exchange(it) written
-      if (prof) {
-        pc[0] += t1 - t0;                                   // epilogue of the previous tile
-        pc[1] += t2 - t1;                                   // convert + LDS writes of the next patch (incl. waiting for its loads)
-        pc[2] += t3 - t2;                                   // issue of the loads of the patch after next
-        pc[3] += t4 - t3;                                   // wait for the M waves
-        pc[4] += now() - t4;                                // wait for the exchange
-      }
-    }
-    epilogue(t_first + (nit - 1) * per, (unsigned)((nit - 1) & 1) * PS_BUF);
-  }
-  if (prof && lane == 0 && (blockIdx.x % 16) == 0) {
-    unsigned long long *q = p.prof + 16 * wave;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) atomicAdd(q + k, pc[k]);
-    atomicAdd(q + 5, (unsigned long long)nit);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(q + 8 + k, ep[k]);
-  }
-}
-
 int stem_mx_slots(int Ho, int Wo) { return ((Ho + TH - 1) / TH) * ((Wo + TW - 1) / TW); }
 
 size_t stem_mx_packed_u16(int pieces, int ntiles) { return (size_t)49 * (pieces * 2 + (pieces >= 2 ? 1 : 0)) * ntiles * 64 * 8; }
@@ -1411,45 +833,6 @@ hipError_t launch_stem_mx_repack(const float *w_oihw, int cin, const float *sc_n
   hipLaunchKernelGGL(stem_mx_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oihw, cin, sc_new, sh_new,
                      slot_ref, slot_new, xslot, wpk3, total);
   return hipGetLastError();
-}
-
-// Persistent form (stem_ps_kernel): float16 pieces, one N-tile, float32 output.  `wgs` = workgroups to launch (one per CU, a
-// multiple of 8).  Takes the launch when the tiles keep every workgroup busy for a few rounds.
-bool stem_ps_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, int wgs) {
-  const long ntiles = (long)a.B * ((a.Wo + TW - 1) / TW) * ((a.Ho + TH - 1) / TH);
-  return pieces == 2 && ntiles_n == 1 && !bf16_out && wgs >= 8 && ntiles >= 4L * wgs;
-}
-
-template <int NL>
-static hipError_t launch_stem_ps_nl(const StemMXArgs &p, unsigned gx, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipSuccess;
-    auto set = [&](const void *f) {
-      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
-    };
-    set(reinterpret_cast<const void *>(stem_ps_kernel<true, true, NL>));
-    set(reinterpret_cast<const void *>(stem_ps_kernel<true, false, NL>));
-    set(reinterpret_cast<const void *>(stem_ps_kernel<false, true, NL>));
-    set(reinterpret_cast<const void *>(stem_ps_kernel<false, false, NL>));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const bool raw = p.raw_depth != nullptr, pool = p.pool != nullptr;
-  const dim3 blk(256 + 64 * NL);
-  if (pool && raw) hipLaunchKernelGGL((stem_ps_kernel<true, true, NL>), dim3(gx), blk, PS_LDS, s, p);
-  else if (pool) hipLaunchKernelGGL((stem_ps_kernel<true, false, NL>), dim3(gx), blk, PS_LDS, s, p);
-  else if (raw) hipLaunchKernelGGL((stem_ps_kernel<false, true, NL>), dim3(gx), blk, PS_LDS, s, p);
-  else hipLaunchKernelGGL((stem_ps_kernel<false, false, NL>), dim3(gx), blk, PS_LDS, s, p);
-  return hipGetLastError();
-}
-
-hipError_t launch_stem_ps(const StemMXArgs &a, int wgs, int nl, hipStream_t s) {
-  StemMXArgs p = a;
-  p.tiles_x = (a.Wo + TW - 1) / TW;
-  p.tiles_y = (a.Ho + TH - 1) / TH;
-  const unsigned gx = (unsigned)(wgs & ~7);
-  return nl == 8 ? launch_stem_ps_nl<8>(p, gx, s) : launch_stem_ps_nl<4>(p, gx, s);
 }
 
 hipError_t launch_stem_mx(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out, hipStream_t s) {

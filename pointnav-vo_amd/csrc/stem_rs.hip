@@ -987,8 +987,9 @@ bool stem_rs_takes(const StemMXArgs &a, int pieces, int ntiles_n, bool bf16_out,
 }
 
 hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, bool fast, int wgs, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::mutex attr_mu;
+  static unsigned long long attr_seen = 0;            // one bit per device: the attribute is per device, not per process
+  if (pnvo_first_launch_on_device(attr_mu, attr_seen)) {
     hipError_t e = hipSuccess;
     auto set = [&](const void *f) {
       if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
@@ -1004,7 +1005,6 @@ hipError_t launch_stem_rs(const StemMXArgs &a, int pieces, bool fast, int wgs, h
     set(reinterpret_cast<const void *>(stem_rs_kernel<1, false, true>));
     set(reinterpret_cast<const void *>(stem_rs_kernel<1, false, false>));
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   StemMXArgs p = a;
   p.tiles_x = (a.Wo + TW - 1) / TW;

@@ -30,16 +30,6 @@ rm -rf $O/${tag}_trace_train
 PNVO_WSM_PROF=1 python bench.py --config train --steps 10 --warmup 3 2>&1 >/dev/null | grep "pnvo\]" > $O/${tag}_wgrad_stem_phases.txt
 PNVO_X3_PROF=1 python bench.py --steps 1 --warmup 0 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] conv_x3" | sort -u -t: -k1,1 > $O/${tag}_conv_x3_phases.txt
 PNVO_STEM_FORM=tiles PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-preheat --no-cpu-baseline --no-secondary 2>&1 >/dev/null | grep "pnvo\] stem_mx" > $O/${tag}_stem_phases.txt
-# the persistent role-specialised stem: phases per wave role, and its timing-only ablations (what bounds it)
-( echo "# stem_ps_kernel (option stem_form=persistent, 8 L waves): cycles per tile and wave role; then ablations (WRONG results, timing only):"
-  echo "# 17 = staging loads hit one address, 18 = no epilogue, 20 = no conversion / LDS writes, 24 = no MFMAs, 32 = no staging loads, 38 = K loop alone"
-  for d in 9 17 18 20 24 32 38; do echo "== PNVO_STEM_DBG=$d"; PNVO_STEM_FORM=persistent PNVO_STEM_DBG=$d python bench.py --steps 6 --warmup 2 --no-preheat --no-cpu-baseline --no-secondary 2>&1 | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        j = json.loads(l); print('stem ms per launch', round([k for k in j['kernels'] if 'conv1.0' in k['name']][0]['ms_per_step'], 4))
-    elif 'pnvo]' in l and ('M wave 0' in l or 'L wave 4' in l or 'L wave 9' in l): print(l.rstrip())
-"; done ) > $O/${tag}_stem_ps_phases.txt 2>&1
 # the resident-weight stem (the default): cycles per tile of its three sections, per wave
 ( echo "# stem_rs_kernel at 256 pairs: cycles per tile (s_memtime) of its three sections per wave, option stem_dbg=9"
   echo "# -- stem_form=fast (the default: 209 MFMAs per wave and tile)"
