@@ -263,6 +263,18 @@ def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2", form="auto
     return tf, peak, pipe
 
 
+def fast_form_layers(model, B):
+    """Which of the 17 layers the headline's arithmetic note is about (the stem + the sixteen 3x3 convs of the residual stages) run on
+    the two-float16-piece form at batch B — the others take three exact bf16 pieces (a GroupNorm-derived range bound of 6e4 on the
+    layer's input decides per layer: pnvo_layer_kernel)."""
+    names = [f"visual_encoder.backbone.layer{s}.{b}.convs.{c}" for s in (1, 2, 3, 4) for b in (0, 1) for c in (0, 3)]
+    fam = {n: model.layer_kernel(n, B)[0] for n in names}
+    stem_fast = model.get_option("pieces") == "2" and model.get_option("stem") in ("auto", "mx")
+    fast = int(stem_fast) + sum(1 for f in fam.values() if f == "x2")
+    return {"layers_on_fast_form": f"{fast}/{1 + len(names)}", "stem": "two float16 pieces" if stem_fast else "other",
+            "not_on_fast_form": sorted(n for n, f in fam.items() if f != "x2")}
+
+
 def frames_of(obs):
     """The sensor frames behind synthetic observation pairs: uint8 rgb [B,2,H,W,3], float32 depth [B,2,H,W] (the pair tensors
     hold [prev | cur] on the channel axis)."""
@@ -544,6 +556,7 @@ def main():
             "kernel_ms_per_step": total_kernel_ms / args.steps,
             "pose_rel_err_vs_fp64_oracle": rel, "oracle_checked_pairs": chk,
             "arithmetic": arithmetic_text(model),
+            **{k: v for k, v in fast_form_layers(model, B).items() if k != "stem"},
             "model_tflops": value * flops_pair / 1e12,
             "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
             "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),

@@ -112,9 +112,11 @@ class VOTrainStep:
                     p.data = view
                     p.grad = self.grad[off:off + k].view(p.shape)
                 off += k
-        _lib.check(_lib.lib.pnvo_train_refresh(self.model._handle, stream), self.model._handle)
-        # an outside edit can move a GroupNorm weight by any amount: the float16-piece range guard (bounds the refresh re-computes on
-        # the device and the next forward reads without a synchronisation — fine for Adam's lr-sized steps) must be current NOW
+        # an outside edit can move a GroupNorm weight by any amount: the float16-piece range guard must be current NOW.  The forward
+        # reads the bounds of the parameters TWO refreshes back (a fixed lag — fine for Adam's lr-sized steps, and the same on every
+        # run and rank): three refreshes fill that ring with the edited parameters' bounds
+        for _ in range(3):
+            _lib.check(_lib.lib.pnvo_train_refresh(self.model._handle, stream), self.model._handle)
         torch.cuda.current_stream(self.dev).synchronize()
         self.model._loaded_sig = None
         self._psig = self._param_sig()

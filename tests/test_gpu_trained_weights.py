@@ -1,0 +1,108 @@
+"""GPU (-m gpu): the headline's two-float16-piece arithmetic on TRAINED-LOOKING weights.  The reference's checkpoints are on Google
+Drive (README.md:70; loader base_trainer_with_vo.py:83-99) and cannot be fetched here, so every other parity test runs on seeded
+kaiming-like weights.  What could differ on a trained model: (a) the range guard — a layer takes the two-float16-piece form only while
+a GroupNorm-derived bound on its input stays below 6e4, else three exact bf16 pieces; (b) heavy-tailed weights and activations in the
+float16 pieces.  Two stand-ins for a trained checkpoint:
+  * a state dict with the statistics trained GroupNorm-ResNets show: heavy-tailed (Laplace) conv weights with a few large outliers,
+    GroupNorm scales from ~0 ("dead" channels) to 6, shifts in +-2, running statistics of real image data;
+  * this repo's own trainer run for 60 optimiser steps from that state dict on synthetic pairs.
+For both: which of the 17 layers take the fast form (pnvo_layer_kernel; the bench line carries the same count), and the pose error of
+the DEFAULT forward against the fp64 oracle at 341 x 192 — within north_star's 1e-4, and not worse than the strict three-piece form."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import oracle
+from pointnav_vo_amd import model_spec as ms, synth
+from pointnav_vo_amd.train import VOTrainStep
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def trained_looking_state_dict(spec, seed=7):
+    sd = synth.make_state_dict(spec, seed=seed)
+    for name, shape in spec:
+        u = synth.uniform(seed, name + "#t", shape)
+        if len(shape) == 4:                                   # conv: Laplace magnitudes, one weight in 500 an outlier 6x larger
+            fan_in = int(np.prod(shape[1:]))
+            lap = -np.log(np.maximum(1.0 - u, 1e-12)) * np.sqrt(1.0 / fan_in)
+            sign = np.where(synth.uniform(seed, name + "#s", shape) < 0.5, -1.0, 1.0)
+            big = np.where(synth.uniform(seed, name + "#o", shape) < 0.002, 6.0, 1.0)
+            sd[name] = (lap * sign * big).astype(np.float32)
+        elif name.startswith("visual_encoder") and len(shape) == 1 and name.endswith(".weight"):     # GroupNorm scale: 0 .. 6
+            g = np.where(u < 0.1, 0.02 * u, np.where(u > 0.95, 2.0 + 80.0 * (u - 0.95), 0.3 + 1.8 * u))
+            sign = np.where(synth.uniform(seed, name + "#s", shape) < 0.08, -1.0, 1.0)
+            sd[name] = (g * sign).astype(np.float32)
+        elif name.startswith("visual_encoder") and len(shape) == 1 and name.endswith(".bias"):       # GroupNorm shift: +-2
+            sd[name] = (4.0 * u - 2.0).astype(np.float32)
+    return sd
+
+
+def _errs(out, ref):
+    return np.linalg.norm(out - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+
+
+def _check(model, sd, obs, n_check=4):
+    """Default forward and the strict three-piece form against the fp64 oracle on the first pairs; the per-layer forms."""
+    sub = {k: v[:n_check].contiguous() for k, v in obs.items()}
+    ref = oracle.forward(sd, {k: v.cpu().numpy() for k, v in sub.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    with torch.no_grad():
+        fast = model(obs)[:n_check].double().cpu().numpy()
+        forms = bench.fast_form_layers(model, obs["depth"].shape[0])
+        model.set_option("pieces", "3")
+        strict = model(obs)[:n_check].double().cpu().numpy()
+        model.set_option("pieces", "2")
+    return _errs(fast, ref), _errs(strict, ref), forms, np.abs(ref).max()
+
+
+def test_fast_form_on_trained_looking_weights_and_after_real_optimiser_steps():
+    model, _ = bench.build_model(DEV)
+    spec = ms.state_dict_spec(model.cfg)
+    sd = trained_looking_state_dict(spec)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    obs = bench.make_inputs(16, DEV, 0)
+    model.eval()
+    e_fast, e_strict, forms, mag = _check(model, sd, obs)
+    print("trained-looking:", forms, "fast", e_fast.max(), "strict", e_strict.max(), "|ref|max", mag)
+    assert forms["layers_on_fast_form"] == "17/17", forms      # GroupNorm scales up to 6: every bound far below 6e4
+    assert e_fast.max() < 1e-4 and e_fast.max() < 3.0 * e_strict.max() + 2e-6, (e_fast, e_strict)
+
+    # 60 optimiser steps of this repo's trainer (fwd + bwd + Adam, dropout 0.2) from there: a regression target the network can fit
+    model.train()
+    ts = VOTrainStep(model, lr=1e-3)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    tgt = (torch.rand((16, 3), device=DEV, generator=g) - 0.5) * 0.4
+    losses = [float(ts.step(obs, tgt)[1]) for _ in range(60)]
+    torch.cuda.synchronize()
+    assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])   # it did train
+    sd2 = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    moved = max(float(np.abs(sd2[k] - sd[k]).max()) for k in sd if sd[k].ndim == 4)
+    assert moved > 1e-3                                            # (the weights are not the ones we started from)
+    fresh, _ = bench.build_model(DEV)                              # an inference-only handle, loaded like a checkpoint (:83-99)
+    fresh.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    fresh.eval()
+    e_fast, e_strict, forms, mag = _check(fresh, sd2, obs)
+    print("after 60 steps:", forms, "fast", e_fast.max(), "strict", e_strict.max(), "|ref|max", mag)
+    assert forms["layers_on_fast_form"] == "17/17", forms
+    assert e_fast.max() < 1e-4 and e_fast.max() < 3.0 * e_strict.max() + 2e-6, (e_fast, e_strict)
+
+
+def test_a_layer_outside_the_range_bound_leaves_the_fast_form():
+    """The guard itself: GroupNorm scales of 400 in one layer put the bound on the NEXT conv's input (|gamma| sqrt(n) + |beta|) above
+    6e4 — that conv, and it alone with its successors in the chain, takes three bf16 pieces; results stay within tolerance."""
+    model, _ = bench.build_model(DEV)
+    spec = ms.state_dict_spec(model.cfg)
+    sd = synth.make_state_dict(spec, seed=0)
+    k = "visual_encoder.backbone.layer2.0.convs.1.weight"         # GroupNorm behind layer2.0.convs.0 -> input of layer2.0.convs.3
+    sd[k] = (sd[k] * 400.0).astype(np.float32)
+    model.load_state_dict({n: torch.from_numpy(np.array(v)) for n, v in sd.items()})
+    model.eval()
+    obs = bench.make_inputs(8, DEV, 0)
+    e_fast, e_strict, forms, _ = _check(model, sd, obs, 2)
+    assert "visual_encoder.backbone.layer2.0.convs.3" in forms["not_on_fast_form"], forms
+    assert "visual_encoder.backbone.layer1.0.convs.0" not in forms["not_on_fast_form"]
+    assert int(forms["layers_on_fast_form"].split("/")[0]) < 17
+    assert e_fast.max() < 1e-4, e_fast
