@@ -265,14 +265,16 @@ def stem_executed(kt_entry, B, per_launch_ms, sel="auto", pieces="2", form="auto
 
 def fast_form_layers(model, B):
     """Which of the 17 layers the headline's arithmetic note is about (the stem + the sixteen 3x3 convs of the residual stages) run on
-    the two-float16-piece form at batch B — the others take three exact bf16 pieces (a GroupNorm-derived range bound of 6e4 on the
-    layer's input decides per layer: pnvo_layer_kernel)."""
+    the two-float16-piece form at batch B.  A layer leaves it for three exact bf16 pieces when a GroupNorm-derived bound on its
+    input reaches 6e4 (`range_guarded`); small launches (deep stages at small batches) run on the fp32 MFMA pipe (`on_fp32_pipe`,
+    exact fp32 arithmetic): pnvo_layer_kernel."""
     names = [f"visual_encoder.backbone.layer{s}.{b}.convs.{c}" for s in (1, 2, 3, 4) for b in (0, 1) for c in (0, 3)]
     fam = {n: model.layer_kernel(n, B)[0] for n in names}
     stem_fast = model.get_option("pieces") == "2" and model.get_option("stem") in ("auto", "mx")
     fast = int(stem_fast) + sum(1 for f in fam.values() if f == "x2")
     return {"layers_on_fast_form": f"{fast}/{1 + len(names)}", "stem": "two float16 pieces" if stem_fast else "other",
-            "not_on_fast_form": sorted(n for n, f in fam.items() if f != "x2")}
+            "range_guarded": sorted(n for n, f in fam.items() if f == "x3"),
+            "on_fp32_pipe": sorted(n for n, f in fam.items() if f not in ("x2", "x3"))}
 
 
 def frames_of(obs):

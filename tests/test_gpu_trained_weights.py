@@ -50,7 +50,7 @@ def _check(model, sd, obs, n_check=4):
     ref = oracle.forward(sd, {k: v.cpu().numpy() for k, v in sub.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
     with torch.no_grad():
         fast = model(obs)[:n_check].double().cpu().numpy()
-        forms = bench.fast_form_layers(model, obs["depth"].shape[0])
+        forms = bench.fast_form_layers(model, 256)            # the headline's batch (deep stages of a small batch take the fp32 pipe)
         model.set_option("pieces", "3")
         strict = model(obs)[:n_check].double().cpu().numpy()
         model.set_option("pieces", "2")
@@ -91,18 +91,18 @@ def test_fast_form_on_trained_looking_weights_and_after_real_optimiser_steps():
 
 
 def test_a_layer_outside_the_range_bound_leaves_the_fast_form():
-    """The guard itself: GroupNorm scales of 400 in one layer put the bound on the NEXT conv's input (|gamma| sqrt(n) + |beta|) above
+    """The guard itself: GroupNorm scales of 2000 in one layer put the bound on the NEXT conv's input (|gamma| sqrt(n) + |beta|) above
     6e4 — that conv, and it alone with its successors in the chain, takes three bf16 pieces; results stay within tolerance."""
     model, _ = bench.build_model(DEV)
     spec = ms.state_dict_spec(model.cfg)
     sd = synth.make_state_dict(spec, seed=0)
     k = "visual_encoder.backbone.layer2.0.convs.1.weight"         # GroupNorm behind layer2.0.convs.0 -> input of layer2.0.convs.3
-    sd[k] = (sd[k] * 400.0).astype(np.float32)
+    sd[k] = (sd[k] * 2000.0).astype(np.float32)               # bound ~ 2000 x 1.5 x sqrt(4128) = 1.9e5
     model.load_state_dict({n: torch.from_numpy(np.array(v)) for n, v in sd.items()})
     model.eval()
     obs = bench.make_inputs(8, DEV, 0)
     e_fast, e_strict, forms, _ = _check(model, sd, obs, 2)
-    assert "visual_encoder.backbone.layer2.0.convs.3" in forms["not_on_fast_form"], forms
-    assert "visual_encoder.backbone.layer1.0.convs.0" not in forms["not_on_fast_form"]
-    assert int(forms["layers_on_fast_form"].split("/")[0]) < 17
+    assert "visual_encoder.backbone.layer2.0.convs.3" in forms["range_guarded"], forms
+    assert "visual_encoder.backbone.layer1.0.convs.0" not in forms["range_guarded"] and not forms["on_fp32_pipe"]
+    assert int(forms["layers_on_fast_form"].split("/")[0]) == 17 - len(forms["range_guarded"]) < 17
     assert e_fast.max() < 1e-4, e_fast
