@@ -582,7 +582,11 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     // (its device-side re-pack builds the three-piece operand from the flat parameters)
     const bool two = x3_two_pieces(m, l);
     xa.np = two ? 2 : 3;
-    if (conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
+    const int x3_mode = tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0);
+    // 32 -> 32 channels (layer1): the row-streaming kernel (conv_rows.hip) where it takes the launch — fewer statistics slots than
+    // the tile plan the buffer is sized for (stats_floats)
+    const bool rows = two && m->opt.x3_rows && m->train == nullptr && conv_rows32_plan(xa, l.k, l.stride, x3_mode, m->num_cus);
+    if (rows || conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
       if (two && (!lm.wpk_x2 || lm.x2_gen != m->weights_gen)) {  // (re)build the two-piece operand of this layer
         const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 2;
@@ -635,7 +639,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       // GroupNorm scale / shift — the same fp64 arithmetic as gn_finalize_kernel, bit for bit, one launch less (option gn_fuse)
       const int cpg = l.groups > 0 ? l.cout / l.groups : 0;
       const bool fuse = m->opt.gn_fuse && xa.slots == 1 && l.cout == l.coutp && cpg >= 1 && cpg <= 32 &&
-                        32 % cpg == 0 && l.cout % cpg == 0 && !(xa.persist_wgs > 0 && l.cin == 32 && l.coutp == 32);
+                        32 % cpg == 0 && l.cout % cpg == 0 && (rows || !(xa.persist_wgs > 0 && l.cin == 32 && l.coutp == 32));
       if (fuse) {
         xa.gn_gamma = l.gamma;
         xa.gn_beta = l.beta;
@@ -649,7 +653,10 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       }
       {
         Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes + (tail ? 8.0 * B * l.hin * l.win * l.cin : 0.0));
-        HIPCHK(m, launch_conv_x3(xa, l.k, l.stride, tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0), mw, nw, ldsb, s));
+        if (rows)
+          HIPCHK(m, launch_conv_rows32(xa, x3_mode, m->num_cus, s));
+        else
+          HIPCHK(m, launch_conv_x3(xa, l.k, l.stride, x3_mode, mw, nw, ldsb, s));
       }
       if (fuse) return PNVO_OK;
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
@@ -1038,6 +1045,7 @@ const OptDef kOptions[] = {
     {"stem_form", "PNVO_STEM_FORM", &PnvoOptions::stem_form, false, {{"auto", 0}, {"tiles", 2}, {"resident", 3}, {"fast", 4}, {nullptr, 0}}},
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_persist", "PNVO_X3_PERSIST", &PnvoOptions::x3_persist, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"x3_rows", "PNVO_X3_ROWS", &PnvoOptions::x3_rows, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},

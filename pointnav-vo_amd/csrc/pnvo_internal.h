@@ -147,6 +147,8 @@ struct ConvX3Args {
   // np == 2 on a GRADIENT input (backward-data): float bits of max |x| over the input tensor (gn_bwd_apply's absmax); the stager
   // multiplies by 2^(14 - e) before the float16 split, the epilogue divides again (both exact)
   const unsigned *in_absmax;         //   (64 slots of 16 uints: readers take the maximum, absmax_of())
+  int rs_bands, rs_rows;             // conv_rows32_plan (conv_rows.hip): bands per sample, rows per band
+  int rs_dbg;                        // developer ablations (env PNVO_ROWS_DBG; WRONG RESULTS, timing only): 1 no loads, 2 no stores, 4 no MFMAs, 8 no conversion
   int np;                            // operand pieces: 3 = bf16 (six exact product terms; 0 means 3), 2 = float16 (three terms)
   float oscale;                      // np == 2: inverse of the power-of-two scale folded into the packed weights
   const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
@@ -188,6 +190,9 @@ __device__ __forceinline__ void gn_finalize_lane(float s1, float s2, int cpg, lo
 }
 #endif
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
+// Row-streaming form of the 32 -> 32 channel 3x3 stride-1 convs (conv_rows.hip): plan fills rs_bands / rs_rows / slots.
+bool conv_rows32_plan(ConvX3Args &a, int ks, int stride, int mode, int num_cus);
+hipError_t launch_conv_rows32(const ConvX3Args &a, int mode, int num_cus, hipStream_t s);
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
 hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,
                                  unsigned short *out, hipStream_t s);

@@ -38,6 +38,7 @@ struct PnvoOptions {
   int pieces = 2;      // operand pieces of conv_x3 at inference: 2 float16 (three product terms) or 3 bf16 (six exact terms)
   int train_pieces = 2;  // the same choice for the TRAINING forward's convs (their backward-data convs keep three bf16 pieces:
                          //   gradients do not fit float16's range)
+  int x3_rows = 1;     // 32 -> 32 channel 3x3 stride-1 convs on the row-streaming kernel (conv_rows.hip) where it takes the launch
   int x3_persist = 1;  // shallow-stage 3x3 convs on the persistent form of conv_x3 (next tile's patch fetched during the K loop)
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
   int gn_fuse = 1;     // conv_x3 launches with one tile per sample finalise their GroupNorm themselves (bit-identical, one launch less)

@@ -142,6 +142,7 @@ def test_persistent_resident_weight_convs_are_bit_identical():
     import bench
     dev = torch.device("cuda", 0)
     model, _ = bench.build_model(dev)
+    model.set_option("x3_rows", "off")                 # (from 64 pairs on the row-streaming kernel would take these layers)
     for B in (16, 64):
         obs = bench.make_inputs(B, dev, 1)
         outs = []
@@ -154,6 +155,68 @@ def test_persistent_resident_weight_convs_are_bit_identical():
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         fam = model.layer_kernel("visual_encoder.backbone.layer1.0.convs.3", B)[0]
         assert fam in ("x2", "x3"), fam
+
+
+@pytest.mark.parametrize("B", [64, 100, 128, 256])
+def test_row_streaming_convs_agree_with_the_tile_kernels(B):
+    """conv_rows32_kernel (option x3_rows, default on: the 32 -> 32 convs of the first stage whose input is a GroupNorm-ed raw tensor,
+    from one band per CU on) against conv_x3_kernel / conv_x3p_kernel: the same float16 pieces and products, two accumulators instead
+    of one and one statistics slot per band — float32-grade agreement (5e-6 of the output range; measured 3e-6), run-to-run
+    reproducible; 4 / 2 / 2 / 1 bands per sample at these batch sizes, the last with the GroupNorm finalised inside the kernel."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 2)
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("x3_rows", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs["on"]).all() and torch.equal(outs["on"], outs["on2"])
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel                                   # (0 would mean the option selected nothing)
+    chk = [0, B // 2, B - 1]
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][chk].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
+
+
+def test_row_streaming_convs_on_an_odd_resolution():
+    """101 x 75 frames (51 x 38 stem output, 26 x 19 maps in the first stage: ragged half-groups, rows shorter than a tile), 300 pairs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    from pointnav_vo_amd import model_spec as ms, synth
+    from pointnav_vo_amd.registry import baseline_registry
+    dev = torch.device("cuda", 0)
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(101, 75), hidden_size=512, backbone="resnet18", normalize_visual_inputs=True,
+        output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    obs = synth.make_obs_pairs(300, 75, 101, observation_space=bench.SPACE, dd_bins=10, seed=3)
+    tobs = {k: torch.from_numpy(v).to(dev) for k, v in obs.items()}
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off"):
+            m.set_option("x3_rows", v)
+            outs[v] = m(tobs).clone()
+        torch.cuda.synchronize()
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel
+    ref = oracle.forward(sd, {k: v[:3] for k, v in obs.items()}, ngroups=m.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][:3].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
 
 
 def test_strip_tiles_of_the_128_channel_stage_agree_with_square_tiles():
