@@ -24,9 +24,13 @@
 // k-chunk inner, the power-of-two weight scale undone on the accumulators) with the even and the odd steps in two accumulators that
 // are added at the end (a chain of 54 MFMAs on one accumulator is paced by the MFMA latency): float32-grade equal to conv_x3_kernel
 // (measured 3e-6 of the output range end to end), deterministic; the statistics are summed in another fixed order.
-// Stager modes as in conv_x3.hip: 0 final activations, 1 relu(x * scale + shift).
+// Stager modes as in conv_x3.hip: 0 final activations, 1 relu(x * scale + shift), 2 the previous block's tail relu(x * scale + shift +
+// skip) with the block output written for the band's own rows (the skip branch is loaded into registers at the top of a stage role and
+// used at its end; one accumulator), 3 pooled stem keys (decode, |scale|, shift, ReLU; pooled activations written): all four convs of
+// the first stage.
 //
-// Measured at 256 pairs (profiles/r5_rows_*): 86 -> 72 us per conv and no GroupNorm finalisation launch behind it (-7 us each).  Role
+// Measured at 256 pairs (profiles/r5_rows_*): the GroupNorm-input convs 86 -> 72-80 us, pooled keys 119 -> 90, block tail 160 -> 138, and
+// no GroupNorm finalisation launch behind any of them (-7 us each): the first stage 0.52 -> 0.41 ms with its finalisations.  Role
 // cycles per half-step: compute 2.7 k (54 MFMAs = 1.7 k), stage 3.3 k (~330 instructions), barrier 0.5 k — the stage role is the pole:
 // a transposed product (positions as columns: dwordx4 stores, one table entry per lane) would cut its epilogue by 55 instructions but
 // needs 32 registers of per-lane partial sums that the 256-register budget (144 of them weights) does not have.
@@ -68,7 +72,9 @@ constexpr int RS_OTAB = RS_RAW + 4 * 16384;       // [2 sets][2][128] output byt
 constexpr int RS_MTAB = RS_OTAB + 4 * RS_HG * 4;  // [2 sets][2][128] oscale for a position that exists, 0 otherwise
 constexpr int RS_SS = RS_MTAB + 4 * RS_HG * 4;    // [2][32] the sample's GroupNorm scale | shift (MODE 1)
 constexpr int RS_RED = RS_SS + 64 * 4;            // [8 waves][32 channels][2]
-constexpr int RS_LDS = RS_RED + 8 * 32 * 2 * 4;   // 152 576 B
+constexpr int RS_DOF = RS_RED + 8 * 32 * 2 * 4;   // [512 threads][4] MODE >= 2: byte offsets of the thread's four pixels in flight (thread-private:
+                                                  // parked here instead of in four registers across the compute role)
+constexpr int RS_LDS = RS_DOF + 512 * 16;         // 160 768 B
 
 // Workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load and store in flight (vmcnt(0)) — here
 // loads issued two half-steps ahead and the raw-output stores must stay in flight across it.
@@ -120,17 +126,21 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   // raw input by LDS-DMA: this wave's 4 KB of slot 0 / 1 of its set; a lane reads back the 16 bytes it asked for
   const unsigned rawbase = (unsigned)(RS_RAW + set * 32768 + sw * 4096);
 
+  // one descriptor per tensor for the whole launch; a pixel's offset carries its sample's base
+  const unsigned tbytes = (unsigned)p.B * (unsigned)(H * W * 128);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void *)(MODE == 2 ? p.res : p.x), 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxo = __builtin_amdgcn_make_buffer_rsrc((void *)(MODE >= 2 ? p.xout : p.y), 0, tbytes, 0x00020000);
+
   for (int item = (int)blockIdx.x; item < nitems; item += (int)gridDim.x) {
     const int n = item / nbands, band = item - n * nbands;
     const int rb = band * brows, re = min(H, rb + brows);
     const int O0 = (rb + 1) * P;                            // first output position: padded row rb + 1, padded column 0
     const int nout = (re - rb) * P;
     const int NH = (nout + RS_HG - 1) / RS_HG;              // output half-groups; input half-groups 1 .. NH + 2 are read
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (size_t)n * H * W * 32), 0, (unsigned)(H * W * 128), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (size_t)n * H * W * 32), 0, (unsigned)(H * W * 128), 0x00020000);
-    if (MODE == 1 && tid < 64) sstab[tid] = tid < 32 ? p.in_scale[(size_t)n * 32 + tid] : p.in_shift[(size_t)n * 32 + tid - 32];
+    const int nbase = n * H * W * 128;                      // the sample's plane inside the tensors (bytes; B H W 128 < 2^31: conv_rows32_plan)
+    if (MODE >= 1 && tid < 64) sstab[tid] = tid < 32 ? p.in_scale[(size_t)n * 32 + tid] : p.in_shift[(size_t)n * 32 + tid - 32];
     const int r_lo = max(rb - 1, 0), r_hi = min(re, H - 1);        // image rows the band reads (halo included)
     // input stream: half-group g starts at flat position O0 - 256 + 128 g.  This thread's first duty: g = 1 (set 0) or 2 (set 1).
     // Tracked for the thread's pixel k = 0: padded row / column and the byte offset of its channel quad in the sample's plane (valid
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       const int f = O0 - 2 * RS_HG + RS_HG * (1 + set) + jb + 256 * P;    // (+ 256 P keeps the dividend positive)
       iR = f / P - 256;
       iC = f - (iR + 256) * P;
-      iD = (((iR - 1) * W + iC - 1) * 32 + 4 * q) * 4;
+      iD = (((iR - 1) * W + iC - 1) * 32 + 4 * q) * 4 + nbase;
     }
     // output tables: thread stid < 128 of a set owns position stid of the set's half-groups (set 0: 0, 2, ..; set 1: 1, 3, ..)
     int oR = 0, oC = 0, oD = 0;
@@ -148,13 +158,16 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       const int f = O0 + RS_HG * set + stid;
       oR = f / P;
       oC = f - oR * P;
-      oD = ((oR - 1) * W + oC - 1) * 128;
+      oD = ((oR - 1) * W + oC - 1) * 128 + nbase;
     }
 
-    unsigned vok = 0, vokn = 0;                                    // bit k: pixel k of the duty being converted / of the loads in flight exists
+    unsigned vok = 0, vokn = 0;                                    // bit k: pixel k of the duty being converted / of the loads in flight exists;
+                                                                   // bit 4 + k (MODE >= 2): ... and lies in the band's own rows (this band writes it to xout)
+    u32x4 *const dofp = reinterpret_cast<u32x4 *>(lds + RS_DOF) + tid;   // MODE >= 2: the pixels' byte offsets in the tensors (bit 31: absent)
     auto issue = [&](int slot) {                                   // LDS-DMA of the thread's four pixels of its next input half-group; the tracker advances
       vokn = 0;
       unsigned off[4];
+      u32x4 dn = {0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int r32 = (32 * k) / P, c32 = 32 * k - r32 * P;      // (scalar)
@@ -163,9 +176,15 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool ok = (unsigned)(R - 1 - r_lo) <= (unsigned)(r_hi - r_lo) && (unsigned)(Cc - 1) < (unsigned)W;
         // (the instruction offset k * 1024 moves the LDS destination AND the memory address: pre-decremented; absent pixels: out of
         //  range -> zeros)
-        off[k] = (unsigned)(iD + (32 * k - 2 * (r32 + cw)) * 128 - 1024 * k) | (ok ? 0u : 0x80000000u);
+        const unsigned dense = (unsigned)(iD + (32 * k - 2 * (r32 + cw)) * 128), absent = ok ? 0u : 0x80000000u;
+        off[k] = (dense - 1024u * k) | absent;
         vokn |= ok ? (1u << k) : 0u;
+        if (MODE >= 2) {
+          dn[k] = dense | absent;
+          vokn |= (ok && (unsigned)(R - 1 - rb) < (unsigned)(re - rb)) ? (16u << k) : 0u;
+        }
       }
+      if (MODE >= 2) *dofp = dn;
       if (!(RS_DBG(p) & 1)) {
         const unsigned m0v = rawbase + (unsigned)slot * 16384u;
         asm volatile(
@@ -182,9 +201,18 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       iR += dR + wrap;
       iD += (2 * RS_HG - 2 * (dR + wrap)) * 128;                   // dense index = flat - 2 R - W - 1
     };
+    f32x4 w[4];                                                    // MODE 2: the skip branch's pixels of this duty (register loads at the top of the stage role,
+                                                                   // used at its end — the epilogue in between covers most of their latency; kept across the
+                                                                   // compute role instead they would cost 16 registers where the budget is tightest)
+    u32x4 dof = {0, 0, 0, 0};                                      // this duty's offsets (read back from the thread's LDS slot where they are needed)
+    auto load_skip = [&]() {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, dof[k], 0, 0));
+      asm volatile("" ::: "memory");
+    };
     auto convert_store = [&](int g, int slot) {                    // the landed pixels -> GroupNorm + ReLU -> float16 pieces -> ring slot of input half-group g
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (MODE == 1) {
+      if (MODE >= 1) {
         sc = *reinterpret_cast<const f32x4 *>(sstab + 4 * q_);
         sh = *reinterpret_cast<const f32x4 *>(sstab + 32 + 4 * q_);
       }
@@ -196,9 +224,19 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = vk[e];
-          if (MODE == 1) x = fmaxf(__builtin_fmaf(x, sc[e], sh[e]), 0.f) * vmk;     // zero padding AFTER GroupNorm + ReLU
+          // (zero padding AFTER the input transform; the float operations of conv_x3_kernel's stager / residual_kernel, in their order)
+          if (MODE == 1) x = fmaxf(__builtin_fmaf(x, sc[e], sh[e]), 0.f) * vmk;     // the producer's GroupNorm + ReLU
+          if (MODE == 2) x = fmaxf(__builtin_fmaf(x, sc[e], sh[e]) + w[k][e], 0.f) * vmk;   // block tail: relu(GN2(conv2) + skip), resnet.py:47-55
+          if (MODE == 3) {                                                          // pooled stem keys: decode, |scale|, shift, ReLU
+            int key = __builtin_bit_cast(int, x);
+            key = key >= 0 ? key : key ^ 0x7fffffff;
+            x = fmaxf(__builtin_fmaf(__builtin_bit_cast(float, key), __builtin_fabsf(sc[e]), sh[e]), 0.f) * vmk;
+          }
           f[e] = x;
         }
+        if (MODE >= 2 && !(RS_DBG(p) & 2))                         // the block output / pooled activations the next skip branch reads: own rows only
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]}), rxo,
+                                                 dof[k] | (((vok >> (4 + k)) & 1u) ? 0u : 0x80000000u), 0, 0);
         u32x2 hi, lo;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -257,6 +295,8 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             arow[kh] = (((base + (unsigned)((kh - 1) * P)) & (RS_RING - 1)) + (unsigned)(lane_ & 31)) * RS_PITCH + (unsigned)((lane_ >> 5) * 16);
           // two accumulators (even / odd steps): a chain of 54 MFMAs on ONE accumulator is paced by the MFMA's latency, not its
           // issue rate; summed once at the end (a fixed order: deterministic, float32-grade equal to conv_x3_kernel's single chain)
+          // (MODE 2 keeps the skip branch's sixteen registers across this role instead: one chain)
+          constexpr bool TWO_ACC = MODE != 2;
           f32x16 acc1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
@@ -270,15 +310,17 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
               an[0] = *reinterpret_cast<const u32x4 *>(lds + arow[nt / 3] + (nt % 3) * RS_PITCH + nk * 32);
               an[1] = *reinterpret_cast<const u32x4 *>(lds + arow[nt / 3] + (nt % 3) * RS_PITCH + nk * 32 + 64);
             }
-            f32x16 &c = (st & 1) ? acc1 : acc;
+            f32x16 &c = (TWO_ACC && (st & 1)) ? acc1 : acc;
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, bres[st][0]), c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, bres[st][1]), c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, bres[st][0]), c, 0, 0, 0);
             a[0] = an[0];
             a[1] = an[1];
           }
+          if (TWO_ACC) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+          }
         }
       } else {
         // ---- stage role.  Everything this wave has in flight — the DMA of this duty's pixels (issued at the top of its previous
@@ -293,6 +335,8 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         //  dozen registers that then spill, and a spill reload waits for everything this wave has in flight)
         asm volatile("" : "+v"(q_), "+v"(jb_), "+v"(lane_));
         vok = vokn;
+        if (MODE >= 2) dof = *dofp;                                // (before issue() parks the next duty's there)
+        if (MODE == 2) load_skip();
         if (h + 6 <= NH + 2) issue((duty + 1) & 1);                // the next duty's pixels: in flight for two half-steps
         // epilogue of the tile multiplied in half-step h - 1 ...
         if (h >= 1) {
@@ -314,6 +358,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         // ... then input half-group h + 4 into the ring, the tables of output half-group h + 1
         if (h + 4 <= NH + 2 && !(RS_DBG(p) & 8)) convert_store(h + 4, duty & 1);
+
         if (h + 1 >= 0 && h + 1 < NH) tables(h + 1);
         ++duty;
       }
@@ -367,8 +412,8 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // (a tile's taps reach P + 1 positions back and ahead: P + 1 <= 128), and enough bands to occupy the chip.
 bool conv_rows32_plan(ConvX3Args &a, int ks, int stride, int mode, int num_cus) {
   if (ks != 3 || stride != 1 || a.np != 2 || a.CIN != 32 || a.COUTP != 32 || a.in_absmax != nullptr) return false;
-  if (mode != 0 && mode != 1) return false;
-  if (a.Ho != a.H || a.Wo != a.W || a.W + 3 > RS_HG || a.W < 8 || a.H < 8 || (long)a.H * a.W * 128 >= (1L << 31)) return false;
+  if (mode < 0 || mode > 3 || (mode == 2 && a.res_scale != nullptr)) return false;      // (a downsample skip branch: 32 -> 32 stride-1 blocks have none)
+  if (a.Ho != a.H || a.Wo != a.W || a.W + 3 > RS_HG || a.W < 8 || a.H < 8 || (long)a.B * a.H * a.W * 128 >= (1L << 31)) return false;
   // bands: whole samples from one per CU on (one wave of items); below that 2 or 4 bands of >= 12 rows (a band re-reads two halo rows:
   // narrower ones measured slower than the tile kernels); fewer items than CUs: the tile kernels spread better
   int bands = 1;
@@ -388,6 +433,10 @@ hipError_t launch_conv_rows32(const ConvX3Args &a, int mode, int num_cus, hipStr
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rows32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     if (e != hipSuccess) return e;
   }
   const long items = (long)a.B * a.rs_bands;
@@ -405,6 +454,10 @@ hipError_t launch_conv_rows32(const ConvX3Args &a, int mode, int num_cus, hipStr
     hipLaunchKernelGGL((conv_rows32_kernel<0>), dim3(gx), dim3(RS_THREADS), RS_LDS, s, q);
   else if (mode == 1)
     hipLaunchKernelGGL((conv_rows32_kernel<1>), dim3(gx), dim3(RS_THREADS), RS_LDS, s, q);
+  else if (mode == 2)
+    hipLaunchKernelGGL((conv_rows32_kernel<2>), dim3(gx), dim3(RS_THREADS), RS_LDS, s, q);
+  else if (mode == 3)
+    hipLaunchKernelGGL((conv_rows32_kernel<3>), dim3(gx), dim3(RS_THREADS), RS_LDS, s, q);
   else
     return hipErrorInvalidValue;
 #if PNVO_ROWS_ABL
