@@ -585,7 +585,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     const int x3_mode = tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0);
     // 32 -> 32 channels (layer1): the row-streaming kernel (conv_rows.hip) where it takes the launch — fewer statistics slots than
     // the tile plan the buffer is sized for (stats_floats)
-    const bool rows = two && m->opt.x3_rows && m->train == nullptr && conv_rows32_plan(xa, l.k, l.stride, x3_mode, m->num_cus);
+    const bool rows = two && m->opt.x3_rows && conv_rows32_plan(xa, l.k, l.stride, x3_mode, m->num_cus);
     if (rows || conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
       if (two && (!lm.wpk_x2 || lm.x2_gen != m->weights_gen)) {  // (re)build the two-piece operand of this layer
