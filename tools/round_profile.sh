@@ -36,6 +36,11 @@ PNVO_STEM_FORM=tiles PNVO_STEM_DBG=9 python bench.py --steps 3 --warmup 1 --no-p
   FORM=fast bash tools/stem_rs_prof.sh
   echo "# -- stem_form=resident (the tile kernel's summation order: 240 / 240 / 240 / 260 MFMAs)"
   FORM=resident bash tools/stem_rs_prof.sh ) > $O/${tag}_stem_rs_phases.txt 2>&1
+# the row-streaming first-stage convs: role cycles per half-step + timing-only ablations (rebuilds conv_rows.o with the profiling code, restores)
+( echo "# conv_rows32_kernel at 256 pairs: cycles per half-step of the two roles (s_memtime; profiling build), then ablations (WRONG results, timing only):"
+  echo "# PNVO_ROWS_DBG bits: 1 no loads, 2 no stores, 4 no MFMAs, 8 no conversion; values = us per launch of the two GroupNorm-input convs"
+  bash tools/rows_prof.sh ) > $O/${tag}_rows_phases.txt 2>&1
+python tools/ab_option.py x3_rows off on > $O/${tag}_ab_x3_rows.txt 2>/dev/null
 python tools/ab_option.py stem_form tiles fast > $O/${tag}_ab_stem_form.txt 2>/dev/null
 python tools/ab_option.py stem_form tiles resident >> $O/${tag}_ab_stem_form.txt 2>/dev/null
 python tools/ab_option.py stem_form tiles persistent >> $O/${tag}_ab_stem_form.txt 2>/dev/null
