@@ -270,6 +270,25 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // un-scale + mask, raw output, partial sums of the tile of output half-group hg held in `acc`
+    constexpr bool EPI_IN_COMPUTE = MODE >= 2;
+    auto epilogue = [&](int hg) {
+      const int rr16 = lane_ >> 5;
+      const unsigned tb = (unsigned)(((hg >> 1) & 1) * RS_HG + 32 * sw + 4 * rr16);
+      const unsigned ch4 = (unsigned)((lane_ & 31) * 4);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const u32x4 ent = *reinterpret_cast<const u32x4 *>(otab + tb + 8 * g4);
+        const f32x4 msk = *reinterpret_cast<const f32x4 *>(mtab + tb + 8 * g4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc[4 * g4 + e] * msk[e];
+          if (!(RS_DBG(p) & 2)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ry, ent[e] + ch4, 0, 0);   // bit 31: out of range, dropped
+          t1 += x;
+          t2 = __builtin_fmaf(x, x, t2);
+        }
+      }
+    };
     __syncthreads();                                              // (the scale / shift table)
     issue(0);                                                     // the set's first input half-group (1 or 2): duty 0, raw slot 0
     int duty = 0;
@@ -321,6 +340,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
           }
+          if (EPI_IN_COMPUTE) epilogue(h);
         }
       } else {
         // ---- stage role.  Everything this wave has in flight — the DMA of this duty's pixels (issued at the top of its previous
@@ -338,24 +358,8 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (MODE >= 2) dof = *dofp;                                // (before issue() parks the next duty's there)
         if (MODE == 2) load_skip();
         if (h + 6 <= NH + 2) issue((duty + 1) & 1);                // the next duty's pixels: in flight for two half-steps
-        // epilogue of the tile multiplied in half-step h - 1 ...
-        if (h >= 1) {
-          const int rr16 = lane_ >> 5;
-          const unsigned tb = (unsigned)((((h - 1) >> 1) & 1) * RS_HG + 32 * sw + 4 * rr16);
-          const unsigned ch4 = (unsigned)((lane_ & 31) * 4);
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const u32x4 ent = *reinterpret_cast<const u32x4 *>(otab + tb + 8 * g4);
-            const f32x4 msk = *reinterpret_cast<const f32x4 *>(mtab + tb + 8 * g4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = acc[4 * g4 + e] * msk[e];
-              if (!(RS_DBG(p) & 2)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), ry, ent[e] + ch4, 0, 0);   // bit 31: out of range, dropped
-              t1 += x;
-              t2 = __builtin_fmaf(x, x, t2);
-            }
-          }
-        }
+        // epilogue of the tile multiplied in half-step h - 1 (modes 0 / 1; the fuller stage roles of modes 2 / 3 leave it to the compute role) ...
+        if (!EPI_IN_COMPUTE && h >= 1) epilogue(h - 1);
         // ... then input half-group h + 4 into the ring, the tables of output half-group h + 1
         if (h + 4 <= NH + 2 && !(RS_DBG(p) & 8)) convert_store(h + 4, duty & 1);
 
