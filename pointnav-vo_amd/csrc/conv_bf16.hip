@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         float *dst = p.stats[z] + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
         dst[0] = s1;
         dst[1] = s2;
+        if (p.gn_scale[z] != nullptr) {                                  // the sample's only slot: finalise here (no launch), as conv_x3_kernel
+          const int c = nt * 32 + lane;
+          gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma[z][c], p.gn_beta[z][c], p.gn_scale[z] + (long)n * p.COUTP + c,
+                           p.gn_shift[z] + (long)n * p.COUTP + c);
+        }
       }
     }
   }

@@ -280,6 +280,21 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       a.in_shift2[z] = mode == 2 && sk.affine ? bs[k]->ssD[1] : nullptr;
       a.xout[z] = mode == 2 && out_buf >= 0 ? bs[k]->bufY[out_buf] : nullptr;
     }
+    // one tile per sample (the 12 x 22 and 6 x 11 maps): the workgroup that sums a sample's channels finalises its GroupNorm too
+    // (gn_finalize_lane: fp64, the butterfly order of the float32 path's fused finalisation) — one launch less per layer
+    const int cpg = l.groups > 0 ? l.cout / l.groups : 0;
+    const bool gfuse = m->opt.gn_fuse && a.slots == 1 && l.cout == l.coutp && cpg >= 1 && cpg <= 32 && 32 % cpg == 0 && l.cout % cpg == 0;
+    auto ssof = [&](int z) { return ss_sel == 0 ? bs[z]->ssA : ss_sel == 1 ? bs[z]->ssB : ss_sel == 2 ? bs[z]->ssD : bs[z]->ssC; };
+    for (int z = 0; z < 2; ++z) {
+      const int k = z < nm ? z : 0;
+      a.gn_gamma[z] = gfuse ? hs[k]->convs[li].gamma : nullptr;
+      a.gn_beta[z] = gfuse ? hs[k]->convs[li].beta : nullptr;
+      a.gn_scale[z] = gfuse ? ssof(k)[0] : nullptr;
+      a.gn_shift[z] = gfuse ? ssof(k)[1] : nullptr;
+    }
+    a.gn_cpg = cpg;
+    a.gn_eps = 1e-5f;
+    a.gn_P = (long)l.hout * l.wout;
     const double macs = (double)B * l.hout * l.wout * l.cout * l.cin * l.k * l.kw;
     {
       PnvoTimed t(m, s, "bf16:conv:" + l.name, 2.0 * nm * macs,
@@ -287,8 +302,8 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       HIPCHK(m, launch_conv_bf16(a, l.k, l.stride, mode, f32out, bs[0]->layers[li].mw, bs[0]->layers[li].nw, bs[0]->layers[li].lds,
                                  nm, s));
     }
+    if (gfuse) return PNVO_OK;
     PnvoTimed t(m, s, "bf16:gn_finalize", 0.0, 0.0);
-    auto ssof = [&](int z) { return ss_sel == 0 ? bs[z]->ssA : ss_sel == 1 ? bs[z]->ssB : ss_sel == 2 ? bs[z]->ssD : bs[z]->ssC; };
     auto st = each([&](int z) { return (const float *)bs[z]->stats; });
     auto ga = each([&](int z) { return (const float *)hs[z]->convs[li].gamma; });
     auto be = each([&](int z) { return (const float *)hs[z]->convs[li].beta; });

@@ -217,6 +217,12 @@ struct ConvBArgs {
   int B, H, W, CIN, Ho, Wo, COUTP;
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_bf16_plan
   int persist_wgs;                   // > 0: 32-input-channel layers run persistent with resident weights on this many workgroups
+  // GroupNorm finalisation inside the conv (slots == 1, as ConvX3Args): scale / shift [B,COUTP] per model; nullptr: the separate launch
+  const float *gn_gamma[2], *gn_beta[2];
+  float *gn_scale[2], *gn_shift[2];
+  int gn_cpg;
+  float gn_eps;
+  long gn_P;
 };
 bool conv_bf16_plan(ConvBArgs &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bool f32out, int mw, int nw, size_t lds_bytes,
