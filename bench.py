@@ -375,6 +375,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="--config train: ONE flat gradient all-reduce after the backward instead of buckets behind it (A/B)")
     ap.add_argument("--no-preheat", action="store_true")
+    ap.add_argument("--secondary-deadline", type=float, default=240.0,
+                    help="N > 1: seconds the side measurements (dual_bf16, train with its all-reduce, ...) may take before every rank gives up "
+                         "on them and rank 0 prints the headline-only line")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = a free one)")
     args = ap.parse_args()
 
@@ -448,6 +451,81 @@ def main():
     multi = None
     if world > 1:
         multi = multi_gpu_report(model, out, dt_local, args.steps, B, rank, world, dist, dev, args.backend)
+
+    res = None
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt
+        flops_pair = 2.0 * ms.macs_per_pair(model.cfg)
+        bytes_pair = float(ms.streaming_bytes_per_pair(model.cfg))
+        dom = max((k for k in kt if k["name"].startswith("conv:")), key=lambda k: k["total_ms"])
+        per_launch_ms = dom["total_ms"] / dom["launches"]
+        alg = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12      # algorithmic FLOPs of the layer
+        total_kernel_ms = sum(k["total_ms"] for k in kt)
+        is_stem = dom["name"].endswith("conv1.0")
+        if is_stem:
+            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"), model.get_option("pieces"), model.get_option("stem_form"))
+        else:
+            fam, ex = model.layer_kernel(dom["name"][len("conv:"):], B)
+            if fam in ("x3", "x2"):                  # six bf16 / three float16 MFMA terms per float32 product, tile padding included
+                ach, peak = ex / (per_launch_ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS
+                pipe = ("bf16 MFMA (three-piece operands, six terms per product)" if fam == "x3" else
+                        "float16 MFMA (two-piece operands, three terms per product)")
+            else:                                    # the fp32-MFMA kernels execute the algorithmic FLOPs
+                ach, peak, pipe = alg, PEAK_FP32_TFLOPS, "fp32 MFMA"
+        traffic, traffic_note = measured_traffic("fwd_fp32", dom["name"], B)
+        res = {
+            "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "float32 storage, accumulation and results; what the multipliers see is stated under `arithmetic`",
+            "config": {"workload": "BASELINE configs[1]: act_forward VO inference (vo_cnn_rgb_d_dd_top_down, 30 input "
+                                   "channels), 341x192, fp32, seeded random weights", "pairs_per_gpu": B,
+                       "global_batch": world * B, "parallelism": f"dp{world} (independent pairs, no collective)"},
+            "ms_per_step_events": per_step,
+            "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
+            "kernel_ms_per_step": total_kernel_ms / args.steps,
+            "pose_rel_err_vs_fp64_oracle": rel, "oracle_checked_pairs": chk,
+            "arithmetic": arithmetic_text(model),
+            **{k: v for k, v in fast_form_layers(model, B).items() if k != "stem"},
+            "model_tflops": value * flops_pair / 1e12,
+            "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
+            "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
+            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s",
+                         "frac": alg / peak, "pipe": pipe,
+                         "definition": "SURVEY 8(d): ALGORITHMIC FLOPs of the layer per launch (2 x MACs of the 30-channel fp32 conv x pairs) "
+                                       "/ HIP-event launch duration / dense peak of the pipe the kernel runs on",
+                         "executed_tflops": ach, "executed_frac": ach / peak,
+                         "executed_note": "matrix-core FLOPs the kernel issues (operand splitting: 2-3 MFMA terms per float32 product, "
+                                          "K and tile padding) / the same duration / the same peak",
+                         "frac_of_fp32_pipe_peak": alg / PEAK_FP32_TFLOPS,
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
+            "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
+                                "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
+                                "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
+                               for k in kt), key=lambda k: -k["ms_per_step"])[:40],
+        }
+        res["rccl_ranks"] = process_group_record(dist, world)
+        res["rccl_ranks"] = process_group_record(dist, world)
+        if multi is not None:
+            res["multi_gpu"] = multi
+
+    # N > 1: the side measurements below walk collectives that no run has ever executed on RCCL hardware.  A rank that hangs in one of
+    # them must not cost the scaling run its headline: after `--secondary-deadline` seconds every rank leaves on its own, rank 0 with
+    # the headline-only line (marked).  N = 1 has no collectives and no deadline.
+    import threading
+    watchdog = None
+    if world > 1 and not args.no_secondary:
+        def bail():
+            if rank == 0:
+                res["secondary"] = {"error": f"side measurements did not finish within {args.secondary_deadline:.0f} s at {world} ranks "
+                                             "(a collective did not return); headline only"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.secondary_deadline, bail)
+        watchdog.daemon = True
+        watchdog.start()
 
     # ---- BASELINE configs[2] and configs[3] (per-GPU shape) next to the headline: 10 timed steps each under the same contract
     #      (tools/bench_configs.py), on the headline's own observation tensors; AFTER the headline's timed region, never in it
@@ -524,62 +602,9 @@ def main():
         except Exception as e:
             navloop = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        pairs = world * B * args.steps
-        value = pairs / dt
-        flops_pair = 2.0 * ms.macs_per_pair(model.cfg)
-        bytes_pair = float(ms.streaming_bytes_per_pair(model.cfg))
-        dom = max((k for k in kt if k["name"].startswith("conv:")), key=lambda k: k["total_ms"])
-        per_launch_ms = dom["total_ms"] / dom["launches"]
-        alg = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12      # algorithmic FLOPs of the layer
-        total_kernel_ms = sum(k["total_ms"] for k in kt)
-        is_stem = dom["name"].endswith("conv1.0")
-        if is_stem:
-            ach, peak, pipe = stem_executed(dom, B, per_launch_ms, model.get_option("stem"), model.get_option("pieces"), model.get_option("stem_form"))
-        else:
-            fam, ex = model.layer_kernel(dom["name"][len("conv:"):], B)
-            if fam in ("x3", "x2"):                  # six bf16 / three float16 MFMA terms per float32 product, tile padding included
-                ach, peak = ex / (per_launch_ms * 1e-3) / 1e12, PEAK_BF16_TFLOPS
-                pipe = ("bf16 MFMA (three-piece operands, six terms per product)" if fam == "x3" else
-                        "float16 MFMA (two-piece operands, three terms per product)")
-            else:                                    # the fp32-MFMA kernels execute the algorithmic FLOPs
-                ach, peak, pipe = alg, PEAK_FP32_TFLOPS, "fp32 MFMA"
-        traffic, traffic_note = measured_traffic("fwd_fp32", dom["name"], B)
-        res = {
-            "metric": "RGB-D frame-pair VO inferences/s @341x192", "value": value, "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "float32 storage, accumulation and results; what the multipliers see is stated under `arithmetic`",
-            "config": {"workload": "BASELINE configs[1]: act_forward VO inference (vo_cnn_rgb_d_dd_top_down, 30 input "
-                                   "channels), 341x192, fp32, seeded random weights", "pairs_per_gpu": B,
-                       "global_batch": world * B, "parallelism": f"dp{world} (independent pairs, no collective)"},
-            "ms_per_step_events": per_step,
-            "preheat_s": pre[0], "preheat_steps": pre[1], "preheat_converged": pre[2],
-            "kernel_ms_per_step": total_kernel_ms / args.steps,
-            "pose_rel_err_vs_fp64_oracle": rel, "oracle_checked_pairs": chk,
-            "arithmetic": arithmetic_text(model),
-            **{k: v for k, v in fast_form_layers(model, B).items() if k != "stem"},
-            "model_tflops": value * flops_pair / 1e12,
-            "frac_fp32_peak_whole_path_algorithmic": value * flops_pair / 1e12 / (PEAK_FP32_TFLOPS * world),
-            "frac_hbm_streaming_model": value * bytes_pair / 1e9 / (PEAK_HBM_GBS * world),
-            "roofline": {"kernel": dom["name"], "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s",
-                         "frac": alg / peak, "pipe": pipe,
-                         "definition": "SURVEY 8(d): ALGORITHMIC FLOPs of the layer per launch (2 x MACs of the 30-channel fp32 conv x pairs) "
-                                       "/ HIP-event launch duration / dense peak of the pipe the kernel runs on",
-                         "executed_tflops": ach, "executed_frac": ach / peak,
-                         "executed_note": "matrix-core FLOPs the kernel issues (operand splitting: 2-3 MFMA terms per float32 product, "
-                                          "K and tile padding) / the same duration / the same peak",
-                         "frac_of_fp32_pipe_peak": alg / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "traffic_note": traffic_note,
-                         "launch_ms": per_launch_ms, "share_of_kernel_time": dom["total_ms"] / total_kernel_ms},
-            "kernels": sorted(({"name": k["name"], "ms_per_step": k["total_ms"] / args.steps,
-                                "tflops": (k["flops"] / (k["total_ms"] * 1e-3) / 1e12) if k["flops"] else None,
-                                "gbs": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["bytes"] else None}
-                               for k in kt), key=lambda k: -k["ms_per_step"])[:40],
-        }
-        res["rccl_ranks"] = process_group_record(dist, world)
-        if multi is not None:
-            res["multi_gpu"] = multi
         if secondary is not None:
             res["secondary"] = secondary
         if raw_rec is not None:

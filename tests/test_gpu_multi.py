@@ -103,6 +103,26 @@ def test_bench_plain_invocation_self_launches_two_ranks_on_the_real_kernels():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["executed_frac"] >= rf["frac"]
 
 
+def test_bench_headline_survives_side_measurements_that_do_not_return():
+    """N > 1: the side measurements walk collectives (the training step's all-reduce ...).  If one of them never returns, every rank
+    leaves after --secondary-deadline and rank 0 still prints the ONE JSON line — the headline, with the side measurements marked as
+    not finished.  Forced here with a deadline no side measurement can meet."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--backend", "gloo", "--shared-gpu", "--no-cpu-baseline", "--batch", "128",
+                        "--secondary-deadline", "0.05"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["multi_gpu"]["shards_equal_single_gpu"] is True
+    assert "did not finish" in rec["secondary"]["error"]
+
+
 @pytest.mark.parametrize("config", ["fwd_fp32", "train"])
 def test_bench_two_ranks_sharing_one_gpu(config):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run), both ranks on cuda:0 over gloo: the real timed

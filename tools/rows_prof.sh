@@ -5,7 +5,7 @@ cp libpnvo.so /tmp/libpnvo.keep
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DPNVO_ROWS_ABL=1 -c conv_rows.hip -o conv_rows.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o libpnvo.so
 cd ../..
-PNVO_ROWS_PROF=1 python - <<'PY' 2>&1 | grep "conv_rows32" | tail -6
+PNVO_ROWS_PROF=1 python - <<'PY' 2>&1 | grep "conv_rows32" | tail -12
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch, bench
