@@ -1140,7 +1140,7 @@ const char *pnvo_version(void) { return "pnvo 0.2 (gfx950: fp32 + bf16 MFMA)"; }
 const char *pnvo_last_error(pnvo_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
 const char *pnvo_last_note(pnvo_handle h) {
-  if (h && h->loaded && h->opt.input_fallback) (void)pnvo_check_inputs(h);     // a raised input-contract flag (host-mapped, no wait) is noted here at the latest
+  if (h && h->loaded && h->opt.input_fallback && stem_lds_serves(h)) (void)pnvo_check_inputs(h);     // a raised input-contract flag (host-mapped, no wait) is noted here at the latest
   return h ? h->note.c_str() : "";
 }
 
@@ -1471,7 +1471,7 @@ int pnvo_get_option(pnvo_handle h, const char *key, char *buf, size_t cap) {
       word = c->word;
       break;
     }
-  if (d->field == &PnvoOptions::stem && h->loaded && h->opt.input_fallback) (void)pnvo_check_inputs(h);   // see pnvo_last_note
+  if (d->field == &PnvoOptions::stem && h->loaded && h->opt.input_fallback && stem_lds_serves(h)) (void)pnvo_check_inputs(h);   // see pnvo_last_note
   if (d->field == &PnvoOptions::stem && h->dense_sticky) word = "dense (fallback)";
   std::snprintf(buf, cap, "%s", word.c_str());
   return PNVO_OK;
