@@ -37,14 +37,18 @@ ORACLE_PAIRS = (0, 1, 63, 127, 128, 190, 254, 255)   # pairs of the headline bat
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/round_profile.sh (PMC passes)
 
 
+# the sources that define the kernels whose HBM traffic is recorded (both records are stem launches): a record measured on other
+# versions of THESE files is reported as stale; edits elsewhere (host API, other kernels) do not touch what was measured
+TRAFFIC_SOURCES = ("stem_rs.hip", "stem_mx.hip", "stem_tile.h", "pnvo_internal.h")
+
+
 def source_hash():
-    """sha256[:12] over the kernel sources: a traffic record measured on other kernels is reported as stale."""
+    """sha256[:12] over the sources of the recorded kernels (TRAFFIC_SOURCES)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pointnav-vo_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in TRAFFIC_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:12]
 
 
