@@ -356,6 +356,7 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   HIPCHK(m, alloc(m->hid, (size_t)B * c.hidden));
   HIPCHK(m, alloc(m->out_ws, (size_t)B * c.out_dim));
   HIPCHK(m, alloc(m->stats, st));
+  m->stats_floats = st;
   for (int k = 0; k < 2; ++k) {
     HIPCHK(m, alloc(m->ssA[k], (size_t)B * maxc));
     HIPCHK(m, alloc(m->ssB[k], (size_t)B * maxc));
@@ -1046,6 +1047,7 @@ const OptDef kOptions[] = {
     {"train_pieces", "PNVO_TRAIN_PIECES", &PnvoOptions::train_pieces, false, {{"2", 2}, {"3", 3}, {nullptr, 0}}},
     {"x3_persist", "PNVO_X3_PERSIST", &PnvoOptions::x3_persist, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_rows", "PNVO_X3_ROWS", &PnvoOptions::x3_rows, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"ds_side", "PNVO_DS_SIDE", &PnvoOptions::ds_side, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1629,6 +1631,24 @@ int forward_dispatch(pnvo_handle m, const float *rgb, const float *depth, const 
 }  // namespace
 
 namespace {
+// Side stream, its two events and a statistics buffer of the main one's size (lazily; nothing while `s` is being captured: a graph
+// keeps the in-stream order).
+bool side_stream_ready(pnvo_handle m, hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  if (!m->side_stream && hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess) return false;
+  if (!m->side_fork && hipEventCreateWithFlags(&m->side_fork, hipEventDisableTiming) != hipSuccess) return false;
+  if (!m->side_join && hipEventCreateWithFlags(&m->side_join, hipEventDisableTiming) != hipSuccess) return false;
+  if (m->stats_side_floats < m->stats_floats) {
+    if (m->stats_side) (void)hipFree(m->stats_side);
+    m->stats_side = nullptr;
+    m->stats_side_floats = 0;
+    if (hipMalloc((void **)&m->stats_side, m->stats_floats * sizeof(float)) != hipSuccess) return false;
+    m->stats_side_floats = m->stats_floats;
+  }
+  return true;
+}
+
 int forward_body(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
                  const int64_t *actions, int B, float *out, hipStream_t s) {
   const pnvo_config &c = m->cfg;
@@ -1745,7 +1765,25 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
         return rc;
       }
       const long P = (long)c2.hout * c2.wout;
-      if (!layer_on_lds(m, c2, nullptr) && !pnvo_conv_on_x3(m, c2, B) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20)) {
+      const bool c2_small_generic = !layer_on_lds(m, c2, nullptr) && !pnvo_conv_on_x3(m, c2, B) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20);
+      // The block's 1x1 stride-2 downsample conv reads only the block input (written by the first conv's stager) and owns rawD / ssD:
+      // it and its GroupNorm finalisation run on a side stream NEXT TO the second 3x3 conv instead of behind it (option ds_side) —
+      // forked here, joined where the downsample used to be launched.  Its GroupNorm partials go to a buffer of their own.
+      bool ds_forked = false;
+      // (measured: 256 pairs 2.331 -> 2.305 ms; 64 pairs no change; 16 pairs +0.05 ms — the fork / join events cost what the small
+      //  launches save, so only from 128 pairs on)
+      if (ds && m->opt.ds_side && B >= 128 && !c2_small_generic && !m->timing && m->tap_dst == nullptr && m->train == nullptr && side_stream_ready(m, s)) {
+        const Layer &cd = m->convs[li + 0];
+        HIPCHK(m, hipEventRecord(m->side_fork, s));
+        HIPCHK(m, hipStreamWaitEvent(m->side_stream, m->side_fork, 0));
+        std::swap(m->stats, m->stats_side);
+        rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, m->side_stream);
+        std::swap(m->stats, m->stats_side);
+        if (rc != PNVO_OK) return rc;
+        HIPCHK(m, hipEventRecord(m->side_join, m->side_stream));
+        ds_forked = true;
+      }
+      if (c2_small_generic) {
         // small deep stage on the generic kernel: its per-tap GroupNorm+ReLU prologue costs more than one streaming
         // pass over the (L2-sized) tensor, so normalise once and run the conv on final activations
         {
@@ -1760,8 +1798,11 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       }
       if (ds) {
         const Layer &cd = m->convs[li++];
-        if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK)
+        if (ds_forked) {
+          HIPCHK(m, hipStreamWaitEvent(s, m->side_join, 0));           // rawD / ssD are complete before the block tail's consumer
+        } else if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK) {
           return rc;
+        }
       }
       const bool last = stage == 4 && bi + 1 == m->nblocks[3];
       if (!last && pnvo_conv_takes_tail(m, m->convs[li], B)) {   // relu(GN2(conv2) + skip): computed by the next block's first conv
@@ -2133,6 +2174,10 @@ int pnvo_destroy(pnvo_handle m) {
   free_workspace(m);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   if (m->stem_ev) (void)hipEventDestroy(m->stem_ev);
+  if (m->side_fork) (void)hipEventDestroy(m->side_fork);
+  if (m->side_join) (void)hipEventDestroy(m->side_join);
+  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  if (m->stats_side) (void)hipFree(m->stats_side);
   for (Layer &l : m->convs) {
     free_dev(l.wpk);
     free_dev(reinterpret_cast<float *&>(l.wpk_x3));

@@ -38,6 +38,9 @@ struct PnvoOptions {
   int pieces = 2;      // operand pieces of conv_x3 at inference: 2 float16 (three product terms) or 3 bf16 (six exact terms)
   int train_pieces = 2;  // the same choice for the TRAINING forward's convs (their backward-data convs keep three bf16 pieces:
                          //   gradients do not fit float16's range)
+  int ds_side = 0;     // (opt-in) the 1x1 stride-2 downsample conv of a block (+ its GroupNorm finalisation) on a side stream next to the block's
+                       // second 3x3 conv: -1 % at 256 pairs on a GPU of its own, but 10x slower when two processes share a GPU (the fork / join
+                       // events across time-sliced queues) — off by default
   int x3_rows = 1;     // 32 -> 32 channel 3x3 stride-1 convs on the row-streaming kernel (conv_rows.hip) where it takes the launch
   int x3_persist = 1;  // shallow-stage 3x3 convs on the persistent form of conv_x3 (next tile's patch fetched during the K loop)
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
@@ -118,6 +121,10 @@ struct pnvo_model_s {
   PnvoOptions opt;
   bool dense_sticky = false;                 // an input outside the mx/dd stems' contract was met: this handle stays on the dense stem
   int fallback_count = 0;                    // forwards re-run on the dense stem
+  hipStream_t side_stream = nullptr;         // option ds_side: forked behind a block's first conv, joined before the block tail's consumer
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  float *stats_side = nullptr;               // the side stream's GroupNorm partials (the main stream's conv writes m->stats meanwhile)
+  size_t stats_side_floats = 0, stats_floats = 0;
   hipEvent_t stem_ev = nullptr;              // recorded behind a contract-checking stem launch (pnvo_mark_stem)
   bool stem_ev_pending = false;
   // pnvo_forward_raw / pnvo_forward_dual_raw: sensor frames of the call in flight (the stem's RAW stager reads them)
