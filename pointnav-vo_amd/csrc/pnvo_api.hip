@@ -586,6 +586,13 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     const int x3_mode = tail ? (tail->res ? 2 : 3) : (in_scale ? 1 : 0);
     // 32 -> 32 channels (layer1): the row-streaming kernel (conv_rows.hip) where it takes the launch — fewer statistics slots than
     // the tile plan the buffer is sized for (stats_floats)
+    // (the plan refuses a block tail whose skip branch carries its own GroupNorm — a downsample skip, reachable with baseplanes 16:
+    //  the rows kernel adds the raw skip tensor — so the tail's fields are in place BEFORE the plan looks at them)
+    if (tail != nullptr) {
+      xa.res = tail->res;
+      xa.res_scale = tail->res_scale;
+      xa.res_shift = tail->res_shift;
+    }
     const bool rows = two && m->opt.x3_rows && conv_rows32_plan(xa, l.k, l.stride, x3_mode, m->num_cus);
     if (rows || conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
@@ -1137,7 +1144,11 @@ int forward_dispatch(pnvo_handle m, const float *rgb, const float *depth, const 
 // ==================================================================================================================
 extern "C" {
 
-const char *pnvo_version(void) { return "pnvo 0.2 (gfx950: fp32 + bf16 MFMA)"; }
+// "pnvo 0.3 (gfx950) src:<sha256[:16] of the tracked sources this library was built from>": the Makefile writes src_hash.h from
+// csrc/*.hip, csrc/*.h and include/pnvo.h (sorted by name), tests/test_abi.py recomputes it — a loaded .so that does not match the
+// tree it sits in is caught by the round-end GPU test, not by a reader of the numbers.
+#include "src_hash.h"
+const char *pnvo_version(void) { return "pnvo 0.3 (gfx950: fp32 + f16/bf16 MFMA) src:" PNVO_SRC_HASH; }
 
 const char *pnvo_last_error(pnvo_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -1512,6 +1523,9 @@ int pnvo_forward_dual(pnvo_handle ha, pnvo_handle hb, const float *rgb, const fl
 int pnvo_check_inputs(pnvo_handle m) {
   if (!m) return fail(m, PNVO_ERR_ARG, "null handle");
   if (m->dd_flag && *(volatile int *)m->dd_flag != 0) {
+    // already repaired: the handle runs the float32 stand-in since an earlier check; the flag only stays up for forwards still in
+    // flight (turning input_fallback off afterwards must not turn every later forward into an error)
+    if (m->dense_sticky) return PNVO_OK;
     if (m->opt.input_fallback && !m->in_train_forward && stem_lds_serves(m)) {
       // The flag is host-mapped: read without waiting for anything.  The forward that raised it repaired itself on the device
       // (pnvo_stem_standin behind its stem); from here on this handle launches the float32 stand-in directly.  The flag stays up
@@ -1528,7 +1542,8 @@ int pnvo_check_inputs(pnvo_handle m) {
     return fail(m, PNVO_ERR_INPUT,
                 "an earlier forward met observation values outside the reference's contract — a discretised-depth pixel "
                 "that is not one-hot (base_trainer_with_vo.py:163) or an rgb value that is not an integer 0..255 — so its "
-                "outputs are invalid (this handle runs with input_fallback=off).  Feed "
+                "outputs are invalid (this handle runs with input_fallback=off, is inside a training forward, or its model is one the "
+                "float32 stand-in stem does not serve — e.g. a forward that was stream-captured on such a model).  Feed "
                 "contract inputs, keep option input_fallback on, or select the dense stem: pnvo_set_option(h, \"stem\", \"dense\")");
   }
   return PNVO_OK;

@@ -895,14 +895,23 @@ int pnvo_train_refresh(pnvo_handle m, void *stream) {
       for (int i = 0; i < 3 * t->gnb_n; ++i) t->gnb_host[i] = -1.f;
       for (hipEvent_t &e : t->gnb_ev) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const int e = (int)(t->gnb_refreshes % 3);
-    hipLaunchKernelGGL(gn_bound_kernel, dim3((unsigned)t->gnb_n), dim3(64), 0, (hipStream_t)stream, t->params, t->gnb_seg,
-                       t->gnb_host + (size_t)e * t->gnb_n);
-    HIPCHK(m, hipGetLastError());
+    // A refresh that is being CAPTURED would bake one ring entry into the graph: every replay rewrites that entry while the host reads
+    // another one behind an event that is never recorded.  So a captured refresh leaves the ring alone and marks every entry unknown
+    // (-1) and restarts the two-refresh lag: chain_tracked_bounds then leaves Layer::in_bound as last chained (the load-time bounds
+    // when nothing was chained yet) instead of reading an entry that no event orders.
     hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing((hipStream_t)stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusNone)
+    const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
+    if (capturing) {
+      for (int i = 0; i < 3 * t->gnb_n; ++i) t->gnb_host[i] = -1.f;
+      t->gnb_refreshes = 0;
+    } else {
+      const int e = (int)(t->gnb_refreshes % 3);
+      hipLaunchKernelGGL(gn_bound_kernel, dim3((unsigned)t->gnb_n), dim3(64), 0, (hipStream_t)stream, t->params, t->gnb_seg,
+                         t->gnb_host + (size_t)e * t->gnb_n);
+      HIPCHK(m, hipGetLastError());
       HIPCHK(m, hipEventRecord(t->gnb_ev[e], (hipStream_t)stream));
-    t->gnb_refreshes += 1;
+      t->gnb_refreshes += 1;
+    }
   }
   if (m->cfg.act_embed) {      // eval-mode bias rows bias[a][o] = b1[o] + W1[o][flat:] . emb[a]  (pnvo_load_weights does this on the host)
     const pnvo_config &c = m->cfg;

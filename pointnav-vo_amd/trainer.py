@@ -283,13 +283,19 @@ class BaseRLTrainerWithVO:
     def _frame_fingerprint(depth, rgb):
         """A strided sample of a frame's bytes (~0.3 KB): what the ring compares on an identity hit, so that an observation buffer
         REFILLED IN PLACE (shared-memory vector environments, preallocated buffers, np.copyto) is recognised as a new frame — a
-        new observation differs in nearly every sampled pixel — and uploaded, instead of being served from the ring."""
-        # (~64 samples per tensor: two strided views + two tobytes, ~1 us per frame; a fresh observation differs in nearly all of them)
-        d = depth.ravel() if type(depth) is np.ndarray else np.asarray(depth).ravel()
+        new observation differs in nearly every sampled pixel — and uploaded, instead of being served from the ring.
+        LIMIT (documented contract): only WHOLE-FRAME refills are detected.  An in-place edit that misses all ~61 / ~67
+        sampled positions (a small moving region, a patch painted into the frame) is served stale; callers that edit recorded frames
+        partially must pass fresh arrays or call reset_frame_ring(env_ids)."""
+        # (~64 samples per tensor through the flat iterator: a view for contiguous frames, and for a non-contiguous one it gathers
+        #  only the sampled elements — ravel() would copy the whole frame on every call)
+        d = depth if type(depth) is np.ndarray else np.asarray(depth)
+        fd = d.reshape(-1)[:: max(1, d.size // 61)] if d.flags.c_contiguous else d.flat[:: max(1, d.size // 61)]
         if rgb is None:
-            return d[:: max(1, d.size // 61)].tobytes()
-        r = rgb.ravel() if type(rgb) is np.ndarray else np.asarray(rgb).ravel()
-        return (d[:: max(1, d.size // 61)].tobytes(), r[:: max(1, r.size // 67)].tobytes())
+            return fd.tobytes()
+        r = rgb if type(rgb) is np.ndarray else np.asarray(rgb)
+        fr = r.reshape(-1)[:: max(1, r.size // 67)] if r.flags.c_contiguous else r.flat[:: max(1, r.size // 67)]
+        return (fd.tobytes(), fr.tobytes())
 
     def _ring_buffers(self, slots, m, H, W, want_rgb, want_tdv):
         """Device ring (one slot per environment: its last cur frame + top-down view) and the upload staging of m frames."""

@@ -48,3 +48,27 @@ def test_bad_arguments_return_error_codes():
     assert _lib.lib.pnvo_forward(None, None, None, None, None, None, 1, None, None) == -1
     assert _lib.lib.pnvo_destroy(None) == 0
     assert _lib.version().startswith("pnvo")
+
+
+def test_loaded_library_was_built_from_this_tree():
+    """pnvo_version() carries sha256[:16] of the sources the library was built from (csrc/Makefile: src_hash.h); recomputed here
+    over the same files in the same order — on the GPU box this proves the .so the tests load is the one HEAD's sources build."""
+    import glob
+    import hashlib
+    csrc = os.path.dirname(_lib.LIB_PATH)
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))
+                   if os.path.basename(f) != "src_hash.h")
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(csrc, "..", "..", "include", "pnvo.h"), "rb").read())
+    assert _lib.version().endswith("src:" + h.hexdigest()[:16]), (_lib.version(), h.hexdigest()[:16])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpu_box_loads_the_library_of_this_tree():
+    """The same check inside the `-m gpu` run: the round-end GPU record then proves which sources the loaded libpnvo.so came from."""
+    test_loaded_library_was_built_from_this_tree()

@@ -149,3 +149,15 @@ def test_bench_two_ranks_sharing_one_gpu(config):
         assert mg["ms_per_step_bucketed"] > 0 and mg["ms_per_step_flat"] > 0 and mg["allreduce_alone_ms"] > 0
         assert mg["allreduce_bytes"] == 4 * 3962305
 
+
+
+def test_more_ranks_than_gpus_is_a_one_line_diagnostic():
+    """`bench.py --gpus N` on a node with fewer than N GPUs (the first real multi-GPU run may land on one): exit code 2 and ONE line
+    on stderr — no launcher, no rank tracebacks, no JSON line that could be mistaken for a measurement."""
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    lines = [ln for ln in r.stderr.splitlines() if ln.strip() and "amdgpu.ids" not in ln]
+    assert len(lines) == 1 and f"--gpus {n}" in lines[0] and "GPU(s)" in lines[0], r.stderr[-800:]
+    assert r.stdout.strip() == ""

@@ -124,10 +124,12 @@ def test_full_batch_256_properties():
 
 
 def test_three_stems_agree():
-    """The default model's stem runs on the bf16 matrix cores with the float32 weights split into three exact bf16
-    pieces (stem_mx.hip, the default); option stem=dd selects the one-hot table-gather stem (stem_dd.hip), stem=dense
-    the all-fp32-MFMA stem (stem_lds.hip).  All three compute the same products exactly; they must agree to float32
-    summation-order noise at every output pixel, borders (zero padding after whitening) included, and match the reference."""
+    """The default model's stem (option stem=auto) runs on the float16 matrix cores: raw inputs exact in float16, the folded
+    float32 weight split into TWO float16 pieces (22-bit operands, pieces=2) — stem_mx_kernel at this batch of 2 pairs, the
+    resident-weight stem_rs_kernel from 8 pairs on (tests/test_gpu_knobs.py compares those two bit for bit).  Option stem=dd selects
+    the one-hot table-gather stem (stem_dd.hip), stem=dense the all-fp32-MFMA stem (stem_lds.hip), both exact float32 products.  The
+    three must agree to float32-grade noise (2e-6 of the output range) at every output pixel, borders (zero padding after
+    whitening) included, and match the reference."""
     rec = load_golden("model_default_341x192_b2.npz")
     model, cfg, sd, obs, tobs, _, _ = build(rec)
     with torch.no_grad():

@@ -12,7 +12,7 @@ for cfg in fwd_fp32 dual_bf16; do
     rocprofv3 --kernel-trace --pmc $set -d $O/${tag}_pmc_${cfg}_$n -o p -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-preheat --no-secondary > $O/${tag}_pmc_${cfg}_$n.log 2>&1
     python tools/rocprof_summary.py $O/${tag}_pmc_${cfg}_$n/p_results.db --pmc 2>&1 | awk '/## counters/{f=1} f' > $O/${tag}_pmc_${cfg}_$n.md
   done
-  python tools/make_traffic.py $cfg 256 $O/${tag}_pmc_${cfg}_FETCH_SIZE/p_results.db $O/${tag}_pmc_${cfg}_WRITE_SIZE/p_results.db $O/${tag}_traffic.json
+  python tools/make_traffic.py $cfg 256 $O/${tag}_pmc_${cfg}_FETCH_SIZE/p_results.db $O/${tag}_pmc_${cfg}_WRITE_SIZE/p_results.db $O/${tag}_traffic.json $O/${tag}_kernel_trace_$cfg.md
   cat $O/${tag}_pmc_${cfg}_*.md > $O/${tag}_pmc_$cfg.md
   python tools/mfma_util.py $O/${tag}_kernel_trace_$cfg.md $O/${tag}_pmc_$cfg.md > $O/${tag}_mfma_util_$cfg.md
   rm -rf $O/${tag}_pmc_${cfg}_* $O/${tag}_trace_$cfg
