@@ -61,10 +61,22 @@ __device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(fl
 // it exactly in the epilogue) so that their second piece stays in float16's normal range.
 // Waves per SIMD: the two-plane patch of the small wave tiles (32- / 64-channel stages) is <= 54 KB, so three workgroups fit a
 // CU; their accumulators are few, so 168 registers do.
-constexpr int x3_wpe(int mw, int nw, int np) { return (np == 2 && mw * nw <= 2) ? 3 : 2; }
+// (DSF — the downsample conv riding on a stride-2 launch — doubles the accumulators: (2,1) tiles drop to two waves per SIMD, the
+//  96 + 96-accumulator (3,2) tile to one: its launches are one workgroup per CU anyway, the 6 x 11 maps)
+constexpr int x3_wpe(int mw, int nw, int np, bool dsf = false) {
+  return dsf ? (mw * nw >= 6 ? 1 : (mw * nw >= 2 ? 2 : 3)) : ((np == 2 && mw * nw <= 2) ? 3 : 2);
+}
 
-template <int KS, int STRIDE, int MODE, int MW, int NW, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, NW, NP), x3_wpe(MW, NW, NP)))) void conv_x3_kernel(const ConvX3Args p) {
+// DSF (KS = 3, STRIDE = 2, NP = 2: the first conv of a stride-2 BasicBlock, resnet.py:189-212): the block's 1x1 stride-2 DOWNSAMPLE conv
+// (resnet.py:192-195) rides on this launch.  It reads the same input pixels as this conv's CENTRE tap — input (2 i, 2 j) for output
+// (i, j) — so its A fragments are the ones the K loop already holds in registers during the centre tap's steps; it only needs its own
+// B fragments (p.ds_wpk, 1/9 of this conv's), a second set of accumulators and a second epilogue (p.ds_y, p.ds_stats, its own
+// GroupNorm).  One launch and one GroupNorm finalisation less per stride-2 block, the block input is read once instead of twice, and
+// in the block-tail mode (MODE 2) the block input need not be written to HBM at all (p.xout == nullptr): both of its readers are here.
+// Same MFMA terms in the same order as the separate 1x1 launch (k-chunks ascending, a1 w0, a0 w1, a0 w0): bit-identical raw output.
+template <int KS, int STRIDE, int MODE, int MW, int NW, int NP, bool DSF = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, NW, NP, DSF), x3_wpe(MW, NW, NP, DSF)))) void conv_x3_kernel(const ConvX3Args p) {
+  static_assert(!DSF || (KS == 3 && STRIDE == 2 && NP == 2 && (MODE == 0 || MODE == 2)), "the downsample rides on a float16-piece 3x3 stride-2 conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
   constexpr int CS = KS == 1 ? 1 : STRIDE;         // patch pixels per output pixel
@@ -110,6 +122,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     for (int j = 0; j < NW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 accd[DSF ? MW : 1][DSF ? NW : 1];                               // DSF: the downsample conv's accumulators
+  if (DSF) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[DSF ? i : 0][DSF ? j : 0][r] = 0.f;
+  }
 
   // a gradient input (backward-data, NP = 2): power-of-two scale 2^(14 - e) from the tensor's absolute maximum = f * 2^e
   float in_mul = 1.f, in_div = 1.f;
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
           r.v[k][0] = r.v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (MODE >= 2) {
             // the tile owns the input pixels under its own outputs (stride 2: the 2 x 2 block of each): every pixel once
-            r.own[k] = r.in[k] && blockIdx.y == 0 && pr >= PAD && pr < PAD + p.TR * CS && pc >= PAD && pc < PAD + p.TC * CS;
+            r.own[k] = r.in[k] && p.xout != nullptr && blockIdx.y == 0 && pr >= PAD && pr < PAD + p.TR * CS && pc >= PAD && pc < PAD + p.TC * CS;
             r.gofs[k] = (hi * p.W + wi) * p.CIN;
           }
           if (r.in[k]) {
@@ -256,9 +277,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
           *reinterpret_cast<u32x4 *>(lds + 2 * plane + r.off[k]) = o2;
         }
       };
-      constexpr bool PIPE = !(MODE == 2 && (MW * NW >= 6 || x3_wpe(MW, NW, NP) == 3));   // (the block-tail stager of the 96-accumulator tile /
+      constexpr bool PIPE = !((MODE == 2 && (MW * NW >= 6 || x3_wpe(MW, NW, NP) == 3 || DSF)) || (DSF && MW * NW == 4));   // (the block-tail stager of the 96-accumulator tile /
                                                                                          //  of the 168-register small tiles would spill)
-      if (MW * NW <= 2 && !(MODE == 2 && x3_wpe(MW, NW, NP) == 3)) {
+      if (MW * NW <= 2 && !(MODE == 2 && (x3_wpe(MW, NW, NP) == 3 || DSF))) {
         // few accumulators: registers for three rounds in flight — the whole patch of the 32- / 64-channel stages is ONE memory
         // latency instead of three (their staging phase is as long as their MFMA phase)
         for (int pix = pl; pix < nppix; pix += 6 * PS) {
@@ -337,7 +358,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     };
     // One step: M-tile by M-tile; as soon as an M-tile's MFMAs are issued its A registers take the NEXT step's fragments, so
     // the LDS latency hides behind the other M-tiles' MFMAs
-    auto step = [&](u32x4 (*a)[MW], const u32x4 (*b)[NW]) {
+    // DSF: `bd` != nullptr on the centre tap's steps — the downsample conv's MFMAs on the same A fragments, before they are replaced
+    auto step = [&](u32x4 (*a)[MW], const u32x4 (*b)[NW], const u32x4 (*bd)[NW] = nullptr) {
 #pragma unroll
       for (int i = 0; i < MW; ++i) {
 #pragma unroll
@@ -348,6 +370,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
             for (int t = 0; t < 3; ++t)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
                                                                  __builtin_bit_cast(f16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
+            if (DSF && bd != nullptr) {
+#pragma unroll
+              for (int t = 0; t < 3; ++t)
+                accd[DSF ? i : 0][DSF ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
+                                                                                        __builtin_bit_cast(f16x8, bd[TB[t]][j]),
+                                                                                        accd[DSF ? i : 0][DSF ? j : 0], 0, 0, 0);
+            }
           } else {
             // smallest terms first: a1 w1, a2 w0, a0 w2, a1 w0, a0 w1, a0 w0
             constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
@@ -363,112 +392,190 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
       }
     };
     u32x4 a[NP][MW], b0[NP][NW], b1[NP][NW];
+    // DSF: B fragments of the downsample conv for the centre tap's steps [4 kcc, 5 kcc) (an even range: kcc is even), fetched one
+    // iteration ahead; layout = a 1x1 conv's operand, [k-chunk][N-tile][piece][lane][8]
+    u32x4 bd[DSF ? NP : 1][NW];
+    auto loadBd = [&](int kc) {
+      const char *wd = reinterpret_cast<const char *>(p.ds_wpk) + (long)((ck0 >> 4) + kc) * kstep;
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) bd[pc][j] = *reinterpret_cast<const u32x4 *>(wd + (size_t)voff[j] + pc * 1024);
+    };
     loadB(b0);
 #pragma unroll
     for (int i = 0; i < MW; ++i) loadA(i, a);
     advance();                                                           // -> step 1
+    if (DSF) {
+      // three plain loops instead of a test per iteration (a branch inside the loop made the register allocator ping-pong the
+      // accumulators between two register blocks): the taps before the centre one, the centre tap with the riding MFMAs, the rest
+      const int sc0 = 4 * kcc, sc1 = 5 * kcc;
 #pragma unroll 1
-    for (int s = 0; s < nsteps; s += 2) {                                // nsteps is even for every supported shape
-      const bool more = s + 2 < nsteps;                                  // (the last iteration re-fetches step s + 1: unused)
-      loadB(b1);
-      __builtin_amdgcn_sched_barrier(0);
-      step(a, b0);                                                       // multiplies step s, fetches A of step s + 1
-      if (more) advance();
-      loadB(b0);
-      __builtin_amdgcn_sched_barrier(0);
-      step(a, b1);                                                       // multiplies step s + 1, fetches A of step s + 2
-      if (more) advance();
+      for (int s = 0; s < sc0; s += 2) {
+        loadB(b1);
+        if (s + 2 == sc0) loadBd(0);                                     // the centre tap's first fragments, one iteration ahead
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b0);
+        advance();
+        loadB(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b1);
+        advance();
+      }
+#pragma unroll 1
+      for (int s = sc0; s < sc1; s += 2) {
+        loadB(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b0, bd);
+        loadBd(s + 1 - sc0);                                             // one set, refilled a step ahead (CIN / 16 short waits per tile)
+        advance();
+        loadB(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b1, bd);
+        if (s + 2 < sc1) loadBd(s + 2 - sc0);
+        advance();
+      }
+#pragma unroll 1
+      for (int s = sc1; s < nsteps; s += 2) {
+        const bool more = s + 2 < nsteps;
+        loadB(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b0);
+        if (more) advance();
+        loadB(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b1);
+        if (more) advance();
+      }
+    } else {
+#pragma unroll 1
+      for (int s = 0; s < nsteps; s += 2) {                              // nsteps is even for every supported shape
+        const bool more = s + 2 < nsteps;                                // (the last iteration re-fetches step s + 1: unused)
+        loadB(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b0);                                                     // multiplies step s, fetches A of step s + 1
+        if (more) advance();
+        loadB(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b1);                                                     // multiplies step s + 1, fetches A of step s + 2
+        if (more) advance();
+      }
     }
     c_mm += __builtin_readcyclecounter() - t_b;
   }
   unsigned long long t_e = __builtin_readcyclecounter();
 
-  // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).
-  if (NP == 2) {                                                         // undo the weights' power-of-two scale (exact)
-    const float os = (p.oscale_ptr != nullptr ? *p.oscale_ptr : p.oscale) * in_div;
-#pragma unroll
-    for (int i = 0; i < MW; ++i)
-#pragma unroll
-      for (int j = 0; j < NW; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] *= os;
-  }
+  // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).  Runs once for the conv and
+  // (DSF) once more for the downsample conv that rode on it: accumulators, output tensor, statistics and GroupNorm outputs of each.
   const int rr16 = lane >> 5;
   const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
-  float t1[NW], t2[NW];
+  auto emit = [&](f32x16 (*ac)[NW], float *yout, float *stats, const float *oscale_ptr, float oscale, const float *gamma, const float *beta,
+                  float *gscale, float *gshift, float *gmu, float *grstd, bool again) {
+    if (NP == 2) {                                                         // undo the weights' power-of-two scale (exact)
+      const float os = (oscale_ptr != nullptr ? *oscale_ptr : oscale) * in_div;
 #pragma unroll
-  for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
+      for (int i = 0; i < MW; ++i)
 #pragma unroll
-  for (int i = 0; i < MW; ++i) {
-    const int mt = wave_m * MW + i;
-    if (mt >= p.MT) continue;
-    u32x4 ent[4];
+        for (int j = 0; j < NW; ++j)
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
-    unsigned flags = 0;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) flags |= ent[g4][0] | ent[g4][1] | ent[g4][2] | ent[g4][3];
-    const bool whole = !__any((int)(flags >> 31));                       // wave-uniform
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int nt = wave_n * NW + j;
-      if (nt >= ntt) continue;
-      const int co = nt * 32 + (lane & 31);
-      float s1 = 0.f, s2 = 0.f;
-      if (whole) {                                                       // every pixel of the M-tile exists: plain stores
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[i][j][r];
-          (p.y + ybase + co)[ent[r >> 2][r & 3]] = v;
-          s1 += v;
-          s2 = __builtin_fmaf(v, v, s2);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned e = ent[r >> 2][r & 3];
-          const bool ok = (int)e >= 0;
-          const float v = ok ? acc[i][j][r] : 0.f;
-          if (ok) (p.y + ybase + co)[e] = v;
-          s1 += v;
-          s2 = __builtin_fmaf(v, v, s2);
-        }
-      }
-      t1[j] += s1 + __shfl_xor(s1, 32);                                  // M-tiles of this wave, in order
-      t2[j] += s2 + __shfl_xor(s2, 32);
+          for (int r = 0; r < 16; ++r) ac[i][j][r] *= os;
     }
-  }
-  if (p.stats != nullptr) {                                              // one slot per tile: the waves along M meet in LDS
-    const int rows = 4 / wn;
-    float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
-    if (rows > 1) {
-      __syncthreads();                                                   // the patch is no longer read
-      if (lane < 32)
+    float t1[NW], t2[NW];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
-      __syncthreads();
-    }
-    if (wave_m == 0 && lane < 32) {
+    for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = wave_m * MW + i;
+      if (mt >= p.MT) continue;
+      u32x4 ent[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
+      unsigned flags = 0;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) flags |= ent[g4][0] | ent[g4][1] | ent[g4][2] | ent[g4][3];
+      const bool whole = !__any((int)(flags >> 31));                       // wave-uniform
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int nt = wave_n * NW + j;
         if (nt >= ntt) continue;
-        float s1 = t1[j], s2 = t2[j];
-        for (int w = 1; w < rows; ++w) {                                 // fixed order: bit-reproducible
-          const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
-          s1 += o[0];
-          s2 += o[1];
+        const int co = nt * 32 + (lane & 31);
+        float s1 = 0.f, s2 = 0.f;
+        if (whole) {                                                       // every pixel of the M-tile exists: plain stores
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = ac[i][j][r];
+            (yout + ybase + co)[ent[r >> 2][r & 3]] = v;
+            s1 += v;
+            s2 = __builtin_fmaf(v, v, s2);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned e = ent[r >> 2][r & 3];
+            const bool ok = (int)e >= 0;
+            const float v = ok ? ac[i][j][r] : 0.f;
+            if (ok) (yout + ybase + co)[e] = v;
+            s1 += v;
+            s2 = __builtin_fmaf(v, v, s2);
+          }
         }
-        float *dst = p.stats + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
-        if (p.gn_scale != nullptr) {                                     // the sample's only slot: finalise here (no launch)
-          const int c = nt * 32 + lane;
-          const bool first = p.gn_mu != nullptr && c % p.gn_cpg == 0;
-          const long gi = (long)n * (p.COUTP / p.gn_cpg) + c / p.gn_cpg;
-          gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma[c], p.gn_beta[c], p.gn_scale + (long)n * p.COUTP + c,
-                           p.gn_shift + (long)n * p.COUTP + c, first ? p.gn_mu + gi : nullptr, first ? p.gn_rstd + gi : nullptr);
+        t1[j] += s1 + __shfl_xor(s1, 32);                                  // M-tiles of this wave, in order
+        t2[j] += s2 + __shfl_xor(s2, 32);
+      }
+    }
+    if (stats != nullptr) {                                                // one slot per tile: the waves along M meet in LDS
+      const int rows = 4 / wn;
+      float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
+      if (rows > 1) {
+        __syncthreads();                                                   // the patch (the first pass's scratch) is no longer read
+        if (lane < 32)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
+        __syncthreads();
+      }
+      if (wave_m == 0 && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const int nt = wave_n * NW + j;
+          if (nt >= ntt) continue;
+          float s1 = t1[j], s2 = t2[j];
+          for (int w = 1; w < rows; ++w) {                                 // fixed order: bit-reproducible
+            const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
+            s1 += o[0];
+            s2 += o[1];
+          }
+          float *dst = stats + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
+          if (p.gn_ctr != nullptr) {                                       // read by the sample's last workgroup inside this launch
+            gn_stats_store(dst, s1, s2);
+            continue;
+          }
+          dst[0] = s1;
+          dst[1] = s2;
+          if (gscale != nullptr) {                                         // the sample's only slot: finalise here (no launch)
+            const int c = nt * 32 + lane;
+            const bool first = gmu != nullptr && c % p.gn_cpg == 0;
+            const long gi = (long)n * (p.COUTP / p.gn_cpg) + c / p.gn_cpg;
+            gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, gamma[c], beta[c], gscale + (long)n * p.COUTP + c,
+                             gshift + (long)n * p.COUTP + c, first ? gmu + gi : nullptr, first ? grstd + gi : nullptr);
+          }
         }
+      }
+    }
+    (void)again;
+  };
+  emit(acc, p.y, p.stats, p.oscale_ptr, p.oscale, p.gn_gamma, p.gn_beta, p.gn_scale, p.gn_shift, p.gn_mu, p.gn_rstd, false);
+  if constexpr (DSF) emit(accd, p.ds_y, p.ds_stats, p.ds_oscale_ptr, p.ds_oscale, p.ds_gamma, p.ds_beta, p.ds_scale, p.ds_shift, nullptr, nullptr, true);
+  if (p.stats != nullptr && p.gn_ctr != nullptr) {                        // several tiles per sample: the last one to arrive finalises
+    if (gn_last_arrival(p.gn_ctr + (long)n * gridDim.y + blockIdx.y, (unsigned)p.slots, reinterpret_cast<int *>(lds + 4096))) {
+      const int nt0 = (int)blockIdx.y * wn * NW, nt1 = min(nt0 + wn * NW, ntt);
+      const int NG = p.COUTP / p.gn_cpg;
+      for (int g = (nt0 * 32) / p.gn_cpg + wave; g < (nt1 * 32) / p.gn_cpg; g += 4) {
+        gn_finalize_group_wave(p.stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma, p.gn_beta,
+                               p.gn_scale + (long)n * p.COUTP, p.gn_shift + (long)n * p.COUTP, p.gn_mu ? p.gn_mu + (long)n * NG + g : nullptr,
+                               p.gn_mu ? p.gn_rstd + (long)n * NG + g : nullptr);
+        if (DSF)
+          gn_finalize_group_wave(p.ds_stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, p.ds_gamma,
+                                 p.ds_beta, p.ds_scale + (long)n * p.COUTP, p.ds_shift + (long)n * p.COUTP, nullptr, nullptr);
       }
     }
   }
@@ -865,6 +972,18 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_, NP>), grid, dim3(256), ldsb, s, a);   \
     return hipGetLastError();                                                                             \
   }
+  if constexpr (KS == 3 && STRIDE == 2 && NP == 2) {
+    if (a.ds_wpk != nullptr) {                                           // the block's downsample conv rides on this launch (DSF)
+#define PNVO_X3D(MODE_, MW_, NW_)                                                                               \
+  if (mode == MODE_ && mw == MW_ && nw == NW_) {                                                                \
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_, NP, true>), grid, dim3(256), ldsb, s, a);   \
+    return hipGetLastError();                                                                                   \
+  }
+      PNVO_X3D(0, 1, 1) PNVO_X3D(2, 1, 1) PNVO_X3D(0, 2, 1) PNVO_X3D(2, 2, 1) PNVO_X3D(0, 2, 2) PNVO_X3D(2, 2, 2) PNVO_X3D(0, 3, 2) PNVO_X3D(2, 3, 2)
+#undef PNVO_X3D
+      return hipErrorInvalidValue;
+    }
+  }
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
   PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2) PNVO_X3(3, 1, 1) PNVO_X3(3, 2, 1) PNVO_X3(3, 2, 2) PNVO_X3(3, 3, 2)
   if (KS == 3 && STRIDE == 1 && NP == 2) {                                                      // wide strips (conv_x3_plan)
@@ -989,6 +1108,15 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   return true;
 }
 
+// Does launch_conv_x3 take the persistent resident-weight form (conv_x3p_kernel) for this planned launch?
+bool conv_x3_persistent(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw) {
+  const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
+  const int ntt = a.COUTP / 32, pwgs = a.persist_wgs;
+  const bool bres = ntt == 1 && a.CIN == 32 && nw == 1 && (mode == 0 || mode == 1);   // the layer's weights stay in registers
+  return a.np == 2 && ks == 3 && stride == 1 && bres && mw * nw <= 2 && a.CK == a.CIN && pwgs >= 8 &&
+         (long)a.PR * a.PC * (a.CK / 8) <= 6 * 256 && ntiles >= 2L * pwgs;
+}
+
 hipError_t launch_conv_x3(const ConvX3Args &a0, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s) {
   ConvX3Args a = a0;
   static unsigned long long *prof = nullptr;             // PNVO_X3_PROF=1: phase cycles of workgroup 13, printed per launch (syncs)
@@ -1020,9 +1148,8 @@ hipError_t launch_conv_x3(const ConvX3Args &a0, int ks, int stride, int mode, in
   // (measured at 256 pairs: with the weights resident the 32 -> 32 convs go 0.107 -> 0.085 ms; the prefetching form WITHOUT resident
   //  weights — 64-channel stage — is 9 % slower than one tile per workgroup, and the pooled-key input mode, which also writes the
   //  pooled activations, loses more from two workgroups per CU than it gains: both stay on conv_x3_kernel)
-  const bool bres = ntt == 1 && a.CIN == 32 && nw == 1 && (mode == 0 || mode == 1);   // the layer's weights stay in registers
-  if (a.np == 2 && ks == 3 && stride == 1 && bres && mw * nw <= 2 && a.CK == a.CIN && pwgs >= 8 &&
-      (long)a.PR * a.PC * (a.CK / 8) <= 6 * 256 && ntiles >= 2L * pwgs) {
+  if (conv_x3_persistent(a, ks, stride, mode, mw, nw)) {
+    const bool bres = true;
     dim3 pg((unsigned)(pwgs & ~7), grid.y, 1u);
     if (bres) pg.x = (unsigned)(((pwgs / 3) * 2) & ~7);                 // two workgroups per CU (256 registers per lane)
 #define PNVO_X3P(MODE_, MW_, NW_)                                                                        \

@@ -96,10 +96,10 @@ hipError_t launch_assemble(const AssembleArgs &h, hipStream_t s) {
 // (sum, sumsq), reduced in a FIXED order in fp64, folded with the affine parameters into
 //   scale[n][c] = rstd * gamma[c],  shift[n][c] = beta[c] - mean * scale[n][c]
 // (torch.nn.GroupNorm, eps inside the sqrt; used at resnet.py:39,42,165,194 and vo_cnn.py:93).
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int slots, int CP, int C, int G, long P,
-                                                        int WM, const float *gamma, const float *beta, float eps,
-                                                        float *scale, float *shift, int fixed_ns, float *mu_out,
-                                                        float *rstd_out) {
+__device__ __forceinline__ void gn_finalize_block(const float *stats, int slots, int CP, int C, int G, long P,
+                                                  int WM, const float *gamma, const float *beta, float eps,
+                                                  float *scale, float *shift, int fixed_ns, float *mu_out,
+                                                  float *rstd_out) {
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const long t0 = ((long)n * P) / WM, t1 = ((long)(n + 1) * P - 1) / WM;
@@ -131,6 +131,41 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
     scale[(long)n * CP + c] = (float)sc;
     shift[(long)n * CP + c] = (float)((double)beta[c] - mu * sc);
   }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int slots, int CP, int C, int G, long P,
+                                                        int WM, const float *gamma, const float *beta, float eps,
+                                                        float *scale, float *shift, int fixed_ns, float *mu_out,
+                                                        float *rstd_out) {
+  gn_finalize_block(stats, slots, CP, C, G, P, WM, gamma, beta, eps, scale, shift, fixed_ns, mu_out, rstd_out);
+}
+
+// Two GroupNorms of the same geometry in one launch (a stride-2 block's first conv and the downsample conv that rode on it):
+// blockIdx.y selects the set; the arithmetic of each is gn_finalize_kernel's.
+struct GnFinPair {
+  const float *stats[2], *gamma[2], *beta[2];
+  float *scale[2], *shift[2];
+};
+__global__ __launch_bounds__(64) void gn_finalize_pair_kernel(const GnFinPair q, int slots, int CP, int C, int G, long P, float eps,
+                                                             float *mu_out, float *rstd_out) {
+  const int z = blockIdx.y;
+  gn_finalize_block(q.stats[z], slots, CP, C, G, P, 1, q.gamma[z], q.beta[z], eps, q.scale[z], q.shift[z], slots, z == 0 ? mu_out : nullptr,
+                    z == 0 ? rstd_out : nullptr);
+}
+
+hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
+                                   const float *const *beta, float eps, float *const *scale, float *const *shift, float *mu_out,
+                                   float *rstd_out, hipStream_t s) {
+  GnFinPair q;
+  for (int z = 0; z < 2; ++z) {
+    q.stats[z] = stats[z];
+    q.gamma[z] = gamma[z];
+    q.beta[z] = beta[z];
+    q.scale[z] = scale[z];
+    q.shift[z] = shift[z];
+  }
+  hipLaunchKernelGGL(gn_finalize_pair_kernel, dim3((unsigned)(B * G), 2u), dim3(64), 0, s, q, slots, CP, C, G, P, eps, mu_out, rstd_out);
+  return hipGetLastError();
 }
 
 // Two models in one launch (the bf16 dual forward): blockIdx.y = model.

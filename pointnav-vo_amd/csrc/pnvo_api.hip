@@ -267,6 +267,8 @@ void free_workspace(pnvo_model_s *m) {
   free_dev(m->comp_raw);
   free_dev(m->hid);
   free_dev(m->stats);
+  free_dev(m->gn_ctr);
+  free_dev(m->stats_ds);
   for (int k = 0; k < 2; ++k) {
     free_dev(m->ssA[k]);
     free_dev(m->ssB[k]);
@@ -357,6 +359,9 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   HIPCHK(m, alloc(m->out_ws, (size_t)B * c.out_dim));
   HIPCHK(m, alloc(m->stats, st));
   m->stats_floats = st;
+  HIPCHK(m, alloc(m->stats_ds, st));
+  HIPCHK(m, alloc(m->gn_ctr, (size_t)B * 16));
+  HIPCHK(m, hipMemset(m->gn_ctr, 0, (size_t)B * 16 * sizeof(float)));
   for (int k = 0; k < 2; ++k) {
     HIPCHK(m, alloc(m->ssA[k], (size_t)B * maxc));
     HIPCHK(m, alloc(m->ssB[k], (size_t)B * maxc));
@@ -506,6 +511,19 @@ bool pnvo_conv_on_x3(pnvo_handle m, const Layer &l, int B) {
   return x3_args(m, l, B, xa, &mw, &nw, &ldsb);
 }
 
+// The block's downsample conv rides on its first 3x3 conv when both run on the float16-piece form of conv_x3_kernel and share the
+// output geometry (they always do: resnet.py:189-212), at inference (a training forward keeps the block input for its backward pass
+// and its own launch schedule), and not while a tap wants the plain schedule.
+bool pnvo_conv_takes_ds(pnvo_handle m, const Layer &c1, const Layer &cd, int B) {
+  if (!m->opt.ds_fuse || m->tap_dst != nullptr || m->in_train_forward || m->bottleneck) return false;
+  if (c1.k != 3 || c1.kw != 3 || c1.stride != 2 || c1.pad != 1 || cd.k != 1 || cd.kw != 1 || cd.stride != 2 || cd.pad != 0) return false;
+  if (c1.cinp != cd.cinp || c1.coutp != cd.coutp || c1.cout != cd.cout || c1.hout != cd.hout || c1.wout != cd.wout || c1.hin != cd.hin ||
+      c1.win != cd.win || c1.cout != c1.coutp || c1.groups != cd.groups || c1.groups <= 0 || cd.host_w.empty())
+    return false;
+  if (!x3_layer(m, c1) || !x3_layer(m, cd) || !x3_two_pieces(m, c1) || !x3_two_pieces(m, cd)) return false;
+  return pnvo_conv_on_x3(m, c1, B);
+}
+
 bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B) {
   if (m->tap_dst != nullptr || !m->opt.tail) return false;   // taps want the block outputs of the plain schedule; option tail=separate: the pass of its own
   return pnvo_conv_on_x3(m, l, B);
@@ -514,7 +532,7 @@ bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B) {
 // One conv + (optionally) the GroupNorm statistics finalisation that follows it.
 int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
                   float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
-                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail) {
+                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail, const DsRide *ride) {
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
   if (src != nullptr) {          // fused stem: gather A from the observation tensors
@@ -596,20 +614,38 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     const bool rows = two && m->opt.x3_rows && conv_rows32_plan(xa, l.k, l.stride, x3_mode, m->num_cus);
     if (rows || conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
-      if (two && (!lm.wpk_x2 || lm.x2_gen != m->weights_gen)) {  // (re)build the two-piece operand of this layer
-        const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 2;
-        if (!lm.wpk_x2) HIPCHK(m, hipMalloc((void **)&lm.wpk_x2, nel * 2));
-        const float *dev_w = m->train ? pnvo_train_weight_ptr(m, l.name + ".weight") : nullptr;
+      auto ensure_x2 = [&](Layer &q) -> int {                    // (re)build the two-piece float16 operand of a layer
+        if (q.wpk_x2 && q.x2_gen == m->weights_gen) return PNVO_OK;
+        const size_t nel = (size_t)q.k * q.kw * q.cinp * q.coutp * 2;
+        if (!q.wpk_x2) HIPCHK(m, hipMalloc((void **)&q.wpk_x2, nel * 2));
+        const float *dev_w = m->train ? pnvo_train_weight_ptr(m, q.name + ".weight") : nullptr;
         if (dev_w != nullptr) {          // training attached: weight and scale live on the device (pnvo_train_refresh)
-          HIPCHK(m, launch_conv_x2_repack(dev_w, l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pnvo_train_x2_scale(m, l.name + ".weight"),
-                                          lm.wpk_x2, s));
+          HIPCHK(m, launch_conv_x2_repack(dev_w, q.cout, q.cin, q.cinp, q.coutp, q.k, q.kw, pnvo_train_x2_scale(m, q.name + ".weight"),
+                                          q.wpk_x2, s));
         } else {
           std::vector<unsigned short> pk(nel);
-          lm.x2_oscale = pack_conv_x2_weight(l.host_w.data(), l.cout, l.cin, l.cinp, l.coutp, l.k, l.kw, pk.data());
-          HIPCHK(m, hipMemcpyAsync(lm.wpk_x2, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
+          q.x2_oscale = pack_conv_x2_weight(q.host_w.data(), q.cout, q.cin, q.cinp, q.coutp, q.k, q.kw, pk.data());
+          HIPCHK(m, hipMemcpyAsync(q.wpk_x2, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
           HIPCHK(m, hipStreamSynchronize(s));
         }
-        lm.x2_gen = m->weights_gen;
+        q.x2_gen = m->weights_gen;
+        return PNVO_OK;
+      };
+      if (two) {
+        if (int rc2 = ensure_x2(lm)) return rc2;
+      }
+      if (ride != nullptr) {             // the block's downsample conv on this launch (pnvo_conv_takes_ds said yes)
+        if (rows || !two || l.stride != 2 || l.k != 3) return fail(m, PNVO_ERR_STATE, "downsample ride on a conv that cannot carry it (" + l.name + ")");
+        Layer &dm = const_cast<Layer &>(*ride->cd);
+        if (int rc2 = ensure_x2(dm)) return rc2;
+        xa.ds_wpk = dm.wpk_x2;
+        xa.ds_oscale = dm.x2_oscale;
+        if (m->train != nullptr) {
+          const float *sp = pnvo_train_x2_scale(m, dm.name + ".weight");
+          xa.ds_oscale_ptr = sp ? sp + 1 : nullptr;
+        }
+        xa.ds_y = ride->y;
+        xa.ds_stats = m->stats_ds;
       }
       if (!two && (!lm.wpk_x3 || lm.x3_gen != m->weights_gen)) {   // (re)build the three-piece operand of this layer
         const size_t nel = (size_t)l.k * l.kw * l.cinp * l.coutp * 3;
@@ -648,7 +684,20 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       const int cpg = l.groups > 0 ? l.cout / l.groups : 0;
       const bool fuse = m->opt.gn_fuse && xa.slots == 1 && l.cout == l.coutp && cpg >= 1 && cpg <= 32 &&
                         32 % cpg == 0 && l.cout % cpg == 0 && (rows || !(xa.persist_wgs > 0 && l.cin == 32 && l.coutp == 32));
-      if (fuse) {
+      // several tiles per sample: the sample's LAST workgroup to arrive finalises (gn_last_arrival; conv_x3_kernel only — the rows
+      // kernel with several bands and the persistent form keep the launch).  Not next to a side stream (one counter array).
+      const long x3_gy = rows ? 1 : ((l.coutp / 32) + xa.wn * nw - 1) / (xa.wn * nw);
+      const bool x3p = !rows && conv_x3_persistent(xa, l.k, l.stride, x3_mode, mw, nw);
+      const bool fuse_last = m->opt.gn_fuse == 1 && !rows && !x3p && xa.slots > 1 && l.cout == l.coutp && cpg >= 1 && cpg <= 32 && 32 % cpg == 0 &&
+                             l.cout % cpg == 0 && x3_gy <= 16 && (m->side_stream == nullptr || s != m->side_stream) && m->gn_ctr != nullptr;
+      if (fuse_last) xa.gn_ctr = reinterpret_cast<unsigned *>(m->gn_ctr);
+      if ((fuse || fuse_last) && ride != nullptr) {
+        xa.ds_gamma = ride->cd->gamma;
+        xa.ds_beta = ride->cd->beta;
+        xa.ds_scale = ride->ss[0];
+        xa.ds_shift = ride->ss[1];
+      }
+      if (fuse || fuse_last) {
         xa.gn_gamma = l.gamma;
         xa.gn_beta = l.beta;
         xa.gn_scale = ss[0];
@@ -666,8 +715,14 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         else
           HIPCHK(m, launch_conv_x3(xa, l.k, l.stride, x3_mode, mw, nw, ldsb, s));
       }
-      if (fuse) return PNVO_OK;
+      if (fuse || fuse_last) return PNVO_OK;
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      if (ride != nullptr) {             // the conv's GroupNorm and the riding downsample conv's in one launch
+        const float *st2[2] = {m->stats, m->stats_ds}, *ga2[2] = {l.gamma, ride->cd->gamma}, *be2[2] = {l.beta, ride->cd->beta};
+        float *sc2[2] = {ss[0], ride->ss[0]}, *sh2[2] = {ss[1], ride->ss[1]};
+        HIPCHK(m, launch_gn_finalize_pair(st2, B, xa.slots, l.coutp, l.cout, l.groups, P, ga2, be2, 1e-5f, sc2, sh2, mu_out, rstd_out, s));
+        return PNVO_OK;
+      }
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
                                    xa.slots, mu_out, rstd_out));
       return PNVO_OK;
@@ -1056,7 +1111,8 @@ const OptDef kOptions[] = {
     {"x3_rows", "PNVO_X3_ROWS", &PnvoOptions::x3_rows, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_side", "PNVO_DS_SIDE", &PnvoOptions::ds_side, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
-    {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 2}, {"single", 2}, {"last", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"tail", "PNVO_TAIL", &PnvoOptions::tail, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
     {"pool", "PNVO_POOL", &PnvoOptions::pool, false, {{"fused", 1}, {"separate", 0}, {nullptr, 0}}},
@@ -1764,6 +1820,10 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       const Layer &c1 = m->convs[li++];
       const Layer &c2 = m->convs[li++];
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
+      // the block's downsample conv rides on c1's launch (conv_x3_kernel DSF): no launch, no finalisation of its own, and in the
+      // block-tail mode the block input is not written to HBM at all — c1 and the downsample conv are its only readers
+      const bool ds_ride = ds && !have_keys && pnvo_conv_takes_ds(m, c1, m->convs[li], B);
+      const DsRide ride{ds_ride ? &m->convs[li] : nullptr, m->rawD, m->ssD};
       if (have_keys) {           // pooled stem keys in `nxt`: decoded + normalised by this conv's stager, activations -> `cur`
         BlockTail keys{nullptr, nullptr, nullptr, cur};
         if ((rc = pnvo_run_conv(m, c1, B, nxt, m->ssA[0], m->ssA[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
@@ -1771,12 +1831,14 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
           return rc;
         have_keys = false;
       } else if (have_tail) {    // the previous block's tail rides on this conv's stager, which also writes the block output
+        if (ds_ride) tail.out = nullptr;                       // (nobody else reads this block's input)
         if ((rc = pnvo_run_conv(m, c1, B, m->rawB, m->ssB[0], m->ssB[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr,
-                                nullptr, nullptr, &tail)) != PNVO_OK)
+                                nullptr, nullptr, &tail, ds_ride ? &ride : nullptr)) != PNVO_OK)
           return rc;
         std::swap(cur, nxt);
         have_tail = false;
-      } else if ((rc = run_conv(m, c1, B, cur, nullptr, nullptr, m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s)) != PNVO_OK) {
+      } else if ((rc = pnvo_run_conv(m, c1, B, cur, nullptr, nullptr, m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
+                                     nullptr, nullptr, ds_ride ? &ride : nullptr)) != PNVO_OK) {
         return rc;
       }
       const long P = (long)c2.hout * c2.wout;
@@ -1787,7 +1849,7 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       bool ds_forked = false;
       // (measured: 256 pairs 2.331 -> 2.305 ms; 64 pairs no change; 16 pairs +0.05 ms — the fork / join events cost what the small
       //  launches save, so only from 128 pairs on)
-      if (ds && m->opt.ds_side && B >= 128 && !c2_small_generic && !m->timing && m->tap_dst == nullptr && m->train == nullptr && side_stream_ready(m, s)) {
+      if (ds && !ds_ride && m->opt.ds_side && B >= 128 && !c2_small_generic && !m->timing && m->tap_dst == nullptr && m->train == nullptr && side_stream_ready(m, s)) {
         const Layer &cd = m->convs[li + 0];
         HIPCHK(m, hipEventRecord(m->side_fork, s));
         HIPCHK(m, hipStreamWaitEvent(m->side_stream, m->side_fork, 0));
@@ -1813,7 +1875,8 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       }
       if (ds) {
         const Layer &cd = m->convs[li++];
-        if (ds_forked) {
+        if (ds_ride) {                                                 // rawD / ssD came out of c1's launch
+        } else if (ds_forked) {
           HIPCHK(m, hipStreamWaitEvent(s, m->side_join, 0));           // rawD / ssD are complete before the block tail's consumer
         } else if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK) {
           return rc;
@@ -2312,6 +2375,12 @@ int pnvo_layer_kernel(pnvo_handle h, const char *name, int B, char *family, size
     ConvX3Args xa;
     int mw, nw;
     size_t ldsb;
+    if (l.k == 1 && l.stride == 2 && li >= 3 && h->convs[li - 2].stride == 2 && pnvo_conv_takes_ds(h, h->convs[li - 2], l, B) &&
+        x3_args(h, h->convs[li - 2], B, xa, &mw, &nw, &ldsb)) {           // a downsample conv riding on its block's first conv
+      std::snprintf(family, cap, "x2-rides");
+      if (executed_flops) *executed_flops = 3.0 * 2.0 * (double)B * xa.tiles_r * xa.tiles_c * xa.MT * 32.0 * l.coutp * (double)l.cinp;
+      return PNVO_OK;
+    }
     if (x3_layer(h, l) && l.groups > 0 && x3_args(h, l, B, xa, &mw, &nw, &ldsb)) {
       std::snprintf(family, cap, xa.np == 2 ? "x2" : "x3");
       // tiles x M-tiles x 32 pixels x padded outputs x K, six bf16 (x3) or three float16 (x2) MFMA terms per float32 product

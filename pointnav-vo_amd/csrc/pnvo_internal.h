@@ -162,6 +162,18 @@ struct ConvX3Args {
   int gn_cpg;                        // channels per group (divides 32)
   float gn_eps;
   long gn_P;                         // pixels per sample
+  // slots > 1 with gn_scale set: [B][gridDim.y] arrival counters (zero between launches) — the LAST tile of a sample (and N-tile
+  // group) finalises (gn_finalize_group_wave: gn_finalize_kernel's arithmetic bit for bit); nullptr with slots > 1: the launch
+  unsigned *gn_ctr;
+  // The block's 1x1 stride-2 downsample conv riding on a 3x3 stride-2 launch (conv_x3_kernel<.., DSF = true>; ds_wpk == nullptr: none):
+  // its float16-piece operand (pack_conv_x2_weight of the 1x1 weight), raw output [B,Ho,Wo,COUTP], partial sums (the layout of `stats`,
+  // a buffer of its own), weight scale, and its GroupNorm (same groups as the conv's; scale / shift written when the conv's are)
+  const unsigned short *ds_wpk;
+  float *ds_y, *ds_stats;
+  float ds_oscale;
+  const float *ds_oscale_ptr;
+  const float *ds_gamma, *ds_beta;
+  float *ds_scale, *ds_shift;
 };
 #if defined(__HIPCC__)
 // One lane = one channel of a sample, lanes of a group adjacent and aligned: GroupNorm scale / shift from the channel's complete
@@ -188,11 +200,70 @@ __device__ __forceinline__ void gn_finalize_lane(float s1, float s2, int cpg, lo
   *scale = (float)sc;
   *shift = (float)((double)beta - mu * sc);
 }
+// ---- GroupNorm finalisation by the LAST workgroup of a sample (multi-slot layers: no finalisation launch) ------------------------
+// Every workgroup that wrote GroupNorm partial sums of sample n bumps a device-scope counter; the one that brings it to `expect`
+// knows that all partials of the sample are in memory and turns them into scale / shift — gn_finalize_kernel's arithmetic, bit for
+// bit (one wave per group: the same lane -> (slot, channel) walk, fp64, the same 64-lane butterfly), so which workgroup arrives
+// last changes nothing.  The partials cross workgroups INSIDE a launch: they are written and read with agent-scope accesses (sc1:
+// coherent across the per-XCD L2s, smallnet.hip's protocol), the counter is bumped after the writer's stores are acknowledged
+// (s_waitcnt vmcnt(0) + workgroup barrier) — no L2 write-back or invalidate.  The last arriver also clears the counter for the next launch.
+__device__ __forceinline__ void gn_stats_store(float *dst, float s1, float s2) {
+  __hip_atomic_store(reinterpret_cast<unsigned *>(dst), __builtin_bit_cast(unsigned, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned *>(dst) + 1, __builtin_bit_cast(unsigned, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One full wave = one (sample, group): `stats` points at the sample's [slots][CP][2] partials, ns slots are summed.
+__device__ __forceinline__ void gn_finalize_group_wave(const float *stats, int ns, int CP, int g, int cpg, long P, float eps, const float *gamma,
+                                                       const float *beta, float *scale_n, float *shift_n, float *mu_out, float *rstd_out) {
+#pragma clang fp contract(off)
+  const int lane = (int)(threadIdx.x & 63);
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < ns * cpg; k += 64) {
+    const int slot = k / cpg, c = g * cpg + k % cpg;
+    const unsigned *src = reinterpret_cast<const unsigned *>(stats + ((long)slot * CP + c) * 2);
+    s1 += (double)__builtin_bit_cast(float, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    s2 += (double)__builtin_bit_cast(float, __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  const double cnt = (double)P * cpg;
+  const double mu = s1 / cnt;
+  double var = s2 / cnt - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (lane == 0 && mu_out != nullptr) {
+    *mu_out = (float)mu;
+    *rstd_out = (float)rstd;
+  }
+  for (int k = lane; k < cpg; k += 64) {
+    const int c = g * cpg + k;
+    const double sc = rstd * (double)gamma[c];
+    scale_n[c] = (float)sc;
+    shift_n[c] = (float)((double)beta[c] - mu * sc);
+  }
+}
+// Arrive (whole workgroup, behind its partial-sum stores); true for every thread of the workgroup that arrived last.
+// `flag` = one int of LDS scratch the caller no longer reads.
+__device__ __forceinline__ bool gn_last_arrival(unsigned *ctr, unsigned expect, int *flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old + 1u == expect;
+    if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
 #endif
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);
 // Row-streaming form of the 32 -> 32 channel 3x3 stride-1 convs (conv_rows.hip): plan fills rs_bands / rs_rows / slots.
 bool conv_rows32_plan(ConvX3Args &a, int ks, int stride, int mode, int num_cus);
 hipError_t launch_conv_rows32(const ConvX3Args &a, int mode, int num_cus, hipStream_t s);
+bool conv_x3_persistent(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw);   // would launch_conv_x3 take conv_x3p_kernel?
 hipError_t launch_conv_x3(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw, size_t lds_bytes, hipStream_t s);
 hipError_t launch_conv_x3_repack(const float *w_oihw, int cout, int cin, int cinp, int coutp, int kh, int kw, int transposed,
                                  unsigned short *out, hipStream_t s);
@@ -256,6 +327,10 @@ hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int 
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
                               hipStream_t s, int fixed_ns = 0, float *mu_out = nullptr, float *rstd_out = nullptr);
 
+// Two GroupNorms of one geometry in one launch (fixed slots per sample), each in gn_finalize_kernel's arithmetic; mu / rstd of set 0.
+hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
+                                   const float *const *beta, float eps, float *const *scale, float *const *shift, float *mu_out,
+                                   float *rstd_out, hipStream_t s);
 hipError_t launch_gn_finalize2(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
                                const float *const *beta, float eps, float *const *scale, float *const *shift, int nmodels,
                                hipStream_t s);

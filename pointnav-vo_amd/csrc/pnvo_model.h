@@ -44,7 +44,11 @@ struct PnvoOptions {
   int x3_rows = 1;     // 32 -> 32 channel 3x3 stride-1 convs on the row-streaming kernel (conv_rows.hip) where it takes the launch
   int x3_persist = 1;  // shallow-stage 3x3 convs on the persistent form of conv_x3 (next tile's patch fetched during the K loop)
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
-  int gn_fuse = 1;     // conv_x3 launches with one tile per sample finalise their GroupNorm themselves (bit-identical, one launch less)
+  int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
+  int gn_fuse = 2;     // conv_x3 launches finalise their GroupNorm themselves (bit-identical, one launch less): 2 = launches with one tile per
+                       // sample (the default, `on`); 1 = `last`: also launches with several tiles per sample, by the sample's last workgroup to
+                       // arrive (round 6: measured SLOWER at every batch — every workgroup waits for its stores and an atomic round trip
+                       // before it leaves — kept as an option and a test of the protocol); 0 = never
   int x3_s2 = 1;       // stride-2 convs on conv_x3
   int tail = 1;        // BasicBlock tails fused into the next conv's stager (0: residual_kernel)
   int pool = 1;        // max-pool fused into the stem's epilogue (0: gn_relu_maxpool_kernel)
@@ -125,6 +129,8 @@ struct pnvo_model_s {
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   float *stats_side = nullptr;               // the side stream's GroupNorm partials (the main stream's conv writes m->stats meanwhile)
   size_t stats_side_floats = 0, stats_floats = 0;
+  float *stats_ds = nullptr;                 // GroupNorm partials of a downsample conv riding on its block's first conv (stats_floats)
+  float *gn_ctr = nullptr;                   // [cap][16] unsigned arrival counters of the in-kernel GroupNorm finalisation (zero between launches)
   hipEvent_t stem_ev = nullptr;              // recorded behind a contract-checking stem launch (pnvo_mark_stem)
   bool stem_ev_pending = false;
   // pnvo_forward_raw / pnvo_forward_dual_raw: sensor frames of the call in flight (the stem's RAW stager reads them)
@@ -195,10 +201,20 @@ struct BlockTail {
   float *out;
 };
 
+// The 1x1 stride-2 downsample conv of a stride-2 BasicBlock (resnet.py:192-195) riding on the launch of the block's first 3x3 conv
+// (conv_x3_kernel<.., DSF>): raw output -> y, GroupNorm scale / shift -> ss[0] / ss[1] (finalised with the conv's own).
+struct DsRide {
+  const Layer *cd;
+  float *y;
+  float *const *ss;
+};
+
 // helpers implemented in pnvo_api.hip
 int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const float *in_scale, const float *in_shift,
                   float *y, int y_cstride, float *ss[2], const float *bias, const int64_t *bias_row, int relu_out,
-                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail = nullptr);
+                  hipStream_t s, const float *const *src, float *mu_out, float *rstd_out, const BlockTail *tail = nullptr,
+                  const DsRide *ride = nullptr);
+bool pnvo_conv_takes_ds(pnvo_handle m, const Layer &c1, const Layer &cd, int B);   // would pnvo_run_conv(c1) carry cd as a DsRide?
 bool pnvo_conv_on_x3(pnvo_handle m, const Layer &l, int B);                        // would pnvo_run_conv(l) use conv_x3.hip?
 bool pnvo_conv_takes_tail(pnvo_handle m, const Layer &l, int B);   // would pnvo_run_conv(l) accept a BlockTail (conv_x3 path)?
 void pnvo_pack_conv_weight_cinp(const float *oihw, int cout, int cin, int cinp, int kh, int kw, std::vector<float> &out);

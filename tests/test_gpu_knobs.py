@@ -243,6 +243,256 @@ def test_strip_tiles_of_the_128_channel_stage_agree_with_square_tiles():
 
 
 def test_in_kernel_groupnorm_finalisation_is_bit_identical():
+    """Option gn_fuse: conv_x3 launches turn their channel sums into the GroupNorm scale / shift themselves, in gn_finalize_kernel's
+    fp64 arithmetic and reduction order.  `on` (default, round 4): launches with one tile per sample (the 12x22 and 6x11 maps) — the
+    tile that holds the sums.  `last` (round 6): also launches with several tiles per sample (24x43 maps, 48x86 below 64 pairs, the
+    stride-2 block heads) — the sample's LAST workgroup to arrive behind a device-scope counter, partial sums moved with agent-scope
+    accesses.  Which workgroup arrives last differs run to run; the network output must not change by a bit against the separate
+    launch, at 8 ... 256 pairs, and repeat identically.  (`last` measured slower than the launches it removes — every workgroup
+    waits for its stores and an atomic round trip — so it is not the default; the protocol is tested all the same.)"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    for B in (8, 16, 33, 64, 256):
+        obs = bench.make_inputs(B, dev, 1)
+        outs = []
+        for v in ("on", "off", "last", "on", "last"):
+            model.set_option("gn_fuse", v)
+            with torch.no_grad():
+                outs.append(model(obs).clone())
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[0]).all()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), B
+        # ... and the launches are really gone: finalisation launches per forward
+        nfin = {}
+        for v in ("last", "on", "off"):
+            model.set_option("gn_fuse", v)
+            model.timing(True)
+            with torch.no_grad():
+                model(obs)
+            torch.cuda.synchronize()
+            nfin[v] = sum(k["launches"] for k in model.timing_read() if k["name"] == "gn_finalize")
+            model.timing(False)
+        model.set_option("gn_fuse", "on")
+        assert nfin["last"] < nfin["on"] <= nfin["off"], (B, nfin)
+        if B == 256:                                       # what `last` leaves: the stem's and the compression conv's
+            assert nfin["last"] <= 2, nfin
+        fam = model.layer_kernel("visual_encoder.backbone.layer1.0.convs.3", B)[0]
+        assert fam in ("x2", "x3"), fam
+
+
+@pytest.mark.parametrize("B", [64, 100, 128, 256])
+def test_row_streaming_convs_agree_with_the_tile_kernels(B):
+    """conv_rows32_kernel (option x3_rows, default on: the 32 -> 32 convs of the first stage whose input is a GroupNorm-ed raw tensor,
+    from one band per CU on) against conv_x3_kernel / conv_x3p_kernel: the same float16 pieces and products, two accumulators instead
+    of one and one statistics slot per band — float32-grade agreement (5e-6 of the output range; measured 3e-6), run-to-run
+    reproducible; 4 / 2 / 2 / 1 bands per sample at these batch sizes, the last with the GroupNorm finalised inside the kernel."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 2)
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("x3_rows", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs["on"]).all() and torch.equal(outs["on"], outs["on2"])
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel                                   # (0 would mean the option selected nothing)
+    chk = [0, B // 2, B - 1]
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][chk].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
+
+
+def test_row_streaming_convs_on_an_odd_resolution():
+    """101 x 75 frames (51 x 38 stem output, 26 x 19 maps in the first stage: ragged half-groups, rows shorter than a tile), 300 pairs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    from pointnav_vo_amd import model_spec as ms, synth
+    from pointnav_vo_amd.registry import baseline_registry
+    dev = torch.device("cuda", 0)
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(101, 75), hidden_size=512, backbone="resnet18", normalize_visual_inputs=True,
+        output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    obs = synth.make_obs_pairs(300, 75, 101, observation_space=bench.SPACE, dd_bins=10, seed=3)
+    tobs = {k: torch.from_numpy(v).to(dev) for k, v in obs.items()}
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off"):
+            m.set_option("x3_rows", v)
+            outs[v] = m(tobs).clone()
+        torch.cuda.synchronize()
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel
+    ref = oracle.forward(sd, {k: v[:3] for k, v in obs.items()}, ngroups=m.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][:3].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
+
+
+def test_strip_tiles_of_the_128_channel_stage_agree_with_square_tiles():
+    """Option x3_strip (default on): the 128-channel stage's conv_x3 launches use full-width strip tiles with a 5x1 wave grid and
+    the N tiles over blockIdx.y.  Another tile plan changes which pixels a workgroup sums for the GroupNorm partials, so the
+    outputs agree to float32 rounding of those sums, not by bit: 2e-5 of the pose norm (measured 3e-6), at 16 and 64 pairs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    for B in (16, 64):
+        obs = bench.make_inputs(B, dev, 1)
+        outs = []
+        for v in ("on", "off", "on"):
+            model.set_option("x3_strip", v)
+            with torch.no_grad():
+                outs.append(model(obs).double().cpu().numpy().copy())
+        assert np.isfinite(outs[0]).all()
+        assert np.array_equal(outs[0], outs[2])          # same plan, same bits
+        err = np.linalg.norm(outs[0] - outs[1], axis=1) / np.maximum(np.linalg.norm(outs[1], axis=1), 1e-2)
+        assert err.max() < 2e-5, err.max()
+
+
+def test_in_kernel_groupnorm_finalisation_is_bit_identical():
+    """Option gn_fuse (default on): conv_x3 launches turn their channel sums into the GroupNorm scale / shift themselves, in
+    gn_finalize_kernel's fp64 arithmetic and reduction order — with one tile per sample (the 12x22 and 6x11 maps) the tile that holds
+    the sums (`single`, round 4), with several tiles per sample (the 24x43 maps; 48x86 below 64 pairs; the stride-2 block heads) the
+    sample's LAST workgroup to arrive, behind a device-scope counter (round 6).  Which workgroup arrives last differs run to run; the
+    network output must not change by a bit against the separate launch, at 8 ... 256 pairs, and repeat identically."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    for B in (8, 16, 33, 64, 256):
+        obs = bench.make_inputs(B, dev, 1)
+        outs = []
+        for v in ("on", "off", "single", "on", "on"):
+            model.set_option("gn_fuse", v)
+            with torch.no_grad():
+                outs.append(model(obs).clone())
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[0]).all()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), B
+        # ... and the launches are really gone: finalisation launches per forward with the option on / one-tile launches only / off
+        nfin = {}
+        for v in ("on", "single", "off"):
+            model.set_option("gn_fuse", v)
+            model.timing(True)
+            with torch.no_grad():
+                model(obs)
+            torch.cuda.synchronize()
+            nfin[v] = sum(k["launches"] for k in model.timing_read() if k["name"] == "gn_finalize")
+            model.timing(False)
+        model.set_option("gn_fuse", "on")
+        assert nfin["on"] < nfin["single"] <= nfin["off"], (B, nfin)
+        if B == 256:                                       # what is left: the stem's and the compression conv's
+            assert nfin["on"] <= 2, nfin
+        fam = model.layer_kernel("visual_encoder.backbone.layer1.0.convs.3", B)[0]
+        assert fam in ("x2", "x3"), fam
+
+
+@pytest.mark.parametrize("B", [64, 100, 128, 256])
+def test_row_streaming_convs_agree_with_the_tile_kernels(B):
+    """conv_rows32_kernel (option x3_rows, default on: the 32 -> 32 convs of the first stage whose input is a GroupNorm-ed raw tensor,
+    from one band per CU on) against conv_x3_kernel / conv_x3p_kernel: the same float16 pieces and products, two accumulators instead
+    of one and one statistics slot per band — float32-grade agreement (5e-6 of the output range; measured 3e-6), run-to-run
+    reproducible; 4 / 2 / 2 / 1 bands per sample at these batch sizes, the last with the GroupNorm finalised inside the kernel."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 2)
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("x3_rows", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs["on"]).all() and torch.equal(outs["on"], outs["on2"])
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel                                   # (0 would mean the option selected nothing)
+    chk = [0, B // 2, B - 1]
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][chk].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
+
+
+def test_row_streaming_convs_on_an_odd_resolution():
+    """101 x 75 frames (51 x 38 stem output, 26 x 19 maps in the first stage: ragged half-groups, rows shorter than a tile), 300 pairs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    from pointnav_vo_amd import model_spec as ms, synth
+    from pointnav_vo_amd.registry import baseline_registry
+    dev = torch.device("cuda", 0)
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(101, 75), hidden_size=512, backbone="resnet18", normalize_visual_inputs=True,
+        output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    obs = synth.make_obs_pairs(300, 75, 101, observation_space=bench.SPACE, dd_bins=10, seed=3)
+    tobs = {k: torch.from_numpy(v).to(dev) for k, v in obs.items()}
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off"):
+            m.set_option("x3_rows", v)
+            outs[v] = m(tobs).clone()
+        torch.cuda.synchronize()
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel
+    ref = oracle.forward(sd, {k: v[:3] for k, v in obs.items()}, ngroups=m.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][:3].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
+
+
+def test_strip_tiles_of_the_128_channel_stage_agree_with_square_tiles():
+    """Option x3_strip (default on): the 128-channel stage's conv_x3 launches use full-width strip tiles with a 5x1 wave grid and
+    the N tiles over blockIdx.y.  Another tile plan changes which pixels a workgroup sums for the GroupNorm partials, so the
+    outputs agree to float32 rounding of those sums, not by bit: 2e-5 of the pose norm (measured 3e-6), at 16 and 64 pairs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    for B in (16, 64):
+        obs = bench.make_inputs(B, dev, 1)
+        outs = []
+        for v in ("on", "off", "on"):
+            model.set_option("x3_strip", v)
+            with torch.no_grad():
+                outs.append(model(obs).double().cpu().numpy().copy())
+        assert np.isfinite(outs[0]).all()
+        assert np.array_equal(outs[0], outs[2])          # same plan, same bits
+        err = np.linalg.norm(outs[0] - outs[1], axis=1) / np.maximum(np.linalg.norm(outs[1], axis=1), 1e-2)
+        assert err.max() < 2e-5, err.max()
+
+
+def test_in_kernel_groupnorm_finalisation_is_bit_identical():
     """Option gn_fuse (default on): conv_x3 launches with one tile per sample (the 12x22 and 6x11 maps) turn their channel sums into
     the GroupNorm scale / shift themselves, in gn_finalize_kernel's fp64 arithmetic and butterfly order: the network output does
     not change by a bit, at 16, 64 and 256 pairs."""
@@ -261,3 +511,77 @@ def test_in_kernel_groupnorm_finalisation_is_bit_identical():
         torch.cuda.synchronize()
         assert torch.isfinite(outs[0]).all()
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("B", [16, 64, 100, 256])
+def test_downsample_conv_riding_on_its_block_head(B):
+    """Option ds_fuse (default on, round 6): the 1x1 stride-2 downsample conv of layer2.0 / layer3.0 / layer4.0 (resnet.py:192-195) is
+    computed by its block's first 3x3 stride-2 conv launch (conv_x3_kernel<.., DSF>): same float16 pieces, the same three MFMA terms
+    per k-chunk in the same order as the separate 1x1 launch — only the GroupNorm partial sums are grouped by the head's tiles instead
+    of the 1x1 plan's, so the network output agrees to float32 summation noise (2e-6 of the output range), reproduces run to run,
+    and matches the fp64 oracle like the separate launches do.  In the block-tail mode the block input is not written at all."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 3)
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("ds_fuse", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    model.set_option("ds_fuse", "on")
+    fams = [model.layer_kernel(f"visual_encoder.backbone.layer{s}.0.downsample.0", B)[0] for s in (2, 3, 4)]
+    assert "x2-rides" in fams, fams                              # (deep stages at small batches stay on the fp32 kernels)
+    model.set_option("ds_fuse", "off")
+    assert all(model.layer_kernel(f"visual_encoder.backbone.layer{s}.0.downsample.0", B)[0] != "x2-rides" for s in (2, 3, 4))
+    assert torch.isfinite(outs["on"]).all() and torch.equal(outs["on"], outs["on2"])
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 2e-6, rel                                   # (0 would mean the option selected nothing)
+    chk = [0, B // 2, B - 1]
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    for v in ("on", "off"):
+        got = outs[v][chk].double().cpu().numpy()
+        err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+        assert err.max() < 2e-5, (v, err)
+
+
+def test_downsample_ride_on_an_odd_resolution_and_with_taps():
+    """101 x 75 frames, 300 pairs (ragged stride-2 tiles: 26 x 19 -> 13 x 10 -> 7 x 5 -> 4 x 3 maps); and a tap of a block output forces the
+    plain schedule (the block input IS materialised then): same network output as the default schedule to float32 noise."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    from pointnav_vo_amd import model_spec as ms, synth
+    from pointnav_vo_amd.registry import baseline_registry
+    dev = torch.device("cuda", 0)
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(101, 75), hidden_size=512, backbone="resnet18", normalize_visual_inputs=True,
+        output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    obs = synth.make_obs_pairs(300, 75, 101, observation_space=bench.SPACE, dd_bins=10, seed=3)
+    tobs = {k: torch.from_numpy(v).to(dev) for k, v in obs.items()}
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off"):
+            m.set_option("ds_fuse", v)
+            outs[v] = m(tobs).clone()
+        m.set_option("ds_fuse", "on")
+        out_tap, _ = m.tap("layer2.0", tobs)
+        torch.cuda.synchronize()
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert rel < 2e-6, rel
+    # (the tap's plain schedule also swaps the fused pool / block tails / row-streaming kernels for their separate passes)
+    assert float((out_tap - outs["on"]).abs().max() / outs["on"].abs().max()) < 2e-5
+    ref = oracle.forward(sd, {k: v[:3] for k, v in obs.items()}, ngroups=m.cfg.ngroups, dtype=np.float64)
+    got = outs["on"][:3].double().cpu().numpy()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+    assert err.max() < 2e-5, err
