@@ -523,6 +523,50 @@ __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float *part, i
   y[e] = v;
 }
 
+// The same reduction for a linear layer (P == 1: one row per sample) with the OUTPUT HEAD riding on it (vo_cnn.py:216-227: Linear
+// hidden -> out_dim behind the hidden layer's ReLU): one workgroup per sample sums the K slices of its row (fixed order), adds the bias,
+// applies the ReLU, writes the hidden vector — and multiplies it with the head's [OD][C] weight on the way: per-lane partial dot
+// products, a butterfly over the wave, the four waves in order (a fixed tree: deterministic; float32-grade equal to the fp32-MFMA head
+// launch it replaces, whose chain runs in K order).
+__global__ __launch_bounds__(256) void ksplit_reduce_head_kernel(const float *part, int ks, long M, int C, const float *bias,
+                                                               const int64_t *bias_row, int relu, float *y, const float *w2,
+                                                               const float *b2, int OD, float *out) {
+  __shared__ float red[4][4];
+  const long m = blockIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = (int)threadIdx.x; c < C; c += 256) {
+    const long e = m * C + c;
+    float v = 0.f;
+    for (int z = 0; z < ks; ++z) v += part[(long)z * M * C + e];      // fixed order (ksplit_reduce_kernel's)
+    if (bias != nullptr) v += bias[(bias_row ? bias_row[m] : 0) * C + c];
+    if (relu) v = fmaxf(v, 0.f);
+    y[e] = v;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (o < OD) acc[o] = __builtin_fmaf(v, w2[(long)o * C + c], acc[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d);
+  const int wave = (int)(threadIdx.x >> 6);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) red[wave][o] = acc[o];
+  __syncthreads();
+  if ((int)threadIdx.x < OD) {
+    const int o = (int)threadIdx.x;
+    out[m * OD + o] = (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]) + b2[o];
+  }
+}
+
+hipError_t launch_ksplit_reduce_head(const ConvArgs &a, const float *w2, const float *b2, int out_dim, float *out, hipStream_t s) {
+  if (a.Ho * a.Wo != 1 || out_dim < 1 || out_dim > 4 || a.y_cstride != a.COUT) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ksplit_reduce_head_kernel, dim3((unsigned)a.B), dim3(256), 0, s, a.kpart, a.ksplit, (long)a.B, a.y_cstride, a.bias,
+                     a.bias_row, a.relu_out, a.y, w2, b2, out_dim, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_ksplit_reduce(const ConvArgs &a, hipStream_t s) {
   const long P = (long)a.Ho * a.Wo, M = (long)a.B * P;
   hipLaunchKernelGGL(ksplit_reduce_kernel, dim3((unsigned)((M * a.y_cstride + 255) / 256)), dim3(256), 0, s, a.kpart, a.ksplit,

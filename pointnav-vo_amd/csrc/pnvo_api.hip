@@ -766,7 +766,12 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
   {
     Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
     HIPCHK(m, launch_conv(a, s));
-    if (a.ksplit > 1) HIPCHK(m, launch_ksplit_reduce(a, s));
+    if (a.ksplit > 1 && m->head_ride_out != nullptr && P == 1 && y_cstride == l.cout) {   // the output head on the reduction launch
+      HIPCHK(m, launch_ksplit_reduce_head(a, m->head_w_plain, m->head_bias, m->cfg.out_dim, m->head_ride_out, s));
+      m->head_rode = true;
+    } else if (a.ksplit > 1) {
+      HIPCHK(m, launch_ksplit_reduce(a, s));
+    }
   }
   if (ss) {
     Timed t(m, s, "gn_finalize", 0.0, 0.0);
@@ -1111,6 +1116,7 @@ const OptDef kOptions[] = {
     {"x3_rows", "PNVO_X3_ROWS", &PnvoOptions::x3_rows, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_side", "PNVO_DS_SIDE", &PnvoOptions::ds_side, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"head_fuse", "PNVO_HEAD_FUSE", &PnvoOptions::head_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 2}, {"single", 2}, {"last", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_s2", nullptr, &PnvoOptions::x3_s2, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1493,6 +1499,7 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     pack_conv_weight_cinp(w2, c.out_dim, c.hidden, c.hidden, 1, 1, pk);
     if ((rc = upload(h, h->head.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
     if ((rc = upload(h, h->head_bias, b2, c.out_dim)) != PNVO_OK) return rc;
+    if ((rc = upload(h, h->head_w_plain, w2, (size_t)c.out_dim * c.hidden)) != PNVO_OK) return rc;
   }
   h->loaded = true;
   h->load_gen += 1;
@@ -1911,10 +1918,15 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
     if ((rc = maybe_tap(m, "compression", m->tapbuf, (size_t)B * m->fh * m->fw * m->comp_cp, s)) != PNVO_OK) return rc;
   }
   // (a11) Flatten + Linear + ReLU, then the output head
-  if ((rc = run_conv(m, m->fc, B, m->comp_raw, m->ssC[0], m->ssC[1], m->hid, c.hidden, nullptr, m->fc_bias,
-                     c.act_embed ? actions : nullptr, 1, s)) != PNVO_OK)
-    return rc;
+  // the output head rides on the hidden layer's split-K reduction when there is one (option head_fuse; not while a training step
+  // moves the weights: the plain copy of the head's weight is the loaded one)
+  m->head_rode = false;
+  m->head_ride_out = (m->opt.head_fuse && !m->features_only && m->train == nullptr && c.out_dim <= 4 && m->head_w_plain != nullptr) ? out : nullptr;
+  rc = run_conv(m, m->fc, B, m->comp_raw, m->ssC[0], m->ssC[1], m->hid, c.hidden, nullptr, m->fc_bias, c.act_embed ? actions : nullptr, 1, s);
+  m->head_ride_out = nullptr;
+  if (rc != PNVO_OK) return rc;
   if ((rc = maybe_tap(m, "hidden", m->hid, (size_t)B * c.hidden, s)) != PNVO_OK) return rc;
+  if (m->head_rode) return PNVO_OK;
   if (m->features_only) {                          // pnvo_forward_features: `out` receives the hidden vector
     HIPCHK(m, hipMemcpyAsync(out, m->hid, (size_t)B * c.hidden * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PNVO_OK;
@@ -2267,6 +2279,7 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->head.wpk);
   free_dev(m->fc_bias);
   free_dev(m->head_bias);
+  free_dev(m->head_w_plain);
   free_dev(m->stem_sc);
   free_dev(m->stem_sh);
   free_dev(m->stem_wpk16);

@@ -310,6 +310,8 @@ void choose_tile(long M, int COUTP, int *MT, int *NT);
 hipError_t launch_conv(const ConvArgs &a, hipStream_t s);
 // y = [relu](sum_z kpart[z] + bias[row]) for a split-K linear layer (a.ksplit > 1)
 hipError_t launch_ksplit_reduce(const ConvArgs &a, hipStream_t s);
+// ... with the output head (Linear COUT -> out_dim <= 4, plain [out_dim][COUT] weight + bias) computed on the reduced row: out [B][out_dim]
+hipError_t launch_ksplit_reduce_head(const ConvArgs &a, const float *w2, const float *b2, int out_dim, float *out, hipStream_t s);
 int conv_ksplit(const ConvArgs &a);   // how many K slices launch_conv would use for `a` when a.kpart is set (1: none)
 
 // LDS-staged 3x3 stride-1 kernel (conv3_lds.hip): same arguments / packing / epilogue contract as launch_conv.

@@ -44,6 +44,7 @@ struct PnvoOptions {
   int x3_rows = 1;     // 32 -> 32 channel 3x3 stride-1 convs on the row-streaming kernel (conv_rows.hip) where it takes the launch
   int x3_persist = 1;  // shallow-stage 3x3 convs on the persistent form of conv_x3 (next tile's patch fetched during the K loop)
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
+  int head_fuse = 1;   // the output head (Linear hidden -> out_dim) is computed by the hidden layer's split-K reduction launch (one launch less)
   int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
   int gn_fuse = 2;     // conv_x3 launches finalise their GroupNorm themselves (bit-identical, one launch less): 2 = launches with one tile per
                        // sample (the default, `on`); 1 = `last`: also launches with several tiles per sample, by the sample's last workgroup to
@@ -86,6 +87,9 @@ struct pnvo_model_s {
   std::vector<Layer> convs;          // stem, residual stages in execution order, compression
   Layer fc, head;
   float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
+  float *head_w_plain = nullptr;             // device [out_dim][hidden]: the head's weight as loaded (the head riding on the hidden layer's split-K reduction)
+  float *head_ride_out = nullptr;            // set around the hidden layer's launch by the forward: where the riding head writes [B][out_dim]
+  bool head_rode = false;                    //   ... and whether it did (else the forward launches the head)
   std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments (reference channel order)
   // fused stem: K-order of the stem = observation tensors concatenated (rgb | depth | dd | tdv), 2-channel pieces
   std::vector<int> stem_ref_of_new;  // new channel -> reference channel (vo_cnn.py:169-174 order), -1 = pad
