@@ -177,7 +177,10 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // (the instruction offset k * 1024 moves the LDS destination AND the memory address: pre-decremented; absent pixels: out of
         //  range -> zeros)
         const unsigned dense = (unsigned)(iD + (32 * k - 2 * (r32 + cw)) * 128), absent = ok ? 0u : 0x80000000u;
-        off[k] = (dense - 1024u * k) | absent;
+        // (a select, not `| absent`: the top-right padding corner of SAMPLE 0 has dense index 0, so dense - 1024 k is "negative", bit 31
+        //  is set either way and the instruction offset wraps it back INTO range — the pad pixel then read pixel (0, 0); masked by the
+        //  input transform in modes 1-3, visible in mode 0: found in round 6 by a tap at 300 pairs)
+        off[k] = ok ? dense - 1024u * k : 0x80000000u;
         vokn |= ok ? (1u << k) : 0u;
         if (MODE >= 2) {
           dn[k] = dense | absent;

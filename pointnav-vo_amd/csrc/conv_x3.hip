@@ -342,9 +342,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
         }
       }
     };
+    // RING (float16 pieces, no riding downsample conv): B fragments are fetched TWO steps ahead into a ring of three register sets —
+    // one step (6-18 MFMAs, 200-600 cycles) is shorter than an L2 round trip under load, and the ISA showed every step waiting for the
+    // fragments it had asked for one step earlier.  A (LDS) stays one step ahead.  The two fetches run on trackers of their own.
+    constexpr bool RING = NP == 2 && !DSF && KS == 3;
+    const char *wb_b = wb_n;                                             // RING: the B step being fetched
+    int kc_b = 0;
+    auto advanceB = [&]() {
+      wb_b += kstep;
+      if (++kc_b == kcc) {
+        kc_b = 0;
+        wb_b += (long)(kct - kcc) * kstep;
+      }
+    };
     unsigned voff[NW];                                                   // lane's byte offset inside a k-chunk of B
 #pragma unroll
     for (int j = 0; j < NW; ++j) voff[j] = (unsigned)min(wave_n * NW + j, ntt - 1) * (NP * 1024u) + (unsigned)lane * 16u;   // (N-tiles past the layer's repeat the last one)
+    auto loadBr = [&](u32x4 (*b)[NW]) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wb_b + (size_t)voff[j] + pc * 1024);
+    };
     // A fragments of M-tile i (three planes) / B fragments (three weight pieces per N-tile) of the step being fetched
     auto loadA = [&](int i, u32x4 (*a)[MW]) {
 #pragma unroll
@@ -446,6 +465,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
         __builtin_amdgcn_sched_barrier(0);
         step(a, b1);
         if (more) advance();
+      }
+    } else if (RING) {
+      // nsteps = 9 taps x kcc is a multiple of three.  Entering step t: toff_n = A offset of step t + 1 (advance() moves it; its B
+      // pointer is not used here), wb_b = B pointer of step t + 2.  Past the last step the trackers stay put (harmless re-fetches).
+      u32x4 b2[NP][NW];
+      advanceB();                                                        // (step 0 came through loadB: wb_n == wb_b there)
+      loadBr(b1);                                                        // step 1
+      advanceB();
+#pragma unroll 1
+      for (int s = 0; s < nsteps; s += 3) {
+        loadBr(b2);                                                      // step s + 2
+        if (s + 3 < nsteps) advanceB();
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b0);                                                     // multiplies step s, fetches A of step s + 1
+        advance();                                                       //   (s + 2 < nsteps always)
+        loadBr(b0);                                                      // step s + 3
+        if (s + 4 < nsteps) advanceB();
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b1);
+        if (s + 3 < nsteps) advance();
+        loadBr(b1);                                                      // step s + 4
+        if (s + 5 < nsteps) advanceB();
+        __builtin_amdgcn_sched_barrier(0);
+        step(a, b2);
+        if (s + 4 < nsteps) advance();
       }
     } else {
 #pragma unroll 1
@@ -564,7 +608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     (void)again;
   };
   emit(acc, p.y, p.stats, p.oscale_ptr, p.oscale, p.gn_gamma, p.gn_beta, p.gn_scale, p.gn_shift, p.gn_mu, p.gn_rstd, false);
-  if constexpr (DSF) emit(accd, p.ds_y, p.ds_stats, p.ds_oscale_ptr, p.ds_oscale, p.ds_gamma, p.ds_beta, p.ds_scale, p.ds_shift, nullptr, nullptr, true);
+  if constexpr (DSF) emit(accd, p.ds_y, p.ds_stats, p.ds_oscale_ptr, p.ds_oscale, p.ds_gamma, p.ds_beta, p.ds_scale, p.ds_shift, p.ds_mu, p.ds_rstd, true);
   if (p.stats != nullptr && p.gn_ctr != nullptr) {                        // several tiles per sample: the last one to arrive finalises
     if (gn_last_arrival(p.gn_ctr + (long)n * gridDim.y + blockIdx.y, (unsigned)p.slots, reinterpret_cast<int *>(lds + 4096))) {
       const int nt0 = (int)blockIdx.y * wn * NW, nt1 = min(nt0 + wn * NW, ntt);
@@ -575,7 +619,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
                                p.gn_mu ? p.gn_rstd + (long)n * NG + g : nullptr);
         if (DSF)
           gn_finalize_group_wave(p.ds_stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, p.ds_gamma,
-                                 p.ds_beta, p.ds_scale + (long)n * p.COUTP, p.ds_shift + (long)n * p.COUTP, nullptr, nullptr);
+                                 p.ds_beta, p.ds_scale + (long)n * p.COUTP, p.ds_shift + (long)n * p.COUTP, p.ds_mu ? p.ds_mu + (long)n * NG + g : nullptr,
+                                 p.ds_mu ? p.ds_rstd + (long)n * NG + g : nullptr);
       }
     }
   }

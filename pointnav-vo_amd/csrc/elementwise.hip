@@ -144,18 +144,16 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
 // blockIdx.y selects the set; the arithmetic of each is gn_finalize_kernel's.
 struct GnFinPair {
   const float *stats[2], *gamma[2], *beta[2];
-  float *scale[2], *shift[2];
+  float *scale[2], *shift[2], *mu[2], *rstd[2];
 };
-__global__ __launch_bounds__(64) void gn_finalize_pair_kernel(const GnFinPair q, int slots, int CP, int C, int G, long P, float eps,
-                                                             float *mu_out, float *rstd_out) {
+__global__ __launch_bounds__(64) void gn_finalize_pair_kernel(const GnFinPair q, int slots, int CP, int C, int G, long P, float eps) {
   const int z = blockIdx.y;
-  gn_finalize_block(q.stats[z], slots, CP, C, G, P, 1, q.gamma[z], q.beta[z], eps, q.scale[z], q.shift[z], slots, z == 0 ? mu_out : nullptr,
-                    z == 0 ? rstd_out : nullptr);
+  gn_finalize_block(q.stats[z], slots, CP, C, G, P, 1, q.gamma[z], q.beta[z], eps, q.scale[z], q.shift[z], slots, q.mu[z], q.rstd[z]);
 }
 
 hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
-                                   const float *const *beta, float eps, float *const *scale, float *const *shift, float *mu_out,
-                                   float *rstd_out, hipStream_t s) {
+                                   const float *const *beta, float eps, float *const *scale, float *const *shift, float *const *mu_out,
+                                   float *const *rstd_out, hipStream_t s) {
   GnFinPair q;
   for (int z = 0; z < 2; ++z) {
     q.stats[z] = stats[z];
@@ -163,8 +161,10 @@ hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, 
     q.beta[z] = beta[z];
     q.scale[z] = scale[z];
     q.shift[z] = shift[z];
+    q.mu[z] = mu_out[z];
+    q.rstd[z] = rstd_out[z];
   }
-  hipLaunchKernelGGL(gn_finalize_pair_kernel, dim3((unsigned)(B * G), 2u), dim3(64), 0, s, q, slots, CP, C, G, P, eps, mu_out, rstd_out);
+  hipLaunchKernelGGL(gn_finalize_pair_kernel, dim3((unsigned)(B * G), 2u), dim3(64), 0, s, q, slots, CP, C, G, P, eps);
   return hipGetLastError();
 }
 

@@ -696,6 +696,8 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         xa.ds_beta = ride->cd->beta;
         xa.ds_scale = ride->ss[0];
         xa.ds_shift = ride->ss[1];
+        xa.ds_mu = ride->mu;
+        xa.ds_rstd = ride->rstd;
       }
       if (fuse || fuse_last) {
         xa.gn_gamma = l.gamma;
@@ -720,7 +722,8 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
       if (ride != nullptr) {             // the conv's GroupNorm and the riding downsample conv's in one launch
         const float *st2[2] = {m->stats, m->stats_ds}, *ga2[2] = {l.gamma, ride->cd->gamma}, *be2[2] = {l.beta, ride->cd->beta};
         float *sc2[2] = {ss[0], ride->ss[0]}, *sh2[2] = {ss[1], ride->ss[1]};
-        HIPCHK(m, launch_gn_finalize_pair(st2, B, xa.slots, l.coutp, l.cout, l.groups, P, ga2, be2, 1e-5f, sc2, sh2, mu_out, rstd_out, s));
+        float *mu2[2] = {mu_out, ride->mu}, *rs2[2] = {rstd_out, ride->rstd};
+        HIPCHK(m, launch_gn_finalize_pair(st2, B, xa.slots, l.coutp, l.cout, l.groups, P, ga2, be2, 1e-5f, sc2, sh2, mu2, rs2, s));
         return PNVO_OK;
       }
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
@@ -767,7 +770,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     Timed t(m, s, "conv:" + l.name, 2.0 * macs, bytes);
     HIPCHK(m, launch_conv(a, s));
     if (a.ksplit > 1 && m->head_ride_out != nullptr && P == 1 && y_cstride == l.cout) {   // the output head on the reduction launch
-      HIPCHK(m, launch_ksplit_reduce_head(a, m->head_w_plain, m->head_bias, m->cfg.out_dim, m->head_ride_out, s));
+      HIPCHK(m, launch_ksplit_reduce_head(a, m->head_ride_w, m->head_bias, m->cfg.out_dim, m->head_ride_out, s));
       m->head_rode = true;
     } else if (a.ksplit > 1) {
       HIPCHK(m, launch_ksplit_reduce(a, s));
@@ -1830,7 +1833,7 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       // the block's downsample conv rides on c1's launch (conv_x3_kernel DSF): no launch, no finalisation of its own, and in the
       // block-tail mode the block input is not written to HBM at all — c1 and the downsample conv are its only readers
       const bool ds_ride = ds && !have_keys && pnvo_conv_takes_ds(m, c1, m->convs[li], B);
-      const DsRide ride{ds_ride ? &m->convs[li] : nullptr, m->rawD, m->ssD};
+      const DsRide ride{ds_ride ? &m->convs[li] : nullptr, m->rawD, m->ssD, nullptr, nullptr};
       if (have_keys) {           // pooled stem keys in `nxt`: decoded + normalised by this conv's stager, activations -> `cur`
         BlockTail keys{nullptr, nullptr, nullptr, cur};
         if ((rc = pnvo_run_conv(m, c1, B, nxt, m->ssA[0], m->ssA[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
@@ -1918,10 +1921,11 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
     if ((rc = maybe_tap(m, "compression", m->tapbuf, (size_t)B * m->fh * m->fw * m->comp_cp, s)) != PNVO_OK) return rc;
   }
   // (a11) Flatten + Linear + ReLU, then the output head
-  // the output head rides on the hidden layer's split-K reduction when there is one (option head_fuse; not while a training step
-  // moves the weights: the plain copy of the head's weight is the loaded one)
+  // the output head rides on the hidden layer's split-K reduction when there is one (option head_fuse); with a training step attached
+  // the head's weight is read where the optimiser keeps it (the flat parameter buffer), the bias from its re-packed copy
   m->head_rode = false;
-  m->head_ride_out = (m->opt.head_fuse && !m->features_only && m->train == nullptr && c.out_dim <= 4 && m->head_w_plain != nullptr) ? out : nullptr;
+  m->head_ride_w = m->train != nullptr ? pnvo_train_weight_ptr(m, "output_head.1.weight") : m->head_w_plain;   // (OIHW of a 1x1 conv = [out_dim][hidden])
+  m->head_ride_out = (m->opt.head_fuse && !m->features_only && c.out_dim <= 4 && m->head_ride_w != nullptr) ? out : nullptr;
   rc = run_conv(m, m->fc, B, m->comp_raw, m->ssC[0], m->ssC[1], m->hid, c.hidden, nullptr, m->fc_bias, c.act_embed ? actions : nullptr, 1, s);
   m->head_ride_out = nullptr;
   if (rc != PNVO_OK) return rc;

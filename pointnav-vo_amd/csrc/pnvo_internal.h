@@ -174,6 +174,7 @@ struct ConvX3Args {
   const float *ds_oscale_ptr;
   const float *ds_gamma, *ds_beta;
   float *ds_scale, *ds_shift;
+  float *ds_mu, *ds_rstd;            // [B,groups] for a backward pass, or nullptr
 };
 #if defined(__HIPCC__)
 // One lane = one channel of a sample, lanes of a group adjacent and aligned: GroupNorm scale / shift from the channel's complete
@@ -331,8 +332,8 @@ hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int 
 
 // Two GroupNorms of one geometry in one launch (fixed slots per sample), each in gn_finalize_kernel's arithmetic; mu / rstd of set 0.
 hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
-                                   const float *const *beta, float eps, float *const *scale, float *const *shift, float *mu_out,
-                                   float *rstd_out, hipStream_t s);
+                                   const float *const *beta, float eps, float *const *scale, float *const *shift, float *const *mu_out,
+                                   float *const *rstd_out, hipStream_t s);
 hipError_t launch_gn_finalize2(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
                                const float *const *beta, float eps, float *const *scale, float *const *shift, int nmodels,
                                hipStream_t s);

@@ -88,6 +88,7 @@ struct pnvo_model_s {
   Layer fc, head;
   float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
   float *head_w_plain = nullptr;             // device [out_dim][hidden]: the head's weight as loaded (the head riding on the hidden layer's split-K reduction)
+  const float *head_ride_w = nullptr;        // ... the weight it reads: head_w_plain, or the flat parameter buffer of an attached training step
   float *head_ride_out = nullptr;            // set around the hidden layer's launch by the forward: where the riding head writes [B][out_dim]
   bool head_rode = false;                    //   ... and whether it did (else the forward launches the head)
   std::vector<float> mean, stdev;    // host copies for the assemble kernel arguments (reference channel order)
@@ -211,6 +212,7 @@ struct DsRide {
   const Layer *cd;
   float *y;
   float *const *ss;
+  float *mu, *rstd;      // [B,groups] statistics of the downsample GroupNorm for a backward pass, or nullptr
 };
 
 // helpers implemented in pnvo_api.hip

@@ -985,17 +985,26 @@ static int train_forward_body(pnvo_handle m, const float *rgb, const float *dept
       size_t ik[3];
       for (int k = 0; k < K; ++k) ik[k] = li++;
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
+      // the block's downsample conv rides on its first conv's launch (conv_x3_kernel DSF); the block input stays in memory here —
+      // the backward pass reads it
+      const bool ds_ride = ds && K == 2 && pnvo_conv_takes_ds(m, m->convs[ik[0]], m->convs[li], B);
+      DsRide ride{nullptr, nullptr, nullptr, nullptr, nullptr};
+      if (ds_ride) {
+        ConvSave &sd = t->cs[li];
+        ride = DsRide{&m->convs[li], sd.raw, sd.ss, sd.mu, sd.rstd};
+      }
       for (int k = 0; k < K; ++k) {
         const Layer &ck = m->convs[ik[k]];
         ConvSave &sk = t->cs[ik[k]];
         const ConvSave *sp = k ? &t->cs[ik[k - 1]] : nullptr;
+        const DsRide *rd = (k == 0 && ds_ride) ? &ride : nullptr;
         if (k == 0 && have_tail) {       // the previous block's tail rides on this conv's stager, which writes xin (= tail.out)
           rc = pnvo_run_conv(m, ck, B, tail_x->raw, tail_x->ss[0], tail_x->ss[1], sk.raw, ck.coutp, sk.ss, nullptr, nullptr, 0, s, nullptr,
-                             sk.mu, sk.rstd, &tail);
+                             sk.mu, sk.rstd, &tail, rd);
           have_tail = false;
         } else {
           rc = pnvo_run_conv(m, ck, B, k ? sp->raw : xin, k ? sp->ss[0] : nullptr, k ? sp->ss[1] : nullptr, sk.raw, ck.coutp, sk.ss, nullptr,
-                             nullptr, 0, s, nullptr, sk.mu, sk.rstd);
+                             nullptr, 0, s, nullptr, sk.mu, sk.rstd, nullptr, rd);
         }
         if (rc != PNVO_OK) return rc;
       }
@@ -1006,8 +1015,8 @@ static int train_forward_body(pnvo_handle m, const float *rgb, const float *dept
         const size_t id = li++;
         const Layer &cd = m->convs[id];
         ConvSave &sd = t->cs[id];
-        if ((rc = pnvo_run_conv(m, cd, B, xin, nullptr, nullptr, sd.raw, cd.coutp, sd.ss, nullptr, nullptr, 0, s, nullptr,
-                                sd.mu, sd.rstd)) != PNVO_OK)
+        if (!ds_ride && (rc = pnvo_run_conv(m, cd, B, xin, nullptr, nullptr, sd.raw, cd.coutp, sd.ss, nullptr, nullptr, 0, s, nullptr,
+                                            sd.mu, sd.rstd)) != PNVO_OK)
           return rc;
         tail = BlockTail{sd.raw, sd.ss[0], sd.ss[1], yout};
       } else {

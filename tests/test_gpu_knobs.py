@@ -579,8 +579,9 @@ def test_downsample_ride_on_an_odd_resolution_and_with_taps():
         torch.cuda.synchronize()
     rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
     assert rel < 2e-6, rel
-    # (the tap's plain schedule also swaps the fused pool / block tails / row-streaming kernels for their separate passes)
-    assert float((out_tap - outs["on"]).abs().max() / outs["on"].abs().max()) < 2e-5
+    # (the tap's plain schedule also swaps the fused pool / block tails for their separate passes and runs the row-streaming kernel in
+    #  its plain-input mode 0 — where round 6 found sample 0's top-right padding corner reading pixel (0, 0): 5e-3 on that sample)
+    assert float((out_tap - outs["on"]).abs().max() / outs["on"].abs().max()) < 1e-5
     ref = oracle.forward(sd, {k: v[:3] for k, v in obs.items()}, ngroups=m.cfg.ngroups, dtype=np.float64)
     got = outs["on"][:3].double().cpu().numpy()
     err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
