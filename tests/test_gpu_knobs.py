@@ -586,3 +586,26 @@ def test_downsample_ride_on_an_odd_resolution_and_with_taps():
     got = outs["on"][:3].double().cpu().numpy()
     err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
     assert err.max() < 2e-5, err
+
+
+def test_narrow_models_are_refused_not_mis_served():
+    """ADVICE r5 asked for a resnet_baseplanes = 16 model: its layer2 would be a 32 -> 32 channel stage whose second block takes a block
+    tail with a DOWNSAMPLE skip (res * scale + shift), which conv_rows32_kernel's block-tail mode does not apply.  conv_rows32_plan now
+    sees the tail's fields before it decides (csrc/pnvo_api.hip) — and such a model cannot reach it in the first place: pnvo_create
+    refuses base widths below 32 (every registered reference variant has 32 or 64, vo_cnn.py:236-561) with an error, never a fallback."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from pointnav_vo_amd import _lib, model_spec as ms, synth
+    from pointnav_vo_amd.registry import baseline_registry
+    dev = torch.device("cuda", 0)
+    m = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+        observation_space=bench.SPACE, observation_size=(101, 75), hidden_size=512, backbone="resnet18", resnet_baseplanes=16,
+        normalize_visual_inputs=True, output_dim=3, dropout_p=0.2, discretized_depth_channels=10)
+    sd = synth.make_state_dict(ms.state_dict_spec(m.cfg), seed=2)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    obs = synth.make_obs_pairs(2, 75, 101, observation_space=bench.SPACE, dd_bins=10, seed=4)
+    with pytest.raises(_lib.PnvoError, match="baseplanes"):
+        with torch.no_grad():
+            m.to(dev).eval()({k: torch.from_numpy(v).to(dev) for k, v in obs.items()})
