@@ -1058,6 +1058,12 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
     if (TR < 1) return false;
     if (TR > a.Ho) TR = a.Ho;
     while (TR > 1 && TR * TC > (ntt == 2 ? 64 : (ntt == 4 ? 128 : 96))) --TR;    // M-tiles the wave grid below covers
+  } else if (ntt == 1 && stride == 1 && ks == 3 && a.CIN > 32 && a.np == 2 && a.Wo < 32 && a.Ho * a.Wo <= 128) {
+    // one N-tile behind MANY input channels on a small map (the compression conv, vo_cnn.py:76-101: 256 -> 31 channels on 6 x 11):
+    // the whole map is one tile, the four waves along M with one M-tile each (round 6; it ran on the fp32 pipe at 60 TFLOP/s —
+    // no A reuse with a single N-tile, but three float16 MFMAs per K = 16 are still five times less pipe time than eight fp32 ones)
+    TC = a.Wo;
+    TR = a.Ho;
   } else if (ntt == 1) {
     // one N-tile (32 output channels): all four waves along M, two M-tiles each -> 16 x 16 outputs (18 x 18 patch = 76 KB)
     if (stride != 1 || ks != 3 || a.CIN != 32) return false;
@@ -1106,7 +1112,7 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
     if (*mw < 5) *mw = 5;                                          // (one instantiation)
   } else if (ntt == 1) {
     a.wn = 1;
-    *mw = 2;
+    *mw = a.CIN > 32 ? 1 : 2;
     *nw = 1;
   } else if (ntt == 2) {
     a.wn = 2;

@@ -470,6 +470,7 @@ void pnvo_chain_in_bounds(pnvo_handle h, const std::function<float(const Layer &
       }
       bin = gn_bound(c2) + skip;
     }
+  if (li < h->convs.size()) h->convs[li].in_bound = bin;      // the compression conv reads the last block's output
 }
 
 namespace {
@@ -1892,8 +1893,8 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
           return rc;
         }
       }
-      const bool last = stage == 4 && bi + 1 == m->nblocks[3];
-      if (!last && pnvo_conv_takes_tail(m, m->convs[li], B)) {   // relu(GN2(conv2) + skip): computed by the next block's first conv
+      // (the last block's tail rides on the compression conv when that runs on conv_x3_kernel: nobody else reads that block output)
+      if (li < m->convs.size() && pnvo_conv_takes_tail(m, m->convs[li], B)) {   // relu(GN2(conv2) + skip): computed by the next conv's stager
         tail.res = ds ? m->rawD : cur;
         tail.res_scale = ds ? m->ssD[0] : nullptr;
         tail.res_shift = ds ? m->ssD[1] : nullptr;
@@ -1914,8 +1915,15 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
 
   // (a10) compression conv + GroupNorm(1, C)
   const Layer &comp = m->convs[li++];
-  if ((rc = run_conv(m, comp, B, cur, nullptr, nullptr, m->comp_raw, comp.coutp, m->ssC, nullptr, nullptr, 0, s)) != PNVO_OK)
+  if (have_tail) {               // the last block's tail in the compression conv's stager; its output is not materialised
+    tail.out = nullptr;
+    if ((rc = pnvo_run_conv(m, comp, B, m->rawB, m->ssB[0], m->ssB[1], m->comp_raw, comp.coutp, m->ssC, nullptr, nullptr, 0, s, nullptr, nullptr,
+                            nullptr, &tail)) != PNVO_OK)
+      return rc;
+    have_tail = false;
+  } else if ((rc = run_conv(m, comp, B, cur, nullptr, nullptr, m->comp_raw, comp.coutp, m->ssC, nullptr, nullptr, 0, s)) != PNVO_OK) {
     return rc;
+  }
   if (m->tap_dst != nullptr && m->tap_name == "compression") {
     HIPCHK(m, launch_apply_ss_relu(m->comp_raw, m->ssC[0], m->ssC[1], B, (long)m->fh * m->fw, m->comp_cp, m->tapbuf, s));
     if ((rc = maybe_tap(m, "compression", m->tapbuf, (size_t)B * m->fh * m->fw * m->comp_cp, s)) != PNVO_OK) return rc;
