@@ -269,6 +269,9 @@ void free_workspace(pnvo_model_s *m) {
   free_dev(m->stats);
   free_dev(m->gn_ctr);
   free_dev(m->stats_ds);
+  if (m->keys_stream) (void)hipStreamSynchronize(m->keys_stream);     // a fill of the key buffer may still be in flight
+  free_dev(m->pool_keys);
+  m->keys_primed = false;
   for (int k = 0; k < 2; ++k) {
     free_dev(m->ssA[k]);
     free_dev(m->ssB[k]);
@@ -360,6 +363,7 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   HIPCHK(m, alloc(m->stats, st));
   m->stats_floats = st;
   HIPCHK(m, alloc(m->stats_ds, st));
+  HIPCHK(m, alloc(m->pool_keys, (size_t)B * m->Hp * m->Wp * m->convs[0].coutp));
   HIPCHK(m, alloc(m->gn_ctr, (size_t)B * 16));
   HIPCHK(m, hipMemset(m->gn_ctr, 0, (size_t)B * 16 * sizeof(float)));
   for (int k = 0; k < 2; ++k) {
@@ -1120,6 +1124,7 @@ const OptDef kOptions[] = {
     {"x3_rows", "PNVO_X3_ROWS", &PnvoOptions::x3_rows, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_side", "PNVO_DS_SIDE", &PnvoOptions::ds_side, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"pool_async", "PNVO_POOL_ASYNC", &PnvoOptions::pool_async, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"head_fuse", "PNVO_HEAD_FUSE", &PnvoOptions::head_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 2}, {"single", 2}, {"last", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1731,6 +1736,16 @@ bool side_stream_ready(pnvo_handle m, hipStream_t s) {
   return true;
 }
 
+// Stream + events of option pool_async (lazily; not while `s` is being captured: a graph keeps the fill in-stream).
+bool keys_stream_ready(pnvo_handle m, hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  if (!m->keys_stream && hipStreamCreateWithFlags(&m->keys_stream, hipStreamNonBlocking) != hipSuccess) return false;
+  if (!m->keys_free_ev && hipEventCreateWithFlags(&m->keys_free_ev, hipEventDisableTiming) != hipSuccess) return false;
+  if (!m->keys_ready_ev && hipEventCreateWithFlags(&m->keys_ready_ev, hipEventDisableTiming) != hipSuccess) return false;
+  return true;
+}
+
 int forward_body(pnvo_handle m, const float *rgb, const float *depth, const float *dd, const float *tdv,
                  const int64_t *actions, int B, float *out, hipStream_t s) {
   const pnvo_config &c = m->cfg;
@@ -1768,6 +1783,8 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
                           stem.coutp == stem.cout && pnvo_conv_takes_tail(m, m->convs[1], B);
   // Batches of the navigation loop (one or two pairs): everything behind the stem conv is ONE persistent launch (smallnet.hip),
   // which also reduces the stem's GroupNorm statistics itself.
+  float *keys = nxt;             // where the pooled keys live: the ping-pong buffer, or (pool_async) a buffer of their own
+  bool keys_async = false;
   const bool small = !pool_fused && stem_writes_slots(m) && pnvo_small_usable(m, B);
   if (small) {
     const float *src[4] = {rgb, depth, dd, tdv};
@@ -1780,10 +1797,17 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   {
     const float *src[4] = {rgb, depth, dd, tdv};
     if (pool_fused) {
-      Timed t(m, s, "pool_init", 0.0, 4.0 * B * m->Hp * m->Wp * stem.coutp);
-      HIPCHK(m, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nxt), STEM_POOL_INIT, (size_t)B * m->Hp * m->Wp * stem.coutp, s));
+      const size_t nkeys = (size_t)B * m->Hp * m->Wp * stem.coutp;
+      keys_async = m->opt.pool_async && !m->timing && m->pool_keys != nullptr && keys_stream_ready(m, s);
+      keys = keys_async ? m->pool_keys : nxt;
+      if (keys_async && m->keys_primed) HIPCHK(m, hipStreamWaitEvent(s, m->keys_ready_ev, 0));   // the fill enqueued behind the last forward
+      if (!(keys_async && m->keys_primed && m->keys_primed_B >= B)) {
+        Timed t(m, s, "pool_init", 0.0, 4.0 * B * m->Hp * m->Wp * stem.coutp);
+        HIPCHK(m, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(keys), STEM_POOL_INIT, nkeys, s));
+      }
+      if (keys_async) m->keys_primed = false;
     }
-    if ((rc = pnvo_run_stem(m, B, src, m->stem_raw, m->ssA, nullptr, nullptr, s, pool_fused ? reinterpret_cast<int *>(nxt) : nullptr)) !=
+    if ((rc = pnvo_run_stem(m, B, src, m->stem_raw, m->ssA, nullptr, nullptr, s, pool_fused ? reinterpret_cast<int *>(keys) : nullptr)) !=
         PNVO_OK)
       return rc;
   }
@@ -1828,6 +1852,17 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
         if ((rc = maybe_tap(m, tnb.c_str(), cur, (size_t)B * Pb * b3.coutp, s)) != PNVO_OK) return rc;
         continue;
       }
+      if (keys_async && !m->keys_primed && (stage >= 3 || (stage == 2 && m->nblocks[2] + m->nblocks[3] == 0))) {
+        // the keys were consumed two stages ago: their fill for the NEXT forward goes to the key stream now, next to the MFMA-bound
+        // deep stages of this one (the first stage's convs are HBM-bound themselves)
+        HIPCHK(m, hipEventRecord(m->keys_free_ev, s));
+        HIPCHK(m, hipStreamWaitEvent(m->keys_stream, m->keys_free_ev, 0));
+        HIPCHK(m, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->pool_keys), STEM_POOL_INIT, (size_t)B * m->Hp * m->Wp * stem.coutp,
+                                    m->keys_stream));
+        HIPCHK(m, hipEventRecord(m->keys_ready_ev, m->keys_stream));
+        m->keys_primed = true;
+        m->keys_primed_B = B;
+      }
       const Layer &c1 = m->convs[li++];
       const Layer &c2 = m->convs[li++];
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
@@ -1836,9 +1871,9 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       const bool ds_ride = ds && !have_keys && pnvo_conv_takes_ds(m, c1, m->convs[li], B);
       const DsRide ride{ds_ride ? &m->convs[li] : nullptr, m->rawD, m->ssD, nullptr, nullptr};
       if (have_keys) {           // pooled stem keys in `nxt`: decoded + normalised by this conv's stager, activations -> `cur`
-        BlockTail keys{nullptr, nullptr, nullptr, cur};
-        if ((rc = pnvo_run_conv(m, c1, B, nxt, m->ssA[0], m->ssA[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
-                                nullptr, &keys)) != PNVO_OK)
+        BlockTail ktail{nullptr, nullptr, nullptr, cur};
+        if ((rc = pnvo_run_conv(m, c1, B, keys, m->ssA[0], m->ssA[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
+                                nullptr, &ktail)) != PNVO_OK)
           return rc;
         have_keys = false;
       } else if (have_tail) {    // the previous block's tail rides on this conv's stager, which also writes the block output
@@ -2276,6 +2311,12 @@ int pnvo_destroy(pnvo_handle m) {
   free_workspace(m);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   if (m->stem_ev) (void)hipEventDestroy(m->stem_ev);
+  if (m->keys_stream) {
+    (void)hipStreamSynchronize(m->keys_stream);
+    (void)hipStreamDestroy(m->keys_stream);
+  }
+  if (m->keys_free_ev) (void)hipEventDestroy(m->keys_free_ev);
+  if (m->keys_ready_ev) (void)hipEventDestroy(m->keys_ready_ev);
   if (m->side_fork) (void)hipEventDestroy(m->side_fork);
   if (m->side_join) (void)hipEventDestroy(m->side_join);
   if (m->side_stream) (void)hipStreamDestroy(m->side_stream);

@@ -44,6 +44,8 @@ struct PnvoOptions {
   int x3_rows = 1;     // 32 -> 32 channel 3x3 stride-1 convs on the row-streaming kernel (conv_rows.hip) where it takes the launch
   int x3_persist = 1;  // shallow-stage 3x3 convs on the persistent form of conv_x3 (next tile's patch fetched during the K loop)
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
+  int pool_async = 0;  // pooled-key buffer of its own, re-initialised for the next forward on a side stream (see pool_keys).  OFF: measured
+                       // slower at every batch (8 pairs 0.44 -> 0.50 ms, 256 pairs 2.37 -> 2.41): the two event hand-overs cost more than the 23 us fill
   int head_fuse = 1;   // the output head (Linear hidden -> out_dim) is computed by the hidden layer's split-K reduction launch (one launch less)
   int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
   int gn_fuse = 2;     // conv_x3 launches finalise their GroupNorm themselves (bit-identical, one launch less): 2 = launches with one tile per
@@ -134,6 +136,14 @@ struct pnvo_model_s {
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   float *stats_side = nullptr;               // the side stream's GroupNorm partials (the main stream's conv writes m->stats meanwhile)
   size_t stats_side_floats = 0, stats_floats = 0;
+  // option pool_async: the pooled stem keys live in a buffer of their own, and their re-initialisation for the NEXT forward (a 135 MB
+  // fill at 256 pairs, 23 us on the critical path before the stem) runs on a stream of its own behind this forward's consumer of the
+  // keys, next to the MFMA-bound deep stages; the next forward's stem waits for it through an event (no host wait)
+  float *pool_keys = nullptr;                // [cap][Hp][Wp][baseplanes] int32 keys
+  hipStream_t keys_stream = nullptr;
+  hipEvent_t keys_free_ev = nullptr, keys_ready_ev = nullptr;
+  bool keys_primed = false;                  // the fill for the next forward is enqueued (keys_ready_ev recorded behind it)
+  int keys_primed_B = 0;                     //   ... for this many pairs
   float *stats_ds = nullptr;                 // GroupNorm partials of a downsample conv riding on its block's first conv (stats_floats)
   float *gn_ctr = nullptr;                   // [cap][16] unsigned arrival counters of the in-kernel GroupNorm finalisation (zero between launches)
   hipEvent_t stem_ev = nullptr;              // recorded behind a contract-checking stem launch (pnvo_mark_stem)

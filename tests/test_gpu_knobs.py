@@ -609,3 +609,39 @@ def test_narrow_models_are_refused_not_mis_served():
     with pytest.raises(_lib.PnvoError, match="baseplanes"):
         with torch.no_grad():
             m.to(dev).eval()({k: torch.from_numpy(v).to(dev) for k, v in obs.items()})
+
+
+def test_pooled_keys_refilled_on_a_side_stream_are_bit_identical():
+    """Option pool_async (round 6; OFF by default — bit-identical but measured slower: the event hand-overs between the streams cost more
+    than the 23 us fill they hide): the pooled stem keys live in a buffer of their own whose re-initialisation for the NEXT
+    forward runs on a side stream behind this forward's consumer (next to the deep stages) instead of in front of the next stem.
+    Same kernels, same arithmetic: outputs bit-identical to the in-stream fill, over repeated forwards, batches that grow and shrink
+    between calls (a fill sized for the smaller batch must not be trusted for the larger one), changing inputs, a timed forward
+    in between (which fills in-stream), and back-to-back forwards without any host synchronisation."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    obs_all = bench.make_inputs(96, dev, 5)
+    seq = [64, 64, 16, 96, 8, 96, 33, 64]
+    def run(mode):
+        model.set_option("pool_async", mode)
+        outs = []
+        with torch.no_grad():
+            for i, B in enumerate(seq):
+                o = {k: v[(i % 3):(i % 3) + B].contiguous() if (i % 3) + B <= 96 else v[:B].contiguous() for k, v in obs_all.items()}
+                outs.append(model(o).clone())
+                if i == 4:
+                    model.timing(True)
+                    outs.append(model(o).clone())
+                    model.timing_read()
+                    model.timing(False)
+            for _ in range(6):                           # a backlog of forwards, no synchronisation in between
+                last = model(o)
+            outs.append(last.clone())
+        torch.cuda.synchronize()
+        return outs
+    a, b, c = run("on"), run("off"), run("on")
+    assert all(torch.isfinite(x).all() for x in a)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(a, c))
