@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     // RING (float16 pieces, no riding downsample conv): B fragments are fetched TWO steps ahead into a ring of three register sets —
     // one step (6-18 MFMAs, 200-600 cycles) is shorter than an L2 round trip under load, and the ISA showed every step waiting for the
     // fragments it had asked for one step earlier.  A (LDS) stays one step ahead.  The two fetches run on trackers of their own.
-    constexpr bool RING = NP == 2 && !DSF && KS == 3;
+    constexpr bool RING = NP == 2 && KS == 3;
     const char *wb_b = wb_n;                                             // RING: the B step being fetched
     int kc_b = 0;
     auto advanceB = [&]() {
@@ -377,8 +377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     };
     // One step: M-tile by M-tile; as soon as an M-tile's MFMAs are issued its A registers take the NEXT step's fragments, so
     // the LDS latency hides behind the other M-tiles' MFMAs
-    // DSF: `bd` != nullptr on the centre tap's steps — the downsample conv's MFMAs on the same A fragments, before they are replaced
-    auto step = [&](u32x4 (*a)[MW], const u32x4 (*b)[NW], const u32x4 (*bd)[NW] = nullptr) {
+    auto step = [&](u32x4 (*a)[MW], const u32x4 (*b)[NW]) {
 #pragma unroll
       for (int i = 0; i < MW; ++i) {
 #pragma unroll
@@ -389,13 +388,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
             for (int t = 0; t < 3; ++t)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
                                                                  __builtin_bit_cast(f16x8, b[TB[t]][j]), acc[i][j], 0, 0, 0);
-            if (DSF && bd != nullptr) {
-#pragma unroll
-              for (int t = 0; t < 3; ++t)
-                accd[DSF ? i : 0][DSF ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[TA[t]][i]),
-                                                                                        __builtin_bit_cast(f16x8, bd[TB[t]][j]),
-                                                                                        accd[DSF ? i : 0][DSF ? j : 0], 0, 0, 0);
-            }
           } else {
             // smallest terms first: a1 w1, a2 w0, a0 w2, a1 w0, a0 w1, a0 w0
             constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
@@ -411,85 +403,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
       }
     };
     u32x4 a[NP][MW], b0[NP][NW], b1[NP][NW];
-    // DSF: B fragments of the downsample conv for the centre tap's steps [4 kcc, 5 kcc) (an even range: kcc is even), fetched one
-    // iteration ahead; layout = a 1x1 conv's operand, [k-chunk][N-tile][piece][lane][8]
-    u32x4 bd[DSF ? NP : 1][NW];
-    auto loadBd = [&](int kc) {
+    // DSF: the riding downsample conv multiplies BEHIND the nine taps of the chunk (ds_tail below): the centre tap's A fragments are read
+    // from LDS once more — kcc steps — so the main K loop is the plain one (and takes the B ring).  Its B fragments: a 1x1 conv's
+    // operand, [k-chunk][N-tile][piece][lane][8]; those of the chunk's first k-chunk are fetched before the main loop.
+    u32x4 bd0[DSF ? NP : 1][NW], bd1[DSF ? NP : 1][NW];
+    auto loadBd = [&](u32x4 (*b)[NW], int kc) {
       const char *wd = reinterpret_cast<const char *>(p.ds_wpk) + (long)((ck0 >> 4) + kc) * kstep;
 #pragma unroll
       for (int j = 0; j < NW; ++j)
 #pragma unroll
-        for (int pc = 0; pc < NP; ++pc) bd[pc][j] = *reinterpret_cast<const u32x4 *>(wd + (size_t)voff[j] + pc * 1024);
+        for (int pc = 0; pc < NP; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wd + (size_t)voff[j] + pc * 1024);
     };
+    if (DSF) loadBd(bd0, 0);
     loadB(b0);
 #pragma unroll
     for (int i = 0; i < MW; ++i) loadA(i, a);
     advance();                                                           // -> step 1
-    if (DSF) {
-      // three plain loops instead of a test per iteration (a branch inside the loop made the register allocator ping-pong the
-      // accumulators between two register blocks): the taps before the centre one, the centre tap with the riding MFMAs, the rest
-      const int sc0 = 4 * kcc, sc1 = 5 * kcc;
-#pragma unroll 1
-      for (int s = 0; s < sc0; s += 2) {
-        loadB(b1);
-        if (s + 2 == sc0) loadBd(0);                                     // the centre tap's first fragments, one iteration ahead
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b0);
-        advance();
-        loadB(b0);
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b1);
-        advance();
+    if (RING) {
+      // nsteps = 9 taps x kcc (kcc = 2, 4, 8) is a multiple of 3 and of 6.  Ring of R register sets, B fetched R - 1 steps ahead: small
+      // wave tiles have short steps (a (1,1) tile: three MFMAs = 96 cycles against an L2 round trip of several hundred — the fine plan's
+      // launches and the compression conv ran at a third of the pipe rate waiting for fragments), so they look further ahead.
+      // Entering step t: toff_n = A offset of step t + 1 (advance() moves it; its B pointer is not used here), wb_b = B pointer of step
+      // t + R - 1.  Past the last step the trackers stay put (harmless re-fetches of the last step).
+      constexpr int R = MW * NW <= 2 ? 6 : 3;
+      u32x4 br[R][NP][NW];
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) br[0][pc][j] = b0[pc][j];           // step 0 came through loadB (wb_n == wb_b there)
+#pragma unroll
+      for (int q = 1; q < R - 1; ++q) {
+        advanceB();
+        loadBr(br[q]);                                                   // steps 1 .. R - 2
+      }
+      advanceB();                                                        // -> step R - 1
+      // Small wave tiles also fetch A (LDS) TWO steps ahead, into two register sets used by the even / odd steps: with one M-tile a step
+      // is three MFMAs = 96 cycles, less than an LDS read under load (measured: 63 cycles per MFMA with A one step ahead).
+      constexpr bool A2 = MW * NW <= 2;
+      u32x4 a1[A2 ? NP : 1][MW];
+      if (A2) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) loadA(i, a1);                        // step 1 (toff_n is there); `a` holds step 0
+        advance();                                                       // -> step 2
       }
 #pragma unroll 1
-      for (int s = sc0; s < sc1; s += 2) {
-        loadB(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b0, bd);
-        loadBd(s + 1 - sc0);                                             // one set, refilled a step ahead (CIN / 16 short waits per tile)
-        advance();
-        loadB(b0);
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b1, bd);
-        if (s + 2 < sc1) loadBd(s + 2 - sc0);
-        advance();
-      }
-#pragma unroll 1
-      for (int s = sc1; s < nsteps; s += 2) {
-        const bool more = s + 2 < nsteps;
-        loadB(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b0);
-        if (more) advance();
-        loadB(b0);
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b1);
-        if (more) advance();
-      }
-    } else if (RING) {
-      // nsteps = 9 taps x kcc is a multiple of three.  Entering step t: toff_n = A offset of step t + 1 (advance() moves it; its B
-      // pointer is not used here), wb_b = B pointer of step t + 2.  Past the last step the trackers stay put (harmless re-fetches).
-      u32x4 b2[NP][NW];
-      advanceB();                                                        // (step 0 came through loadB: wb_n == wb_b there)
-      loadBr(b1);                                                        // step 1
-      advanceB();
-#pragma unroll 1
-      for (int s = 0; s < nsteps; s += 3) {
-        loadBr(b2);                                                      // step s + 2
-        if (s + 3 < nsteps) advanceB();
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b0);                                                     // multiplies step s, fetches A of step s + 1
-        advance();                                                       //   (s + 2 < nsteps always)
-        loadBr(b0);                                                      // step s + 3
-        if (s + 4 < nsteps) advanceB();
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b1);
-        if (s + 3 < nsteps) advance();
-        loadBr(b1);                                                      // step s + 4
-        if (s + 5 < nsteps) advanceB();
-        __builtin_amdgcn_sched_barrier(0);
-        step(a, b2);
-        if (s + 4 < nsteps) advance();
+      for (int s = 0; s < nsteps; s += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          loadBr(br[(u + R - 1) % R]);                                   // step s + u + R - 1 into the set step s + u - 1 just left
+          if (s + u + R < nsteps) advanceB();
+          __builtin_amdgcn_sched_barrier(0);
+          if (A2) {
+            step((u & 1) ? a1 : a, br[u]);                               // multiplies step s + u, refills ITS A set with step s + u + 2
+            if (s + u + 3 < nsteps) advance();
+          } else {
+            step(a, br[u]);                                              // multiplies step s + u, fetches A of step s + u + 1
+            if (s + u + 2 < nsteps) advance();
+          }
+        }
       }
     } else {
 #pragma unroll 1
@@ -503,6 +474,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
         __builtin_amdgcn_sched_barrier(0);
         step(a, b1);                                                     // multiplies step s + 1, fetches A of step s + 2
         if (more) advance();
+      }
+    }
+    if constexpr (DSF) {
+      // ds_tail: the downsample conv = this conv's centre tap (patch offset (PC + 1) pixels) on its own weights, k-chunks ascending,
+      // terms a1 w0, a0 w1, a0 w0 — the order of the separate 1x1 launch (bit-identical raw output)
+      const unsigned tc0 = (unsigned)((PC + 1) * pitch);
+      u32x4 ad[NP][MW];
+      auto loadAd = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+          for (int pc = 0; pc < NP; ++pc) ad[pc][i] = *reinterpret_cast<const u32x4 *>(lds + pc * plane + aoff[i] + tc0 + (unsigned)kc * 32u);
+      };
+      auto mm = [&](const u32x4 (*bd)[NW]) {
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+          for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              accd[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ad[TA[t]][i]), __builtin_bit_cast(f16x8, bd[TB[t]][j]),
+                                                                  accd[i][j], 0, 0, 0);
+      };
+#pragma unroll 1
+      for (int kc = 0; kc < kcc; kc += 2) {                                // (kcc is even)
+        loadAd(kc);
+        loadBd(bd1, kc + 1);
+        mm(bd0);
+        loadAd(kc + 1);
+        if (kc + 2 < kcc) loadBd(bd0, kc + 2);
+        mm(bd1);
       }
     }
     c_mm += __builtin_readcyclecounter() - t_b;
@@ -1040,7 +1043,51 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
 }  // namespace
 
 // Fills the plan fields of `a` from its shape fields; false: the layer is outside what the kernel covers.
+namespace {
+bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes, bool fine);
+long plan_wgs(const ConvX3Args &a, int nw) {
+  const int ntt = a.COUTP / 32;
+  return (long)a.B * a.tiles_r * a.tiles_c * ((ntt + a.wn * nw - 1) / (a.wn * nw));
+}
+}  // namespace
+
+// The plan of a launch.  Round 6: when the regular plan would give the launch fewer than 224 workgroups (small batches: the deep
+// stages have one or two tiles per sample) a FINE plan is tried — one N-tile per workgroup (blockIdx.y = N-tile), the four waves
+// along M, no strips — which multiplies the workgroups by the layer's N-tiles at the price of staging the patch once per N-tile
+// (L2 serves it).  It keeps the deep stages of 8-48-pair batches on the float16 matrix pipe, with block tails, riding
+// downsample convs and in-kernel GroupNorm finalisation, where they used to fall back to the fp32-pipe kernels plus separate
+// residual / normalisation passes (option x3_fine; same MFMA order per output: bit-identical raw outputs to the regular plan).
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes) {
+  ConvX3Args reg = a;
+  int rmw = 0, rnw = 0;
+  size_t rlds = 0;
+  const int force0 = a.force;
+  reg.force = 1;                                                       // (the regular plan's shape, whatever its size)
+  const bool reg_ok = conv_x3_plan_impl(reg, ks, stride, &rmw, &rnw, &rlds, false);
+  const long reg_wgs = reg_ok ? plan_wgs(reg, rnw) : 0;
+  const int ntt = a.COUTP / 32;
+  if (a.fine && a.np == 2 && ntt >= 2 && (!reg_ok || reg_wgs < 224)) {
+    ConvX3Args f = a;
+    int fmw = 0, fnw = 0;
+    size_t flds = 0;
+    f.force = 1;
+    if (conv_x3_plan_impl(f, ks, stride, &fmw, &fnw, &flds, true)) {
+      const long fw = plan_wgs(f, fnw);
+      if (fw > reg_wgs && (fw >= 48 || force0)) {
+        f.force = force0;
+        a = f;
+        *mw = fmw;
+        *nw = fnw;
+        *lds_bytes = flds;
+        return true;
+      }
+    }
+  }
+  return conv_x3_plan_impl(a, ks, stride, mw, nw, lds_bytes, false);
+}
+
+namespace {
+bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes, bool fine) {
   if (a.CIN % 32 || a.COUTP % 32 || a.COUTP > 1024 || a.CIN > 1024) return false;
   if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 2))) return false;
   const int ntt = a.COUTP / 32;
@@ -1072,7 +1119,7 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
     while (TR > 1 && (TR + 2) * (TC + 2) > 324) --TR;
     if (TR > a.Ho) TR = a.Ho;
     if (TR * TC <= 96) return false;                               // (small maps: not worth it)
-  } else if (a.strip && a.np == 2 && stride == 1 && ks == 3 && ntt == 4 && a.Wo >= 16 && a.Ho >= 8) {
+  } else if (a.strip && !fine && a.np == 2 && stride == 1 && ks == 3 && ntt == 4 && a.Wo >= 16 && a.Ho >= 8) {
     // Round 4: what bounds these layers is the CU's vector-memory pipe, and most of its traffic is weight fragments — every workgroup
     // streams the layer's whole B operand for ITS pixels.  Wide strips (up to 288 pixels = nine M-tiles: the 12 x 22 map whole, the
     // 24 x 43 map in four) with the N-tiles split over blockIdx.y (two per workgroup, one per wave column, five M-tiles per wave)
@@ -1103,8 +1150,13 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   a.PR = (TR - 1) * cs + ks;
   a.PC = (TC - 1) * cs + ks;
   // wave grid (4 / wn) x wn and accumulators per wave (accumulators + one A set + two B sets within 256 registers)
-  const bool strip = a.strip && a.np == 2 && stride == 1 && ks == 3 && ntt == 4 && a.Wo >= 16 && a.Ho >= 8 && a.MT > 6;
-  if (strip) {
+  const bool strip = a.strip && !fine && a.np == 2 && stride == 1 && ks == 3 && ntt == 4 && a.Wo >= 16 && a.Ho >= 8 && a.MT > 6;
+  if (fine) {                                                      // one N-tile per workgroup, the four waves along M
+    if (a.MT > 8) return false;
+    a.wn = 1;
+    *mw = (a.MT + 3) / 4;
+    *nw = 1;
+  } else if (strip) {
     a.wn = 2;
     *mw = (a.MT + 1) / 2;                                          // two wave rows
     *nw = 1;
@@ -1158,6 +1210,7 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
   return true;
 }
+}  // namespace
 
 // Does launch_conv_x3 take the persistent resident-weight form (conv_x3p_kernel) for this planned launch?
 bool conv_x3_persistent(const ConvX3Args &a, int ks, int stride, int mode, int mw, int nw) {

@@ -495,6 +495,7 @@ bool x3_args(pnvo_handle m, const Layer &l, int B, ConvX3Args &xa, int *mw, int 
   std::memset(&xa, 0, sizeof(xa));
   xa.force = m->opt.conv == 1;
     xa.strip = m->opt.x3_strip;
+    xa.fine = m->opt.x3_fine;
   xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
   xa.np = x3_two_pieces(m, l) ? 2 : 3;
   xa.B = B;
@@ -591,6 +592,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     std::memset(&xa, 0, sizeof(xa));
     xa.force = m->opt.conv == 1;
     xa.strip = m->opt.x3_strip;
+    xa.fine = m->opt.x3_fine;
     xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
     xa.B = B;
     xa.H = l.hin;
@@ -1125,6 +1127,7 @@ const OptDef kOptions[] = {
     {"ds_side", "PNVO_DS_SIDE", &PnvoOptions::ds_side, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"pool_async", "PNVO_POOL_ASYNC", &PnvoOptions::pool_async, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"x3_fine", "PNVO_X3_FINE", &PnvoOptions::x3_fine, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"head_fuse", "PNVO_HEAD_FUSE", &PnvoOptions::head_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 2}, {"single", 2}, {"last", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1909,11 +1912,13 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       if (c2_small_generic) {
         // small deep stage on the generic kernel: its per-tap GroupNorm+ReLU prologue costs more than one streaming
         // pass over the (L2-sized) tensor, so normalise once and run the conv on final activations
+        // (scratch: rawD — unless the downsample conv rode on c1 and its output already sits there; `nxt` is free until the block tail)
+        float *napp = ds_ride ? nxt : m->rawD;
         {
           Timed t(m, s, "gn_relu_apply", 0.0, 8.0 * B * P * c2.cinp);
-          HIPCHK(m, launch_apply_ss_relu(m->rawA, m->ssA[0], m->ssA[1], B, P, c2.cinp, m->rawD, s));
+          HIPCHK(m, launch_apply_ss_relu(m->rawA, m->ssA[0], m->ssA[1], B, P, c2.cinp, napp, s));
         }
-        if ((rc = run_conv(m, c2, B, m->rawD, nullptr, nullptr, m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s)) != PNVO_OK)
+        if ((rc = run_conv(m, c2, B, napp, nullptr, nullptr, m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s)) != PNVO_OK)
           return rc;
       } else if ((rc = run_conv(m, c2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0,
                                 s)) != PNVO_OK) {

@@ -46,6 +46,7 @@ struct PnvoOptions {
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
   int pool_async = 0;  // pooled-key buffer of its own, re-initialised for the next forward on a side stream (see pool_keys).  OFF: measured
                        // slower at every batch (8 pairs 0.44 -> 0.50 ms, 256 pairs 2.37 -> 2.41): the two event hand-overs cost more than the 23 us fill
+  int x3_fine = 1;     // small launches of the float16-piece convs take one N-tile per workgroup instead of falling back to the fp32-pipe kernels
   int head_fuse = 1;   // the output head (Linear hidden -> out_dim) is computed by the hidden layer's split-K reduction launch (one launch less)
   int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
   int gn_fuse = 2;     // conv_x3 launches finalise their GroupNorm themselves (bit-identical, one launch less): 2 = launches with one tile per

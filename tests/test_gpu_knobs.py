@@ -645,3 +645,44 @@ def test_pooled_keys_refilled_on_a_side_stream_are_bit_identical():
     a, b, c = run("on"), run("off"), run("on")
     assert all(torch.isfinite(x).all() for x in a)
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(a, c))
+
+
+@pytest.mark.parametrize("B", [6, 8, 16, 32, 48])
+def test_fine_plan_keeps_small_batches_on_the_float16_pipe(B):
+    """Option x3_fine (default on, round 6): a conv launch that the regular tile plan would give fewer than 224 workgroups takes ONE
+    N-tile per workgroup (blockIdx.y = N-tile, four waves along M) instead of falling back to the fp32-pipe kernels: the deep stages
+    of 6-48-pair batches then run on the float16 pieces with block tails, riding downsample convs and in-kernel GroupNorm
+    finalisation.  Against the fallback (x3_fine=off) the output agrees to float32 noise, both match the fp64 oracle, the option
+    really changes the kernel family of the deep layers, and there are fewer launches."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 7)
+    outs, fam, nl = {}, {}, {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("x3_fine", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+            fam[v] = [model.layer_kernel(f"visual_encoder.backbone.layer{s}.1.convs.3", B)[0] for s in (3, 4)]
+            model.timing(True)
+            model(obs)
+            torch.cuda.synchronize()
+            nl[v] = sum(k["launches"] for k in model.timing_read())
+            model.timing(False)
+        torch.cuda.synchronize()
+    model.set_option("x3_fine", "on")
+    assert torch.isfinite(outs["on"]).all() and torch.equal(outs["on"], outs["on2"])
+    assert "x2" in fam["on"] and fam["on"] != fam["off"], (fam, B)
+    assert nl["on"] < nl["off"], nl
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel
+    chk = sorted({0, B // 2, B - 1})
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    for v in ("on", "off"):
+        got = outs[v][chk].double().cpu().numpy()
+        err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+        assert err.max() < 2e-5, (v, err)
