@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     // RING (float16 pieces, no riding downsample conv): B fragments are fetched TWO steps ahead into a ring of three register sets —
     // one step (6-18 MFMAs, 200-600 cycles) is shorter than an L2 round trip under load, and the ISA showed every step waiting for the
     // fragments it had asked for one step earlier.  A (LDS) stays one step ahead.  The two fetches run on trackers of their own.
-    constexpr bool RING = NP == 2 && KS == 3;
+    constexpr bool RING = NP == 2 && KS == 3 && !(MODE == 2 && MW * NW == 5);   // (the block-tail strip tile has no registers to spare)
     const char *wb_b = wb_n;                                             // RING: the B step being fetched
     int kc_b = 0;
     auto advanceB = [&]() {
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
       advanceB();                                                        // -> step R - 1
       // Small wave tiles also fetch A (LDS) TWO steps ahead, into two register sets used by the even / odd steps: with one M-tile a step
       // is three MFMAs = 96 cycles, less than an LDS read under load (measured: 63 cycles per MFMA with A one step ahead).
-      constexpr bool A2 = MW * NW <= 2;
+      constexpr bool A2 = MW * NW <= 2 && !(MODE == 2 && MW * NW == 2 && !DSF);   // (the (2,1) block-tail tile runs three waves per SIMD: 168 registers)
       u32x4 a1[A2 ? NP : 1][MW];
       if (A2) {
 #pragma unroll
@@ -1034,6 +1034,7 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
   }
   PNVO_X3(0, 1, 1) PNVO_X3(1, 1, 1) PNVO_X3(0, 2, 1) PNVO_X3(1, 2, 1) PNVO_X3(0, 2, 2) PNVO_X3(1, 2, 2) PNVO_X3(0, 3, 2) PNVO_X3(1, 3, 2)      // what conv_x3_plan picks
   PNVO_X3(2, 1, 1) PNVO_X3(2, 2, 1) PNVO_X3(2, 2, 2) PNVO_X3(2, 3, 2) PNVO_X3(3, 1, 1) PNVO_X3(3, 2, 1) PNVO_X3(3, 2, 2) PNVO_X3(3, 3, 2)
+
   if (KS == 3 && STRIDE == 1 && NP == 2) {                                                      // wide strips (conv_x3_plan)
     PNVO_X3(0, 5, 1) PNVO_X3(1, 5, 1) PNVO_X3(2, 5, 1) PNVO_X3(3, 5, 1)   // (mode 3 on a strip plan: a 128-channel first block)
   }
@@ -1141,6 +1142,8 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     if (TR < 1) TR = 1;
     if (TR > a.Ho) TR = a.Ho;
   }
+  // (fine plan with the 12 x 22 map whole — nine M-tiles on (3,1) wave tiles, GroupNorm finalised in the kernel — was measured: three
+  //  launches fewer but 32 pairs 0.626 -> 0.640 ms, and below 12 pairs its 4 B workgroups miss the threshold: not kept)
   a.TR = TR;
   a.TC = TC;
   a.tiles_r = (a.Ho + TR - 1) / TR;
