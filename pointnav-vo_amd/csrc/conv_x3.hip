@@ -1067,7 +1067,8 @@ bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *l
   const bool reg_ok = conv_x3_plan_impl(reg, ks, stride, &rmw, &rnw, &rlds, false);
   const long reg_wgs = reg_ok ? plan_wgs(reg, rnw) : 0;
   const int ntt = a.COUTP / 32;
-  if (a.fine && a.np == 2 && ntt >= 2 && (!reg_ok || reg_wgs < 224)) {
+  static const long fine_below = std::getenv("PNVO_FINE_BELOW") ? std::atol(std::getenv("PNVO_FINE_BELOW")) : 224;   // (developer sweep; 224 measured best)
+  if (a.fine && a.np == 2 && ntt >= 2 && (!reg_ok || reg_wgs < fine_below)) {
     ConvX3Args f = a;
     int fmw = 0, fnw = 0;
     size_t flds = 0;

@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 model, sd = bench.build_model(dev)
 full = bench.make_inputs(256, dev, 0)
 with torch.no_grad():
-    for B in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+    for B in ([int(x) for x in sys.argv[1:]] or (1, 2, 4, 8, 16, 32, 64, 128, 256)):
         obs = {k: v[:B].contiguous() for k, v in full.items()}
         for _ in range(5): model(obs)
         torch.cuda.synchronize(); t0 = time.perf_counter()
