@@ -137,6 +137,24 @@ int pnvo_forward_dual_raw(pnvo_handle ha, pnvo_handle hb, const uint8_t *rgb_fra
                           float *out_a, float *out_b, int32_t *err_flag, void *stream);
 
 /*
+ * GROUPED forward (round 6): the pairs of up to three SEPARATE-ACTION models in one launch chain — what the navigation loop's call
+ * needs when BaseRLTrainerWithVO._compute_local_delta_states_from_vo (base_trainer_with_vo.py:277-294: vo_model[act]) is batched over
+ * environments: 8-32 pairs per simulator step split over the "forward" / "left" / "right" models are three forwards of ~50 dependent
+ * launches each, bound by launch latency.  The pairs are sorted by model: handles[k] serves counts[k] consecutive pairs of the frame
+ * tensors (layout of pnvo_forward_raw), sum(counts) == B, n_models <= 3, a count may be 0.  Every kernel of the chain picks a pair's
+ * weights, weight scales and GroupNorm affine parameters by its model; the hidden layer and head run per model on its rows.
+ * Requirements (else PNVO_ERR_STATE, never a fallback): float32 inference handles of one architecture on one device, default
+ * float16-piece kernels, no training step attached, no tap, not an act-embed model.  Per pair float32-grade equal (same
+ * tolerances against the fp64 oracle) to the model's own pnvo_forward_raw, whose kernel choice depends on the batch size.
+ * One model with a non-zero count: the call is pnvo_forward_raw on that handle.
+ */
+int pnvo_forward_grouped_raw(const pnvo_handle *handles, const int32_t *counts, int n_models, const uint8_t *rgb_frames,
+                             const float *depth_frames, const float *tdv, int B, float *out, int32_t *err_flag, void *stream);
+/* PNVO_OK when these (1..3, non-null) handles can share a grouped forward, else the error it would return with the reason in
+ * pnvo_last_error(handles[0]): what a caller's dispatch between one grouped and several per-model forwards asks. */
+int pnvo_grouped_supported(const pnvo_handle *handles, int n_models);
+
+/*
  * Arithmetic of pnvo_forward for this handle: 0 = float32 (default: exact-float32 products on the matrix cores), 1 = bfloat16
  * (BASELINE config 3: bf16 operands and bf16 activations in HBM, float32 accumulation / GroupNorm statistics / Linear layers).
  * The reference has no such switch (it would be model.bfloat16(), which also rounds the normalisation and the head);

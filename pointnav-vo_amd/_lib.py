@@ -49,6 +49,9 @@ _SIGNATURES = {
                                    C.c_void_p]),
     "pnvo_forward_dual_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "pnvo_forward_grouped_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "pnvo_grouped_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "pnvo_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pnvo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "pnvo_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),

@@ -94,6 +94,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
   const int n = bid / p.tiles_r;
   const int r0 = tri * p.TR, c0 = tci * p.TC;
   const int hi0 = r0 * STRIDE - PAD, wi0 = c0 * STRIDE - PAD;
+  // grouped forward: the sample's action model picks the operands (wave-uniform; one model: both ends are INT_MAX)
+  const int mdl = (p.grp_end0 > 0 && n >= p.grp_end0) + (p.grp_end1 > 0 && n >= p.grp_end1);   // (0: no such model)
+  const unsigned short *g_wpk = mdl == 0 ? p.wpk : p.wpk_g[mdl - 1];
+  const unsigned short *g_ds_wpk = mdl == 0 ? p.ds_wpk : p.ds_wpk_g[mdl - 1];
+  const float g_oscale = mdl == 0 ? p.oscale : p.oscale_g[mdl - 1], g_ds_oscale = mdl == 0 ? p.ds_oscale : p.ds_oscale_g[mdl - 1];
+  const float *g_gamma = mdl == 0 ? p.gn_gamma : p.gn_gamma_g[mdl - 1], *g_beta = mdl == 0 ? p.gn_beta : p.gn_beta_g[mdl - 1];
+  const float *g_ds_gamma = mdl == 0 ? p.ds_gamma : p.ds_gamma_g[mdl - 1], *g_ds_beta = mdl == 0 ? p.ds_beta : p.ds_beta_g[mdl - 1];
   const int PR = p.PR, PC = p.PC, CK = p.CK;
   const int pitch = CK * 2 + 16;                   // bytes per patch pixel in one piece plane (odd number of 16-byte units)
   const int plane = PR * PC * pitch;               // bytes of one piece plane
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     // The step being fetched (one ahead of the one being multiplied), kept as running offsets: a division per step costs the
     // wave ~50 scalar instructions between two MFMA groups, and with one wave per SIMD (6 x 11 maps) nobody fills that gap.
     const unsigned kstep = (unsigned)ntt * (NP * 1024u);                 // bytes of one k-chunk of B (all N-tiles, NP pieces)
-    const char *wb_n = reinterpret_cast<const char *>(p.wpk) + (long)(ck0 >> 4) * kstep;
+    const char *wb_n = reinterpret_cast<const char *>(g_wpk) + (long)(ck0 >> 4) * kstep;
     unsigned toff_n = 0;                                                 // patch byte offset of the step's (tap, k-chunk)
     int kc_n = 0, kw_n = 0;
     auto advance = [&]() {
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     // operand, [k-chunk][N-tile][piece][lane][8]; those of the chunk's first k-chunk are fetched before the main loop.
     u32x4 bd0[DSF ? NP : 1][NW], bd1[DSF ? NP : 1][NW];
     auto loadBd = [&](u32x4 (*b)[NW], int kc) {
-      const char *wd = reinterpret_cast<const char *>(p.ds_wpk) + (long)((ck0 >> 4) + kc) * kstep;
+      const char *wd = reinterpret_cast<const char *>(g_ds_wpk) + (long)((ck0 >> 4) + kc) * kstep;
 #pragma unroll
       for (int j = 0; j < NW; ++j)
 #pragma unroll
@@ -610,19 +617,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     }
     (void)again;
   };
-  emit(acc, p.y, p.stats, p.oscale_ptr, p.oscale, p.gn_gamma, p.gn_beta, p.gn_scale, p.gn_shift, p.gn_mu, p.gn_rstd, false);
-  if constexpr (DSF) emit(accd, p.ds_y, p.ds_stats, p.ds_oscale_ptr, p.ds_oscale, p.ds_gamma, p.ds_beta, p.ds_scale, p.ds_shift, p.ds_mu, p.ds_rstd, true);
+  emit(acc, p.y, p.stats, p.oscale_ptr, g_oscale, g_gamma, g_beta, p.gn_scale, p.gn_shift, p.gn_mu, p.gn_rstd, false);
+  if constexpr (DSF) emit(accd, p.ds_y, p.ds_stats, p.ds_oscale_ptr, g_ds_oscale, g_ds_gamma, g_ds_beta, p.ds_scale, p.ds_shift, p.ds_mu, p.ds_rstd, true);
   if (p.stats != nullptr && p.gn_ctr != nullptr) {                        // several tiles per sample: the last one to arrive finalises
     if (gn_last_arrival(p.gn_ctr + (long)n * gridDim.y + blockIdx.y, (unsigned)p.slots, reinterpret_cast<int *>(lds + 4096))) {
       const int nt0 = (int)blockIdx.y * wn * NW, nt1 = min(nt0 + wn * NW, ntt);
       const int NG = p.COUTP / p.gn_cpg;
       for (int g = (nt0 * 32) / p.gn_cpg + wave; g < (nt1 * 32) / p.gn_cpg; g += 4) {
-        gn_finalize_group_wave(p.stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma, p.gn_beta,
+        gn_finalize_group_wave(p.stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, g_gamma, g_beta,
                                p.gn_scale + (long)n * p.COUTP, p.gn_shift + (long)n * p.COUTP, p.gn_mu ? p.gn_mu + (long)n * NG + g : nullptr,
                                p.gn_mu ? p.gn_rstd + (long)n * NG + g : nullptr);
         if (DSF)
-          gn_finalize_group_wave(p.ds_stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, p.ds_gamma,
-                                 p.ds_beta, p.ds_scale + (long)n * p.COUTP, p.ds_shift + (long)n * p.COUTP, p.ds_mu ? p.ds_mu + (long)n * NG + g : nullptr,
+          gn_finalize_group_wave(p.ds_stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, g_ds_gamma,
+                                 g_ds_beta, p.ds_scale + (long)n * p.COUTP, p.ds_shift + (long)n * p.COUTP, p.ds_mu ? p.ds_mu + (long)n * NG + g : nullptr,
                                  p.ds_mu ? p.ds_rstd + (long)n * NG + g : nullptr);
       }
     }

@@ -99,8 +99,13 @@ hipError_t launch_assemble(const AssembleArgs &h, hipStream_t s) {
 __device__ __forceinline__ void gn_finalize_block(const float *stats, int slots, int CP, int C, int G, long P,
                                                   int WM, const float *gamma, const float *beta, float eps,
                                                   float *scale, float *shift, int fixed_ns, float *mu_out,
-                                                  float *rstd_out) {
+                                                  float *rstd_out, const GnGroup &grp) {
   const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int mdl = (n >= grp.end0) + (n >= grp.end1);           // grouped forward: the sample's action model
+  if (mdl > 0) {
+    gamma = grp.gamma[mdl - 1];
+    beta = grp.beta[mdl - 1];
+  }
   const int cpg = C / G;
   const long t0 = ((long)n * P) / WM, t1 = ((long)(n + 1) * P - 1) / WM;
   const int ns = fixed_ns > 0 ? fixed_ns : (int)(t1 - t0 + 1);
@@ -136,8 +141,8 @@ __device__ __forceinline__ void gn_finalize_block(const float *stats, int slots,
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int slots, int CP, int C, int G, long P,
                                                         int WM, const float *gamma, const float *beta, float eps,
                                                         float *scale, float *shift, int fixed_ns, float *mu_out,
-                                                        float *rstd_out) {
-  gn_finalize_block(stats, slots, CP, C, G, P, WM, gamma, beta, eps, scale, shift, fixed_ns, mu_out, rstd_out);
+                                                        float *rstd_out, const GnGroup grp) {
+  gn_finalize_block(stats, slots, CP, C, G, P, WM, gamma, beta, eps, scale, shift, fixed_ns, mu_out, rstd_out, grp);
 }
 
 // Two GroupNorms of the same geometry in one launch (a stride-2 block's first conv and the downsample conv that rode on it):
@@ -145,16 +150,20 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *stats, int
 struct GnFinPair {
   const float *stats[2], *gamma[2], *beta[2];
   float *scale[2], *shift[2], *mu[2], *rstd[2];
+  GnGroup grp[2];
 };
 __global__ __launch_bounds__(64) void gn_finalize_pair_kernel(const GnFinPair q, int slots, int CP, int C, int G, long P, float eps) {
   const int z = blockIdx.y;
-  gn_finalize_block(q.stats[z], slots, CP, C, G, P, 1, q.gamma[z], q.beta[z], eps, q.scale[z], q.shift[z], slots, q.mu[z], q.rstd[z]);
+  gn_finalize_block(q.stats[z], slots, CP, C, G, P, 1, q.gamma[z], q.beta[z], eps, q.scale[z], q.shift[z], slots, q.mu[z], q.rstd[z], q.grp[z]);
 }
 
 hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
                                    const float *const *beta, float eps, float *const *scale, float *const *shift, float *const *mu_out,
-                                   float *const *rstd_out, hipStream_t s) {
+                                   float *const *rstd_out, hipStream_t s, const GnGroup *grp0, const GnGroup *grp1) {
   GnFinPair q;
+  const GnGroup none{0x7fffffff, 0x7fffffff, {nullptr, nullptr}, {nullptr, nullptr}};
+  q.grp[0] = grp0 ? *grp0 : none;
+  q.grp[1] = grp1 ? *grp1 : none;
   for (int z = 0; z < 2; ++z) {
     q.stats[z] = stats[z];
     q.gamma[z] = gamma[z];
@@ -229,9 +238,10 @@ hipError_t launch_gn_finalize2(const float *const *stats, int B, int slots, int 
 
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
-                              hipStream_t s, int fixed_ns, float *mu_out, float *rstd_out) {
+                              hipStream_t s, int fixed_ns, float *mu_out, float *rstd_out, const GnGroup *grp) {
+  const GnGroup none{0x7fffffff, 0x7fffffff, {nullptr, nullptr}, {nullptr, nullptr}};
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, stats, slots, CP, C, G, P, WM, gamma,
-                     beta, eps, scale, shift, fixed_ns, mu_out, rstd_out);
+                     beta, eps, scale, shift, fixed_ns, mu_out, rstd_out, grp ? *grp : none);
   return hipGetLastError();
 }
 

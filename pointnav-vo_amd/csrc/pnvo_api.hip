@@ -621,13 +621,14 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     const bool rows = two && m->opt.x3_rows && conv_rows32_plan(xa, l.k, l.stride, x3_mode, m->num_cus);
     if (rows || conv_x3_plan(xa, l.k, l.stride, &mw, &nw, &ldsb)) {     // (the statistics buffer is sized for it: stats_floats)
       Layer &lm = const_cast<Layer &>(l);
-      auto ensure_x2 = [&](Layer &q) -> int {                    // (re)build the two-piece float16 operand of a layer
-        if (q.wpk_x2 && q.x2_gen == m->weights_gen) return PNVO_OK;
+      auto ensure_x2 = [&](Layer &q, pnvo_handle hq = nullptr) -> int {   // (re)build the two-piece float16 operand of a layer (of handle hq)
+        if (hq == nullptr) hq = m;
+        if (q.wpk_x2 && q.x2_gen == hq->weights_gen) return PNVO_OK;
         const size_t nel = (size_t)q.k * q.kw * q.cinp * q.coutp * 2;
         if (!q.wpk_x2) HIPCHK(m, hipMalloc((void **)&q.wpk_x2, nel * 2));
-        const float *dev_w = m->train ? pnvo_train_weight_ptr(m, q.name + ".weight") : nullptr;
+        const float *dev_w = hq->train ? pnvo_train_weight_ptr(hq, q.name + ".weight") : nullptr;
         if (dev_w != nullptr) {          // training attached: weight and scale live on the device (pnvo_train_refresh)
-          HIPCHK(m, launch_conv_x2_repack(dev_w, q.cout, q.cin, q.cinp, q.coutp, q.k, q.kw, pnvo_train_x2_scale(m, q.name + ".weight"),
+          HIPCHK(m, launch_conv_x2_repack(dev_w, q.cout, q.cin, q.cinp, q.coutp, q.k, q.kw, pnvo_train_x2_scale(hq, q.name + ".weight"),
                                           q.wpk_x2, s));
         } else {
           std::vector<unsigned short> pk(nel);
@@ -635,7 +636,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
           HIPCHK(m, hipMemcpyAsync(q.wpk_x2, pk.data(), nel * 2, hipMemcpyHostToDevice, s));
           HIPCHK(m, hipStreamSynchronize(s));
         }
-        q.x2_gen = m->weights_gen;
+        q.x2_gen = hq->weights_gen;
         return PNVO_OK;
       };
       if (two) {
@@ -667,6 +668,36 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
           HIPCHK(m, hipStreamSynchronize(s));
         }
         lm.x3_gen = m->weights_gen;
+      }
+      GnGroup gg{0x7fffffff, 0x7fffffff, {nullptr, nullptr}, {nullptr, nullptr}}, ggd = gg;   // grouped forward: models 1 / 2 of this layer
+      if (m->grp_n > 1) {
+        if (!two || rows) return fail(m, PNVO_ERR_STATE, "grouped forward: layer " + l.name + " is not on the float16-piece tile kernel");
+        const size_t idx = (size_t)(&l - m->convs.data());
+        if (idx >= m->convs.size()) return fail(m, PNVO_ERR_STATE, "grouped forward: layer outside the conv list");
+        xa.grp_end0 = m->grp_end[0];
+        xa.grp_end1 = m->grp_n > 2 ? m->grp_end[1] : 0;
+        gg.end0 = ggd.end0 = m->grp_end[0];
+        if (m->grp_n > 2) gg.end1 = ggd.end1 = m->grp_end[1];
+        for (int k = 1; k < m->grp_n; ++k) {
+          pnvo_handle hk = m->grp[k];
+          Layer &lk = hk->convs[idx];
+          if (!x3_two_pieces(hk, lk)) return fail(m, PNVO_ERR_STATE, "grouped forward: a model's " + l.name + " left the float16-piece form");
+          if (int rc2 = ensure_x2(lk, hk)) return rc2;
+          xa.wpk_g[k - 1] = lk.wpk_x2;
+          xa.oscale_g[k - 1] = lk.x2_oscale;
+          xa.gn_gamma_g[k - 1] = gg.gamma[k - 1] = lk.gamma;
+          xa.gn_beta_g[k - 1] = gg.beta[k - 1] = lk.beta;
+          if (ride != nullptr) {
+            const size_t idd = (size_t)(ride->cd - m->convs.data());
+            Layer &dk = hk->convs[idd];
+            if (!x3_two_pieces(hk, dk)) return fail(m, PNVO_ERR_STATE, "grouped forward: a model's downsample conv left the float16-piece form");
+            if (int rc2 = ensure_x2(dk, hk)) return rc2;
+            xa.ds_wpk_g[k - 1] = dk.wpk_x2;
+            xa.ds_oscale_g[k - 1] = dk.x2_oscale;
+            xa.ds_gamma_g[k - 1] = ggd.gamma[k - 1] = dk.gamma;
+            xa.ds_beta_g[k - 1] = ggd.beta[k - 1] = dk.beta;
+          }
+        }
       }
       xa.x = x;
       xa.wpk = two ? lm.wpk_x2 : lm.wpk_x3;
@@ -730,15 +761,17 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         const float *st2[2] = {m->stats, m->stats_ds}, *ga2[2] = {l.gamma, ride->cd->gamma}, *be2[2] = {l.beta, ride->cd->beta};
         float *sc2[2] = {ss[0], ride->ss[0]}, *sh2[2] = {ss[1], ride->ss[1]};
         float *mu2[2] = {mu_out, ride->mu}, *rs2[2] = {rstd_out, ride->rstd};
-        HIPCHK(m, launch_gn_finalize_pair(st2, B, xa.slots, l.coutp, l.cout, l.groups, P, ga2, be2, 1e-5f, sc2, sh2, mu2, rs2, s));
+        HIPCHK(m, launch_gn_finalize_pair(st2, B, xa.slots, l.coutp, l.cout, l.groups, P, ga2, be2, 1e-5f, sc2, sh2, mu2, rs2, s,
+                                          m->grp_n > 1 ? &gg : nullptr, m->grp_n > 1 ? &ggd : nullptr));
         return PNVO_OK;
       }
       HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
-                                   xa.slots, mu_out, rstd_out));
+                                   xa.slots, mu_out, rstd_out, m->grp_n > 1 ? &gg : nullptr));
       return PNVO_OK;
     }
   }
   if (tail != nullptr) return fail(m, PNVO_ERR_STATE, "block tail handed to a conv that cannot take it (" + l.name + ")");
+  if (m->grp_n > 1 && ss != nullptr) return fail(m, PNVO_ERR_STATE, "grouped forward: layer " + l.name + " fell off the float16-piece tile kernel");
   const bool lds3 = conv3_lds_supported(a) && m->opt.conv != 3;
   if (lds3) {                    // 3x3 stride-1 residual-stage conv: input patch staged in LDS
     int nt = (l.coutp / 32) % 2 == 0 ? 2 : 1;
@@ -947,6 +980,20 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     a.pool_gamma = stem.gamma;
     a.Hp = m->Hp;
     a.Wp = m->Wp;
+    GnGroup sgg{0x7fffffff, 0x7fffffff, {nullptr, nullptr}, {nullptr, nullptr}};
+    if (m->grp_n > 1) {                 // grouped forward: the other models' stem operands (tile kernel only)
+      if (pieces != 2 || pool_keys == nullptr) return fail(m, PNVO_ERR_STATE, "grouped forward needs the float16-piece stem with pooled keys");
+      a.grp_end0 = sgg.end0 = m->grp_end[0];
+      if (m->grp_n > 2) a.grp_end1 = sgg.end1 = m->grp_end[1];
+      for (int k = 1; k < m->grp_n; ++k) {
+        pnvo_handle hk = m->grp[k];
+        if (hk->mx_wpk2 == nullptr || hk->mx_wpk2_dev) return fail(m, PNVO_ERR_STATE, "grouped forward: a model has no host-packed float16 stem operand");
+        a.wpk_g[k - 1] = hk->mx_wpk2;
+        a.oscale_g[k - 1] = hk->mx_oscale;
+        a.pool_gamma_g[k - 1] = sgg.gamma[k - 1] = hk->convs[0].gamma;
+        sgg.beta[k - 1] = hk->convs[0].beta;
+      }
+    }
     a.dbg = m->opt.stem_dbg >= 16 ? m->opt.stem_dbg - 16 : 0;
     if (m->opt.stem_dbg == 9 || m->opt.stem_dbg >= 16) {
       if (!m->mx_prof) {
@@ -972,7 +1019,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
       //   tiles (auto otherwise): one tile per workgroup, two workgroups per CU — 0.99 ms, bound by the CU's vector-memory pipe
       //     (245 KB of weight fragments + 93 KB of patch per 128-pixel tile);
       //   (round 4's role-specialised persistent form — stem_ps_kernel, as fast as tiles — was retired in round 5: HISTORY.md.)
-      const bool rs = (m->opt.stem_form == 3 || m->opt.stem_form == 4 || m->opt.stem_form == 0) && stem_rs_takes(a, pieces, ntn, false, m->num_cus);
+      const bool rs = m->grp_n <= 1 && (m->opt.stem_form == 3 || m->opt.stem_form == 4 || m->opt.stem_form == 0) && stem_rs_takes(a, pieces, ntn, false, m->num_cus);
       m->mx_prof_rs = rs;
       if (rs)
         HIPCHK(m, launch_stem_rs(a, pieces, m->opt.stem_form == 4 || m->opt.stem_form == 0, m->num_cus, s));
@@ -990,7 +1037,7 @@ int pnvo_run_stem(pnvo_handle m, int B, const float *const *src, float *y, float
     if (!m->stem_skip_finalize) {
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
       HIPCHK(m, launch_gn_finalize(m->stats, B, a.slots, stem.coutp, stem.cout, stem.groups, (long)m->Hs * m->Ws, 1,
-                                   stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out));
+                                   stem.gamma, stem.beta, 1e-5f, ss[0], ss[1], s, a.slots, mu_out, rstd_out, m->grp_n > 1 ? &sgg : nullptr));
     }
   } else if (m->dd_ok && m->opt.stem != 3 && m->dense_sticky && !m->in_train_forward && stem_lds_serves(m)) {
     // the input fallback engaged on the one-hot-aware stem: the float32 stem stands in, in that stem's slot layout
@@ -1739,6 +1786,8 @@ bool side_stream_ready(pnvo_handle m, hipStream_t s) {
   return true;
 }
 
+int run_fc_head(pnvo_handle m, int B, const float *comp_raw, const float *sc, const float *sh, const int64_t *actions, float *out, hipStream_t s);
+
 // Stream + events of option pool_async (lazily; not while `s` is being captured: a graph keeps the fill in-stream).
 bool keys_stream_ready(pnvo_handle m, hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -1968,13 +2017,35 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
     HIPCHK(m, launch_apply_ss_relu(m->comp_raw, m->ssC[0], m->ssC[1], B, (long)m->fh * m->fw, m->comp_cp, m->tapbuf, s));
     if ((rc = maybe_tap(m, "compression", m->tapbuf, (size_t)B * m->fh * m->fw * m->comp_cp, s)) != PNVO_OK) return rc;
   }
-  // (a11) Flatten + Linear + ReLU, then the output head
+  // (a11) Flatten + Linear + ReLU, then the output head — per action model in a grouped forward (each on its own handle: its
+  // weights, bias rows and split-K scratch; the sample ranges are contiguous)
+  if (m->grp_n > 1) {
+    int start = 0;
+    for (int k = 0; k < m->grp_n; ++k) {
+      const int Bk = m->grp_end[k] - start;
+      pnvo_handle hk = m->grp[k];
+      if (k > 0 && (rc = ensure_workspace(hk, Bk)) != PNVO_OK) return fail(m, rc, std::string("grouped forward: ") + pnvo_last_error(hk));
+      const size_t crow = (size_t)m->fh * m->fw * m->comp_cp;
+      rc = run_fc_head(hk, Bk, m->comp_raw + start * crow, m->ssC[0] + (size_t)start * m->comp_cp, m->ssC[1] + (size_t)start * m->comp_cp,
+                       nullptr, out + (size_t)start * c.out_dim, s);
+      if (rc != PNVO_OK) return k > 0 ? fail(m, rc, std::string("grouped forward: ") + pnvo_last_error(hk)) : rc;
+      start = m->grp_end[k];
+    }
+    return PNVO_OK;
+  }
+  return run_fc_head(m, B, m->comp_raw, m->ssC[0], m->ssC[1], actions, out, s);
+}
+
+// The hidden layer and the output head of handle m on B rows of the compression output.
+int run_fc_head(pnvo_handle m, int B, const float *comp_raw, const float *sc, const float *sh, const int64_t *actions, float *out, hipStream_t s) {
+  const pnvo_config &c = m->cfg;
+  int rc = PNVO_OK;
   // the output head rides on the hidden layer's split-K reduction when there is one (option head_fuse); with a training step attached
   // the head's weight is read where the optimiser keeps it (the flat parameter buffer), the bias from its re-packed copy
   m->head_rode = false;
   m->head_ride_w = m->train != nullptr ? pnvo_train_weight_ptr(m, "output_head.1.weight") : m->head_w_plain;   // (OIHW of a 1x1 conv = [out_dim][hidden])
   m->head_ride_out = (m->opt.head_fuse && !m->features_only && c.out_dim <= 4 && m->head_ride_w != nullptr) ? out : nullptr;
-  rc = run_conv(m, m->fc, B, m->comp_raw, m->ssC[0], m->ssC[1], m->hid, c.hidden, nullptr, m->fc_bias, c.act_embed ? actions : nullptr, 1, s);
+  rc = run_conv(m, m->fc, B, comp_raw, sc, sh, m->hid, c.hidden, nullptr, m->fc_bias, c.act_embed ? actions : nullptr, 1, s);
   m->head_ride_out = nullptr;
   if (rc != PNVO_OK) return rc;
   if ((rc = maybe_tap(m, "hidden", m->hid, (size_t)B * c.hidden, s)) != PNVO_OK) return rc;
@@ -2051,6 +2122,91 @@ int pnvo_forward_raw(pnvo_handle m, const uint8_t *rgb_frames, const float *dept
   m->raw_rgb = nullptr;
   m->raw_depth = nullptr;
   m->raw_err = nullptr;
+  return rc;
+}
+
+// Can these handles share a grouped forward?  PNVO_OK, or the error pnvo_forward_grouped_raw would return (reason in pnvo_last_error
+// of the first handle) — the caller's dispatch between one grouped and several per-model forwards asks here, no exception-driven retry.
+int pnvo_grouped_supported(const pnvo_handle *hs, int n) {
+  if (!hs || n < 1 || n > 3 || !hs[0]) return fail(nullptr, PNVO_ERR_ARG, "bad handle list");
+  pnvo_handle m = hs[0];
+  const pnvo_config &c = m->cfg;
+  for (int k = 0; k < n; ++k) {
+    pnvo_handle h = hs[k];
+    if (!h) return fail(m, PNVO_ERR_ARG, "grouped forward: null handle");
+    for (int j = 0; j < k; ++j)
+      if (hs[j] == h) return fail(m, PNVO_ERR_ARG, "grouped forward: a handle appears twice");
+    if (!h->loaded) return fail(m, PNVO_ERR_STATE, "grouped forward before pnvo_load_weights");
+    if (std::memcmp(&h->cfg, &c, sizeof(pnvo_config)) != 0 || h->device != m->device)
+      return fail(m, PNVO_ERR_ARG, "the models of a grouped forward must share architecture and device");
+    if (h->precision != 0 || h->train != nullptr || h->bottleneck || c.act_embed || h->dense_sticky || h->opt.pieces != 2 || !h->mx_ok ||
+        h->mx_wpk2 == nullptr || h->tap_dst != nullptr || h->opt.stem > 1 || !h->opt.pool || !h->opt.tail || h->opt.conv > 1)
+      return fail(m, PNVO_ERR_STATE, "grouped forward needs float32 inference handles on the default float16-piece kernels (no training step, "
+                                     "no tap, no act-embed, options pieces=2 / stem=auto / conv=auto / pool / tail at their defaults)");
+    for (size_t li = 1; li < h->convs.size(); ++li)
+      if (h->convs[li].groups > 0 && !x3_two_pieces(h, h->convs[li]))
+        return fail(m, PNVO_ERR_STATE, "grouped forward: layer " + h->convs[li].name + " of a model is range-guarded off the float16-piece form");
+  }
+  return PNVO_OK;
+}
+
+// One launch chain for the pairs of up to three action models (round 6; the navigation loop's call shape: 8-32 pairs per simulator
+// step split over the forward / left / right models, base_trainer_with_vo.py:277-294 — three small forwards of ~58 dependent launches
+// each are bound by launch latency, not work).  Pairs are sorted by model: handles[k] serves counts[k] consecutive pairs.  Every
+// conv runs on conv_x3_kernel (forced; fine plan for small launches) and the tile stem, which pick a sample's weights, weight scale
+// and GroupNorm affine by its model; the hidden layer and head run per model on its rows.  Same arithmetic per pair as a forward
+// of its model that selects these kernels (options conv=x3, x3_rows=off, stem_form=tiles): float32-grade equal to the default
+// forward of the same pairs, whose kernel choice depends on the batch size.
+int pnvo_forward_grouped_raw(const pnvo_handle *handles, const int32_t *counts, int n_models, const uint8_t *rgb_frames,
+                             const float *depth_frames, const float *tdv, int B, float *out, int32_t *err_flag, void *stream) {
+  if (!handles || !counts || n_models < 1 || n_models > 3 || !handles[0]) return fail(nullptr, PNVO_ERR_ARG, "bad handle list");
+  pnvo_handle hs[3] = {nullptr, nullptr, nullptr};
+  int cnt[3] = {0, 0, 0}, ng = 0, total = 0;
+  for (int k = 0; k < n_models; ++k) {
+    if (counts[k] < 0 || (counts[k] > 0 && !handles[k])) return fail(handles[0], PNVO_ERR_ARG, "bad pair count / null handle");
+    total += counts[k];
+    if (counts[k] > 0) {
+      hs[ng] = handles[k];
+      cnt[ng++] = counts[k];
+    }
+  }
+  pnvo_handle m = hs[0];
+  if (ng == 0 || total != B || B <= 0 || !out) return fail(handles[0], PNVO_ERR_ARG, "pair counts do not add up to the batch / null output");
+  if (ng == 1) return pnvo_forward_raw(m, rgb_frames, depth_frames, tdv, nullptr, B, out, err_flag, stream);
+  const pnvo_config &c = m->cfg;
+  if (int rcs = pnvo_grouped_supported(hs, ng)) return rcs;
+  for (int k = 0; k < ng; ++k)
+    if (int rc0 = pnvo_check_inputs(hs[k])) return rc0;
+  if ((c.n_rgb > 0) != (rgb_frames != nullptr) || ((c.n_depth > 0 || c.n_dd > 0) && depth_frames == nullptr) || (c.n_tdv > 0) != (tdv != nullptr))
+    return fail(m, PNVO_ERR_ARG, "sensor frames do not match the models' observation_space");
+  if (!raw_direct(m, depth_frames)) return fail(m, PNVO_ERR_STATE, "grouped forward needs the sensor-frame stager of the float16-piece stem");
+  HIPCHK(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_workspace(m, B);
+  if (rc != PNVO_OK) return rc;
+  const PnvoOptions saved = m->opt;
+  m->opt.conv = 1;                 // every GroupNorm-ed conv on conv_x3_kernel (its fine plan for small launches)
+  m->opt.x3_rows = 0;              // (the row-streaming and resident-weight kernels hold ONE model's weights per workgroup)
+  m->opt.x3_persist = 0;
+  if (m->opt.gn_fuse == 1) m->opt.gn_fuse = 2;
+  m->grp_n = ng;
+  int acc = 0;
+  for (int k = 0; k < ng; ++k) {
+    m->grp[k] = hs[k];
+    acc += cnt[k];
+    m->grp_end[k] = acc;
+  }
+  m->raw_rgb = rgb_frames;
+  m->raw_depth = depth_frames;
+  m->raw_err = err_flag;
+  rc = forward_body(m, nullptr, nullptr, nullptr, tdv, nullptr, B, out, s);
+  m->stem_ev_pending = false;
+  m->raw_rgb = nullptr;
+  m->raw_depth = nullptr;
+  m->raw_err = nullptr;
+  m->grp_n = 0;
+  for (int k = 0; k < 3; ++k) m->grp[k] = nullptr;
+  m->opt = saved;
   return rc;
 }
 

@@ -115,6 +115,11 @@ struct StemMXArgs {
   float edges[12];                // bin edges e_0 .. e_10 of the one-hot depth (float32(i / 10))
   // developer ablations of stem_rs_kernel (option stem_dbg = 16 + bits; WRONG RESULTS, timing only)
   int dbg;
+  // grouped forward (see ConvX3Args): operands of models 1 / 2 (stem_mx_kernel only)
+  int grp_end0, grp_end1;
+  const unsigned short *wpk_g[2];
+  float oscale_g[2];
+  const float *pool_gamma_g[2];
 };
 constexpr int STEM_POOL_INIT = (int)0x807fffffu;   // key of -inf
 int stem_mx_slots(int Ho, int Wo);
@@ -176,6 +181,13 @@ struct ConvX3Args {
   const float *ds_gamma, *ds_beta;
   float *ds_scale, *ds_shift;
   float *ds_mu, *ds_rstd;            // [B,groups] for a backward pass, or nullptr
+  // GROUPED forward (pnvo_forward_grouped_raw: pairs of up to three action models in one launch chain, sorted by model): sample n
+  // belongs to model (n >= grp_end0) + (n >= grp_end1), an end of 0 meaning "no such model" (the structs are zero-filled); models 1 / 2
+  // take their operands from [0] / [1]
+  int grp_end0, grp_end1;
+  const unsigned short *wpk_g[2], *ds_wpk_g[2];
+  float oscale_g[2], ds_oscale_g[2];
+  const float *gn_gamma_g[2], *gn_beta_g[2], *ds_gamma_g[2], *ds_beta_g[2];
 };
 #if defined(__HIPCC__)
 // One lane = one channel of a sample, lanes of a group adjacent and aligned: GroupNorm scale / shift from the channel's complete
@@ -327,14 +339,19 @@ void pack_conv_weight(const float *oihw, int cout, int cin, int kh, int kw, floa
 // GroupNorm statistics -> per-(sample,channel) scale/shift.
 // fixed_ns > 0: every sample has exactly fixed_ns slots (stem tiles); else slots follow the flattened wave tiles.
 // mu_out / rstd_out (optional, [B,G]) keep the statistics for the backward pass.
+struct GnGroup {                     // grouped forward: affine parameters of models 1 / 2 (sample n -> model as in ConvX3Args)
+  int end0, end1;
+  const float *gamma[2], *beta[2];
+};
 hipError_t launch_gn_finalize(const float *stats, int B, int slots, int CP, int C, int G, long P, int WM,
                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
-                              hipStream_t s, int fixed_ns = 0, float *mu_out = nullptr, float *rstd_out = nullptr);
+                              hipStream_t s, int fixed_ns = 0, float *mu_out = nullptr, float *rstd_out = nullptr,
+                              const GnGroup *grp = nullptr);
 
 // Two GroupNorms of one geometry in one launch (fixed slots per sample), each in gn_finalize_kernel's arithmetic; mu / rstd of set 0.
 hipError_t launch_gn_finalize_pair(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
                                    const float *const *beta, float eps, float *const *scale, float *const *shift, float *const *mu_out,
-                                   float *const *rstd_out, hipStream_t s);
+                                   float *const *rstd_out, hipStream_t s, const GnGroup *grp0 = nullptr, const GnGroup *grp1 = nullptr);
 hipError_t launch_gn_finalize2(const float *const *stats, int B, int slots, int CP, int C, int G, long P, const float *const *gamma,
                                const float *const *beta, float eps, float *const *scale, float *const *shift, int nmodels,
                                hipStream_t s);

@@ -90,6 +90,11 @@ struct pnvo_model_s {
   std::vector<Layer> convs;          // stem, residual stages in execution order, compression
   Layer fc, head;
   float *fc_bias = nullptr, *head_bias = nullptr;   // device; fc_bias has 1 or n_acts+1 rows
+  // grouped forward (pnvo_forward_grouped_raw), set on the LEADER handle for the duration of the call: handles of the action models
+  // in sample order (grp[0] = this handle), cumulative sample ends; kernels pick a sample's operands by its model
+  int grp_n = 0;
+  struct pnvo_model_s *grp[3] = {nullptr, nullptr, nullptr};
+  int grp_end[3] = {0, 0, 0};
   float *head_w_plain = nullptr;             // device [out_dim][hidden]: the head's weight as loaded (the head riding on the hidden layer's split-K reduction)
   const float *head_ride_w = nullptr;        // ... the weight it reads: head_w_plain, or the flat parameter buffer of an attached training step
   float *head_ride_out = nullptr;            // set around the hidden layer's launch by the forward: where the riding head writes [B][out_dim]

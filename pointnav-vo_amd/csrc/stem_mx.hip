@@ -89,6 +89,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
+  // grouped forward (pnvo_forward_grouped_raw): the sample's action model picks the weights (one model: both ends INT_MAX)
+  const int g_mdl = (p.grp_end0 > 0 && n >= p.grp_end0) + (p.grp_end1 > 0 && n >= p.grp_end1);   // (0: no such model)
+  const unsigned short *g_wpk = g_mdl == 0 ? p.wpk : p.wpk_g[g_mdl - 1];
   const int ho0 = ty * TH, wo0 = tx * TW;
   const int hi_base = 2 * ho0 - 3, wi_base = 2 * wo0 - 3;
 
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     const unsigned baseX = (unsigned)(2 * rr * ROW + c * PITCH + 64);
     const int nfrag = NFT * ntg;                          // fragments per tap in the packed array
     auto loadB = [&](int tap, u32x4 *b) {                 // uniform base (SGPRs) + lane offset + immediates
-      const u32x4 *wt = reinterpret_cast<const u32x4 *>(p.wpk) + ((long)tap * nfrag + gy * NT) * 64;
+      const u32x4 *wt = reinterpret_cast<const u32x4 *>(g_wpk) + ((long)tap * nfrag + gy * NT) * 64;
 #pragma unroll
       for (int f = 0; f < NFT; ++f)
 #pragma unroll
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   // M-tile `wave` in wave order 0,1,2,3 — no data-dependent register selection, bit-reproducible.
   const int rr16 = lane >> 5;                             // accumulator row = (r & 3) + 8 (r >> 2) + 4 rr16
   const bool full = ho0 + TH <= p.Ho && wo0 + TW <= p.Wo; // the whole tile is inside the output (wave-uniform)
-  const float oscale = (H && p.oscale_ptr != nullptr) ? *p.oscale_ptr : p.oscale;
+  const float oscale = (H && p.oscale_ptr != nullptr) ? *p.oscale_ptr : (g_mdl == 0 ? p.oscale : p.oscale_g[g_mdl - 1]);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     __syncthreads();                                      // patch (or the previous N-tile's exchange) no longer read
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       // maxima — plain stores for windows inside the tile, integer atomic max (exact, order-free) for windows that straddle
       // tiles; the consumer (conv_x3 MODE 3) decodes, applies |scale|, shift and ReLU: the same bits as pooling afterwards.
       // The raw stem output is never written.  GroupNorm partial sums come from the full-resolution values as always.
-      const float sgn = p.pool_gamma[co] < 0.f ? -1.f : 1.f;
+      const float sgn = (g_mdl == 0 ? p.pool_gamma : p.pool_gamma_g[g_mdl - 1])[co] < 0.f ? -1.f : 1.f;
       __syncthreads();                                    // every wave has its `tot`: the exchange area is free
       float *pb = reinterpret_cast<float *>(lds);        // [8 rows][16 cols][33: 32 channels + 1 pad]
 #pragma unroll

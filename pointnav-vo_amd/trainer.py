@@ -495,7 +495,26 @@ class BaseRLTrainerWithVO:
                         p(st["dd"], lo), p(st["tdv"], lo), p(st["flag"]), _stream(dev)))
                 elif want_tdv:                            # :239-249: prev frames -> channel 0, cur frames -> channel 1
                     gen.gen_top_down_view_pairs(st["d_dep"][lo:hi], st["tdv"][lo:hi])
-            for key in sorted(set(keys)):
+            ukeys = sorted(set(keys))
+            # Several action models, few pairs each (the navigation loop: 8-32 environments over forward / left / right): ONE launch
+            # chain over all pairs (vo_cnn.grouped_forward_raw) instead of one small forward per model — each of those is bound by its
+            # ~50 dependent launches, not by its work.  From `group_max_pairs` on the per-model forwards win (larger batches run on
+            # the resident-weight stem and the row-streaming kernels, which hold one model's weights).
+            grouped = (rm.mode == "det" and "act_embed" not in name and 2 <= len(ukeys) <= 3 and n <= int(getattr(self, "group_max_pairs", 48))
+                       and all(getattr(self.vo_model[k], "_precision", "float32") == "float32" for k in ukeys))
+            if grouped:
+                models = [self.vo_model[k] for k in ukeys]
+                for mdl in models:
+                    if mdl.training:
+                        mdl.eval()
+                from .vo_cnn import grouped_forward_raw, grouped_supported
+                grouped, self._grouped_reason = grouped_supported(models)      # (handles off the default kernels: per-model forwards)
+            if grouped:
+                counts = [sum(1 for k in keys if k == key) for key in ukeys]      # (the pairs are sorted by key)
+                pending.append((list(range(n)), grouped_forward_raw(models, counts, st["d_rgb"][:n] if want_rgb else None, st["d_dep"][:n],
+                                                                    st["tdv"][:n] if want_tdv else None, err_flag=st["flag"])))
+                ukeys = []
+            for key in ukeys:
                 idx = [i for i, k in enumerate(keys) if k == key]            # contiguous: the pairs are sorted by key
                 lo_k, hi_k = idx[0], idx[-1] + 1
                 pick = lambda t: None if t is None else t[lo_k:hi_k]

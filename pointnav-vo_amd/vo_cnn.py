@@ -408,6 +408,61 @@ def dual_forward_raw(model_a, model_b, rgb_frames, depth_frames, top_down_view=N
     return oa, ob
 
 
+def grouped_supported(models):
+    """Can these eval-mode models share a grouped forward (pnvo_grouped_supported)?  -> (bool, reason)."""
+    models = list(models)
+    if not 1 <= len(models) <= 3 or any(m.training for m in models):
+        return False, "one to three eval-mode models"
+    dev = next(models[0].parameters()).device
+    if dev.type != "cuda" or any(next(m.parameters()).device != dev for m in models):
+        return False, "models on one MI355X"
+    for m in models:
+        m._ensure_handle(dev)
+        m._sync_weights()
+    hs = (C.c_void_p * len(models))(*[m._handle for m in models])
+    rc = _lib.lib.pnvo_grouped_supported(hs, len(models))
+    return rc == 0, ("" if rc == 0 else _lib.lib.pnvo_last_error(models[0]._handle).decode())
+
+
+def grouped_forward_raw(models, counts, rgb_frames, depth_frames, top_down_view=None, err_flag=None):
+    """The eval forward of up to three SEPARATE-ACTION models over one batch of sensor frames in ONE launch chain
+    (pnvo_forward_grouped_raw): models[k] serves counts[k] consecutive pairs (the batch sorted by action model, as
+    BaseRLTrainerWithVO.compute_local_delta_states_batch sorts it; tensor contract as VisualOdometryCNNBase.forward_raw).
+    What the navigation loop's batched call needs (base_trainer_with_vo.py:277-294 picks vo_model[act] per environment): three
+    forwards of a few pairs each are bound by launch latency, one chain over all pairs costs what ONE forward of that size does."""
+    models, counts = list(models), [int(x) for x in counts]
+    if not 1 <= len(models) <= 3 or len(models) != len(counts):
+        raise ValueError("grouped_forward_raw takes one to three models and as many pair counts")
+    ref = next(models[0].parameters())
+    dev = ref.device
+    if dev.type != "cuda" or any(next(m.parameters()).device != dev for m in models):
+        raise RuntimeError("grouped_forward_raw: every model must be on the same MI355X (there is no CPU fallback)")
+    if any(m.training for m in models):
+        raise RuntimeError("grouped_forward_raw is the eval-mode forward of every model")
+    for m in models:
+        m._ensure_handle(dev)
+        m._sync_weights()
+    c = models[0].cfg
+    B = depth_frames.shape[0]
+    if sum(counts) != B:
+        raise ValueError(f"pair counts {counts} do not add up to the batch {B}")
+    rgb = rgb_frames.contiguous() if c.n_rgb else None
+    dep = depth_frames.contiguous()
+    tdv = top_down_view.contiguous() if c.n_tdv else None
+    assert dep.dtype == torch.float32 and tuple(dep.shape) == (B, 2, c.height, c.width) and dep.device == dev
+    assert rgb is None or (rgb.dtype == torch.uint8 and tuple(rgb.shape) == (B, 2, c.height, c.width, 3) and rgb.device == dev)
+    assert tdv is None or (tdv.dtype == torch.float32 and tuple(tdv.shape) == (B, c.height, c.width, 2) and tdv.device == dev)
+    out = torch.empty((B, c.out_dim), device=dev, dtype=torch.float32)
+    hs = (C.c_void_p * len(models))(*[m._handle for m in models])
+    cn = (C.c_int32 * len(models))(*counts)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.pnvo_forward_grouped_raw(hs, cn, len(models), p(rgb), p(dep), p(tdv), int(B), p(out), p(err_flag),
+                                                     C.c_void_p(stream)), models[0]._handle)
+    return out
+
+
 class VisualOdometryCNNActEmbedBase(VisualOdometryCNNBase):
     """Mirror of VisualOdometryCNNActEmbed (vo_cnn_act_embed.py:17-75): forward(observation_pairs, actions)."""
     _ACT_EMBED = True

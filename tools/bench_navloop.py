@@ -86,27 +86,49 @@ def run(envs, steps, episode_steps=150.0, dev=None):
         prev_obs = [frames[e % 96] for e in range(E)]
         env_ids = list(range(E)) if os.environ.get("PNVO_NAVLOOP_RING", "1") != "0" else None
 
+        phases = os.environ.get("PNVO_NAVLOOP_PHASES") is not None      # developer: host-synchronised time of each part (slower loop)
+        ph = {"policy input (stack + H2D)": 0.0, "policy.act": 0.0, "actions to host": 0.0, "VO boundary call": 0.0, "goal update": 0.0}
+
+        def mark(name, t_prev):
+            if not phases:
+                return t_prev
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            ph[name] += now - t_prev
+            return now
+
         def step(s):
             nonlocal hid, prev_a, prev_obs
+            tp = time.perf_counter()
             depth = torch.from_numpy(np.stack([o["depth"] for o in prev_obs])).to(dev, non_blocking=True)
             polar = geometry.compute_goal_pos_batch(np.stack(goals), np.zeros((E, 3)))["polar"]
             obs = {"depth": depth, "pointgoal_with_gps_compass": torch.from_numpy(polar).to(dev)}
+            tp = mark("policy input (stack + H2D)", tp)
             _, act, _, hid = pol.act(obs, hid, prev_a, masks, deterministic=False)
+            tp = mark("policy.act", tp)
             acts = (act.view(-1).cpu().numpy() % 3 + 1).tolist()          # STOP never ends a synthetic episode here
+            tp = mark("actions to host", tp)
             cur_obs = [frames[(e + s + 1) % 96] for e in range(E)]
             deltas = t.compute_local_delta_states_batch(prev_obs, cur_obs, acts, env_ids=env_ids)   # prev_obs IS last step's cur_obs: frame ring
+            tp = mark("VO boundary call", tp)
             goals[:] = list(geometry.compute_goal_pos_batch(np.stack(goals), deltas)["cartesian"])
             prev_a = torch.as_tensor(acts, device=dev).view(E, 1)
             prev_obs = cur_obs
+            mark("goal update", tp)
 
         for s in range(12):                 # (every action model, the policy and their small-batch kernels have run before the clock starts)
             step(s)
         torch.cuda.synchronize()
+        for k in ph:
+            ph[k] = 0.0
         t0 = time.perf_counter()
         for s in range(a.steps):
             step(s)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
+        if phases:
+            print(f"[navloop] {E} envs, ms per loop step by phase (host-synchronised):",
+                  {k: round(1e3 * v / a.steps, 3) for k, v in ph.items()}, file=sys.stderr)
         res["results"].append({"envs": E, "ms_per_loop_step": dt * 1e3, "env_steps_per_s": E / dt,
                                "gpu_side_minutes_for_994_episodes": 994 * a.episode_steps / (E / dt) / 60.0})
     res["note"] = (f"extrapolation assumes {a.episode_steps:.0f} steps per episode on one GPU; the reference's 4.5 h includes "
