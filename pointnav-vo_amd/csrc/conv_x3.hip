@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     // RING (float16 pieces, no riding downsample conv): B fragments are fetched TWO steps ahead into a ring of three register sets —
     // one step (6-18 MFMAs, 200-600 cycles) is shorter than an L2 round trip under load, and the ISA showed every step waiting for the
     // fragments it had asked for one step earlier.  A (LDS) stays one step ahead.  The two fetches run on trackers of their own.
-    constexpr bool RING = NP == 2 && KS == 3 && !(MODE == 2 && MW * NW == 5);   // (the block-tail strip tile has no registers to spare)
+    constexpr bool RING = NP == 2 && KS == 3 && !(MODE == 2 && MW * NW == 5) && !(DSF && MW * NW == 4);   // (the block-tail strip tile and the
+                                                                                                           //  (2,2) riding head have no registers to spare)
     const char *wb_b = wb_n;                                             // RING: the B step being fetched
     int kc_b = 0;
     auto advanceB = [&]() {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
       advanceB();                                                        // -> step R - 1
       // Small wave tiles also fetch A (LDS) TWO steps ahead, into two register sets used by the even / odd steps: with one M-tile a step
       // is three MFMAs = 96 cycles, less than an LDS read under load (measured: 63 cycles per MFMA with A one step ahead).
-      constexpr bool A2 = MW * NW <= 2 && !(MODE == 2 && MW * NW == 2 && !DSF);   // (the (2,1) block-tail tile runs three waves per SIMD: 168 registers)
+      constexpr bool A2 = MW * NW <= 2 && !(MODE == 2 && MW * NW == 2 && !DSF) && !(MODE == 2 && DSF && MW * NW == 1);   // (168-register tiles: three waves per SIMD)
       u32x4 a1[A2 ? NP : 1][MW];
       if (A2) {
 #pragma unroll
@@ -505,14 +506,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
               accd[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ad[TA[t]][i]), __builtin_bit_cast(f16x8, bd[TB[t]][j]),
                                                                   accd[i][j], 0, 0, 0);
       };
+      if constexpr (MW * NW == 4) {                                        // (one fragment set: 16 registers this tile does not have twice)
 #pragma unroll 1
-      for (int kc = 0; kc < kcc; kc += 2) {                                // (kcc is even)
-        loadAd(kc);
-        loadBd(bd1, kc + 1);
-        mm(bd0);
-        loadAd(kc + 1);
-        if (kc + 2 < kcc) loadBd(bd0, kc + 2);
-        mm(bd1);
+        for (int kc = 0; kc < kcc; ++kc) {
+          loadAd(kc);
+          mm(bd0);
+          if (kc + 1 < kcc) loadBd(bd0, kc + 1);
+        }
+      } else {
+#pragma unroll 1
+        for (int kc = 0; kc < kcc; kc += 2) {                              // (kcc is even)
+          loadAd(kc);
+          loadBd(bd1, kc + 1);
+          mm(bd0);
+          loadAd(kc + 1);
+          if (kc + 2 < kcc) loadBd(bd0, kc + 2);
+          mm(bd1);
+        }
       }
     }
     c_mm += __builtin_readcyclecounter() - t_b;
