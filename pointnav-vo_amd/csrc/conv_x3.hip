@@ -101,6 +101,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
   const float g_oscale = mdl == 0 ? p.oscale : p.oscale_g[mdl - 1], g_ds_oscale = mdl == 0 ? p.ds_oscale : p.ds_oscale_g[mdl - 1];
   const float *g_gamma = mdl == 0 ? p.gn_gamma : p.gn_gamma_g[mdl - 1], *g_beta = mdl == 0 ? p.gn_beta : p.gn_beta_g[mdl - 1];
   const float *g_ds_gamma = mdl == 0 ? p.ds_gamma : p.ds_gamma_g[mdl - 1], *g_ds_beta = mdl == 0 ? p.ds_beta : p.ds_beta_g[mdl - 1];
+  // Deferred GroupNorm finalisation (round 6, small launches): the producer of this conv's input (fin_in) / of the skip branch (fin_res)
+  // left its partial sums un-finalised; waves 0 and 1 turn them into this sample's scale / shift tables before anything else holds
+  // registers (gn_finalize_wave16: gn_finalize_kernel's arithmetic, bit for bit).  One memory round trip + ~0.5 us of fp64 per
+  // workgroup: cheaper than a launch while launches are the bound (8-48 pairs), dearer at 256 pairs — the host defers accordingly.
+  if ((MODE == 1 || MODE == 2) && (p.fin_in.stats != nullptr || p.fin_res.stats != nullptr)) {
+    float *ftab0 = reinterpret_cast<float *>(lds + NP * ((p.PR * p.PC) * (p.CK * 2 + 16)) + (size_t)p.MT * 32 * 8);
+    const long P_in = (long)p.H * p.W;
+    if (p.fin_in.stats != nullptr && wave == 0) {
+      const int Gn = p.CIN / p.fin_in.cpg;
+      const float *ga = mdl == 0 ? p.fin_in.gamma : p.fin_in.gamma_g[mdl - 1], *be = mdl == 0 ? p.fin_in.beta : p.fin_in.beta_g[mdl - 1];
+      for (int g0 = 0; g0 < Gn; g0 += 16)
+        gn_finalize_wave16(p.fin_in.stats + (long)n * p.fin_in.slots * p.CIN * 2, p.fin_in.slots, p.CIN, g0, Gn, p.fin_in.cpg, P_in, 1e-5f, ga, be,
+                           ftab0, ftab0 + p.CIN);
+    }
+    if (MODE == 2 && p.fin_res.stats != nullptr && wave == 1) {
+      const int Gn = p.CIN / p.fin_res.cpg;
+      const float *ga = mdl == 0 ? p.fin_res.gamma : p.fin_res.gamma_g[mdl - 1], *be = mdl == 0 ? p.fin_res.beta : p.fin_res.beta_g[mdl - 1];
+      for (int g0 = 0; g0 < Gn; g0 += 16)
+        gn_finalize_wave16(p.fin_res.stats + (long)n * p.fin_res.slots * p.CIN * 2, p.fin_res.slots, p.CIN, g0, Gn, p.fin_res.cpg, P_in, 1e-5f, ga, be,
+                           ftab0 + 2 * p.CIN, ftab0 + 3 * p.CIN);
+    }
+    __syncthreads();
+  }
   const int PR = p.PR, PC = p.PC, CK = p.CK;
   const int pitch = CK * 2 + 16;                   // bytes per patch pixel in one piece plane (odd number of 16-byte units)
   const int plane = PR * PC * pitch;               // bytes of one piece plane
@@ -162,23 +185,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     if (ck0 > 0) __syncthreads();                                        // the previous chunk's patch is no longer read
     {
       f32x4 sc0, sc1, sh0, sh1, rs0, rs1, rt0, rt1;
-      const bool res_ss = MODE == 2 && p.res_scale != nullptr;
-      if (MODE >= 1) {
-        const float *ps = p.in_scale + (long)n * p.CIN + ck0 + 8 * cg;
-        const float *pt = p.in_shift + (long)n * p.CIN + ck0 + 8 * cg;
-        sc0 = *reinterpret_cast<const f32x4 *>(ps);
-        sc1 = *reinterpret_cast<const f32x4 *>(ps + 4);
-        sh0 = *reinterpret_cast<const f32x4 *>(pt);
-        sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
-      }
-      if (res_ss) {
-        const float *ps = p.res_scale + (long)n * p.CIN + ck0 + 8 * cg;
-        const float *pt = p.res_shift + (long)n * p.CIN + ck0 + 8 * cg;
-        rs0 = *reinterpret_cast<const f32x4 *>(ps);
-        rs1 = *reinterpret_cast<const f32x4 *>(ps + 4);
-        rt0 = *reinterpret_cast<const f32x4 *>(pt);
-        rt1 = *reinterpret_cast<const f32x4 *>(pt + 4);
-      }
+      const bool fin_i = (MODE == 1 || MODE == 2) && p.fin_in.stats != nullptr;
+      const bool fin_r = MODE == 2 && p.fin_res.stats != nullptr;
+      const bool res_ss = MODE == 2 && (p.res_scale != nullptr || fin_r);
+      // Deferred GroupNorm finalisation (p.fin_in / p.fin_res): the sample's scale / shift tables were built at the top of the kernel,
+      // in LDS behind the pixel tables
+      float *ftab = reinterpret_cast<float *>(lds + NP * plane + (size_t)p.MT * 32 * 8);   // [in scale | in shift | res scale | res shift][CIN]
+      auto load_ss = [&]() {
+        if (MODE >= 1) {
+          const float *ps = fin_i ? ftab + ck0 + 8 * cg : p.in_scale + (long)n * p.CIN + ck0 + 8 * cg;
+          const float *pt = fin_i ? ftab + p.CIN + ck0 + 8 * cg : p.in_shift + (long)n * p.CIN + ck0 + 8 * cg;
+          sc0 = *reinterpret_cast<const f32x4 *>(ps);
+          sc1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+          sh0 = *reinterpret_cast<const f32x4 *>(pt);
+          sh1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+        }
+        if (res_ss) {
+          const float *ps = fin_r ? ftab + 2 * p.CIN + ck0 + 8 * cg : p.res_scale + (long)n * p.CIN + ck0 + 8 * cg;
+          const float *pt = fin_r ? ftab + 3 * p.CIN + ck0 + 8 * cg : p.res_shift + (long)n * p.CIN + ck0 + 8 * cg;
+          rs0 = *reinterpret_cast<const f32x4 *>(ps);
+          rs1 = *reinterpret_cast<const f32x4 *>(ps + 4);
+          rt0 = *reinterpret_cast<const f32x4 *>(pt);
+          rt1 = *reinterpret_cast<const f32x4 *>(pt + 4);
+        }
+      };
+      load_ss();
       int pr = pl / PC, pc = pl - pr * PC;
       const long img = ((long)n * p.H * p.W) * p.CIN + ck0 + 8 * cg;
       const float *xb = p.x + img;
@@ -1228,7 +1259,8 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     if (wgs < (a.np == 2 ? 112 : 192) && !force) return false;
   }
   a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
-  *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
+  *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;   // planes, pixel tables (a launch with a deferred GroupNorm adds 16 B per input
+                                                                                // channel behind them: pnvo_run_conv — 1 KB more would cost the 64-channel convs their third workgroup per CU)
   return true;
 }
 }  // namespace

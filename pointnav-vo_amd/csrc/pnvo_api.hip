@@ -269,6 +269,7 @@ void free_workspace(pnvo_model_s *m) {
   free_dev(m->stats);
   free_dev(m->gn_ctr);
   free_dev(m->stats_ds);
+  free_dev(m->statsB);
   if (m->keys_stream) (void)hipStreamSynchronize(m->keys_stream);     // a fill of the key buffer may still be in flight
   free_dev(m->pool_keys);
   m->keys_primed = false;
@@ -363,6 +364,7 @@ int ensure_workspace(pnvo_handle m, int B) {   // (also exported as pnvo_ensure_
   HIPCHK(m, alloc(m->stats, st));
   m->stats_floats = st;
   HIPCHK(m, alloc(m->stats_ds, st));
+  HIPCHK(m, alloc(m->statsB, st));
   HIPCHK(m, alloc(m->pool_keys, (size_t)B * m->Hp * m->Wp * m->convs[0].coutp));
   HIPCHK(m, alloc(m->gn_ctr, (size_t)B * 16));
   HIPCHK(m, hipMemset(m->gn_ctr, 0, (size_t)B * 16 * sizeof(float)));
@@ -706,10 +708,37 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
         const float *sp = pnvo_train_x2_scale(m, l.name + ".weight");
         xa.oscale_ptr = sp ? sp + 1 : nullptr;
       }
+      // partial sums: the convs that write ssB keep a buffer of their own (a deferred finalisation reads the producer's sums while
+      // the consumer writes its own)
+      float *stats_buf = (ss[0] == m->ssB[0] && m->statsB != nullptr) ? m->statsB : m->stats;
+      auto pend_key = [&](const float *sc) { return sc == nullptr ? -1 : sc == m->ssA[0] ? 0 : sc == m->ssB[0] ? 1 : sc == m->ssD[0] ? 2 : -1; };
+      auto take_pend = [&](const float *sc, ConvX3Args::Fin &f) -> int {      // a pending finalisation behind `sc`: this launch does it
+        const int k = pend_key(sc);
+        if (k < 0 || !m->gn_pend[k].valid) return PNVO_OK;
+        if (rows || !(x3_mode == 1 || x3_mode == 2))
+          return fail(m, PNVO_ERR_STATE, "a deferred GroupNorm finalisation reached a launch that cannot do it (" + l.name + ")");
+        const auto &pd = m->gn_pend[k];
+        const Layer &pl = m->convs[pd.layer];
+        f.stats = pd.stats;
+        f.slots = pd.slots;
+        f.cpg = pd.cpg;
+        f.gamma = pl.gamma;
+        f.beta = pl.beta;
+        for (int g = 1; g < m->grp_n; ++g) {
+          f.gamma_g[g - 1] = m->grp[g]->convs[pd.layer].gamma;
+          f.beta_g[g - 1] = m->grp[g]->convs[pd.layer].beta;
+        }
+        m->gn_pend[k].valid = false;
+        return PNVO_OK;
+      };
+      if (int rcp = take_pend(in_scale, xa.fin_in)) return rcp;
+      if (tail != nullptr)
+        if (int rcp = take_pend(tail->res_scale, xa.fin_res)) return rcp;
+      if (xa.fin_in.stats != nullptr || xa.fin_res.stats != nullptr) ldsb += (size_t)xa.CIN * 16;   // the scale / shift tables built in the prologue
       xa.y = y;
       xa.in_scale = in_scale;
       xa.in_shift = in_shift;
-      xa.stats = m->stats;
+      xa.stats = stats_buf;
       if (tail != nullptr) {
         if (in_scale == nullptr) return fail(m, PNVO_ERR_STATE, "block tail without the conv's GroupNorm scale/shift");
         xa.res = tail->res;
@@ -756,16 +785,45 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
           HIPCHK(m, launch_conv_x3(xa, l.k, l.stride, x3_mode, mw, nw, ldsb, s));
       }
       if (fuse || fuse_last) return PNVO_OK;
+      // deferred: the consumer launch finalises (the forward set defer_main / defer_ride for this call: it knows the consumer)
+      const bool can_defer = l.cout == l.coutp && cpg >= 1 && l.cout % cpg == 0 && mu_out == nullptr;
+      const bool dm = can_defer && m->defer_main && pend_key(ss[0]) >= 0, dr = can_defer && ride != nullptr && m->defer_ride && ride->mu == nullptr && pend_key(ride->ss[0]) >= 0;
+      if (dm) {
+        auto &pd = m->gn_pend[pend_key(ss[0])];
+        pd.stats = stats_buf;
+        pd.slots = xa.slots;
+        pd.cpg = cpg;
+        pd.layer = (size_t)(&l - m->convs.data());
+        pd.valid = true;
+      }
+      if (dr) {
+        auto &pd = m->gn_pend[pend_key(ride->ss[0])];
+        pd.stats = m->stats_ds;
+        pd.slots = xa.slots;
+        pd.cpg = cpg;
+        pd.layer = (size_t)(ride->cd - m->convs.data());
+        pd.valid = true;
+      }
+      if (dm && (ride == nullptr || dr)) return PNVO_OK;
       Timed t(m, s, "gn_finalize", 0.0, 0.0);
+      if (ride != nullptr && (dm || dr)) {      // one of the two stays a launch
+        if (!dm)
+          HIPCHK(m, launch_gn_finalize(stats_buf, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s, xa.slots,
+                                       mu_out, rstd_out, m->grp_n > 1 ? &gg : nullptr));
+        if (!dr)
+          HIPCHK(m, launch_gn_finalize(m->stats_ds, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, ride->cd->gamma, ride->cd->beta, 1e-5f,
+                                       ride->ss[0], ride->ss[1], s, xa.slots, ride->mu, ride->rstd, m->grp_n > 1 ? &ggd : nullptr));
+        return PNVO_OK;
+      }
       if (ride != nullptr) {             // the conv's GroupNorm and the riding downsample conv's in one launch
-        const float *st2[2] = {m->stats, m->stats_ds}, *ga2[2] = {l.gamma, ride->cd->gamma}, *be2[2] = {l.beta, ride->cd->beta};
+        const float *st2[2] = {stats_buf, m->stats_ds}, *ga2[2] = {l.gamma, ride->cd->gamma}, *be2[2] = {l.beta, ride->cd->beta};
         float *sc2[2] = {ss[0], ride->ss[0]}, *sh2[2] = {ss[1], ride->ss[1]};
         float *mu2[2] = {mu_out, ride->mu}, *rs2[2] = {rstd_out, ride->rstd};
         HIPCHK(m, launch_gn_finalize_pair(st2, B, xa.slots, l.coutp, l.cout, l.groups, P, ga2, be2, 1e-5f, sc2, sh2, mu2, rs2, s,
                                           m->grp_n > 1 ? &gg : nullptr, m->grp_n > 1 ? &ggd : nullptr));
         return PNVO_OK;
       }
-      HIPCHK(m, launch_gn_finalize(m->stats, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
+      HIPCHK(m, launch_gn_finalize(stats_buf, B, xa.slots, l.coutp, l.cout, l.groups, P, 1, l.gamma, l.beta, 1e-5f, ss[0], ss[1], s,
                                    xa.slots, mu_out, rstd_out, m->grp_n > 1 ? &gg : nullptr));
       return PNVO_OK;
     }
@@ -1174,6 +1232,7 @@ const OptDef kOptions[] = {
     {"ds_side", "PNVO_DS_SIDE", &PnvoOptions::ds_side, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_strip", "PNVO_X3_STRIP", &PnvoOptions::x3_strip, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"pool_async", "PNVO_POOL_ASYNC", &PnvoOptions::pool_async, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"gn_defer", "PNVO_GN_DEFER", &PnvoOptions::gn_defer, true, {{nullptr, 0}}},
     {"x3_fine", "PNVO_X3_FINE", &PnvoOptions::x3_fine, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"head_fuse", "PNVO_HEAD_FUSE", &PnvoOptions::head_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1826,6 +1885,8 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
     if ((rc = maybe_tap(m, "input", m->xin, (size_t)B * c.height * c.width * m->CP, s)) != PNVO_OK) return rc;
   }
   size_t li = 0;
+  for (auto &pd : m->gn_pend) pd.valid = false;
+  m->defer_main = m->defer_ride = false;
   const Layer &stem = m->convs[li++];
   // (a7) GN + ReLU + maxpool.  Default: no pass at all — the stem writes pooled order-preserving keys (stem_mx.hip POOL), the
   // first block's first conv decodes / normalises them while staging and writes the pooled activations the skip branch needs
@@ -1918,10 +1979,19 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
       const Layer &c1 = m->convs[li++];
       const Layer &c2 = m->convs[li++];
       const bool ds = (li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos);
+      // Deferred GroupNorm finalisation (option gn_defer, launches of up to that many pairs): c1's GroupNorm is finalised by c2's
+      // launch when that is a conv_x3_kernel launch; c2's and the downsample conv's by the launch that takes this block's tail
+      const bool defer_on = m->opt.gn_defer > 0 && B <= m->opt.gn_defer && m->tap_dst == nullptr && m->train == nullptr;
+      const size_t li_next = li + (ds ? 1 : 0);
+      const bool next_takes = li_next < m->convs.size() && pnvo_conv_takes_tail(m, m->convs[li_next], B);
+      const bool c2_x3 = pnvo_conv_on_x3(m, c2, B);
+      const bool defer_c1 = defer_on && c2_x3, defer_tail = defer_on && next_takes;
       // the block's downsample conv rides on c1's launch (conv_x3_kernel DSF): no launch, no finalisation of its own, and in the
       // block-tail mode the block input is not written to HBM at all — c1 and the downsample conv are its only readers
       const bool ds_ride = ds && !have_keys && pnvo_conv_takes_ds(m, c1, m->convs[li], B);
       const DsRide ride{ds_ride ? &m->convs[li] : nullptr, m->rawD, m->ssD, nullptr, nullptr};
+      m->defer_main = defer_c1;
+      m->defer_ride = defer_tail;
       if (have_keys) {           // pooled stem keys in `nxt`: decoded + normalised by this conv's stager, activations -> `cur`
         BlockTail ktail{nullptr, nullptr, nullptr, cur};
         if ((rc = pnvo_run_conv(m, c1, B, keys, m->ssA[0], m->ssA[1], m->rawA, c1.coutp, m->ssA, nullptr, nullptr, 0, s, nullptr, nullptr,
@@ -1939,6 +2009,7 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
                                      nullptr, nullptr, ds_ride ? &ride : nullptr)) != PNVO_OK) {
         return rc;
       }
+      m->defer_main = m->defer_ride = false;
       const long P = (long)c2.hout * c2.wout;
       const bool c2_small_generic = !layer_on_lds(m, c2, nullptr) && !pnvo_conv_on_x3(m, c2, B) && (size_t)B * P * c2.cinp * 4 <= ((size_t)48 << 20);
       // The block's 1x1 stride-2 downsample conv reads only the block input (written by the first conv's stager) and owns rawD / ssD:
@@ -1969,18 +2040,23 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
         }
         if ((rc = run_conv(m, c2, B, napp, nullptr, nullptr, m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s)) != PNVO_OK)
           return rc;
-      } else if ((rc = run_conv(m, c2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0,
-                                s)) != PNVO_OK) {
-        return rc;
+      } else {
+        m->defer_main = defer_tail;
+        rc = run_conv(m, c2, B, m->rawA, m->ssA[0], m->ssA[1], m->rawB, c2.coutp, m->ssB, nullptr, nullptr, 0, s);
+        m->defer_main = false;
+        if (rc != PNVO_OK) return rc;
       }
       if (ds) {
         const Layer &cd = m->convs[li++];
+        m->defer_main = defer_tail && !ds_ride && !ds_forked;          // (a downsample conv launched on its own: the same consumer)
         if (ds_ride) {                                                 // rawD / ssD came out of c1's launch
         } else if (ds_forked) {
           HIPCHK(m, hipStreamWaitEvent(s, m->side_join, 0));           // rawD / ssD are complete before the block tail's consumer
         } else if ((rc = run_conv(m, cd, B, cur, nullptr, nullptr, m->rawD, cd.coutp, m->ssD, nullptr, nullptr, 0, s)) != PNVO_OK) {
+          m->defer_main = false;
           return rc;
         }
+        m->defer_main = false;
       }
       // (the last block's tail rides on the compression conv when that runs on conv_x3_kernel: nobody else reads that block output)
       if (li < m->convs.size() && pnvo_conv_takes_tail(m, m->convs[li], B)) {   // relu(GN2(conv2) + skip): computed by the next conv's stager

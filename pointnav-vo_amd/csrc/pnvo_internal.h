@@ -184,12 +184,22 @@ struct ConvX3Args {
   // GROUPED forward (pnvo_forward_grouped_raw: pairs of up to three action models in one launch chain, sorted by model): sample n
   // belongs to model (n >= grp_end0) + (n >= grp_end1), an end of 0 meaning "no such model" (the structs are zero-filled); models 1 / 2
   // take their operands from [0] / [1]
+  // DEFERRED GroupNorm finalisation (round 6, option gn_defer): the producer of this conv's input skipped its gn_finalize launch; this
+  // kernel turns the producer's partial sums into the scale / shift table of ITS sample in its prologue (fin_in: the input's GroupNorm,
+  // replaces in_scale / in_shift; fin_res: the skip branch's, replaces res_scale / res_shift) — gn_finalize_kernel's arithmetic bit for
+  // bit (gn_finalize_wave16), overlapped with the first patch loads.  stats == nullptr: the tables come from memory as before.
+  struct Fin {
+    const float *stats;              // [B][slots][CIN][2] partial sums of the producer
+    int slots, cpg;
+    const float *gamma, *beta, *gamma_g[2], *beta_g[2];   // affine parameters (and those of models 1 / 2 of a grouped forward)
+  } fin_in, fin_res;
   int grp_end0, grp_end1;
   const unsigned short *wpk_g[2], *ds_wpk_g[2];
   float oscale_g[2], ds_oscale_g[2];
   const float *gn_gamma_g[2], *gn_beta_g[2], *ds_gamma_g[2], *ds_beta_g[2];
 };
 #if defined(__HIPCC__)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // One lane = one channel of a sample, lanes of a group adjacent and aligned: GroupNorm scale / shift from the channel's complete
 // sums (s1, s2), in gn_finalize_kernel's arithmetic — fp64, the butterfly over the group's lanes in its order (the wider offsets
 // of that kernel's 64-lane butterfly add exact zeros), no a*b+c contraction (elementwise.hip is compiled without it).
@@ -271,6 +281,68 @@ __device__ __forceinline__ bool gn_last_arrival(unsigned *ctr, unsigned expect, 
   }
   __syncthreads();
   return *flag != 0;
+}
+// One WAVE finalises SIXTEEN groups at once — gn_finalize_kernel's result bit for bit with four lanes per group instead of a block
+// of 64.  That kernel: lane k of 64 adds elements k, k + 64, ... (element e = (slot e / cpg, channel g cpg + e % cpg)) in fp64, then a
+// xor-butterfly over 32, 16, ..., 1 — after every step the partner lanes hold the same value, so the result is the fixed tree
+// ((x[v] + x[v ^ 32]) + ...) whatever lane reads it.  Here lane 4 g' + q holds the sixteen "virtual lanes" v = 16 q + i of group g0 + g':
+// steps 32 and 16 are xor-shuffles across the four lanes (q ^ 2, q ^ 1), steps 8 ... 1 run inside the lane.  Same operands, same
+// order (a + b == b + a), no a*b+c contraction.  Groups >= G are skipped.  scale_tab / shift_tab: the sample's tables (LDS).
+__device__ __forceinline__ void gn_finalize_wave16(const float *stats_n, int ns, int CP, int g0, int G, int cpg, long P, float eps,
+                                                   const float *gamma, const float *beta, float *scale_tab, float *shift_tab) {
+#pragma clang fp contract(off)
+  const int lane = (int)(threadIdx.x & 63), q = lane & 3, g = g0 + (lane >> 2);
+  const bool live = g < G;
+  const int ne = ns * cpg;
+  double x1[16], x2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    x1[i] = 0.0;
+    x2[i] = 0.0;
+  }
+  if (live) {
+    for (int e0 = 0; e0 < ne; e0 += 64) {                       // (one pass whenever slots * cpg <= 64)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = e0 + 16 * q + i;
+        if (e < ne) {
+          const int slot = e / cpg, c = g * cpg + e % cpg;
+          const f32x2_t v = *reinterpret_cast<const f32x2_t *>(stats_n + ((long)slot * CP + c) * 2);
+          x1[i] += (double)v[0];
+          x2[i] += (double)v[1];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                                 // butterfly steps 32 and 16: across the group's four lanes
+    x1[i] += __shfl_xor(x1[i], 2);
+    x2[i] += __shfl_xor(x2[i], 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    x1[i] += __shfl_xor(x1[i], 1);
+    x2[i] += __shfl_xor(x2[i], 1);
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1)                               // steps 8, 4, 2, 1: inside the lane
+#pragma unroll
+    for (int i = 0; i < o; ++i) {
+      x1[i] += x1[i + o];
+      x2[i] += x2[i + o];
+    }
+  if (!live) return;
+  const double cnt = (double)P * cpg;
+  const double mu = x1[0] / cnt;
+  double var = x2[0] / cnt - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int t = q; t < cpg; t += 4) {
+    const int c = g * cpg + t;
+    const double sc = rstd * (double)gamma[c];
+    scale_tab[c] = (float)sc;
+    shift_tab[c] = (float)((double)beta[c] - mu * sc);
+  }
 }
 #endif
 bool conv_x3_plan(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes);

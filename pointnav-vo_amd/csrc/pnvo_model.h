@@ -46,6 +46,9 @@ struct PnvoOptions {
   int x3_strip = 1;    // 64- / 128-channel stride-1 convs on wide strip tiles with the N-tiles split over blockIdx.y (half the weight bytes per pixel)
   int pool_async = 0;  // pooled-key buffer of its own, re-initialised for the next forward on a side stream (see pool_keys).  OFF: measured
                        // slower at every batch (8 pairs 0.44 -> 0.50 ms, 256 pairs 2.37 -> 2.41): the two event hand-overs cost more than the 23 us fill
+  int gn_defer = 0;    // pairs up to which multi-tile GroupNorm finalisations move into the consumer conv's prologue (0: never = default).
+                       // Round 6: bit-identical, 4-10 launches fewer per forward — and slower (8 pairs 0.427 -> 0.448 ms, 32: 0.630 -> 0.663):
+                       // a memory round trip + ~0.5 us of fp64 in EVERY consumer workgroup costs more than a 4 us launch
   int x3_fine = 1;     // small launches of the float16-piece convs take one N-tile per workgroup instead of falling back to the fp32-pipe kernels
   int head_fuse = 1;   // the output head (Linear hidden -> out_dim) is computed by the hidden layer's split-K reduction launch (one launch less)
   int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
@@ -150,6 +153,19 @@ struct pnvo_model_s {
   hipEvent_t keys_free_ev = nullptr, keys_ready_ev = nullptr;
   bool keys_primed = false;                  // the fill for the next forward is enqueued (keys_ready_ev recorded behind it)
   int keys_primed_B = 0;                     //   ... for this many pairs
+  // Deferred GroupNorm finalisation (option gn_defer, small launches): a conv_x3 producer whose consumer is a conv_x3_kernel launch
+  // leaves its partial sums un-finalised; the consumer builds its sample's scale / shift table in its prologue (ConvX3Args::fin_in /
+  // fin_res).  gn_pend[k]: what is pending behind the scale / shift pair ssA (0), ssB (1), ssD (2); defer_main / defer_ride: set by the
+  // forward around a producer's pnvo_run_conv call.
+  struct GnPend {
+    const float *stats = nullptr;
+    int slots = 0, cpg = 0;
+    size_t layer = 0;                         // index into convs (gamma / beta; the same layer of the other models of a grouped forward)
+    bool valid = false;
+  } gn_pend[3];
+  bool defer_main = false, defer_ride = false;
+  float *statsB = nullptr;                   // partial sums of the convs that write ssB (the second conv of a block): a producer's sums
+                                             // must outlive the next launch, which writes its own
   float *stats_ds = nullptr;                 // GroupNorm partials of a downsample conv riding on its block's first conv (stats_floats)
   float *gn_ctr = nullptr;                   // [cap][16] unsigned arrival counters of the in-kernel GroupNorm finalisation (zero between launches)
   hipEvent_t stem_ev = nullptr;              // recorded behind a contract-checking stem launch (pnvo_mark_stem)

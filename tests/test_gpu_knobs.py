@@ -686,3 +686,52 @@ def test_fine_plan_keeps_small_batches_on_the_float16_pipe(B):
         got = outs[v][chk].double().cpu().numpy()
         err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
         assert err.max() < 2e-5, (v, err)
+
+
+@pytest.mark.parametrize("B", [5, 8, 16, 33, 48])
+def test_groupnorm_finalisation_deferred_to_the_consumer_is_bit_identical(B):
+    """Option gn_defer (round 6; OFF by default = 0 pairs — bit-identical but measured slower: a memory round trip and half a microsecond
+    of fp64 in every consumer workgroup cost more than the 4 us launches they remove): up to that batch a conv_x3 producer with several tiles per sample leaves its
+    GroupNorm partial sums un-finalised and the CONSUMER launch (the block's second conv; the conv that takes the block tail, for
+    the second conv's and the downsample conv's GroupNorms) builds its sample's scale / shift table in its prologue — one wave,
+    sixteen groups at once, gn_finalize_kernel's fp64 arithmetic and reduction tree reproduced with four lanes per group.  Bit for
+    bit the separate launches' result; about ten launches fewer per forward."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 9)
+    outs, nfin = {}, {}
+    with torch.no_grad():
+        for v in ("48", "0", "48"):
+            model.set_option("gn_defer", v)
+            o = model(obs).clone()
+            outs.setdefault(v, []).append(o)
+            model.timing(True)
+            model(obs)
+            torch.cuda.synchronize()
+            nfin[v] = sum(k["launches"] for k in model.timing_read() if k["name"] == "gn_finalize")
+            model.timing(False)
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs["48"][0]).all()
+    assert torch.equal(outs["48"][0], outs["0"][0]) and torch.equal(outs["48"][0], outs["48"][1])
+    assert nfin["48"] < nfin["0"], nfin
+
+
+def test_deferred_finalisation_in_the_grouped_forward():
+    """The grouped forward with and without deferred finalisation (the consumer picks the PRODUCER layer's affine parameters of the
+    sample's own model): bit-identical."""
+    import torch
+    from test_gpu_grouped import _frames, _models
+    from pointnav_vo_amd.vo_cnn import grouped_forward_raw
+    models = _models(3)
+    rgb, dep, tdv = _frames(14, 77)
+    outs = []
+    with torch.no_grad():
+        for v in ("48", "0"):
+            for m, _ in models:
+                m.set_option("gn_defer", v)
+            outs.append(grouped_forward_raw([m for m, _ in models], (5, 4, 5), rgb, dep, tdv).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
