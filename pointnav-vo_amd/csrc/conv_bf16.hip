@@ -44,8 +44,13 @@ __device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(fl
 // k-chunks = 18 fragments (72 registers), are loaded once and stay in registers.  What bounds these layers is the CU's vector-memory
 // pipe (~20 B/clk), and re-fetching the same 18 KB of weights for every tile, by each of the four waves, was most of its traffic
 // (conv_x3.hip conv_x3p_kernel: the float32-grade path's measurement).  Same MFMA order: bit-identical outputs.
-template <int KS, int STRIDE, int MODE, bool F32OUT, int MW, int NW, bool BRES = false>
+// DSF (round 6; KS = 3, STRIDE = 2: the first conv of a stride-2 block): the block's 1x1 stride-2 downsample conv rides on the launch — it
+// reads this conv's centre-tap pixels, so behind the nine taps of a chunk the centre tap's A fragments are read once more and multiplied
+// with the downsample conv's weights (p.ds_wpk) into a second accumulator set; second epilogue (p.ds_y, p.ds_stats, own GroupNorm).  Same
+// MFMAs in the same order as the separate 1x1 launch: bit-identical raw output.  As conv_x3_kernel's DSF.
+template <int KS, int STRIDE, int MODE, bool F32OUT, int MW, int NW, bool BRES = false, bool DSF = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
+  static_assert(!DSF || (KS == 3 && STRIDE == 2 && !F32OUT), "the downsample conv rides on a 3x3 stride-2 conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
   constexpr int CS = KS == 1 ? 1 : STRIDE;         // patch pixels per output pixel
@@ -70,6 +75,16 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         const int nt = min(wave_n_ * NW + j, ntt_ - 1);
         bres[st][j] = wpk[(((st >> 1) * kct_ + (st & 1)) * ntt_ + nt) * 64 + lane];
       }
+  }
+  u32x4 bresd[(BRES && DSF) ? 2 : 1][NW];                               // BRES + DSF: the downsample conv's two k-chunks, resident too
+  if (BRES && DSF) {
+    const int wn_ = p.wn, ntt_ = p.COUTP >> 5;
+    const int wave_n_ = (wave & (wn_ - 1)) + (int)blockIdx.y * (8 / NW);
+    const u32x4 *wd = reinterpret_cast<const u32x4 *>(p.ds_wpk[z]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) bresd[(BRES && DSF) ? st : 0][j] = wd[(st * ntt_ + min(wave_n_ * NW + j, ntt_ - 1)) * 64 + lane];
   }
   for (int vb = (int)blockIdx.x;; vb += (int)gridDim.x) {                // (one pass unless BRES)
   int bid = (vb & 7) * chunk + (vb >> 3);                               // consecutive tiles of an XCD are neighbours
@@ -108,6 +123,15 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
     for (int j = 0; j < NW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 accd[DSF ? MW : 1][DSF ? NW : 1];
+  if (DSF) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[DSF ? i : 0][DSF ? j : 0][r] = 0.f;
+  }
 
   // staging role: thread -> (pixel lane, 8-channel group); G groups per pixel, 256 / G pixels per step
   const int G = CK >> 3;
@@ -293,6 +317,34 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
       if (more) advance();
     }
     }
+    if constexpr (DSF) {
+      // the riding downsample conv: this conv's centre tap (patch offset (PC + 1) pixels) on its own weights, k-chunks ascending
+      const unsigned tc0 = (unsigned)((PC + 1) * pitch);
+      const char *wd = reinterpret_cast<const char *>(p.ds_wpk[z]) + (long)(ck0 >> 4) * kstep;
+      auto dstep = [&](int kc, const u32x4 *bd) {
+        u32x4 ad[MW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) ad[i] = *reinterpret_cast<const u32x4 *>(lds + aoff[i] + tc0 + (unsigned)kc * 32u);
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+          for (int i = 0; i < MW; ++i)
+            accd[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ad[i]), __builtin_bit_cast(bf16x8, bd[j]), accd[i][j], 0,
+                                                                 0, 0);
+      };
+      if constexpr (BRES) {                                               // (32 input channels: two k-chunks, fragments resident)
+        dstep(0, bresd[0]);
+        dstep(1, bresd[(BRES && DSF) ? 1 : 0]);
+      } else {
+#pragma unroll 1
+        for (int kc = 0; kc < kcc; ++kc) {
+          u32x4 bd[NW];
+#pragma unroll
+          for (int j = 0; j < NW; ++j) bd[j] = *reinterpret_cast<const u32x4 *>(wd + (long)kc * kstep + (size_t)voff[j]);
+          dstep(kc, bd);
+        }
+      }
+    }
   }
 
   // ---- epilogue: raw output + per-(sample, slot, channel) GroupNorm partial sums (one writer per slot).
@@ -300,72 +352,77 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
   // pixel's output offset comes from the table (four 16-byte LDS reads per M-tile), the store is base + 32-bit offset.
   const int rr16 = lane >> 5;
   const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
-  float t1[NW], t2[NW];
-#pragma unroll
-  for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < MW; ++i) {
-    const int mt = wave_m * MW + i;
-    if (mt >= p.MT) continue;
-    u32x4 ent[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int nt = wave_n * NW + j;
-      if (nt >= ntt) continue;
-      const int co = nt * 32 + (lane & 31);
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned e = ent[r >> 2][r & 3];
-        const bool ok = (int)e >= 0;
-        const float v = ok ? acc[i][j][r] : 0.f;
-        if (ok) {
-          if (F32OUT)
-            (reinterpret_cast<float *>(p.y[z]) + ybase + co)[e] = v;
-          else
-            (reinterpret_cast<__bf16 *>(p.y[z]) + ybase + co)[e] = (__bf16)v;
-        }
-        s1 += v;
-        s2 = __builtin_fmaf(v, v, s2);
-      }
-      t1[j] += s1 + __shfl_xor(s1, 32);                                  // M-tiles of this wave, in order
-      t2[j] += s2 + __shfl_xor(s2, 32);
-    }
-  }
-  if (p.stats[z] != nullptr) {                                           // one slot per tile: the waves along M meet in LDS
-    const int rows = 4 / wn;
-    float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
-    if (rows > 1) {
-      __syncthreads();                                                   // the patch is no longer read
-      if (lane < 32)
-#pragma unroll
-        for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
-      __syncthreads();
-    }
-    if (wave_m == 0 && lane < 32) {
-#pragma unroll
+  // (runs once for the conv and, DSF, once more for the downsample conv that rode on it)
+  auto emit = [&](f32x16 (*ac)[NW], void *yout, float *stats, const float *ggamma, const float *gbeta, float *gscale, float *gshift, bool f32o) {
+    float t1[NW], t2[NW];
+  #pragma unroll
+    for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
+  #pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = wave_m * MW + i;
+      if (mt >= p.MT) continue;
+      u32x4 ent[4];
+  #pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) ent[g4] = *reinterpret_cast<const u32x4 *>(otab + mt * 32 + 8 * g4 + 4 * rr16);
+  #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int nt = wave_n * NW + j;
         if (nt >= ntt) continue;
-        float s1 = t1[j], s2 = t2[j];
-        for (int w = 1; w < rows; ++w) {                                 // fixed order: bit-reproducible
-          const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
-          s1 += o[0];
-          s2 += o[1];
+        const int co = nt * 32 + (lane & 31);
+        float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned e = ent[r >> 2][r & 3];
+          const bool ok = (int)e >= 0;
+          const float v = ok ? ac[i][j][r] : 0.f;
+          if (ok) {
+            if (f32o)
+              (reinterpret_cast<float *>(yout) + ybase + co)[e] = v;
+            else
+              (reinterpret_cast<__bf16 *>(yout) + ybase + co)[e] = (__bf16)v;
+          }
+          s1 += v;
+          s2 = __builtin_fmaf(v, v, s2);
         }
-        float *dst = p.stats[z] + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
-        if (p.gn_scale[z] != nullptr) {                                  // the sample's only slot: finalise here (no launch), as conv_x3_kernel
-          const int c = nt * 32 + lane;
-          gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, p.gn_gamma[z][c], p.gn_beta[z][c], p.gn_scale[z] + (long)n * p.COUTP + c,
-                           p.gn_shift[z] + (long)n * p.COUTP + c);
+        t1[j] += s1 + __shfl_xor(s1, 32);                                  // M-tiles of this wave, in order
+        t2[j] += s2 + __shfl_xor(s2, 32);
+      }
+    }
+    if (stats != nullptr) {                                           // one slot per tile: the waves along M meet in LDS
+      const int rows = 4 / wn;
+      float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
+      if (rows > 1) {
+        __syncthreads();                                                   // the patch is no longer read
+        if (lane < 32)
+  #pragma unroll
+          for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x2 *>(red + ((wave * NW + j) * 32 + lane) * 2) = f32x2{t1[j], t2[j]};
+        __syncthreads();
+      }
+      if (wave_m == 0 && lane < 32) {
+  #pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const int nt = wave_n * NW + j;
+          if (nt >= ntt) continue;
+          float s1 = t1[j], s2 = t2[j];
+          for (int w = 1; w < rows; ++w) {                                 // fixed order: bit-reproducible
+            const f32x2 o = *reinterpret_cast<const f32x2 *>(red + (((w * wn + (wave & (wn - 1))) * NW + j) * 32 + lane) * 2);
+            s1 += o[0];
+            s2 += o[1];
+          }
+          float *dst = stats + (((long)n * p.slots + tri * p.tiles_c + tci) * p.COUTP + nt * 32 + lane) * 2;
+          dst[0] = s1;
+          dst[1] = s2;
+          if (gscale != nullptr) {                                  // the sample's only slot: finalise here (no launch), as conv_x3_kernel
+            const int c = nt * 32 + lane;
+            gn_finalize_lane(s1, s2, p.gn_cpg, p.gn_P, p.gn_eps, ggamma[c], gbeta[c], gscale + (long)n * p.COUTP + c,
+                             gshift + (long)n * p.COUTP + c);
+          }
         }
       }
     }
-  }
+  };
+  emit(acc, p.y[z], p.stats[z], p.gn_gamma[z], p.gn_beta[z], p.gn_scale[z], p.gn_shift[z], F32OUT);
+  if constexpr (DSF) emit(accd, p.ds_y[z], p.ds_stats[z], p.ds_gamma[z], p.ds_beta[z], p.ds_scale[z], p.ds_shift[z], false);
   if (!BRES) return;
   __syncthreads();                                                       // patch, tables and reduction scratch are free again
   }
@@ -380,6 +437,19 @@ hipError_t launch_ks(const ConvBArgs &a, int mode, bool f32out, int mw, int nw, 
   if (mode == MODE_ && f32out == F32_ && mw == MW_ && nw == NW_) {                                             \
     hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, MODE_, F32_, MW_, NW_>), grid, dim3(256), ldsb, s, a);    \
     return hipGetLastError();                                                                                  \
+  }
+  if constexpr (KS == 3 && STRIDE == 2) {
+    if (a.ds_wpk[0] != nullptr) {                  // the block's downsample conv rides on this launch
+#define PNVO_CBD(MODE_, MW_, NW_)                                                                                        \
+  if (mode == MODE_ && !f32out && mw == MW_ && nw == NW_) {                                                             \
+    hipLaunchKernelGGL((conv_bf16_kernel<KS, STRIDE, MODE_, false, MW_, NW_, false, true>), grid, dim3(256), ldsb, s, a); \
+    return hipGetLastError();                                                                                           \
+  }
+      PNVO_CBD(0, 1, 1) PNVO_CBD(2, 1, 1) PNVO_CBD(0, 2, 1) PNVO_CBD(2, 2, 1) PNVO_CBD(0, 3, 1) PNVO_CBD(2, 3, 1)
+      PNVO_CBD(0, 4, 1) PNVO_CBD(2, 4, 1)          // (two N-tiles per wave: 2 x 128 accumulator registers, not built; the host keeps the launch)
+#undef PNVO_CBD
+      return hipErrorInvalidValue;
+    }
   }
   PNVO_CB(0, false, 1, 1) PNVO_CB(1, false, 1, 1) PNVO_CB(0, false, 2, 1) PNVO_CB(1, false, 2, 1)
   PNVO_CB(0, false, 4, 1) PNVO_CB(1, false, 4, 1) PNVO_CB(0, false, 4, 2) PNVO_CB(1, false, 4, 2)
@@ -485,7 +555,24 @@ hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bo
     // (measured at 256 pairs x 2 models: the block-tail convs 0.240 -> 0.199 and 0.167 -> 0.146 ms, the 1x1 downsample conv 0.047 ->
     //  0.039; the plain and GroupNorm-input convs LOSE — 0.11 -> 0.13 ms: their 60-register streaming form keeps five workgroups
     //  per CU in flight, the 72 resident registers leave three — and stay on the streaming form)
+    if (a.ds_wpk[0] != nullptr) {                  // (the riding downsample conv's two k-chunks resident as well)
+#define PNVO_CBPD(MODE_, MW_)                                                                                           \
+  if (ks == 3 && stride == 2 && mode == MODE_ && mw == MW_) {                                                           \
+    auto kfn = conv_bf16_kernel<3, 2, MODE_, false, MW_, 1, true, true>;                                                \
+    int occ = 0;                                                                                                        \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds_bytes) != hipSuccess || occ < 1) occ = 1;      \
+    const int per_cu = std::max(1, occ / (int)(grid.y * grid.z));                                                       \
+    dim3 pg((unsigned)((per_cu * cus) & ~7), grid.y, grid.z);                                                           \
+    if (pg.x >= 8 && ntiles >= 2L * pg.x) {                                                                             \
+      hipLaunchKernelGGL(kfn, pg, dim3(256), lds_bytes, s, a);                                                          \
+      return hipGetLastError();                                                                                         \
+    }                                                                                                                   \
+  }
+      PNVO_CBPD(2, 2) PNVO_CBPD(2, 1)
+#undef PNVO_CBPD
+    } else {
     PNVO_CBP(3, 1, 2, 2) PNVO_CBP(3, 1, 2, 4) PNVO_CBP(3, 2, 2, 2) PNVO_CBP(1, 2, 0, 2) PNVO_CBP(3, 2, 2, 1) PNVO_CBP(1, 2, 0, 1)
+    }
 #undef PNVO_CBP
   }
   if (ks == 3 && stride == 1) return launch_ks<3, 1>(a, mode, f32out, mw, nw, grid, lds_bytes, s);

@@ -36,7 +36,7 @@ struct Bf16State {
   unsigned long long dual_partner_gen = 0, dual_self_gen = 0;
   int cap = 0;
   unsigned short *stem_raw = nullptr, *bufY[2] = {nullptr, nullptr}, *rawA = nullptr, *rawB = nullptr, *rawD = nullptr;
-  float *comp_raw = nullptr, *hid = nullptr, *stats = nullptr;
+  float *comp_raw = nullptr, *hid = nullptr, *stats = nullptr, *stats_ds = nullptr;   // stats_ds: partial sums of a riding downsample conv
   float *ssA[2] = {nullptr, nullptr}, *ssB[2] = {nullptr, nullptr}, *ssD[2] = {nullptr, nullptr}, *ssC[2] = {nullptr, nullptr};
 };
 
@@ -56,6 +56,7 @@ void free_ws(Bf16State *b) {
   dfree(b->comp_raw);
   dfree(b->hid);
   dfree(b->stats);
+  dfree(b->stats_ds);
   for (int k = 0; k < 2; ++k) {
     dfree(b->ssA[k]);
     dfree(b->ssB[k]);
@@ -134,6 +135,7 @@ int ensure_ws(pnvo_handle m, int B) {
   HIPCHK(m, hipMalloc((void **)&b->comp_raw, (size_t)B * m->fh * m->fw * m->comp_cp * 4));
   HIPCHK(m, hipMalloc((void **)&b->hid, (size_t)B * c.hidden * 4));
   HIPCHK(m, hipMalloc((void **)&b->stats, st * 4));
+  HIPCHK(m, hipMalloc((void **)&b->stats_ds, st * 4));
   for (int k = 0; k < 2; ++k) {
     HIPCHK(m, hipMalloc((void **)&b->ssA[k], (size_t)B * maxc * 4));
     HIPCHK(m, hipMalloc((void **)&b->ssB[k], (size_t)B * maxc * 4));
@@ -261,8 +263,10 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     int buf = 0;                         // else: the block input bufY[buf]
   };
   const bool fuse = m->opt.bf16_fuse != 0;
+  // ride (>= 0): the layer index of the block's 1x1 stride-2 downsample conv, computed by this launch (conv_bf16_kernel DSF): raw output ->
+  // rawD, GroupNorm -> ssD
   auto conv = [&](size_t li, int mode, auto xin, auto yout, int ss_sel /*0 A, 1 B, 2 D, 3 C*/, bool f32out, const Skip &sk,
-                  int out_buf) -> int {
+                  int out_buf, long ride = -1) -> int {
     const Layer &l = m->convs[li];
     ConvBArgs a = bs[0]->layers[li].plan;
     a.B = B;
@@ -279,6 +283,11 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       a.in_scale2[z] = mode == 2 && sk.affine ? bs[k]->ssD[0] : nullptr;
       a.in_shift2[z] = mode == 2 && sk.affine ? bs[k]->ssD[1] : nullptr;
       a.xout[z] = mode == 2 && out_buf >= 0 ? bs[k]->bufY[out_buf] : nullptr;
+      if (ride >= 0) {
+        a.ds_wpk[z] = bs[k]->layers[ride].wpk;
+        a.ds_y[z] = bs[k]->rawD;
+        a.ds_stats[z] = bs[k]->stats_ds;
+      }
     }
     // one tile per sample (the 12 x 22 and 6 x 11 maps): the workgroup that sums a sample's channels finalises its GroupNorm too
     // (gn_finalize_lane: fp64, the butterfly order of the float32 path's fused finalisation) — one launch less per layer
@@ -291,6 +300,12 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       a.gn_beta[z] = gfuse ? hs[k]->convs[li].beta : nullptr;
       a.gn_scale[z] = gfuse ? ssof(k)[0] : nullptr;
       a.gn_shift[z] = gfuse ? ssof(k)[1] : nullptr;
+      if (ride >= 0) {
+        a.ds_gamma[z] = gfuse ? hs[k]->convs[ride].gamma : nullptr;
+        a.ds_beta[z] = gfuse ? hs[k]->convs[ride].beta : nullptr;
+        a.ds_scale[z] = gfuse ? bs[k]->ssD[0] : nullptr;
+        a.ds_shift[z] = gfuse ? bs[k]->ssD[1] : nullptr;
+      }
     }
     a.gn_cpg = cpg;
     a.gn_eps = 1e-5f;
@@ -311,6 +326,15 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     auto sh = each([&](int z) { return ssof(z)[1]; });
     HIPCHK(m, launch_gn_finalize2(st.v, B, a.slots, l.coutp, l.cout, l.groups, (long)l.hout * l.wout, ga.v, be.v, 1e-5f, sc.v, sh.v,
                                   nm, s));
+    if (ride >= 0) {                     // the riding downsample conv's GroupNorm (same geometry, its own sums and parameters)
+      auto std_ = each([&](int z) { return (const float *)bs[z]->stats_ds; });
+      auto gad = each([&](int z) { return (const float *)hs[z]->convs[ride].gamma; });
+      auto bed = each([&](int z) { return (const float *)hs[z]->convs[ride].beta; });
+      auto scd = each([&](int z) { return bs[z]->ssD[0]; });
+      auto shd = each([&](int z) { return bs[z]->ssD[1]; });
+      HIPCHK(m, launch_gn_finalize2(std_.v, B, a.slots, l.coutp, l.cout, l.groups, (long)l.hout * l.wout, gad.v, bed.v, 1e-5f, scd.v, shd.v,
+                                    nm, s));
+    }
     return PNVO_OK;
   };
 
@@ -326,13 +350,22 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       const size_t l1 = li++, l2 = li++;
       const bool ds = li < m->convs.size() && m->convs[li].name.find("downsample") != std::string::npos;
       const Layer &c2 = m->convs[l2];
+      // the block's downsample conv rides on its first conv's launch (option ds_fuse); in the block-tail mode the block input is then
+      // not written at all: both of its readers are that launch
+      const Layer &c1 = m->convs[l1];
+      const bool ride_ok = ds && m->opt.ds_fuse && !(pend.on && pend.affine) /* the stager would read rawD while the ride writes it */ &&
+                           bs[0]->layers[l1].nw == 1 /* two N-tiles per wave: the second accumulator set does not fit (measured 56 -> 103 us) */ &&
+                           c1.k == 3 && c1.stride == 2 && m->convs[li].k == 1 && m->convs[li].stride == 2 &&
+                           c1.cinp == m->convs[li].cinp && c1.coutp == m->convs[li].coutp && c1.hout == m->convs[li].hout &&
+                           c1.wout == m->convs[li].wout && c1.groups == m->convs[li].groups;
+      const long ride = ride_ok ? (long)li : -1;
       if (pend.on) {                               // input = relu(GN2(rawB) + skip) of the previous block -> bufY[cur ^ 1]
         if ((rc = conv(l1, 2, [&](int z) { return (const unsigned short *)bs[z]->rawB; }, [&](int z) { return (void *)bs[z]->rawA; }, 0,
-                       false, pend, cur ^ 1)) != PNVO_OK)
+                       false, pend, ride_ok ? -1 : (cur ^ 1), ride)) != PNVO_OK)
           return rc;
         cur ^= 1;
       } else if ((rc = conv(l1, 0, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; },
-                            [&](int z) { return (void *)bs[z]->rawA; }, 0, false, none, -1)) != PNVO_OK) {
+                            [&](int z) { return (void *)bs[z]->rawA; }, 0, false, none, -1, ride)) != PNVO_OK) {
         return rc;
       }
       if ((rc = conv(l2, 1, [&](int z) { return (const unsigned short *)bs[z]->rawA; }, [&](int z) { return (void *)bs[z]->rawB; }, 1,
@@ -341,8 +374,8 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       const long P = (long)c2.hout * c2.wout;
       if (ds) {
         const size_t ld = li++;
-        if ((rc = conv(ld, 0, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; }, [&](int z) { return (void *)bs[z]->rawD; },
-                       2, false, none, -1)) != PNVO_OK)
+        if (!ride_ok && (rc = conv(ld, 0, [&](int z) { return (const unsigned short *)bs[z]->bufY[cur]; },
+                                   [&](int z) { return (void *)bs[z]->rawD; }, 2, false, none, -1)) != PNVO_OK)
           return rc;
       }
       if (fuse) {
@@ -382,9 +415,14 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
     pnvo_handle h = hs[z];
     const int tm = h->timing;
     h->timing = 0;                                  // (their event records belong to the fp32 path's table)
+    // (the output head rides on the hidden layer's split-K reduction when there is one: option head_fuse, as in the float32 forward)
+    h->head_rode = false;
+    h->head_ride_w = h->train != nullptr ? nullptr : h->head_w_plain;
+    h->head_ride_out = (h->opt.head_fuse && c.out_dim <= 4 && h->head_ride_w != nullptr) ? outs[z] : nullptr;
     rc = pnvo_run_conv(h, h->fc, B, bs[z]->comp_raw, bs[z]->ssC[0], bs[z]->ssC[1], bs[z]->hid, c.hidden, nullptr, h->fc_bias,
                        c.act_embed ? actions : nullptr, 1, s, nullptr, nullptr, nullptr);
-    if (rc == PNVO_OK)
+    h->head_ride_out = nullptr;
+    if (rc == PNVO_OK && !h->head_rode)
       rc = pnvo_run_conv(h, h->head, B, bs[z]->hid, nullptr, nullptr, outs[z], c.out_dim, nullptr, h->head_bias, nullptr, 0, s,
                          nullptr, nullptr, nullptr);
     h->timing = tm;

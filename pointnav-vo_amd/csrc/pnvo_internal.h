@@ -374,6 +374,12 @@ struct ConvBArgs {
   int B, H, W, CIN, Ho, Wo, COUTP;
   int TR, TC, tiles_r, tiles_c, PR, PC, CK, MT, wn, slots;   // filled by conv_bf16_plan
   int persist_wgs;                   // > 0: 32-input-channel layers run persistent with resident weights on this many workgroups
+  // the block's 1x1 stride-2 downsample conv riding on a 3x3 stride-2 launch (conv_bf16_kernel DSF; ds_wpk[0] == nullptr: none)
+  const unsigned short *ds_wpk[2];
+  void *ds_y[2];
+  float *ds_stats[2];
+  const float *ds_gamma[2], *ds_beta[2];
+  float *ds_scale[2], *ds_shift[2];
   // GroupNorm finalisation inside the conv (slots == 1, as ConvX3Args): scale / shift [B,COUTP] per model; nullptr: the separate launch
   const float *gn_gamma[2], *gn_beta[2];
   float *gn_scale[2], *gn_shift[2];

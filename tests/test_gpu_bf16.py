@@ -149,6 +149,34 @@ def test_dual_forward_at_baseline_batch_256():
         assert torch.equal(oa[k], ra[k % 3]) and torch.equal(ob[k], rb[k % 3]), k
 
 
+@pytest.mark.parametrize("pairs", [2, 40, 256])
+def test_downsample_ride_equals_the_separate_downsample_conv(pairs):
+    """Option ds_fuse in the bf16 path (round 6): the 1x1 stride-2 downsample conv of layer2.0 / 3.0 / 4.0 (resnet.py:192-195) is computed
+    by the launch of the block's first 3x3 stride-2 conv from that conv's centre-tap A fragments (conv_bf16.hip DSF) — in the block-tail
+    and in the plain-input form (bf16_fuse off), streaming and persistent workgroups.  Same bf16 products in the same k order; only the
+    GroupNorm partial sums are grouped by the riding conv's tiles, so the outputs agree to float32 summation order."""
+    rec = load_golden("model_default_341x192_b2.npz")
+    ma, cfg, _, _, tobs, _, _ = build(rec)
+    mb, _, _, _, _, _, _ = build(rec, seed=77)
+    big = {k: v.repeat(((pairs + v.shape[0] - 1) // v.shape[0],) + (1,) * (v.dim() - 1))[:pairs].contiguous() for k, v in tobs.items()}
+    res = {}
+    with torch.no_grad():
+        for fuse in ("on", "off"):
+            for v in ("on", "off"):
+                for m in (ma, mb):
+                    m.set_option("bf16_fuse", fuse)
+                    m.set_option("ds_fuse", v)
+                res[fuse, v] = [o.clone() for o in vo_cnn.dual_forward(ma, mb, big)] + [ma(big).clone()]
+        for m in (ma, mb):
+            m.set_option("bf16_fuse", "on")
+            m.set_option("ds_fuse", "on")
+    for fuse in ("on", "off"):
+        for a, b in zip(res[fuse, "on"], res[fuse, "off"]):
+            d = (a - b).abs().max().item()
+            print(f"pairs {pairs} bf16_fuse {fuse}: ride vs separate max |diff| {d:.3e} (|out| max {b.abs().max().item():.3f})")
+            assert torch.isfinite(a).all() and d <= 2e-3 * max(1.0, b.abs().max().item()), (fuse, d)
+
+
 def test_fused_block_tail_equals_the_separate_residual_pass():
     """conv1 of the next block computes relu(GN2(conv2) + skip) while staging (conv_bf16.hip MODE 2) and writes the block
     output; option bf16_fuse=off keeps the separate residual kernel.  Same float32 expression, same bf16 rounding: the
