@@ -74,8 +74,13 @@ constexpr int x3_wpe(int mw, int nw, int np, bool dsf = false) {
 // GroupNorm).  One launch and one GroupNorm finalisation less per stride-2 block, the block input is read once instead of twice, and
 // in the block-tail mode (MODE 2) the block input need not be written to HBM at all (p.xout == nullptr): both of its readers are here.
 // Same MFMA terms in the same order as the separate 1x1 launch (k-chunks ascending, a1 w0, a0 w1, a0 w0): bit-identical raw output.
-template <int KS, int STRIDE, int MODE, int MW, int NW, int NP, bool DSF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, NW, NP, DSF), x3_wpe(MW, NW, NP, DSF)))) void conv_x3_kernel(const ConvX3Args p) {
+// W8: eight waves per workgroup instead of four (wave grid (8 / wn) x wn).  The 256-channel convs on 6 x 11 maps are ONE tile per sample
+// = one workgroup per CU at 256 pairs: with four waves of (3,2) tiles each SIMD holds a single wave and its K loop issues MFMAs 75 % of
+// the time (in-order issue: the fragment waits are not covered); eight waves of (3,1) tiles are two per SIMD and issue 92 %
+// (profiles/r6_experiments.md), staging the patch once with twice the threads.
+template <int KS, int STRIDE, int MODE, int MW, int NW, int NP, bool DSF = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(W8 ? 2 : x3_wpe(MW, NW, NP, DSF), W8 ? 2 : x3_wpe(MW, NW, NP, DSF)))) void conv_x3_kernel(const ConvX3Args p) {
+  constexpr int NTH = W8 ? 512 : 256, NWV = NTH / 64;
   static_assert(!DSF || (KS == 3 && STRIDE == 2 && NP == 2 && (MODE == 0 || MODE == 2)), "the downsample rides on a float16-piece 3x3 stride-2 conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
   // pixel inside the sample's output plane, bit 31 set when the pixel does not exist
   unsigned *qtab = reinterpret_cast<unsigned *>(lds + NP * plane);
   unsigned *otab = qtab + p.MT * 32;
-  for (int e = (int)threadIdx.x; e < p.MT * 32; e += 256) {               // (strip tiles: nine M-tiles = 288 entries)
+  for (int e = (int)threadIdx.x; e < p.MT * 32; e += NTH) {               // (strip tiles: nine M-tiles = 288 entries)
     const int q = min(e, npix - 1);
     const int tr = q / p.TC, tc = q - tr * p.TC;
     qtab[e] = (unsigned)(((tr * CS) * PC + tc * CS) * pitch);
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     otab[e] = (unsigned)((tr * p.Wo + tc) * p.COUTP) | (ok ? 0u : 0x80000000u);
   }
 
-  const int wn = p.wn;                                                   // wave grid: (4 / wn) x wn
+  const int wn = p.wn;                                                   // wave grid: (NWV / wn) x wn
   const int wave_m = wave / wn;
   const int wave_n = (wave & (wn - 1)) + (int)blockIdx.y * wn;            // blockIdx.y = group of wn * NW N-tiles
   const int ntt = p.COUTP >> 5, kct = p.CIN >> 4;                        // N-tiles, 16-channel k-chunks of the layer
@@ -173,9 +178,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     in_mul = __builtin_bit_cast(float, (unsigned)(14 - e + 127) << 23);
     in_div = __builtin_bit_cast(float, (unsigned)(e - 14 + 127) << 23);
   }
-  // staging role: thread -> (pixel lane, 8-channel group); G groups per pixel, 256 / G pixels per step
+  // staging role: thread -> (pixel lane, 8-channel group); G groups per pixel, NTH / G pixels per step
   const int G = CK >> 3;
-  const int cg = threadIdx.x & (G - 1), pl = threadIdx.x / G, PS = 256 / G;
+  const int cg = threadIdx.x & (G - 1), pl = threadIdx.x / G, PS = NTH / G;
   const int dr = PS / PC, dc = PS - dr * PC;
   const int nppix = PR * PC;
 
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
       }
     }
     if (stats != nullptr) {                                                // one slot per tile: the waves along M meet in LDS
-      const int rows = 4 / wn;
+      const int rows = NWV / wn;
       float *red = reinterpret_cast<float *>(lds);                        // [wave][NW][32 channels][2]
       if (rows > 1) {
         __syncthreads();                                                   // the patch (the first pass's scratch) is no longer read
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(x3_wpe(MW, 
     if (gn_last_arrival(p.gn_ctr + (long)n * gridDim.y + blockIdx.y, (unsigned)p.slots, reinterpret_cast<int *>(lds + 4096))) {
       const int nt0 = (int)blockIdx.y * wn * NW, nt1 = min(nt0 + wn * NW, ntt);
       const int NG = p.COUTP / p.gn_cpg;
-      for (int g = (nt0 * 32) / p.gn_cpg + wave; g < (nt1 * 32) / p.gn_cpg; g += 4) {
+      for (int g = (nt0 * 32) / p.gn_cpg + wave; g < (nt1 * 32) / p.gn_cpg; g += NWV) {
         gn_finalize_group_wave(p.stats + (long)n * p.slots * p.COUTP * 2, p.slots, p.COUTP, g, p.gn_cpg, p.gn_P, p.gn_eps, g_gamma, g_beta,
                                p.gn_scale + (long)n * p.COUTP, p.gn_shift + (long)n * p.COUTP, p.gn_mu ? p.gn_mu + (long)n * NG + g : nullptr,
                                p.gn_mu ? p.gn_rstd + (long)n * NG + g : nullptr);
@@ -1085,6 +1090,16 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
 
   if (KS == 3 && STRIDE == 1 && NP == 2) {                                                      // wide strips (conv_x3_plan)
     PNVO_X3(0, 5, 1) PNVO_X3(1, 5, 1) PNVO_X3(2, 5, 1) PNVO_X3(3, 5, 1)   // (mode 3 on a strip plan: a 128-channel first block)
+    if constexpr (KS == 3 && STRIDE == 1 && NP == 2) if (a.w8) {          // eight waves: the 256-channel 6 x 11 maps
+#define PNVO_X3W(MODE_)                                                                                                  \
+  if (mode == MODE_ && mw == 3 && nw == 1) {                                                                            \
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, 3, 1, NP, false, true>), grid, dim3(512), ldsb, s, a);        \
+    return hipGetLastError();                                                                                           \
+  }
+      PNVO_X3W(0) PNVO_X3W(1) PNVO_X3W(2) PNVO_X3W(3)
+#undef PNVO_X3W
+      return hipErrorInvalidValue;
+    }
   }
 #undef PNVO_X3
   return hipErrorInvalidValue;
@@ -1140,6 +1155,7 @@ namespace {
 bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size_t *lds_bytes, bool fine) {
   if (a.CIN % 32 || a.COUTP % 32 || a.COUTP > 1024 || a.CIN > 1024) return false;
   if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 2))) return false;
+  a.w8 = 0;
   const int ntt = a.COUTP / 32;
   // Operand bandwidth decides the wave tile: per wave and cycle the MFMAs want 16/NW bytes of A (LDS, 128 B/clk per CU) and
   // 16/MW bytes of B (L1, 64 B/clk per CU) at full rate, eight waves per CU.  (MW, NW) = (3, 2) keeps both under their limits
@@ -1237,13 +1253,22 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
       a.wn = 2;
       *mw = 2;
     }
+    // one tile per sample and a tile per CU or more: eight waves of (3,1) tiles, all eight N-tiles in one workgroup (W8)
+    if (a.w8_ok && !fine && ntiles >= 200 && a.MT == 3 && ntt == 8 && a.np == 2 && stride == 1 && ks == 3) {
+      a.w8 = 1;
+      a.wn = 8;
+      *mw = 3;
+      *nw = 1;
+    }
   }
-  if ((4 / a.wn) * *mw < a.MT) return false;
+  if (((a.w8 ? 8 : 4) / a.wn) * *mw < a.MT) return false;
   // channel chunk: the largest multiple-of-32 divisor of CIN (power-of-two steps) whose three planes fit 72 KB
   // (a power of two: the stager's thread -> (pixel, 8-channel group) split uses masks; 32 always divides CIN)
   const size_t np = a.np == 2 ? 2 : 3;                          // operand pieces = LDS planes (tiles are sized for three: same plan)
   int ck = 32;
   while (ck < 256 && a.CIN % (2 * ck) == 0) ck *= 2;
+  // (W8 with the whole K = 256 in one 110 KB chunk — its launches are one workgroup per CU anyway: staging 14.5 k -> 7.8 k cycles per
+  //  workgroup, the conv's time unchanged, 77-82 us on either form: not kept)
   while (ck > 32 && np * a.PR * a.PC * (ck * 2 + 16) > (size_t)72 * 1024) ck /= 2;
   if (np * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
   if (a.CIN % ck) return false;

@@ -688,6 +688,28 @@ def test_fine_plan_keeps_small_batches_on_the_float16_pipe(B):
         assert err.max() < 2e-5, (v, err)
 
 
+@pytest.mark.parametrize("B", [200, 256])
+def test_eight_wave_deep_stage_is_bit_identical(B):
+    """Option x3_w8 (default on, round 6): the 256-channel 3x3 convs on the 6 x 11 maps (resnet.py:29-55, layer4) are one tile per pair;
+    from 200 pairs on their workgroup is eight waves of (3,1) tiles — two waves per SIMD — instead of four of (3,2).  Every output is
+    the same MFMA chain in the same order and the GroupNorm sums are taken per wave over the same three M-tiles: bit-identical."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, _ = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 11)
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("x3_w8", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    model.set_option("x3_w8", "on")
+    assert torch.isfinite(outs["on"]).all()
+    assert torch.equal(outs["on"], outs["off"]) and torch.equal(outs["on"], outs["on2"])
+
+
 @pytest.mark.parametrize("B", [5, 8, 16, 33, 48])
 def test_groupnorm_finalisation_deferred_to_the_consumer_is_bit_identical(B):
     """Option gn_defer (round 6; OFF by default = 0 pairs — bit-identical but measured slower: a memory round trip and half a microsecond
