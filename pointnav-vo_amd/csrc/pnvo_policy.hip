@@ -68,15 +68,70 @@ __global__ __launch_bounds__(256) void policy_inputs_kernel(const float *visual,
   x[e] = v;
 }
 
-// y[b][n] (+)= row_scale[b] * sum_k x[b][k] * W[n][k] + bias[n]   — one wave per output feature n, all rows b.
-// W is torch's [N][K] row-major; K % 4 == 0.
-__global__ __launch_bounds__(256) void linear_rows_kernel(const float *x, const float *W, const float *bias,
-                                                        const float *row_scale, int B, int K, int N, int accum,
-                                                        float *y) {
+// One LSTM layer in one launch (round 6; it was two linear_rows launches + lstm_cell): workgroup = hidden unit j, wave = gate (i, f, g, o),
+// gate[b] = (h_prev[b] . W_hh[n] * mask[b] + b_hh[n]) + (x[b] . W_ih[n] + b_ih[n]) with n = gate * Hd + j — one wave per gate row, all rows b, W in torch's
+// [N][K] layout, K % 4 == 0; torch.nn.LSTM gate order, c_prev masked like h_prev — then the cell for (b, j) by the first lanes.
+__global__ __launch_bounds__(256) void lstm_layer_kernel(const float *x, int K, const float *w_ih, const float *b_ih, const float *h_prev,
+                                                       const float *w_hh, const float *b_hh, const float *c_prev, const float *masks,
+                                                       int B, int Hd, float *h_out, float *c_out) {
+  __shared__ float sg[4][64];
+  const int lane = threadIdx.x & 63, gate = (int)(threadIdx.x >> 6), j = blockIdx.x;
+  const int n = gate * Hd + j;
+  const f32x4 *wi = reinterpret_cast<const f32x4 *>(w_ih + (long)n * K), *wh = reinterpret_cast<const f32x4 *>(w_hh + (long)n * Hd);
+  const int K4 = K >> 2, H4 = Hd >> 2;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = min(64, B - b0);
+    for (int bb = 0; bb < nb; ++bb) {
+      const int b = b0 + bb;
+      const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (long)b * K), *hr = reinterpret_cast<const f32x4 *>(h_prev + (long)b * Hd);
+      float s = 0.f, u = 0.f;
+      for (int k = lane; k < K4; k += 64) {
+        const f32x4 w = wi[k], v = xr[k];
+        s = __builtin_fmaf(w[0], v[0], s);
+        s = __builtin_fmaf(w[1], v[1], s);
+        s = __builtin_fmaf(w[2], v[2], s);
+        s = __builtin_fmaf(w[3], v[3], s);
+      }
+      for (int k = lane; k < H4; k += 64) {
+        const f32x4 w = wh[k], v = hr[k];
+        u = __builtin_fmaf(w[0], v[0], u);
+        u = __builtin_fmaf(w[1], v[1], u);
+        u = __builtin_fmaf(w[2], v[2], u);
+        u = __builtin_fmaf(w[3], v[3], u);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        u += __shfl_xor(u, o);
+      }
+      if (lane == 0) sg[gate][bb] = (u * masks[b] + b_hh[n]) + (s + b_ih[n]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const int b = b0 + (int)threadIdx.x;
+      const long e = (long)b * Hd + j;
+      const float i_ = 1.f / (1.f + expf(-sg[0][threadIdx.x]));
+      const float f_ = 1.f / (1.f + expf(-sg[1][threadIdx.x]));
+      const float g_ = tanhf(sg[2][threadIdx.x]);
+      const float o_ = 1.f / (1.f + expf(-sg[3][threadIdx.x]));
+      const float c = f_ * (c_prev[e] * masks[b]) + i_ * g_;
+      c_out[e] = c;
+      h_out[e] = o_ * tanhf(c);
+    }
+    __syncthreads();
+  }
+}
+
+// action logits and value in one launch: rows 0 .. n_actions - 1 of the actor, then the critic's single row (one wave per output row)
+__global__ __launch_bounds__(256) void policy_heads_kernel(const float *x, const float *act_w, const float *act_b, const float *cr_w,
+                                                         const float *cr_b, int B, int K, int n_actions, float *logits, float *value) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-  if (n >= N) return;
-  const f32x4 *wr = reinterpret_cast<const f32x4 *>(W + (long)n * K);
+  if (n > n_actions) return;
+  const bool critic = n == n_actions;
+  if ((critic ? value : logits) == nullptr) return;
+  const f32x4 *wr = reinterpret_cast<const f32x4 *>(critic ? cr_w : act_w + (long)n * K);
+  const float bias = critic ? cr_b[0] : act_b[n];
   const int K4 = K >> 2;
   for (int b = 0; b < B; ++b) {
     const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (long)b * K);
@@ -91,29 +146,10 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float *x, const 
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) {
-      float r = s;
-      if (row_scale != nullptr) r *= row_scale[b];
-      if (bias != nullptr) r += bias[n];
-      if (accum) r += y[(long)b * N + n];
-      y[(long)b * N + n] = r;
+      if (critic) value[b] = s + bias;
+      else logits[(long)b * n_actions + n] = s + bias;
     }
   }
-}
-
-// torch.nn.LSTM cell, gate order (i, f, g, o); c_prev is masked like h_prev.
-__global__ __launch_bounds__(256) void lstm_cell_kernel(const float *gates, const float *c_prev, const float *masks, int B,
-                                                      int Hd, float *h_out, float *c_out) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long)B * Hd) return;
-  const int b = (int)(e / Hd), j = (int)(e % Hd);
-  const float *g = gates + (long)b * 4 * Hd;
-  const float i_ = 1.f / (1.f + expf(-g[j]));
-  const float f_ = 1.f / (1.f + expf(-g[Hd + j]));
-  const float g_ = tanhf(g[2 * Hd + j]);
-  const float o_ = 1.f / (1.f + expf(-g[3 * Hd + j]));
-  const float c = f_ * (c_prev[e] * masks[b]) + i_ * g_;
-  c_out[e] = c;
-  h_out[e] = o_ * tanhf(c);
 }
 
 struct Policy {
@@ -127,7 +163,7 @@ struct Policy {
   float *act_w = nullptr, *act_b = nullptr, *cr_w = nullptr, *cr_b = nullptr;
   // workspace
   int cap = 0;
-  float *pooled = nullptr, *visual = nullptr, *x = nullptr, *gates = nullptr;
+  float *pooled = nullptr, *visual = nullptr, *x = nullptr;
 };
 
 int pfail(int code, const std::string &msg) { return pnvo_fail(nullptr, code, msg); }
@@ -332,11 +368,9 @@ int pnvo_policy_act(pnvo_policy_handle h, const float *depth, const float *goal,
     dfree(p.pooled);
     dfree(p.visual);
     dfree(p.x);
-    dfree(p.gates);
     PCHK(hipMalloc((void **)&p.pooled, (size_t)B * (c.height / 2) * (c.width / 2) * 2 * sizeof(float)));
     PCHK(hipMalloc((void **)&p.visual, (size_t)B * Hd * sizeof(float)));
     PCHK(hipMalloc((void **)&p.x, (size_t)B * K0 * sizeof(float)));
-    PCHK(hipMalloc((void **)&p.gates, (size_t)B * 4 * Hd * sizeof(float)));
     p.cap = B;
   }
   int rc = pnvo_avgpool2(depth, B, c.height, c.width, p.pooled, stream);
@@ -351,23 +385,16 @@ int pnvo_policy_act(pnvo_policy_handle h, const float *depth, const float *goal,
   for (int l = 0; l < L; ++l) {
     const float *h_prev = hidden_in + (size_t)l * B * Hd, *c_prev = hidden_in + (size_t)(L + l) * B * Hd;
     float *h_new = hidden_out + (size_t)l * B * Hd, *c_new = hidden_out + (size_t)(L + l) * B * Hd;
-    const unsigned gb = (unsigned)((4 * Hd + 3) / 4);
-    hipLaunchKernelGGL(linear_rows_kernel, dim3(gb), dim3(256), 0, s, xin, p.w_ih[l], p.b_ih[l], nullptr, B, K, 4 * Hd, 0,
-                       p.gates);
-    hipLaunchKernelGGL(linear_rows_kernel, dim3(gb), dim3(256), 0, s, h_prev, p.w_hh[l], p.b_hh[l], masks, B, Hd, 4 * Hd, 1,
-                       p.gates);
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)(((long)B * Hd + 255) / 256)), dim3(256), 0, s, p.gates, c_prev,
-                       masks, B, Hd, h_new, c_new);
+    hipLaunchKernelGGL(lstm_layer_kernel, dim3((unsigned)Hd), dim3(256), 0, s, xin, K, p.w_ih[l], p.b_ih[l], h_prev, p.w_hh[l], p.b_hh[l],
+                       c_prev, masks, B, Hd, h_new, c_new);
     xin = h_new;
     K = Hd;
   }
   const float *feat = hidden_out + (size_t)(L - 1) * B * Hd;
   if (features) PCHK(hipMemcpyAsync(features, feat, (size_t)B * Hd * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (logits)
-    hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)((c.n_actions + 3) / 4)), dim3(256), 0, s, feat, p.act_w, p.act_b,
-                       nullptr, B, Hd, c.n_actions, 0, logits);
-  if (value)
-    hipLaunchKernelGGL(linear_rows_kernel, dim3(1), dim3(256), 0, s, feat, p.cr_w, p.cr_b, nullptr, B, Hd, 1, 0, value);
+  if (logits || value)
+    hipLaunchKernelGGL(policy_heads_kernel, dim3((unsigned)((c.n_actions + 1 + 3) / 4)), dim3(256), 0, s, feat, p.act_w, p.act_b, p.cr_w,
+                       p.cr_b, B, Hd, c.n_actions, logits, value);
   PCHK(hipGetLastError());
   return PNVO_OK;
 }
@@ -391,7 +418,6 @@ int pnvo_policy_destroy(pnvo_policy_handle h) {
   dfree(p.pooled);
   dfree(p.visual);
   dfree(p.x);
-  dfree(p.gates);
   delete h;
   return PNVO_OK;
 }

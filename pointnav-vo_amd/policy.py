@@ -161,9 +161,11 @@ class PointNavResNetPolicy(nn.Module):
             h = C.c_void_p()
             _lib.check(_lib.lib.pnvo_policy_create(C.byref(cc), int(device.index or 0), C.byref(h)))
             self._handle, self._handle_dev, self._loaded_sig = h, device.index, None
-        sd = dict(self.named_parameters())
-        tensors = [(n, sd[n]) for n, _ in self._spec]
-        sig = tuple((t.data_ptr(), t._version) for _, t in tensors)
+        tensors = getattr(self, "_spec_tensors", None)      # (the walk over the module tree costs ~50 us per step: kept until _apply)
+        if tensors is None:
+            sd = dict(self.named_parameters())
+            tensors = self._spec_tensors = [(n, sd[n]) for n, _ in self._spec]
+        sig = tuple([(t.data_ptr(), t._version) for _, t in tensors])
         if sig != self._loaded_sig:
             blob = np.ascontiguousarray(np.concatenate(
                 [t.detach().to("cpu", torch.float32).reshape(-1).numpy() for _, t in tensors]), dtype=np.float32)
@@ -180,6 +182,10 @@ class PointNavResNetPolicy(nn.Module):
                                                          len(tensors)))
             self._loaded_sig = sig
 
+    def _apply(self, fn, *a, **k):                          # .to() / .cuda() / .float(): parameters may be replaced
+        self._spec_tensors = None
+        return super()._apply(fn, *a, **k)
+
     def _release(self):
         if getattr(self, "_handle", None) is not None:
             _lib.lib.pnvo_policy_destroy(self._handle)
@@ -192,7 +198,7 @@ class PointNavResNetPolicy(nn.Module):
             pass
 
     # ------------------------------------------------------------------ forward
-    def _net(self, observations, rnn_hidden_states, prev_actions, masks):
+    def _net(self, observations, rnn_hidden_states, prev_actions, masks, want_features=True):
         ref = next(self.parameters())
         if ref.device.type != "cuda":
             raise RuntimeError("pointnav_vo_amd policies run on an MI355X only: move the policy with .to('cuda') "
@@ -209,10 +215,10 @@ class PointNavResNetPolicy(nn.Module):
         hin = rnn_hidden_states.to(device=dev, dtype=torch.float32).contiguous()
         assert tuple(hin.shape) == (2 * self._layers, B, self._hidden), tuple(hin.shape)
         hout = torch.empty_like(hin)
-        feats = torch.empty((B, self._hidden), device=dev, dtype=torch.float32)
+        feats = torch.empty((B, self._hidden), device=dev, dtype=torch.float32) if want_features else None
         logits = torch.empty((B, self.dim_actions), device=dev, dtype=torch.float32)
         value = torch.empty((B, 1), device=dev, dtype=torch.float32)
-        p = lambda t: C.c_void_p(t.data_ptr())
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(_lib.lib.pnvo_policy_act(self._handle, p(depth), p(goal), p(pa), p(mk), p(hin), int(B), p(hout),
@@ -225,7 +231,7 @@ class PointNavResNetPolicy(nn.Module):
     def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False):
         """-> (value [B,1], action [B,1] int64, action_log_probs [B,1], rnn_hidden_states)  (policy.py:29-46)."""
         with torch.no_grad():
-            _, hout, logits, value = self._net(observations, rnn_hidden_states, prev_actions, masks)
+            _, hout, logits, value = self._net(observations, rnn_hidden_states, prev_actions, masks, want_features=False)
             # (validate_args=False: the distribution's argument checks are five more launches and a host sync per step; the logits
             #  come from the kernels above, the sampling call and its generator use are unchanged)
             dist = torch.distributions.Categorical(logits=logits, validate_args=False)

@@ -406,6 +406,47 @@ class BaseRLTrainerWithVO:
         self._ring_stats = dict(pairs=n, uploaded_frames=m, ring_hits=n - len(miss))
         return keep_d, keep_r
 
+    def ring_depth(self, obs_list, env_ids):
+        """Depth observations of the given environments as ONE device tensor [E,H,W,1] float32 — what the navigation policy consumes
+        (rl/ppo/ppo_trainer.py:760-770: `batch["depth"]` of the step's observations, uploaded there by batch_obs).  In the reference's
+        loop the observation the policy acts on is the frame the VO call of the step before received as cur_obs (`prev_obs = observations`,
+        ppo_trainer.py:724-841): with env_ids that frame's bytes are already in the device ring, so an environment whose observation is
+        the recorded array (object identity + the strided fingerprint, the ring's own hit rule) is served from there by one gather
+        launch and only the others are uploaded.  Bit-identical to uploading obs["depth"] of every environment.  The result is a new
+        tensor (not a view of the ring)."""
+        E, dev = len(env_ids), self.device
+        first = np.asarray(obs_list[0]["depth"])
+        H, W = first.shape[0], first.shape[1]
+        rg, src = getattr(self, "_ring", None), getattr(self, "_ring_src", None)
+        hit = []
+        if rg is not None and src is not None and rg["shape"][:2] == (H, W):
+            want_rgb = rg["shape"][2]
+            for o, e in zip(obs_list, env_ids):
+                rec = src.get(e)
+                hit.append(rec is not None and e in rg["slot_of"] and rec[0] is o["depth"] and (not want_rgb or rec[1] is o.get("rgb"))
+                           and rec[2] == self._frame_fingerprint(o["depth"], o["rgb"] if want_rgb else None))
+        else:
+            hit = [False] * E
+        if not any(hit):
+            return torch.from_numpy(np.stack([np.asarray(o["depth"], dtype=np.float32).reshape(H, W, 1) for o in obs_list])).to(dev)
+        cache = rg.setdefault("gather_idx", {})
+        if all(hit):
+            key = tuple(rg["slot_of"][e] for e in env_ids)
+            idx = cache.get(key)
+            if idx is None:
+                if len(cache) > 64:
+                    cache.clear()
+                idx = cache[key] = torch.tensor(key, dtype=torch.long, device=dev)
+            return rg["dep"].index_select(0, idx).unsqueeze(-1)
+        out = torch.empty((E, H, W, 1), dtype=torch.float32, device=dev)
+        hi = [i for i in range(E) if hit[i]]
+        mi = [i for i in range(E) if not hit[i]]
+        out[torch.tensor(hi, device=dev)] = rg["dep"].index_select(
+            0, torch.tensor([rg["slot_of"][env_ids[i]] for i in hi], dtype=torch.long, device=dev)).unsqueeze(-1)
+        out[torch.tensor(mi, device=dev)] = torch.from_numpy(
+            np.stack([np.asarray(obs_list[i]["depth"], dtype=np.float32).reshape(H, W, 1) for i in mi])).to(dev)
+        return out
+
     def compute_local_delta_states_batch(self, prev_obs_list, cur_obs_list, acts, env_ids=None):
         """Batched sibling of _compute_local_delta_states_from_vo: lists of observation dicts and actions ->
         float32 array [N,3].  env_ids (optional, one hashable id per pair, distinct within a call; mode 'det'): the call keeps each

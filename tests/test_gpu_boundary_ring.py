@@ -153,3 +153,40 @@ def test_ring_slots_are_reused_after_a_reset():
         ring.reset_frame_ring(ids)
     assert ring._ring["slots"] == 8 and len(ring._ring["slot_of"]) == 0 and len(ring._ring["free"]) == 4
     assert len(ring._ring_src) == 0
+
+
+def test_ring_depth_serves_the_policy_the_frames_the_ring_holds():
+    """ring_depth(obs_list, env_ids): the depth batch the navigation policy consumes (rl/ppo/ppo_trainer.py:760-770), taken from the
+    device ring for environments whose observation is the frame the last VO call recorded as cur, uploaded otherwise — bit-identical
+    to uploading every frame, for hits, misses (new environment, copied frame, frame refilled in place) and a mix, in any order."""
+    rec = load_golden("boundary.npz")
+    H, W = int(rec["height"]), int(rec["width"])
+    t = make_trainer(rec)
+    E = 5
+    seq = {e: [frames(H, W, e, k, fp16=(e % 2 == 0)) for k in range(4)] for e in range(E)}
+
+    def want(obs):
+        return torch.from_numpy(np.stack([o["depth"].reshape(H, W, 1) for o in obs])).cuda()
+
+    obs0 = [seq[e][0] for e in range(E)]
+    got = t.ring_depth(obs0, list(range(E)))                       # no ring yet: uploaded
+    assert got.shape == (E, H, W, 1) and torch.equal(got, want(obs0))
+    t.compute_local_delta_states_batch(obs0, [seq[e][1] for e in range(E)], [1] * E, env_ids=list(range(E)))
+    obs1 = [seq[e][1] for e in range(E)]
+    g1 = t.ring_depth(obs1, list(range(E)))                        # all from the ring
+    assert torch.equal(g1, want(obs1))
+    order = [3, 0, 4]
+    assert torch.equal(t.ring_depth([obs1[e] for e in order], order), want([obs1[e] for e in order]))
+    mixed = list(obs1)
+    mixed[1] = {k: v.copy() for k, v in obs1[1].items()}           # a copy: identity miss
+    mixed[2] = seq[2][3]                                           # another frame
+    assert torch.equal(t.ring_depth(mixed, list(range(E))), want(mixed))
+    assert torch.equal(t.ring_depth(obs1 + [seq[0][2]], list(range(E)) + ["new"]), want(obs1 + [seq[0][2]]))
+    keep = obs1[0]["depth"].copy()
+    np.copyto(obs1[0]["depth"], seq[0][3]["depth"])                # refilled in place: the fingerprint guard
+    assert torch.equal(t.ring_depth(obs1, list(range(E))), want(obs1))
+    np.copyto(obs1[0]["depth"], keep)
+    # the result is not a view of the ring: the next VO call overwrites the slots, the tensor keeps its values
+    t.compute_local_delta_states_batch(obs1, [seq[e][2] for e in range(E)], [2] * E, env_ids=list(range(E)))
+    torch.cuda.synchronize()
+    assert torch.equal(g1, want(obs1))

@@ -85,6 +85,7 @@ def run(envs, steps, episode_steps=150.0, dev=None):
         masks = torch.ones(E, 1, device=dev)
         prev_obs = [frames[e % 96] for e in range(E)]
         env_ids = list(range(E)) if os.environ.get("PNVO_NAVLOOP_RING", "1") != "0" else None
+        ring_depth = os.environ.get("PNVO_NAVLOOP_RING_DEPTH", "1") != "0"
 
         phases = os.environ.get("PNVO_NAVLOOP_PHASES") is not None      # developer: host-synchronised time of each part (slower loop)
         ph = {"policy input (stack + H2D)": 0.0, "policy.act": 0.0, "actions to host": 0.0, "VO boundary call": 0.0, "goal update": 0.0}
@@ -100,7 +101,10 @@ def run(envs, steps, episode_steps=150.0, dev=None):
         def step(s):
             nonlocal hid, prev_a, prev_obs
             tp = time.perf_counter()
-            depth = torch.from_numpy(np.stack([o["depth"] for o in prev_obs])).to(dev, non_blocking=True)
+            if env_ids is not None and ring_depth:       # the policy's depth = the frames the last VO call left in the device ring
+                depth = t.ring_depth(prev_obs, env_ids)
+            else:
+                depth = torch.from_numpy(np.stack([o["depth"] for o in prev_obs])).to(dev, non_blocking=True)
             polar = geometry.compute_goal_pos_batch(np.stack(goals), np.zeros((E, 3)))["polar"]
             obs = {"depth": depth, "pointgoal_with_gps_compass": torch.from_numpy(polar).to(dev)}
             tp = mark("policy input (stack + H2D)", tp)
