@@ -35,7 +35,7 @@ namespace pnvo {
 
 typedef float sn_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SN_THREADS = 512, SN_WAVES = 8, SN_TAB = 512, SN_MAXB = 4;
+constexpr int SN_THREADS = 512, SN_WAVES = 8, SN_TAB = 1024, SN_MAXB = 8;   // (MAXB 8, TAB 1024: the policy's quarter-size frames, see pnvo_small_usable)
 constexpr int sn_mblocks(int c4) { return c4 <= 8 ? 4 : c4 <= 16 ? 2 : 1; }   // M-blocks (16 output pixels) of a conv tile, by input channels / 4
 constexpr int SN_KP = SN_WAVES / 4, SN_WPRE = 6;                  // linear layers: K parts per output, weight vectors fetched ahead
 constexpr int SN_RED_FLOATS = 2 * SN_WAVES * 256;                 // K-split partials: two convs x 8 waves x (64 lanes x 4)
@@ -879,7 +879,12 @@ void pnvo_small_free(pnvo_handle m) {
 // Is this call shape one the persistent kernel takes?  (BasicBlock backbones whose channel counts are multiples of 32, batch
 // <= small_max, no taps / per-launch timing / training forward; otherwise the per-layer launches run.)
 bool pnvo_small_usable(pnvo_handle m, int B) {
-  if (!m->opt.small_net || B < 1 || B > m->opt.small_max || B > SN_MAXB) return false;
+  // small_max is quoted for the VO model's 48 x 86 pooled map (4 pairs: where the per-layer launches catch up); a model on smaller
+  // frames — the navigation policy's encoder works on 96 x 170 depth, a 24 x 43 pooled map — has a quarter of the work per sample,
+  // and the same amount of work is that many more samples (up to SN_MAXB)
+  const long px = (long)m->Hp * m->Wp;
+  const long bmax = std::min<long>(SN_MAXB, std::max<long>(m->opt.small_max, px > 0 ? (long)m->opt.small_max * (48 * 86) / px : 0));
+  if (!m->opt.small_net || B < 1 || B > bmax) return false;
   if (m->bottleneck || m->tap_dst != nullptr || m->train != nullptr || m->graph_mode > 0) return false;
   if (m->precision != 0) return false;
   if (m->opt.conv != 0 || !m->opt.tail || !m->opt.pool || m->opt.conv3_nt) return false;   // an explicit kernel selection is honoured
