@@ -89,3 +89,25 @@ def test_policy_sampling_and_value():
     torch.testing.assert_close(v, value)
     with pytest.raises(NotImplementedError):
         pol.evaluate_actions(obs, hidden, pa, mk, action)
+
+
+@pytest.mark.parametrize("B", [5, 8, 9, 16])
+def test_policy_batches_of_a_nav_loop_match_the_oracle(B):
+    """Environment counts of one nav-loop process (5-16).  Up to 8 quarter-size frames the policy's encoder runs behind its stem as ONE
+    persistent launch (smallnet.hip: the same amount of work as 2 VO pairs), above that as per-layer launches; the LSTM layers and the
+    two heads are one launch each.  Both sides of the threshold against the pinned oracle, two steps (the second on a carried state)."""
+    H, W = 192, 341
+    pol, sd = build(H, W, 5)
+    dev = torch.device("cuda", 0)
+    hidden = torch.zeros(pol.num_recurrent_layers, B, 512, device=dev)
+    hid_o = np.zeros((4, B, 512))
+    for t, (depth, goal, prev, mask) in enumerate(synth.make_policy_inputs(H, W, B, 2, 21)):
+        obs = {"depth": torch.from_numpy(depth).to(dev), "pointgoal_with_gps_compass": torch.from_numpy(goal).to(dev)}
+        pa, mk = torch.from_numpy(prev).view(B, 1).to(dev), torch.from_numpy(mask).view(B, 1).to(dev)
+        feats, hnew, logits, value = pol.features_and_logits(obs, hidden, pa, mk)
+        o = policy_oracle.policy_step(sd, depth, goal, prev, mask, hid_o)
+        assert torch.isfinite(hnew).all() and close(hnew.cpu().numpy(), o["hidden"]), (B, t)
+        for k, got in (("logits", logits), ("value", value)):
+            if k in o:
+                assert close(got.cpu().numpy().reshape(np.asarray(o[k]).shape), np.asarray(o[k])), (B, t, k)
+        hid_o, hidden = o["hidden"], hnew

@@ -1,5 +1,6 @@
+"""Per-launch HIP-event times of one forward at the given batch sizes: python tools/layer_breakdown.py 8 16 32 256"""
 import sys, os, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 dev = torch.device("cuda", 0)

@@ -68,3 +68,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CYCLES SQ
   rm -rf $O/${tag}_pmc_b1_$n
 done
 head -14 $O/${tag}_kernel_trace_fwd_fp32.md
+# navigation-loop proxy, its phases, the policy step alone, and the launches of small batches
+python tools/bench_navloop.py --envs 8 16 32 --steps 100 > $O/${tag}_navloop.json 2>/dev/null
+PNVO_NAVLOOP_PHASES=1 python tools/bench_navloop.py --envs 8 16 32 --steps 60 2>&1 >/dev/null | grep "\[navloop\]" > $O/${tag}_navloop_phases.txt
+python tools/bench_policy.py --envs 1 4 8 16 32 > $O/${tag}_bench_policy.json 2>/dev/null
+python tools/layer_breakdown.py 8 16 32 2>/dev/null > $O/${tag}_small_batch_breakdown.txt
+python tools/grouped_breakdown.py 2>/dev/null > $O/${tag}_grouped_breakdown.txt
