@@ -78,9 +78,15 @@ constexpr int x3_wpe(int mw, int nw, int np, bool dsf = false) {
 // = one workgroup per CU at 256 pairs: with four waves of (3,2) tiles each SIMD holds a single wave and its K loop issues MFMAs 75 % of
 // the time (in-order issue: the fragment waits are not covered); eight waves of (3,1) tiles are two per SIMD and issue 92 %
 // (profiles/r6_experiments.md), staging the patch once with twice the threads.
-template <int KS, int STRIDE, int MODE, int MW, int NW, int NP, bool DSF = false, bool W8 = false>
+// KSW (fine plan, round 6): the tile's MT = MW M-tiles are ALL multiplied by every wave, each wave over a quarter of the K steps of every
+// staged chunk (B fragments fetched once per workgroup instead of once per wave, MW MFMA triples per fragment pair instead of one); the
+// four partial accumulator sets meet in LDS in wave order and wave w finishes M-tile w as before.  For the deep stages of small batches:
+// a (1,1) wave tile walks 432 dependent-latency-bound MFMAs alone, a quarter of the K walk with three or four tiles is half of that.
+template <int KS, int STRIDE, int MODE, int MW, int NW, int NP, bool DSF = false, bool W8 = false, bool KSW = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(W8 ? 2 : x3_wpe(MW, NW, NP, DSF), W8 ? 2 : x3_wpe(MW, NW, NP, DSF)))) void conv_x3_kernel(const ConvX3Args p) {
   constexpr int NTH = W8 ? 512 : 256, NWV = NTH / 64;
+  constexpr int EMW = KSW ? 1 : MW;                 // M-tiles a wave finishes in the epilogue
+  static_assert(!KSW || (NW == 1 && NP == 2 && KS == 3 && !DSF && !W8), "K split over the waves: float16-piece 3x3 convs, one N-tile");
   static_assert(!DSF || (KS == 3 && STRIDE == 2 && NP == 2 && (MODE == 0 || MODE == 2)), "the downsample rides on a float16-piece 3x3 stride-2 conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
   // registers (gn_finalize_wave16: gn_finalize_kernel's arithmetic, bit for bit).  One memory round trip + ~0.5 us of fp64 per
   // workgroup: cheaper than a launch while launches are the bound (8-48 pairs), dearer at 256 pairs — the host defers accordingly.
   if ((MODE == 1 || MODE == 2) && (p.fin_in.stats != nullptr || p.fin_res.stats != nullptr)) {
-    float *ftab0 = reinterpret_cast<float *>(lds + NP * ((p.PR * p.PC) * (p.CK * 2 + 16)) + (size_t)p.MT * 32 * 8);
+    const int planes0 = NP * ((p.PR * p.PC) * (p.CK * 2 + 16));
+    float *ftab0 = reinterpret_cast<float *>(lds + (KSW ? max(planes0, 4 * MW * 4096) : planes0) + (size_t)p.MT * 32 * 8);
     const long P_in = (long)p.H * p.W;
     if (p.fin_in.stats != nullptr && wave == 0) {
       const int Gn = p.CIN / p.fin_in.cpg;
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
   const int npix = p.TR * p.TC;
   // pixel table behind the three planes: [0] patch byte offset of tile pixel q's top-left tap; [1] element offset of its output
   // pixel inside the sample's output plane, bit 31 set when the pixel does not exist
-  unsigned *qtab = reinterpret_cast<unsigned *>(lds + NP * plane);
+  // (KSW: the tables sit behind the partial-sum area of the K-split reduction as well: the epilogue reads them after it)
+  const int tab_off = KSW ? max(NP * plane, 4 * MW * 4096) : NP * plane;
+  unsigned *qtab = reinterpret_cast<unsigned *>(lds + tab_off);
   unsigned *otab = qtab + p.MT * 32;
   for (int e = (int)threadIdx.x; e < p.MT * 32; e += NTH) {               // (strip tiles: nine M-tiles = 288 entries)
     const int q = min(e, npix - 1);
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
       const bool res_ss = MODE == 2 && (p.res_scale != nullptr || fin_r);
       // Deferred GroupNorm finalisation (p.fin_in / p.fin_res): the sample's scale / shift tables were built at the top of the kernel,
       // in LDS behind the pixel tables
-      float *ftab = reinterpret_cast<float *>(lds + NP * plane + (size_t)p.MT * 32 * 8);   // [in scale | in shift | res scale | res shift][CIN]
+      float *ftab = reinterpret_cast<float *>(lds + tab_off + (size_t)p.MT * 32 * 8);   // [in scale | in shift | res scale | res shift][CIN]
       auto load_ss = [&]() {
         if (MODE >= 1) {
           const float *ps = fin_i ? ftab + ck0 + 8 * cg : p.in_scale + (long)n * p.CIN + ck0 + 8 * cg;
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     unsigned aoff[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-      const int mt = min(wave_m * MW + i, p.MT - 1);
+      const int mt = min(KSW ? i : wave_m * MW + i, p.MT - 1);
       aoff[i] = qtab[mt * 32 + (lane & 31)] + (unsigned)((lane >> 5) * 16);
     }
     const int kcc = CK >> 4;                                             // k-chunks per staged chunk
@@ -458,6 +467,41 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc) b[pc][j] = *reinterpret_cast<const u32x4 *>(wd + (size_t)voff[j] + pc * 1024);
     };
+    if constexpr (KSW) {
+      // this wave's quarter of the chunk's steps, B through a ring of three register sets (two steps ahead), A one step ahead
+      const int s0 = (wave * nsteps) >> 2, s1 = ((wave + 1) * nsteps) >> 2;
+      {
+        const int tap = s0 / kcc, kc = s0 - tap * kcc, kh = tap / KS, kw = tap - kh * KS;
+        kc_n = kc;
+        kw_n = kw;
+        toff_n = (unsigned)((kh * PC + kw) * pitch + kc * 32);
+        wb_n += ((long)tap * kct + kc) * kstep;
+        kc_b = kc;
+        wb_b = wb_n;
+      }
+      u32x4 br[3][NP][NW];
+      int fb = s0;                                                       // the next step whose B fragments are fetched
+      auto fetchB = [&](u32x4 (*bq)[NW]) {
+        loadBr(bq);
+        if (++fb < s1) advanceB();                                       // (past the last step: harmless re-fetches of it)
+      };
+      fetchB(br[0]);
+      fetchB(br[1]);
+#pragma unroll
+      for (int i = 0; i < MW; ++i) loadA(i, a);
+      if (s0 + 1 < s1) advance();
+#pragma unroll 1
+      for (int s = s0; s < s1; s += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (s + u >= s1) break;
+          fetchB(br[(u + 2) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          step(a, br[u]);                                                // multiplies step s + u, fetches A of step s + u + 1
+          if (s + u + 2 < s1) advance();
+        }
+      }
+    } else {
     if (DSF) loadBd(bd0, 0);
     loadB(b0);
 #pragma unroll
@@ -520,6 +564,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         if (more) advance();
       }
     }
+    }
     if constexpr (DSF) {
       // ds_tail: the downsample conv = this conv's centre tap (patch offset (PC + 1) pixels) on its own weights, k-chunks ascending,
       // terms a1 w0, a0 w1, a0 w0 — the order of the separate 1x1 launch (bit-identical raw output)
@@ -563,6 +608,26 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     }
     c_mm += __builtin_readcyclecounter() - t_b;
   }
+  if constexpr (KSW) {
+    // the four waves' partial sums of the tile meet in LDS ([wave][M-tile][register][lane]: conflict-free), added in wave order;
+    // wave w goes on with M-tile w in acc[0]
+    __syncthreads();                                                     // the patch is no longer read
+    float *part = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[((wave * MW + i) * 16 + r) * 64 + lane] = acc[i][0][r];
+    __syncthreads();
+    const int mt = min(wave, MW - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = part[((0 * MW + mt) * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += part[((w * MW + mt) * 16 + r) * 64 + lane];
+      acc[0][0][r] = v;
+    }
+    __syncthreads();                                                     // (the statistics scratch of the epilogue reuses this memory)
+  }
   unsigned long long t_e = __builtin_readcyclecounter();
 
   // ---- epilogue: raw output + per-(sample, tile, channel) GroupNorm partial sums (one writer per slot).  Runs once for the conv and
@@ -574,7 +639,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     if (NP == 2) {                                                         // undo the weights' power-of-two scale (exact)
       const float os = (oscale_ptr != nullptr ? *oscale_ptr : oscale) * in_div;
 #pragma unroll
-      for (int i = 0; i < MW; ++i)
+      for (int i = 0; i < EMW; ++i)
 #pragma unroll
         for (int j = 0; j < NW; ++j)
 #pragma unroll
@@ -584,8 +649,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < MW; ++i) {
-      const int mt = wave_m * MW + i;
+    for (int i = 0; i < EMW; ++i) {
+      const int mt = KSW ? wave : wave_m * MW + i;
       if (mt >= p.MT) continue;
       u32x4 ent[4];
 #pragma unroll
@@ -1090,6 +1155,16 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
 
   if (KS == 3 && STRIDE == 1 && NP == 2) {                                                      // wide strips (conv_x3_plan)
     PNVO_X3(0, 5, 1) PNVO_X3(1, 5, 1) PNVO_X3(2, 5, 1) PNVO_X3(3, 5, 1)   // (mode 3 on a strip plan: a 128-channel first block)
+    if constexpr (KS == 3 && STRIDE == 1 && NP == 2) if (a.ksw) {          // fine plan, K split over the waves (three / four M-tiles)
+#define PNVO_X3K(MODE_, MW_)                                                                                             \
+  if (mode == MODE_ && mw == MW_ && nw == 1) {                                                                          \
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, 1, NP, false, false, true>), grid, dim3(256), ldsb, s, a); \
+    return hipGetLastError();                                                                                           \
+  }
+      PNVO_X3K(0, 3) PNVO_X3K(1, 3) PNVO_X3K(2, 3) PNVO_X3K(0, 4) PNVO_X3K(1, 4) PNVO_X3K(2, 4)
+#undef PNVO_X3K
+      return hipErrorInvalidValue;
+    }
     if constexpr (KS == 3 && STRIDE == 1 && NP == 2) if (a.w8) {          // eight waves: the 256-channel 6 x 11 maps
 #define PNVO_X3W(MODE_)                                                                                                  \
   if (mode == MODE_ && mw == 3 && nw == 1) {                                                                            \
@@ -1156,6 +1231,7 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
   if (a.CIN % 32 || a.COUTP % 32 || a.COUTP > 1024 || a.CIN > 1024) return false;
   if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 2))) return false;
   a.w8 = 0;
+  a.ksw = 0;
   const int ntt = a.COUTP / 32;
   // Operand bandwidth decides the wave tile: per wave and cycle the MFMAs want 16/NW bytes of A (LDS, 128 B/clk per CU) and
   // 16/MW bytes of B (L1, 64 B/clk per CU) at full rate, eight waves per CU.  (MW, NW) = (3, 2) keeps both under their limits
@@ -1202,7 +1278,9 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     TC = 16;
   } else {
     TC = a.Wo;
-    const int target = ntt == 4 ? 192 : (ntt >= 8 ? 96 : 128);     // pixels per tile: six / three / four M-tiles
+    int target = ntt == 4 ? 192 : (ntt >= 8 ? 96 : 128);           // pixels per tile: six / three / four M-tiles
+    // fine plan with the K split over the waves: three M-tiles per tile (12 x 22 maps: three balanced tiles of four rows instead of 8 + 4)
+    if (fine && a.ksw_ok && ks == 3 && stride == 1 && a.np == 2 && a.CIN >= 128) target = 96;
     TR = target / TC;
     if (TR < 1) TR = 1;
     if (TR > a.Ho) TR = a.Ho;
@@ -1224,6 +1302,11 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     a.wn = 1;
     *mw = (a.MT + 3) / 4;
     *nw = 1;
+    // three / four M-tiles behind many input channels (the 128- / 256-channel stages): the waves split K instead of M (KSW)
+    if (a.ksw_ok && (a.MT == 3 || a.MT == 4) && ks == 3 && stride == 1 && a.np == 2 && a.CIN >= 128) {
+      a.ksw = 1;
+      *mw = a.MT;
+    }
   } else if (strip) {
     a.wn = 2;
     *mw = (a.MT + 1) / 2;                                          // two wave rows
@@ -1261,7 +1344,7 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
       *nw = 1;
     }
   }
-  if (((a.w8 ? 8 : 4) / a.wn) * *mw < a.MT) return false;
+  if (!a.ksw && ((a.w8 ? 8 : 4) / a.wn) * *mw < a.MT) return false;
   // channel chunk: the largest multiple-of-32 divisor of CIN (power-of-two steps) whose three planes fit 72 KB
   // (a power of two: the stager's thread -> (pixel, 8-channel group) split uses masks; 32 always divides CIN)
   const size_t np = a.np == 2 ? 2 : 3;                          // operand pieces = LDS planes (tiles are sized for three: same plan)
@@ -1284,7 +1367,8 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     if (wgs < (a.np == 2 ? 112 : 192) && !force) return false;
   }
   a.slots = a.tiles_r * a.tiles_c;                               // one GroupNorm partial per tile
-  *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;   // planes, pixel tables (a launch with a deferred GroupNorm adds 16 B per input
+  *lds_bytes = np * a.PR * a.PC * (ck * 2 + 16) + (size_t)a.MT * 32 * 4 * 2;
+  if (a.ksw) *lds_bytes = std::max(np * a.PR * a.PC * (ck * 2 + 16), (size_t)4 * a.MT * 4096) + (size_t)a.MT * 32 * 4 * 2;   // planes / the four waves' partial accumulator tiles, then the tables   // planes, pixel tables (a launch with a deferred GroupNorm adds 16 B per input
                                                                                 // channel behind them: pnvo_run_conv — 1 KB more would cost the 64-channel convs their third workgroup per CU)
   return true;
 }

@@ -499,6 +499,7 @@ bool x3_args(pnvo_handle m, const Layer &l, int B, ConvX3Args &xa, int *mw, int 
     xa.strip = m->opt.x3_strip;
     xa.fine = m->opt.x3_fine;
     xa.w8_ok = m->opt.x3_w8;
+    xa.ksw_ok = m->opt.x3_ksplit;
   xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
   xa.np = x3_two_pieces(m, l) ? 2 : 3;
   xa.B = B;
@@ -597,6 +598,7 @@ int pnvo_run_conv(pnvo_handle m, const Layer &l, int B, const float *x, const fl
     xa.strip = m->opt.x3_strip;
     xa.fine = m->opt.x3_fine;
     xa.w8_ok = m->opt.x3_w8;
+    xa.ksw_ok = m->opt.x3_ksplit;
     xa.persist_wgs = m->opt.x3_persist ? 3 * m->num_cus : 0;
     xa.B = B;
     xa.H = l.hin;
@@ -1237,6 +1239,7 @@ const OptDef kOptions[] = {
     {"gn_defer", "PNVO_GN_DEFER", &PnvoOptions::gn_defer, true, {{nullptr, 0}}},
     {"x3_fine", "PNVO_X3_FINE", &PnvoOptions::x3_fine, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_w8", "PNVO_X3_W8", &PnvoOptions::x3_w8, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"x3_ksplit", "PNVO_X3_KSPLIT", &PnvoOptions::x3_ksplit, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"head_fuse", "PNVO_HEAD_FUSE", &PnvoOptions::head_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 2}, {"single", 2}, {"last", 1}, {"off", 0}, {nullptr, 0}}},

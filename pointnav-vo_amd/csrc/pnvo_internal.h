@@ -159,6 +159,7 @@ struct ConvX3Args {
   const float *oscale_ptr;           //   ... or where it lives on the device (training: the scale follows the weights)
   int persist_wgs;                   // > 0: eligible launches take conv_x3p_kernel with this many workgroups (3 per CU); 0: never
   int w8_ok, w8;                     // option x3_w8 / conv_x3_plan's decision: eight waves per workgroup (two per SIMD) — 256-channel 6 x 11 maps, one tile per sample
+  int ksw_ok, ksw;                   // option x3_ksplit / conv_x3_plan's decision: fine-plan tiles of three / four M-tiles split K over the four waves
   int fine;                          // conv_x3_plan: allow the fine plan (one N-tile per workgroup) for launches below 224 workgroups (option x3_fine)
   int strip;                         // conv_x3_plan: wide strip tiles with the N-tiles split over blockIdx.y for 64 / 128 output channels
   // GroupNorm finalisation inside the conv (slots == 1: the workgroup that wrote a sample's only partial sums holds the complete sums

@@ -51,6 +51,7 @@ struct PnvoOptions {
                        // a memory round trip + ~0.5 us of fp64 in EVERY consumer workgroup costs more than a 4 us launch
   int x3_fine = 1;     // small launches of the float16-piece convs take one N-tile per workgroup instead of falling back to the fp32-pipe kernels
   int x3_w8 = 1;       // 256-channel convs on 6 x 11 maps with a tile per CU or more: eight waves of (3,1) tiles per workgroup (two per SIMD) instead of four of (3,2)
+  int x3_ksplit = 1;   // fine-plan conv tiles of three / four M-tiles behind >= 128 input channels: the four waves split the K walk, partial sums meet in LDS
   int head_fuse = 1;   // the output head (Linear hidden -> out_dim) is computed by the hidden layer's split-K reduction launch (one launch less)
   int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
   int gn_fuse = 2;     // conv_x3 launches finalise their GroupNorm themselves (bit-identical, one launch less): 2 = launches with one tile per

@@ -688,6 +688,38 @@ def test_fine_plan_keeps_small_batches_on_the_float16_pipe(B):
         assert err.max() < 2e-5, (v, err)
 
 
+@pytest.mark.parametrize("B", [5, 8, 33, 64, 100])
+def test_k_split_over_the_waves_agrees_with_the_m_split_fine_plan(B):
+    """Option x3_ksplit (default on, round 6): fine-plan tiles of three / four M-tiles behind >= 128 input channels (the 12 x 22 and 6 x 11
+    stages of 5-~110-pair batches) are multiplied by all four waves, each over a quarter of the K steps, and the partial accumulators
+    meet in LDS in wave order — instead of one M-tile per wave over the whole K walk.  Another summation order of the same float32-grade
+    products: agreement with the M-split plan to float32 noise, both within the oracle tolerance, deterministic."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 13)
+    outs = {}
+    with torch.no_grad():
+        for v in ("on", "off", "on2"):
+            model.set_option("x3_ksplit", v[:2] if v != "off" else "off")
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    model.set_option("x3_ksplit", "on")
+    assert torch.isfinite(outs["on"]).all() and torch.equal(outs["on"], outs["on2"])
+    rel = float((outs["on"] - outs["off"]).abs().max() / outs["off"].abs().max())
+    assert 0 < rel < 5e-6, rel
+    chk = sorted({0, B // 2, B - 1})
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    for v in ("on", "off"):
+        got = outs[v][chk].double().cpu().numpy()
+        err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+        assert err.max() < 2e-5, (v, err)
+
+
 @pytest.mark.parametrize("B", [200, 256])
 def test_eight_wave_deep_stage_is_bit_identical(B):
     """Option x3_w8 (default on, round 6): the 256-channel 3x3 convs on the 6 x 11 maps (resnet.py:29-55, layer4) are one tile per pair;
