@@ -1317,6 +1317,10 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     a.wn = 1;
     *mw = a.CIN > 32 ? 1 : 2;
     *nw = 1;
+    if (a.ksw_ok && a.CIN >= 128 && (a.MT == 3 || a.MT == 4) && ks == 3 && stride == 1 && a.np == 2) {   // the compression conv: K over the waves
+      a.ksw = 1;
+      *mw = a.MT;
+    }
   } else if (ntt == 2) {
     a.wn = 2;
     *mw = a.MT > 2 ? 2 : 1;
