@@ -1145,6 +1145,16 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, MW_, NW_, NP, true>), grid, dim3(256), ldsb, s, a);   \
     return hipGetLastError();                                                                                   \
   }
+      if (a.w8) {                                                         // eight waves: the 256-channel head on 6 x 11 maps
+#define PNVO_X3DW(MODE_)                                                                                                  \
+  if (mode == MODE_ && mw == 3 && nw == 1) {                                                                             \
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, 3, 1, NP, true, true>), grid, dim3(512), ldsb, s, a);          \
+    return hipGetLastError();                                                                                            \
+  }
+        PNVO_X3DW(0) PNVO_X3DW(2)
+#undef PNVO_X3DW
+        return hipErrorInvalidValue;
+      }
       PNVO_X3D(0, 1, 1) PNVO_X3D(2, 1, 1) PNVO_X3D(0, 2, 1) PNVO_X3D(2, 2, 1) PNVO_X3D(0, 2, 2) PNVO_X3D(2, 2, 2) PNVO_X3D(0, 3, 2) PNVO_X3D(2, 3, 2)
 #undef PNVO_X3D
       return hipErrorInvalidValue;
@@ -1165,16 +1175,16 @@ hipError_t launch_ks(const ConvX3Args &a, int mode, int mw, int nw, dim3 grid, s
 #undef PNVO_X3K
       return hipErrorInvalidValue;
     }
-    if constexpr (KS == 3 && STRIDE == 1 && NP == 2) if (a.w8) {          // eight waves: the 256-channel 6 x 11 maps
+  }
+  if constexpr (KS == 3 && NP == 2) if (a.w8) {          // eight waves: the 256-channel 6 x 11 maps
 #define PNVO_X3W(MODE_)                                                                                                  \
   if (mode == MODE_ && mw == 3 && nw == 1) {                                                                            \
-    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, 3, 1, NP, false, true>), grid, dim3(512), ldsb, s, a);        \
-    return hipGetLastError();                                                                                           \
+  hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, MODE_, 3, 1, NP, false, true>), grid, dim3(512), ldsb, s, a);        \
+  return hipGetLastError();                                                                                           \
   }
-      PNVO_X3W(0) PNVO_X3W(1) PNVO_X3W(2) PNVO_X3W(3)
+    PNVO_X3W(0) PNVO_X3W(1) PNVO_X3W(2) PNVO_X3W(3)
 #undef PNVO_X3W
-      return hipErrorInvalidValue;
-    }
+    return hipErrorInvalidValue;
   }
 #undef PNVO_X3
   return hipErrorInvalidValue;
@@ -1243,7 +1253,8 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
     // chunks (PR x PC <= 324 pixels of 240 B): 4 x 16 outputs on the wide maps, else whole rows
     TC = a.Wo >= 32 ? 16 : a.Wo;
     const int pc = 2 * TC + 1;
-    TR = (324 / pc - 1) / 2;
+    TR = (324 / pc - 1) / 2;                                     // (two-piece patches would allow 486 pixels: 12 x 22 outputs in three tiles of four rows
+                                                                 //  instead of four of three — measured neutral, 93.2 vs 93.8 us: that head is not MFMA-bound)
     if (TR < 1) return false;
     if (TR > a.Ho) TR = a.Ho;
     while (TR > 1 && TR * TC > (ntt == 2 ? 64 : (ntt == 4 ? 128 : 96))) --TR;    // M-tiles the wave grid below covers
@@ -1341,7 +1352,7 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
       *mw = 2;
     }
     // one tile per sample and a tile per CU or more: eight waves of (3,1) tiles, all eight N-tiles in one workgroup (W8)
-    if (a.w8_ok && !fine && ntiles >= 200 && a.MT == 3 && ntt == 8 && a.np == 2 && stride == 1 && ks == 3) {
+    if (a.w8_ok && !fine && ntiles >= 200 && a.MT == 3 && ntt == 8 && a.np == 2 && ks == 3) {   // (stride 1 and the stride-2 block head)
       a.w8 = 1;
       a.wn = 8;
       *mw = 3;
@@ -1356,8 +1367,10 @@ bool conv_x3_plan_impl(ConvX3Args &a, int ks, int stride, int *mw, int *nw, size
   while (ck < 256 && a.CIN % (2 * ck) == 0) ck *= 2;
   // (W8 with the whole K = 256 in one 110 KB chunk — its launches are one workgroup per CU anyway: staging 14.5 k -> 7.8 k cycles per
   //  workgroup, the conv's time unchanged, 77-82 us on either form: not kept)
-  while (ck > 32 && np * a.PR * a.PC * (ck * 2 + 16) > (size_t)72 * 1024) ck /= 2;
-  if (np * a.PR * a.PC * (ck * 2 + 16) > (size_t)76 * 1024) return false;
+  static const long w8_s2_lds = std::getenv("PNVO_X3_W8_LDS") ? std::atol(std::getenv("PNVO_X3_W8_LDS")) : 72;   // (developer sweep)
+  const size_t cap = (size_t)(a.w8 && stride == 2 ? w8_s2_lds : 72) * 1024;
+  while (ck > 32 && np * a.PR * a.PC * (ck * 2 + 16) > cap) ck /= 2;
+  if (np * a.PR * a.PC * (ck * 2 + 16) > cap + 4096) return false;
   if (a.CIN % ck) return false;
   a.CK = ck;
   // Few workgroups (small batches: the reference's navigation loop calls with ONE pair): a workgroup walks its whole K loop alone
