@@ -72,7 +72,7 @@ struct PnvoOptions {
   int bf16_stem3 = 0;  // bf16 path: exact three-piece stem (experiment)
   int input_fallback = 1;   // contract-breaking input (fractional rgb, soft depth codes): re-run on the dense stem and stay on it
   int small_net = 1;   // batches of <= small_max pairs: everything behind the stem conv in ONE persistent launch (smallnet.hip)
-  int small_max = 4;   // largest batch the persistent kernel takes (1..4: faster than the per-layer launches up to there)
+  int small_max = 3;   // largest batch the persistent kernel takes (1..4; round 6: the per-layer launches with their fine plans win from 4 pairs on — 0.370 against 0.400 ms)
   int small_prof = 0;  // developer instrumentation: per-phase times of the persistent kernel on stderr
   int small_coop = 1;  // cooperative launch (hipLaunchCooperativeKernel): every workgroup resident by the runtime's guarantee, also next to other
                        // processes' kernels (+17 us); 0: plain launch of <= 144 workgroups (one per CU) for a process that owns the GPU

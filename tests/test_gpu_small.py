@@ -132,11 +132,14 @@ def test_models_it_does_not_fit_keep_the_per_layer_launches():
 def test_batches_above_small_max_and_explicit_kernel_choices_keep_the_per_layer_launches():
     rec = load_golden("model_default_341x192_b2.npz")
     model, cfg, sd, obs, tobs, actions, tact = build(rec)
-    assert model.layer_kernel(FIRST_CONV, 4)[0] == "smallnet"     # default small_max = 4
+    assert model.layer_kernel(FIRST_CONV, 3)[0] == "smallnet"     # default small_max = 3 (round 6: four pairs are faster as per-layer launches)
+    assert model.layer_kernel(FIRST_CONV, 4)[0] != "smallnet"
+    model.set_option("small_max", "4")
+    assert model.layer_kernel(FIRST_CONV, 4)[0] == "smallnet"
     assert model.layer_kernel(FIRST_CONV, 5)[0] != "smallnet"
     model.set_option("small_max", "1")
     assert model.layer_kernel(FIRST_CONV, 2)[0] != "smallnet"
-    model.set_option("small_max", "4")
+    model.set_option("small_max", "3")
     for key, value in (("conv", "fp32"), ("tail", "separate"), ("pool", "separate")):
         model.set_option(key, value)
         assert model.layer_kernel(FIRST_CONV, 1)[0] != "smallnet", key
