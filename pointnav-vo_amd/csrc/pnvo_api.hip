@@ -1240,6 +1240,7 @@ const OptDef kOptions[] = {
     {"x3_fine", "PNVO_X3_FINE", &PnvoOptions::x3_fine, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_w8", "PNVO_X3_W8", &PnvoOptions::x3_w8, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"x3_ksplit", "PNVO_X3_KSPLIT", &PnvoOptions::x3_ksplit, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
+    {"fc_rows", "PNVO_FC_ROWS", &PnvoOptions::fc_rows, true, {{nullptr, 0}}},
     {"head_fuse", "PNVO_HEAD_FUSE", &PnvoOptions::head_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"ds_fuse", "PNVO_DS_FUSE", &PnvoOptions::ds_fuse, false, {{"on", 1}, {"off", 0}, {nullptr, 0}}},
     {"gn_fuse", "PNVO_GN_FUSE", &PnvoOptions::gn_fuse, false, {{"on", 2}, {"single", 2}, {"last", 1}, {"off", 0}, {nullptr, 0}}},
@@ -1595,6 +1596,14 @@ int pnvo_load_weights(pnvo_handle h, const float *blob, size_t n_floats, const p
     for (int o = 0; o < c.hidden; ++o) std::memcpy(&vis[(size_t)o * flat], w1 + (size_t)o * fc_in, sizeof(float) * flat);
     std::vector<float> pk;
     h->fc.host_w = vis;                                    // (smallnet.hip packs its own layout from these)
+    {                                                      // fc_rows.hip: plain rows in the activation's (h, w, padded channel) order
+      const int hw = h->fh * h->fw, kp = hw * h->comp_cp;
+      std::vector<float> rows((size_t)c.hidden * kp, 0.f);
+      for (int o = 0; o < c.hidden; ++o)
+        for (int ch = 0; ch < h->comp_c; ++ch)
+          for (int q = 0; q < hw; ++q) rows[(size_t)o * kp + (size_t)q * h->comp_cp + ch] = vis[(size_t)o * flat + (size_t)ch * hw + q];
+      if ((rc = upload(h, h->fc_rows_w, rows.data(), rows.size())) != PNVO_OK) return rc;
+    }
     pack_conv_weight_cinp(vis.data(), c.hidden, h->comp_c, h->comp_cp, h->fh, h->fw, pk);
     if ((rc = upload(h, h->fc.wpk, pk.data(), pk.size())) != PNVO_OK) return rc;
     const int rows = c.act_embed ? c.n_acts + 1 : 1;
@@ -1852,6 +1861,9 @@ bool side_stream_ready(pnvo_handle m, hipStream_t s) {
 }
 
 int run_fc_head(pnvo_handle m, int B, const float *comp_raw, const float *sc, const float *sh, const int64_t *actions, float *out, hipStream_t s);
+bool fc_rows_usable(pnvo_handle m, int B);
+int run_fc_rows(pnvo_handle m, pnvo_handle const *grp, const int *end, int ng, int B, const float *comp_raw, const float *sc, const float *sh,
+                const int64_t *actions, float *out, hipStream_t s);
 
 // Stream + events of option pool_async (lazily; not while `s` is being captured: a graph keeps the fill in-stream).
 bool keys_stream_ready(pnvo_handle m, hipStream_t s) {
@@ -2102,6 +2114,9 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   // (a11) Flatten + Linear + ReLU, then the output head — per action model in a grouped forward (each on its own handle: its
   // weights, bias rows and split-K scratch; the sample ranges are contiguous)
   if (m->grp_n > 1) {
+    bool rows_ok = !c.act_embed;
+    for (int k = 0; k < m->grp_n; ++k) rows_ok = rows_ok && fc_rows_usable(m->grp[k], B);
+    if (rows_ok) return run_fc_rows(m, m->grp, m->grp_end, m->grp_n, B, m->comp_raw, m->ssC[0], m->ssC[1], nullptr, out, s);
     int start = 0;
     for (int k = 0; k < m->grp_n; ++k) {
       const int Bk = m->grp_end[k] - start;
@@ -2118,10 +2133,54 @@ int forward_body(pnvo_handle m, const float *rgb, const float *depth, const floa
   return run_fc_head(m, B, m->comp_raw, m->ssC[0], m->ssC[1], actions, out, s);
 }
 
+// fc_rows.hip takes the two Linear layers of this handle at B samples (inference handles on float32, default kernels)
+bool fc_rows_usable(pnvo_handle m, int B) {
+  const long kp = (long)m->fh * m->fw * m->comp_cp;
+  return m->opt.fc_rows >= B && B >= 1 && m->fc_rows_w != nullptr && m->train == nullptr && m->precision == 0 && m->opt.conv == 0 &&
+         m->comp_cp > 0 && 256 % m->comp_cp == 0 && kp % 4 == 0 && kp / 4 <= 64L * FC_ROWS_MAXV && m->cfg.hidden % 4 == 0 &&
+         (m->features_only || m->head_w_plain != nullptr);
+}
+
+// ... of up to three handles (a grouped forward: grp[k] serves the samples up to end[k]) in one launch each
+int run_fc_rows(pnvo_handle m, pnvo_handle const *grp, const int *end, int ng, int B, const float *comp_raw, const float *sc, const float *sh,
+                const int64_t *actions, float *out, hipStream_t s) {
+  const pnvo_config &c = m->cfg;
+  FcRowsArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = comp_raw;
+  a.sc = sc;
+  a.sh = sh;
+  a.hid = m->features_only ? out : m->hid;
+  a.out = out;
+  a.actions = c.act_embed ? actions : nullptr;
+  a.B = B;
+  a.Kp = m->fh * m->fw * m->comp_cp;
+  a.cp = m->comp_cp;
+  a.hidden = c.hidden;
+  a.out_dim = c.out_dim;
+  a.ngroups = ng;
+  for (int k = 0; k < ng; ++k) {
+    a.end[k] = end[k];
+    a.w[k] = grp[k]->fc_rows_w;
+    a.bias[k] = grp[k]->fc_bias;
+    a.head_w[k] = grp[k]->head_w_plain;
+    a.head_b[k] = grp[k]->head_bias;
+  }
+  Timed t(m, s, "conv:" + m->fc.name, 2.0 * B * (double)a.Kp * c.hidden, 4.0 * ng * (double)a.Kp * c.hidden);
+  HIPCHK(m, launch_fc_rows(a, !m->features_only, s));
+  return PNVO_OK;
+}
+
 // The hidden layer and the output head of handle m on B rows of the compression output.
 int run_fc_head(pnvo_handle m, int B, const float *comp_raw, const float *sc, const float *sh, const int64_t *actions, float *out, hipStream_t s) {
   const pnvo_config &c = m->cfg;
   int rc = PNVO_OK;
+  if (fc_rows_usable(m, B)) {
+    pnvo_handle one[1] = {m};
+    const int end[1] = {B};
+    if ((rc = run_fc_rows(m, one, end, 1, B, comp_raw, sc, sh, actions, out, s)) != PNVO_OK) return rc;
+    return m->features_only ? PNVO_OK : maybe_tap(m, "hidden", m->hid, (size_t)B * c.hidden, s);
+  }
   // the output head rides on the hidden layer's split-K reduction when there is one (option head_fuse); with a training step attached
   // the head's weight is read where the optimiser keeps it (the flat parameter buffer), the bias from its re-packed copy
   m->head_rode = false;
@@ -2574,6 +2633,7 @@ int pnvo_destroy(pnvo_handle m) {
   free_dev(m->fc.wpk);
   free_dev(m->head.wpk);
   free_dev(m->fc_bias);
+  free_dev(m->fc_rows_w);
   free_dev(m->head_bias);
   free_dev(m->head_w_plain);
   free_dev(m->stem_sc);

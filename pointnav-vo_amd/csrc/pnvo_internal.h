@@ -405,6 +405,18 @@ hipError_t launch_conv(const ConvArgs &a, hipStream_t s);
 // y = [relu](sum_z kpart[z] + bias[row]) for a split-K linear layer (a.ksplit > 1)
 hipError_t launch_ksplit_reduce(const ConvArgs &a, hipStream_t s);
 // ... with the output head (Linear COUT -> out_dim <= 4, plain [out_dim][COUT] weight + bias) computed on the reduced row: out [B][out_dim]
+// fc_rows.hip: the hidden layer (+ GroupNorm / ReLU of its input) and the output head for <= 32 samples, every action model of a grouped
+// forward in one launch each
+constexpr int FC_ROWS_MAXV = 12;          // 16-byte vectors of a weight row per lane: Kp <= 3072
+struct FcRowsArgs {
+  const float *x, *sc, *sh;               // compression conv's raw output [B][Kp] (Kp = fh * fw * cp), its GroupNorm scale / shift [B][cp]
+  float *hid, *out;                       // [B][hidden], [B][out_dim]
+  const int64_t *actions;                 // act-embed models: the bias row of a sample (nullptr: row 0)
+  int B, Kp, cp, hidden, out_dim, ngroups;
+  int end[3];                             // one past the last sample of each action model
+  const float *w[3], *bias[3], *head_w[3], *head_b[3];   // per model: [hidden][Kp] rows in the activation's (h, w, padded c) order, bias rows, head
+};
+hipError_t launch_fc_rows(const FcRowsArgs &a, bool with_head, hipStream_t s);
 hipError_t launch_ksplit_reduce_head(const ConvArgs &a, const float *w2, const float *b2, int out_dim, float *out, hipStream_t s);
 int conv_ksplit(const ConvArgs &a);   // how many K slices launch_conv would use for `a` when a.kpart is set (1: none)
 

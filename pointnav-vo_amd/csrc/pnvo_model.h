@@ -52,6 +52,7 @@ struct PnvoOptions {
   int x3_fine = 1;     // small launches of the float16-piece convs take one N-tile per workgroup instead of falling back to the fp32-pipe kernels
   int x3_w8 = 1;       // 256-channel convs on 6 x 11 maps with a tile per CU or more: eight waves of (3,1) tiles per workgroup (two per SIMD) instead of four of (3,2)
   int x3_ksplit = 1;   // fine-plan conv tiles of three / four M-tiles behind >= 128 input channels: the four waves split the K walk, partial sums meet in LDS
+  int fc_rows = 48;    // up to this many samples the hidden layer and the head run as fc_rows.hip's two launches (every model of a grouped forward in one)
   int head_fuse = 1;   // the output head (Linear hidden -> out_dim) is computed by the hidden layer's split-K reduction launch (one launch less)
   int ds_fuse = 1;     // the 1x1 stride-2 downsample conv rides on its block's first 3x3 conv (bit-identical raw output, one launch less, block input read once)
   int gn_fuse = 2;     // conv_x3 launches finalise their GroupNorm themselves (bit-identical, one launch less): 2 = launches with one tile per
@@ -100,6 +101,7 @@ struct pnvo_model_s {
   int grp_n = 0;
   struct pnvo_model_s *grp[3] = {nullptr, nullptr, nullptr};
   int grp_end[3] = {0, 0, 0};
+  float *fc_rows_w = nullptr;                // device [hidden][fh * fw * comp_cp]: the hidden layer's weight rows in the activation's order (fc_rows.hip)
   float *head_w_plain = nullptr;             // device [out_dim][hidden]: the head's weight as loaded (the head riding on the hidden layer's split-K reduction)
   const float *head_ride_w = nullptr;        // ... the weight it reads: head_w_plain, or the flat parameter buffer of an attached training step
   float *head_ride_out = nullptr;            // set around the hidden layer's launch by the forward: where the riding head writes [B][out_dim]

@@ -720,6 +720,38 @@ def test_k_split_over_the_waves_agrees_with_the_m_split_fine_plan(B):
         assert err.max() < 2e-5, (v, err)
 
 
+@pytest.mark.parametrize("B", [4, 7, 17, 48])
+def test_hidden_layer_and_head_as_row_kernels_agree_with_the_mfma_path(B):
+    """Option fc_rows (default 48 samples, round 6): up to that batch the Linear(flat, hidden) + ReLU and the output head (vo_cnn.py:216-227)
+    run as fc_rows.hip's two launches — a wave per hidden unit and chunk of four samples, the compression conv's GroupNorm + ReLU applied
+    while reading — instead of the split-K MFMA kernel and its reduction.  float32 FMA chains against float32 MFMA accumulation:
+    agreement to float32 noise, both within the oracle tolerance; fc_rows=0 keeps the MFMA path."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(B, dev, 17)
+    outs = {}
+    with torch.no_grad():
+        for v in ("48", "0", "48b"):
+            model.set_option("fc_rows", v[:2].rstrip("b"))
+            outs[v] = model(obs).clone()
+        torch.cuda.synchronize()
+    model.set_option("fc_rows", "48")
+    assert torch.isfinite(outs["48"]).all() and torch.equal(outs["48"], outs["48b"])
+    rel = float((outs["48"] - outs["0"]).abs().max() / outs["0"].abs().max())
+    assert 0 < rel < 5e-6, rel
+    chk = sorted({0, B // 2, B - 1})
+    ref = oracle.forward(sd, {k: v[chk].cpu().numpy() for k, v in obs.items()}, ngroups=model.cfg.ngroups, dtype=np.float64)
+    for v in ("48", "0"):
+        got = outs[v][chk].double().cpu().numpy()
+        err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-2)
+        assert err.max() < 2e-5, (v, err)
+
+
 @pytest.mark.parametrize("B", [200, 256])
 def test_eight_wave_deep_stage_is_bit_identical(B):
     """Option x3_w8 (default on, round 6): the 256-channel 3x3 convs on the 6 x 11 maps (resnet.py:29-55, layer4) are one tile per pair;
