@@ -720,6 +720,37 @@ def test_k_split_over_the_waves_agrees_with_the_m_split_fine_plan(B):
         assert err.max() < 2e-5, (v, err)
 
 
+def test_eight_wave_forms_in_a_training_step_are_bit_identical():
+    """From 200 pairs on the training forward takes the eight-wave deep-stage forms too (the stride-2 head keeps the block input and
+    hands mean / rstd to the backward): two training steps at 208 pairs with x3_w8 on / off end in the same losses and parameters."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from pointnav_vo_amd import model_spec as ms, synth
+    from pointnav_vo_amd.registry import baseline_registry
+    from pointnav_vo_amd.train import VOTrainStep
+    dev = torch.device("cuda", 0)
+    B, res = 208, {}
+    obs = bench.make_inputs(B, dev, 0)
+    tgt = (torch.arange(B * 3, device=dev, dtype=torch.float32).reshape(B, 3) % 7 - 3) * 0.05
+    for v in ("on", "off"):
+        model = baseline_registry.get_vo_model("vo_cnn_rgb_d_dd_top_down")(
+            observation_space=bench.SPACE, observation_size=(bench.W, bench.H), hidden_size=512, backbone="resnet18",
+            normalize_visual_inputs=True, output_dim=3, dropout_p=0.2, discretized_depth_channels=bench.BINS)
+        sd = synth.make_state_dict(ms.state_dict_spec(model.cfg), seed=0)
+        model.load_state_dict({k: torch.from_numpy(np.array(x)) for k, x in sd.items()})
+        model = model.to(dev)
+        model.set_option("x3_w8", v)
+        ts = VOTrainStep(model)
+        losses = [float(ts.step(obs, tgt)[1]) for _ in range(2)]
+        torch.cuda.synchronize()
+        res[v] = (losses, torch.cat([q.detach().reshape(-1) for q in model.parameters()]).clone())
+        del ts, model
+    assert res["on"][0] == res["off"][0], (res["on"][0], res["off"][0])
+    assert torch.isfinite(res["on"][1]).all() and torch.equal(res["on"][1], res["off"][1])
+
+
 @pytest.mark.parametrize("B", [4, 7, 17, 48])
 def test_hidden_layer_and_head_as_row_kernels_agree_with_the_mfma_path(B):
     """Option fc_rows (default 48 samples, round 6): up to that batch the Linear(flat, hidden) + ReLU and the output head (vo_cnn.py:216-227)
