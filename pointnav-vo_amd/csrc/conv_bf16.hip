@@ -49,8 +49,10 @@ __device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(fl
 // with the downsample conv's weights (p.ds_wpk) into a second accumulator set; second epilogue (p.ds_y, p.ds_stats, own GroupNorm).  Same
 // MFMAs in the same order as the separate 1x1 launch: bit-identical raw output.  As conv_x3_kernel's DSF.
 template <int KS, int STRIDE, int MODE, bool F32OUT, int MW, int NW, bool BRES = false, bool DSF = false>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
-  static_assert(!DSF || (KS == 3 && STRIDE == 2 && !F32OUT), "the downsample conv rides on a 3x3 stride-2 conv");
+// (the resident-weight form is built for TWO waves per SIMD — its persistent grid is sized by the occupancy: 224 + 32 registers fit exactly,
+//  two more and the compiler falls to one wave per SIMD, half the workgroups and 194 -> 309 us on the first stage's block tail)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BRES && MW <= 2 ? 2 : 1))) void conv_bf16_kernel(const ConvBArgs p) {
+  static_assert(!DSF || (KS == 3 && STRIDE == 2 && !F32OUT && !BRES), "the downsample conv rides on a streaming 3x3 stride-2 conv");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int PSTEP = KS == 1 ? STRIDE : 1;      // input pixels per patch pixel (a 1x1 conv stages only what it reads)
   constexpr int CS = KS == 1 ? 1 : STRIDE;         // patch pixels per output pixel
@@ -75,16 +77,6 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
         const int nt = min(wave_n_ * NW + j, ntt_ - 1);
         bres[st][j] = wpk[(((st >> 1) * kct_ + (st & 1)) * ntt_ + nt) * 64 + lane];
       }
-  }
-  u32x4 bresd[(BRES && DSF) ? 2 : 1][NW];                               // BRES + DSF: the downsample conv's two k-chunks, resident too
-  if (BRES && DSF) {
-    const int wn_ = p.wn, ntt_ = p.COUTP >> 5;
-    const int wave_n_ = (wave & (wn_ - 1)) + (int)blockIdx.y * (8 / NW);
-    const u32x4 *wd = reinterpret_cast<const u32x4 *>(p.ds_wpk[z]);
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-      for (int j = 0; j < NW; ++j) bresd[(BRES && DSF) ? st : 0][j] = wd[(st * ntt_ + min(wave_n_ * NW + j, ntt_ - 1)) * 64 + lane];
   }
   for (int vb = (int)blockIdx.x;; vb += (int)gridDim.x) {                // (one pass unless BRES)
   int bid = (vb & 7) * chunk + (vb >> 3);                               // consecutive tiles of an XCD are neighbours
@@ -332,17 +324,12 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
             accd[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ad[i]), __builtin_bit_cast(bf16x8, bd[j]), accd[i][j], 0,
                                                                  0, 0);
       };
-      if constexpr (BRES) {                                               // (32 input channels: two k-chunks, fragments resident)
-        dstep(0, bresd[0]);
-        dstep(1, bresd[(BRES && DSF) ? 1 : 0]);
-      } else {
 #pragma unroll 1
-        for (int kc = 0; kc < kcc; ++kc) {
-          u32x4 bd[NW];
+      for (int kc = 0; kc < kcc; ++kc) {
+        u32x4 bd[NW];
 #pragma unroll
-          for (int j = 0; j < NW; ++j) bd[j] = *reinterpret_cast<const u32x4 *>(wd + (long)kc * kstep + (size_t)voff[j]);
-          dstep(kc, bd);
-        }
+        for (int j = 0; j < NW; ++j) bd[j] = *reinterpret_cast<const u32x4 *>(wd + (long)kc * kstep + (size_t)voff[j]);
+        dstep(kc, bd);
       }
     }
   }
@@ -353,7 +340,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
   const int rr16 = lane >> 5;
   const long ybase = (((long)n * p.Ho + r0) * p.Wo + c0) * p.COUTP;
   // (runs once for the conv and, DSF, once more for the downsample conv that rode on it)
-  auto emit = [&](f32x16 (*ac)[NW], void *yout, float *stats, const float *ggamma, const float *gbeta, float *gscale, float *gshift, bool f32o) {
+  auto emit = [&](f32x16 (*ac)[NW], void *yout, float *stats, const float *ggamma, const float *gbeta, float *gscale, float *gshift, bool is_ds) {
+    const bool f32o = F32OUT && !is_ds;                                  // (compile-time false for every bf16-output variant: the riding conv's output is bf16)
     float t1[NW], t2[NW];
   #pragma unroll
     for (int j = 0; j < NW; ++j) t1[j] = t2[j] = 0.f;
@@ -421,8 +409,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBArgs p) {
       }
     }
   };
-  emit(acc, p.y[z], p.stats[z], p.gn_gamma[z], p.gn_beta[z], p.gn_scale[z], p.gn_shift[z], F32OUT);
-  if constexpr (DSF) emit(accd, p.ds_y[z], p.ds_stats[z], p.ds_gamma[z], p.ds_beta[z], p.ds_scale[z], p.ds_shift[z], false);
+  emit(acc, p.y[z], p.stats[z], p.gn_gamma[z], p.gn_beta[z], p.gn_scale[z], p.gn_shift[z], false);
+  if constexpr (DSF) emit(accd, p.ds_y[z], p.ds_stats[z], p.ds_gamma[z], p.ds_beta[z], p.ds_scale[z], p.ds_shift[z], true);
   if (!BRES) return;
   __syncthreads();                                                       // patch, tables and reduction scratch are free again
   }
@@ -536,7 +524,7 @@ hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bo
   const long ntiles = (long)a.B * a.tiles_r * a.tiles_c;
   dim3 grid((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)((a.COUTP + 255) / 256)   /* groups of 8 N-tiles */, (unsigned)nmodels);
   // persistent workgroups with the weights resident in registers (BRES): 32 input channels in one staged chunk, one N-tile per wave
-  if (a.persist_wgs >= 8 && a.CIN == 32 && a.CK == 32 && nw == 1 && !f32out && ntiles >= 2L * a.persist_wgs) {
+  if (a.persist_wgs >= 8 && a.CIN == 32 && a.CK == 32 && nw == 1 && !f32out && a.ds_wpk[0] == nullptr && ntiles >= 2L * a.persist_wgs) {
     const int cus = a.persist_wgs / 3;
     // as many workgroups as are RESIDENT at once (registers / LDS of the variant decide: 2-4 per CU): a persistent grid larger than
     // that would run its surplus workgroups as a second, unbalanced round
@@ -555,24 +543,7 @@ hipError_t launch_conv_bf16(const ConvBArgs &a, int ks, int stride, int mode, bo
     // (measured at 256 pairs x 2 models: the block-tail convs 0.240 -> 0.199 and 0.167 -> 0.146 ms, the 1x1 downsample conv 0.047 ->
     //  0.039; the plain and GroupNorm-input convs LOSE — 0.11 -> 0.13 ms: their 60-register streaming form keeps five workgroups
     //  per CU in flight, the 72 resident registers leave three — and stay on the streaming form)
-    if (a.ds_wpk[0] != nullptr) {                  // (the riding downsample conv's two k-chunks resident as well)
-#define PNVO_CBPD(MODE_, MW_)                                                                                           \
-  if (ks == 3 && stride == 2 && mode == MODE_ && mw == MW_) {                                                           \
-    auto kfn = conv_bf16_kernel<3, 2, MODE_, false, MW_, 1, true, true>;                                                \
-    int occ = 0;                                                                                                        \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds_bytes) != hipSuccess || occ < 1) occ = 1;      \
-    const int per_cu = std::max(1, occ / (int)(grid.y * grid.z));                                                       \
-    dim3 pg((unsigned)((per_cu * cus) & ~7), grid.y, grid.z);                                                           \
-    if (pg.x >= 8 && ntiles >= 2L * pg.x) {                                                                             \
-      hipLaunchKernelGGL(kfn, pg, dim3(256), lds_bytes, s, a);                                                          \
-      return hipGetLastError();                                                                                         \
-    }                                                                                                                   \
-  }
-      PNVO_CBPD(2, 2) PNVO_CBPD(2, 1)
-#undef PNVO_CBPD
-    } else {
     PNVO_CBP(3, 1, 2, 2) PNVO_CBP(3, 1, 2, 4) PNVO_CBP(3, 2, 2, 2) PNVO_CBP(1, 2, 0, 2) PNVO_CBP(3, 2, 2, 1) PNVO_CBP(1, 2, 0, 1)
-    }
 #undef PNVO_CBP
   }
   if (ks == 3 && stride == 1) return launch_ks<3, 1>(a, mode, f32out, mw, nw, grid, lds_bytes, s);

@@ -355,6 +355,8 @@ int pnvo_forward_bf16(pnvo_handle *hs, int nm, const float *rgb, const float *de
       const Layer &c1 = m->convs[l1];
       const bool ride_ok = ds && m->opt.ds_fuse && !(pend.on && pend.affine) /* the stager would read rawD while the ride writes it */ &&
                            bs[0]->layers[l1].nw == 1 /* two N-tiles per wave: the second accumulator set does not fit (measured 56 -> 103 us) */ &&
+                           c1.cinp != 32 /* 32 input channels: the resident-weight persistent form takes the head (140 + 39 us with the separate
+                                            downsample conv against 235 us with the ride on the streaming form) */ &&
                            c1.k == 3 && c1.stride == 2 && m->convs[li].k == 1 && m->convs[li].stride == 2 &&
                            c1.cinp == m->convs[li].cinp && c1.coutp == m->convs[li].coutp && c1.hout == m->convs[li].hout &&
                            c1.wout == m->convs[li].wout && c1.groups == m->convs[li].groups;
