@@ -151,9 +151,9 @@ def test_dual_forward_at_baseline_batch_256():
 
 @pytest.mark.parametrize("pairs", [2, 40, 256])
 def test_downsample_ride_equals_the_separate_downsample_conv(pairs):
-    """Option ds_fuse in the bf16 path (round 6): the 1x1 stride-2 downsample conv of layer2.0 / 3.0 / 4.0 (resnet.py:192-195) is computed
+    """Option ds_fuse in the bf16 path (round 6): the 1x1 stride-2 downsample conv of layer3.0 (resnet.py:192-195; layer2.0 / 4.0 keep their own launch) is computed
     by the launch of the block's first 3x3 stride-2 conv from that conv's centre-tap A fragments (conv_bf16.hip DSF) — in the block-tail
-    and in the plain-input form (bf16_fuse off), streaming and persistent workgroups.  Same bf16 products in the same k order; only the
+    and in the plain-input form (bf16_fuse off).  Same bf16 products in the same k order; only the
     GroupNorm partial sums are grouped by the riding conv's tiles, so the outputs agree to float32 summation order."""
     rec = load_golden("model_default_341x192_b2.npz")
     ma, cfg, _, _, tobs, _, _ = build(rec)
