@@ -397,8 +397,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     // RING (float16 pieces, no riding downsample conv): B fragments are fetched TWO steps ahead into a ring of three register sets —
     // one step (6-18 MFMAs, 200-600 cycles) is shorter than an L2 round trip under load, and the ISA showed every step waiting for the
     // fragments it had asked for one step earlier.  A (LDS) stays one step ahead.  The two fetches run on trackers of their own.
-    constexpr bool RING = NP == 2 && KS == 3 && !(MODE == 2 && MW * NW == 5) && !(DSF && MW * NW == 4);   // (the block-tail strip tile and the
-                                                                                                           //  (2,2) riding head have no registers to spare)
+    // Small wave tiles only (one or two accumulator tiles: the fine plan's launches, the 32- / 64-channel stages): on the larger tiles
+    // the ring was neutral at 256 pairs (2.275 against 2.270 ms) and cost the 128-pair training step 0.4 % (15-28 registers per variant).
+    constexpr bool RING = NP == 2 && KS == 3 && MW * NW <= 2;
     const char *wb_b = wb_n;                                             // RING: the B step being fetched
     int kc_b = 0;
     auto advanceB = [&]() {
