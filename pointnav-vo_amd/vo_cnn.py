@@ -126,20 +126,40 @@ class VisualOdometryCNNBase(nn.Module):
         return msg.decode() if msg else ""
 
     def _tensors(self):
-        """(name, tensor) in state_dict order.  The owning (module, attribute) pairs are resolved once — walking the module
-        tree costs ~0.1 ms, which a batch-1 boundary call pays on every forward — and read through getattr each time, so a
-        buffer re-assigned by a train-mode forward (RunningMeanAndVar) or a parameter re-pointed by .to() is seen."""
-        slots = getattr(self, "_tensor_slots", None)
-        if slots is None:
-            slots = []
+        """(name, tensor) in state_dict order.  Walking the module tree costs ~0.1 ms and even one getattr per tensor through
+        nn.Module.__getattr__ ~50 us — which a batch-1 boundary call pays on every forward, and a grouped call of three action models
+        six times.  PARAMETERS are therefore resolved once and kept (nn.Module._apply — .to() / .cuda() / .float() — swaps their .data
+        in place or, with the overwrite-params future flag, replaces them: _apply below drops the cache; load_state_dict copies in
+        place: the version counter in _sync_weights' signature sees it); the BUFFERS (RunningMeanAndVar's three, re-assigned by every
+        train-mode forward) are read through getattr each time.  A parameter object replaced by hand (module.weight = nn.Parameter(..))
+        needs model._tensor_cache = None."""
+        cache = getattr(self, "_tensor_cache", None)
+        if cache is None:
+            cache = []
             for name, _ in self._spec:
                 parts = name.split(".")
                 mod = self
                 for q in parts[:-1]:
                     mod = getattr(mod, q)
-                slots.append((name, mod, parts[-1]))
-            object.__setattr__(self, "_tensor_slots", slots)
-        return [(name, getattr(mod, leaf)) for name, mod, leaf in slots]
+                leaf = parts[-1]
+                cache.append((name, None, mod, leaf) if leaf in mod._buffers else (name, getattr(mod, leaf), None, None))
+            object.__setattr__(self, "_tensor_cache", cache)
+        return [(name, t if mod is None else getattr(mod, leaf)) for name, t, mod, leaf in cache]
+
+    def _apply(self, fn, *a, **k):
+        object.__setattr__(self, "_tensor_cache", None)
+        return super()._apply(fn, *a, **k)
+
+    def _ref_param(self):
+        """The model's first parameter (its device decides where the handle lives) without walking the module tree."""
+        cache = getattr(self, "_tensor_cache", None)
+        if cache is None:
+            self._tensors()
+            cache = self._tensor_cache
+        for _, t, mod, _leaf in cache:
+            if mod is None:
+                return t
+        return next(self.parameters())
 
     def _ensure_handle(self, device):
         if self._handle is not None and self._handle_dev == device.index:
@@ -171,7 +191,7 @@ class VisualOdometryCNNBase(nn.Module):
 
     def _sync_weights(self):
         tensors = self._tensors()
-        sig = tuple((t.data_ptr(), t._version) for _, t in tensors)
+        sig = tuple([(t.data_ptr(), t._version) for _, t in tensors])
         if sig == self._loaded_sig:
             return
         blob = np.concatenate([t.detach().to("cpu", torch.float32).reshape(-1).numpy() for _, t in tensors])
@@ -202,7 +222,7 @@ class VisualOdometryCNNBase(nn.Module):
                 ts = VOTrainStep(self)
                 object.__setattr__(self, "_train_step", ts)
             return ts.forward_train(observation_pairs, actions)
-        ref = next(self.parameters())
+        ref = self._ref_param()
         if ref.device.type != "cuda":
             raise RuntimeError("pointnav_vo_amd VO models run on an MI355X only: move the model with .to('cuda') "
                                "(there is no CPU fallback)")
@@ -246,7 +266,7 @@ class VisualOdometryCNNBase(nn.Module):
         observation-pair tensors are built.  err_flag: optional int32 CUDA tensor [1], set when a depth is outside [0, 1]."""
         if self.training:
             raise RuntimeError("forward_raw is the eval-mode forward (train-mode forwards take observation pairs)")
-        ref = next(self.parameters())
+        ref = self._ref_param()
         if ref.device.type != "cuda":
             raise RuntimeError("pointnav_vo_amd VO models run on an MI355X only (there is no CPU fallback)")
         dev = ref.device
@@ -413,8 +433,8 @@ def grouped_supported(models):
     models = list(models)
     if not 1 <= len(models) <= 3 or any(m.training for m in models):
         return False, "one to three eval-mode models"
-    dev = next(models[0].parameters()).device
-    if dev.type != "cuda" or any(next(m.parameters()).device != dev for m in models):
+    dev = models[0]._ref_param().device
+    if dev.type != "cuda" or any(m._ref_param().device != dev for m in models):
         return False, "models on one MI355X"
     for m in models:
         m._ensure_handle(dev)
@@ -433,9 +453,9 @@ def grouped_forward_raw(models, counts, rgb_frames, depth_frames, top_down_view=
     models, counts = list(models), [int(x) for x in counts]
     if not 1 <= len(models) <= 3 or len(models) != len(counts):
         raise ValueError("grouped_forward_raw takes one to three models and as many pair counts")
-    ref = next(models[0].parameters())
+    ref = models[0]._ref_param()
     dev = ref.device
-    if dev.type != "cuda" or any(next(m.parameters()).device != dev for m in models):
+    if dev.type != "cuda" or any(m._ref_param().device != dev for m in models):
         raise RuntimeError("grouped_forward_raw: every model must be on the same MI355X (there is no CPU fallback)")
     if any(m.training for m in models):
         raise RuntimeError("grouped_forward_raw is the eval-mode forward of every model")
