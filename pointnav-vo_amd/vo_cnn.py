@@ -438,7 +438,8 @@ def grouped_supported(models):
         return False, "models on one MI355X"
     for m in models:
         m._ensure_handle(dev)
-        m._sync_weights()
+        if m._loaded_sig is None:                  # (the query needs loaded handles, not current values: the forward itself syncs)
+            m._sync_weights()
     hs = (C.c_void_p * len(models))(*[m._handle for m in models])
     rc = _lib.lib.pnvo_grouped_supported(hs, len(models))
     return rc == 0, ("" if rc == 0 else _lib.lib.pnvo_last_error(models[0]._handle).decode())
