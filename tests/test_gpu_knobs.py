@@ -720,6 +720,42 @@ def test_k_split_over_the_waves_agrees_with_the_m_split_fine_plan(B):
         assert err.max() < 2e-5, (v, err)
 
 
+def test_weight_changes_reach_the_handle_through_the_cached_tensor_list():
+    """The module's parameter objects are resolved once (round 6); what changes afterwards must still reach the handle: an in-place
+    edit (version counter), load_state_dict, a re-assigned buffer (RunningMeanAndVar's, read through getattr every call), .to() / .float()
+    (nn.Module._apply drops the cache).  Each against a fresh model built with the same values."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    model, sd = bench.build_model(dev)
+    obs = bench.make_inputs(5, dev, 3)
+
+    def fresh_out(state):
+        m, _ = bench.build_model(dev)
+        m.load_state_dict(state)
+        with torch.no_grad():
+            return m(obs).clone()
+
+    with torch.no_grad():
+        base = model(obs).clone()
+        p = dict(model.named_parameters())["visual_encoder.backbone.layer2.0.convs.0.weight"]
+        p.mul_(1.25)                                               # in place: same object, same pointer, version + 1
+        a = model(obs).clone()
+        assert not torch.equal(a, base)
+        assert torch.equal(a, fresh_out({k: v.clone() for k, v in model.state_dict().items()}))
+        rm = model.visual_encoder.running_mean_and_var
+        rm._mean = (rm._mean + 0.05).clone()                       # a buffer re-assigned (what a train-mode forward does)
+        b = model(obs).clone()
+        assert not torch.equal(b, a)
+        assert torch.equal(b, fresh_out({k: v.clone() for k, v in model.state_dict().items()}))
+        model = model.cpu().to(dev)                                # _apply twice: tensors re-resolved, handle re-fed
+        assert torch.equal(model(obs), b)
+        model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        assert torch.equal(model(obs), base)
+
+
 def test_eight_wave_forms_in_a_training_step_are_bit_identical():
     """From 200 pairs on the training forward takes the eight-wave deep-stage forms too (the stride-2 head keeps the block input and
     hands mean / rstd to the backward): two training steps at 208 pairs with x3_w8 on / off end in the same losses and parameters."""
