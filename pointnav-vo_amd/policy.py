@@ -232,11 +232,13 @@ class PointNavResNetPolicy(nn.Module):
         """-> (value [B,1], action [B,1] int64, action_log_probs [B,1], rnn_hidden_states)  (policy.py:29-46)."""
         with torch.no_grad():
             _, hout, logits, value = self._net(observations, rnn_hidden_states, prev_actions, masks, want_features=False)
-            # (validate_args=False: the distribution's argument checks are five more launches and a host sync per step; the logits
-            #  come from the kernels above, the sampling call and its generator use are unchanged)
-            dist = torch.distributions.Categorical(logits=logits, validate_args=False)
-            action = dist.probs.argmax(dim=-1, keepdim=True) if deterministic else dist.sample().unsqueeze(-1)
-            logp = dist.log_prob(action.squeeze(-1)).view(action.size(0), -1).sum(-1).unsqueeze(-1)
+            # CategoricalNet's distribution (policy.py:29-46 -> utils.CategoricalNet): log-probabilities = logits - logsumexp, probabilities
+            # = their softmax, sample = multinomial(probabilities, 1), log_prob = gather.  Written out (log_softmax, exp, multinomial,
+            # gather: four launches instead of the distribution object's ten; the sampling call and its generator use are unchanged)
+            logp_all = torch.log_softmax(logits, dim=-1)
+            probs = logp_all.exp()
+            action = probs.argmax(dim=-1, keepdim=True) if deterministic else torch.multinomial(probs, 1, True)
+            logp = logp_all.gather(-1, action)
         return value, action, logp, hout
 
     def get_value(self, observations, rnn_hidden_states, prev_actions, masks):
